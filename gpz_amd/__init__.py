@@ -1,0 +1,8 @@
+"""gpz_amd — MI355X (gfx950) implementation of GPz's marginal-likelihood objective/gradient path.
+
+The numeric work lives in ``lib/libgpz_hip.so`` (hand-written HIP, built by ``./build.sh`` or
+``__graft_entry__.build()``); ``api`` mirrors the reference's MATLAB interface on top of its C ABI and
+``dist`` shards rows across GPUs with an RCCL all-reduce of the m x m / m x d partials.
+"""
+from .api import (GPz, GPzContext, Model, getPHI, inv_logdet, Dxy, nan_groups, predict, reset, globals_)  # noqa: F401
+from . import dist  # noqa: F401

@@ -1,0 +1,98 @@
+"""ctypes binding of libgpz_hip.so (the C ABI declared in include/gpz_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a call needs a GPU that is not
+there, this module raises instead of computing anything on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpz_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_uint8_p = C.POINTER(C.c_uint8)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class gpz_desc(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32),
+        ("m", C.c_int32),
+        ("k", C.c_int32),
+        ("method", C.c_char * 4),
+        ("heteroscedastic", C.c_int32),
+        ("device", C.c_int32),
+        ("stream", C.c_void_p),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/gpz_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "gpz_ctx_create": (C.c_int, [C.POINTER(gpz_desc), C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int32,
+                                 c_double_p, c_uint8_p, c_uint8_p, C.POINTER(C.c_void_p)]),
+    "gpz_ctx_destroy": (None, [C.c_void_p]),
+    "gpz_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "gpz_theta_len": (C.c_int64, [C.c_void_p]),
+    "gpz_n_train": (C.c_int64, [C.c_void_p]),
+    "gpz_n_valid": (C.c_int64, [C.c_void_p]),
+    "gpz_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_get_phi": (C.c_int, [C.c_void_p, c_double_p]),
+    "gpz_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpz_ctx_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_double_p, C.POINTER(C.c_int64), C.c_int]),
+    "gpz_ctx_reset_timings": (C.c_int, [C.c_void_p]),
+    "gpz_phi": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    "gpz_predict_full": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64,
+                                   c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_inv_logdet": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_int32_p]),
+    "gpz_dxy": (C.c_int, [c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
+    "gpz_nan_groups": (C.c_int, [c_double_p, C.c_int64, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
+    "gpz_last_error": (C.c_char_p, []),
+    "gpz_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+class GpzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgpz_hip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libgpz_hip.so and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with ./build.sh or __graft_entry__.build(); "
+            "gpz_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().gpz_last_error()
+        raise GpzError(rc, msg.decode() if msg else "")
+
+
+def dptr(a):
+    """double* of a contiguous float64 numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(c_double_p)

@@ -1,0 +1,331 @@
+"""Host-side mirror of the reference's interface for the objective/gradient path.
+
+Same names, argument order and meaning as the MATLAB functions they stand in for
+(paths relative to the OxfordML/GPz tree):
+
+    GPz(theta, model, X, Y, Psi, omega, training, validation)   GPz/GPz.m:1
+    getPHI(X, Psi, theta, model, selection)                      GPz/getPHI.m:1
+    inv_logdet(X)                                                GPz/inv_logdet.m:1
+    Dxy(X, Y)                                                    GPz/Dxy.m:1
+    predict(X, model, whichSet=..., selection=...)               GPz/predict.m:1 (no-Psi / no-NaN branch)
+
+Everything numeric happens in libgpz_hip.so on the GPU; this file only marshals numpy arrays
+(column-major, like MATLAB) across the C ABI.  ``model`` is any object with the reference's struct fields
+``m, d, k, method, heteroscedastic`` (+ ``muX, sdX, muY`` and ``sets`` for predict).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+# the reference's globals (GPz.m:3-7), refreshed by every 2-output GPz() call and left alone by solve-only calls
+globals_ = {"trainRMSE": None, "trainLL": None, "validRMSE": None, "validLL": None}
+
+
+@dataclass
+class Model:
+    """model struct of init.m:16-20,41-43,86."""
+    m: int
+    d: int
+    k: int = 1
+    method: str = "VD"
+    heteroscedastic: bool = True
+    g_dim: int = 0
+    muX: Optional[np.ndarray] = None
+    sdX: Optional[np.ndarray] = None
+    muY: Optional[np.ndarray] = None
+    sets: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if self.g_dim == 0:
+            self.g_dim = {"GL": 1, "VL": self.m, "GD": self.d, "VD": self.m * self.d, "GC": self.d ** 2,
+                          "VC": self.d ** 2 * self.m}[self.method]
+        if self.muX is None:
+            self.muX = np.zeros(self.d)
+        if self.sdX is None:
+            self.sdX = np.ones(self.d)
+        if self.muY is None:
+            self.muY = np.zeros(self.k)
+
+
+def _desc(model, device=0, stream=None, rank=0, world=1):
+    ds = _lib.gpz_desc()
+    ds.d, ds.m, ds.k = int(model.d), int(model.m), int(model.k)
+    ds.method = str(model.method).encode()
+    ds.heteroscedastic = 1 if model.heteroscedastic else 0
+    ds.device = int(device)
+    ds.stream = stream
+    ds.rank, ds.world = int(rank), int(world)
+    return ds
+
+
+def _f64(a, ndim=None):
+    if a is None:
+        return None
+    a = np.asarray(a, dtype=np.float64)
+    if ndim == 2 and a.ndim == 1:
+        a = a[:, None]
+    return np.asfortranarray(a)
+
+
+def _mask(a, n):
+    if a is None:
+        return None
+    a = np.asarray(a)
+    if a.size == 0:
+        return None
+    a = np.ascontiguousarray(a.astype(bool).ravel().astype(np.uint8))
+    if a.size != n:
+        raise ValueError("mask length must equal the number of rows of X")
+    return a
+
+
+class GPzContext:
+    """The closure ``f = @(theta) GPz(theta,model,X,Y,Psi,omega,training,validation)`` (train.m:40) with the data
+    resident on the GPU.  ``X`` must already be normalised and ``Y`` centred, as train.m:30-33 does before
+    building the closure."""
+
+    def __init__(self, model, X, Y, Psi=None, omega=None, training=None, validation=None, device=0, stream=None,
+                 rank=0, world=1, allreduce=None):
+        lib = _lib.load()
+        X = _f64(X, 2)
+        Y = _f64(Y, 2)
+        n_tot = X.shape[0]
+        if X.shape[1] != model.d or Y.shape != (n_tot, model.k):
+            raise ValueError("X must be n x d and Y n x k")
+        om = _f64(omega, 2)
+        if om is not None:
+            if om.shape[1] != 1 or om.shape[0] != n_tot:
+                raise ValueError("omega must be n x 1")
+        psi_kind = 0
+        psi = None
+        if Psi is not None:
+            psi = _f64(Psi)
+            psi_kind = 2 if psi.ndim == 3 else 1
+        self._tr = _mask(training, n_tot)
+        self._va = _mask(validation, n_tot)
+        self.model = model
+        self._desc = _desc(model, device, stream, rank, world)
+        h = C.c_void_p()
+        _lib.check(lib.gpz_ctx_create(
+            C.byref(self._desc), n_tot, _lib.dptr(X), _lib.dptr(Y), _lib.dptr(psi), psi_kind, _lib.dptr(om),
+            None if self._tr is None else self._tr.ctypes.data_as(_lib.c_uint8_p),
+            None if self._va is None else self._va.ctypes.data_as(_lib.c_uint8_p), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.p = int(lib.gpz_theta_len(h))
+        self.n_train = int(lib.gpz_n_train(h))
+        self.n_valid = int(lib.gpz_n_valid(h))
+        self.stats = {}
+        self.info = 0
+        self.n_global = self.n_train
+        self._cb = None
+        if allreduce is not None:
+            self._cb = _lib.ALLREDUCE_FN(allreduce)
+            _lib.check(lib.gpz_ctx_set_allreduce(h, self._cb, None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpz_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self, theta):
+        """[nlogML, grad] = GPz(theta, ...) plus the four global statistics (self.stats)."""
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        if theta.size != self.p:
+            raise ValueError(f"theta must have {self.p} elements")
+        f = C.c_double()
+        g = np.empty(self.p)
+        st = (C.c_double * 4)(float("nan"), float("nan"), float("nan"), float("nan"))
+        dg = (C.c_double * 2)()
+        _lib.check(self._lib.gpz_eval(self._h, _lib.dptr(theta), C.byref(f), _lib.dptr(g), st, dg))
+        self.stats = {"trainRMSE": st[0], "trainLL": st[1]}
+        if self.n_valid > 0 or (self._va is not None and self._desc.world > 1):
+            self.stats.update(validRMSE=st[2], validLL=st[3])
+        self.info = int(dg[0])
+        self.n_global = int(dg[1])
+        return f.value, g
+
+    def solve(self, theta):
+        """[~, ~, w, iSigma_w] = GPz(theta, ...)  (GPz.m:84-87); also returns the 1 x k partial nlogML."""
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        m, k = self.model.m, self.model.k
+        w = np.empty((m, k), order="F")
+        iS = np.empty((m, m, k), order="F")
+        part = np.empty(k)
+        _lib.check(self._lib.gpz_solve(self._h, _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(part)))
+        return w, iS, part
+
+    def phi(self):
+        """PHI (n_train x m) of the last eval/solve — the 5th output of GPz.m:1."""
+        out = np.empty((self.n_train, self.model.m), order="F")
+        _lib.check(self._lib.gpz_get_phi(self._h, _lib.dptr(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.gpz_ctx_enable_timing(self._h, 1 if on else 0))
+
+    def reset_timings(self):
+        _lib.check(self._lib.gpz_ctx_reset_timings(self._h))
+
+    def timings(self):
+        """{stage: (total_ms, calls)} measured with HIP events on the context's stream."""
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        calls = (C.c_int64 * cap)()
+        n = self._lib.gpz_ctx_timings(self._h, names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], int(calls[i])) for i in range(min(n, cap))}
+
+
+_cache = {}
+
+
+def _ctx_for(model, X, Y, Psi, omega, training, validation):
+    """One context per closure: keyed on the identity of the data arrays (the MEX shim keys on mxArray
+    pointers the same way)."""
+    def ident(a):
+        return None if a is None else (id(a), getattr(a, "shape", None))
+    key = (id(model), ident(X), ident(Y), ident(Psi), ident(omega), ident(training), ident(validation))
+    ctx = _cache.get(key)
+    if ctx is None:
+        if len(_cache) >= 4:
+            _, old = _cache.popitem()
+            old[0].close()
+        ctx = (GPzContext(model, X, Y, Psi, omega, training, validation), (X, Y, Psi, omega, training, validation))
+        _cache[key] = ctx
+    return ctx[0]
+
+
+def reset():
+    """Drop cached contexts (``clear global`` / new data)."""
+    for ctx, _ in _cache.values():
+        ctx.close()
+    _cache.clear()
+
+
+def GPz(theta, model, X, Y, Psi=None, omega=None, training=None, validation=None, nargout=2):
+    """[nlogML,grad,w,iSigma_w,PHI] = GPz(theta,model,X,Y,Psi,omega,training,validation)   (GPz.m:1).
+
+    ``nargout`` <= 2 returns (nlogML, grad) and refreshes ``globals_``; > 2 returns
+    (nlogML_partial, 0, w, iSigma_w[, PHI]) exactly like the early return at GPz.m:84-87."""
+    if Y is None:                      # GPz.m:34-40
+        return 0.0, 0.0, 0.0, 0.0
+    ctx = _ctx_for(model, X, Y, Psi, omega, training, validation)
+    if nargout <= 2:
+        f, g = ctx.eval(theta)
+        globals_.update(ctx.stats)
+        return f, g
+    w, iS, part = ctx.solve(theta)
+    out = (part, 0.0, w, iS)
+    if nargout >= 5:
+        out = out + (ctx.phi(),)
+    return out
+
+
+def getPHI(X, Psi, theta, model, selection=None, device=0):
+    """[PHI,Gamma,lnBeta_i] = getPHI(X,Psi,theta,model,selection)   (getPHI.m:1); Gamma is the expanded
+    parameter array of getPHI.m:26-40 (pure reshaping of theta, done on the host)."""
+    if Psi is not None:
+        raise _lib.GpzError(-5, "input-noise (Psi) paths are not built yet")
+    lib = _lib.load()
+    X = np.asarray(X, dtype=np.float64)
+    if selection is not None:
+        X = X[np.asarray(selection, dtype=bool)]
+    X = _f64(X, 2)
+    theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+    ns = X.shape[0]
+    PHI = np.empty((ns, model.m), order="F")
+    lnB = np.empty((ns, model.k), order="F")
+    ds = _desc(model, device)
+    _lib.check(lib.gpz_phi(C.byref(ds), _lib.dptr(theta), _lib.dptr(X), ns, _lib.dptr(PHI), _lib.dptr(lnB)))
+    return PHI, _expand_gamma(theta, model), lnB
+
+
+def _expand_gamma(theta, model):
+    m, d = model.m, model.d
+    G = theta[m * d:m * d + model.g_dim]
+    mt = model.method
+    if mt == "GL":
+        return np.full((m, d), G[0])
+    if mt == "VL":
+        return np.tile(G.reshape(m, 1), (1, d))
+    if mt == "GD":
+        return np.tile(G.reshape(1, d), (m, 1))
+    if mt == "VD":
+        return G.reshape((m, d), order="F")
+    if mt == "GC":
+        return np.repeat(G.reshape((d, d), order="F")[:, :, None], m, axis=2)
+    return G.reshape((d, d, m), order="F")
+
+
+def inv_logdet(X, device=0, return_info=False):
+    """[Xi,logdet] = inv_logdet(X)   (inv_logdet.m:1) for symmetric positive-definite X."""
+    lib = _lib.load()
+    A = _f64(X)
+    m = A.shape[0]
+    Xi = np.empty((m, m), order="F")
+    ld = C.c_double()
+    info = C.c_int32()
+    _lib.check(lib.gpz_inv_logdet(_lib.dptr(A), m, device, _lib.dptr(Xi), C.byref(ld), C.byref(info)))
+    if return_info:
+        return Xi, ld.value, int(info.value)
+    return Xi, ld.value
+
+
+def Dxy(X, Y, device=0):
+    """D = Dxy(X,Y)   (Dxy.m:1)."""
+    lib = _lib.load()
+    X = _f64(X, 2)
+    Y = _f64(Y, 2)
+    D = np.empty((X.shape[0], Y.shape[0]), order="F")
+    _lib.check(lib.gpz_dxy(_lib.dptr(X), X.shape[0], _lib.dptr(Y), Y.shape[0], X.shape[1], device, _lib.dptr(D)))
+    return D
+
+
+def nan_groups(X, device=0):
+    """Group id per row by NaN pattern, in first-occurrence order (the loop of getPHI.m:43-54)."""
+    lib = _lib.load()
+    X = _f64(X, 2)
+    n, d = X.shape
+    gid = np.empty(n, dtype=np.int32)
+    ng = C.c_int32()
+    _lib.check(lib.gpz_nan_groups(_lib.dptr(X), n, d, device, gid.ctypes.data_as(_lib.c_int32_p), C.byref(ng)))
+    return gid, int(ng.value)
+
+
+def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
+    """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1), branch without input
+    noise and without missing values (predict.m:60-73 -> predictFull)."""
+    if Psi is not None:
+        raise _lib.GpzError(-5, "predict with input noise is not built yet")
+    lib = _lib.load()
+    X = np.asarray(X, dtype=np.float64)
+    if selection is not None:
+        X = X[np.asarray(selection, dtype=bool)]                     # predict.m:25
+    st = model.sets[whichSet]                                        # predict.m:10-14
+    Xn = _f64((X - model.muX) / model.sdX, 2)                        # predict.m:35-36
+    theta = np.ascontiguousarray(np.asarray(st["theta"], dtype=np.float64).ravel())
+    w = _f64(st["w"], 2)
+    iS = np.asfortranarray(np.asarray(st["iSigma_w"], dtype=np.float64).reshape(model.m, model.m, model.k))
+    ns, k = Xn.shape[0], model.k
+    mu = np.empty((ns, k), order="F"); nu = np.empty((ns, k), order="F"); beta_i = np.empty((ns, k), order="F")
+    PHI = np.empty((ns, model.m), order="F")
+    ds = _desc(model, device)
+    _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
+                                    _lib.dptr(mu), _lib.dptr(nu), _lib.dptr(beta_i), _lib.dptr(PHI)))
+    gamma = np.zeros((ns, k))                                        # predictDiag.m:74
+    sigma = nu + beta_i + gamma                                      # predict.m:72
+    mu = mu + model.muY                                              # predict.m:73
+    return mu, sigma, nu, beta_i, gamma, PHI, w, iS

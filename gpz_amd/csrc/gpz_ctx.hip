@@ -1,0 +1,875 @@
+// Host side of libgpz_hip.so: the evaluation context and the C ABI of include/gpz_hip.h.
+//
+// A context owns the device-resident data of one closure f = @(theta) GPz(theta,model,X,Y,Psi,omega,
+// training,validation) (GPz/train.m:40): the training-selected rows of X (both layouts), Y, omega, the
+// validation rows, and every work buffer.  An evaluation ships theta down (p doubles) and
+// [f, grad, 4 statistics] up; everything else stays in HBM.
+//
+// Evaluation pipeline (one HIP stream, no host synchronisation until the result copy):
+//   unpack theta -> PHI build (+ ln beta, omega*beta) -> SYRK slabs -> reduce -> [all-reduce #1]
+//   -> per output: SIGMA, Cholesky, triangular inverse, inv(SIGMA), w, dwda -> T = PHI*[inv|w]
+//   -> row epilogue (nu, delta, dbeta, dPHI, column sums) -> dP/dGamma moments -> validation sums
+//   -> [all-reduce #2] -> finish (gradient packing, objective, statistics) -> copy out.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gpz_hip.h"
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(GPZ_ERR_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *gpz_last_error(void) { return g_err.c_str(); }
+extern "C" int gpz_version(void) { return GPZ_VERSION; }
+
+static int method_id_of(const char *m) {
+    static const char *names[6] = {"GL", "VL", "GD", "VD", "GC", "VC"};
+    for (int i = 0; i < 6; ++i)
+        if (m[0] == names[i][0] && m[1] == names[i][1]) return i;
+    return -1;
+}
+static int g_dim_of(int mid, int m, int d) {
+    switch (mid) {
+        case 0: return 1;
+        case 1: return m;
+        case 2: return d;
+        case 3: return m * d;
+        case 4: return d * d;
+        default: return d * d * m;
+    }
+}
+// dimensions the PHI / moment kernels are instantiated for; d is zero-padded up to the next one
+static int pad_dim(int d) {
+    static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
+    for (int s : sup)
+        if (d <= s) return s;
+    return -1;
+}
+static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
+
+// device allocation bookkeeping
+struct Arena {
+    std::vector<void *> ptrs;
+    size_t bytes = 0;
+    template <typename T>
+    int alloc(T **p, size_t count) {
+        *p = nullptr;
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+        if (e != hipSuccess) return fail(GPZ_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        ptrs.push_back(*p);
+        bytes += count * sizeof(T);
+        return 0;
+    }
+    void release() {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+struct RowSet {          // a device-resident row selection of the data
+    int n = 0, n_pad = 0;
+    double *Xc = nullptr;   // de x n_pad
+    double *Xr = nullptr;   // n_pad x de
+    double *Y = nullptr;    // k x n_pad
+    double *om = nullptr;   // n_pad (nullptr => ones)
+};
+
+struct StageTimer {
+    std::vector<const char *> names;
+    std::vector<double> ms;
+    std::vector<int64_t> calls;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    int find(const char *n) {
+        for (size_t i = 0; i < names.size(); ++i)
+            if (names[i] == n || strcmp(names[i], n) == 0) return (int)i;
+        names.push_back(n);
+        ms.push_back(0.0);
+        calls.push_back(0);
+        return (int)names.size() - 1;
+    }
+    hipEvent_t get() {
+        if (pool_used == pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool.push_back(e);
+        }
+        return pool[pool_used++];
+    }
+};
+
+struct gpz_ctx {
+    gpz_desc desc;
+    int mid = 0, kind = 0, d = 0, de = 0, m = 0, mp = 0, mq = 0, k = 1, hetero = 0, g_dim = 0;
+    long p = 0;
+    int device = 0;
+    hipStream_t st = nullptr;
+    Arena ar;
+    RowSet tr, va;
+    // parameters
+    double *theta_d = nullptr;
+    GpzParams pr{};
+    // big buffers
+    double *Phi = nullptr, *T = nullptr, *dL = nullptr;
+    double *lnbeta = nullptr, *wbeta = nullptr, *phiw = nullptr;
+    double *lnbeta_v = nullptr, *phiw_v = nullptr;
+    double *slab = nullptr;
+    size_t slab_count = 0;
+    int nsplit = 1, rows_per_split = 16;
+    int nsplit_l = 1, rows_per_split_l = 16;
+    // communication buffers
+    double *comm1 = nullptr;   // [k * mp*mp | GPZ_NS]
+    size_t comm1_count = 0;
+    double *comm2 = nullptr;   // [m*nm | k*2*mp | k*4 | GPZ_NS]
+    size_t comm2_count = 0;
+    int nm = 0;
+    // m x m work
+    double *A = nullptr, *Lm = nullptr, *Wm = nullptr, *Tmp = nullptr, *Sinv = nullptr, *Bext = nullptr;
+    double *w = nullptr, *dwda = nullptr, *dgi = nullptr, *logdet = nullptr;
+    int *info = nullptr;
+    // row epilogue / moments
+    double *colslab = nullptr, *scal_slab = nullptr;
+    int nwg_rows = 1;
+    double *mom_slab = nullptr;
+    int nchunk = 1, rows_per_chunk = 1;
+    double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
+    double *out_d = nullptr;
+    double *out_h = nullptr, *theta_h = nullptr;   // pinned
+    gpz_allreduce_fn ar_fn = nullptr;
+    void *ar_user = nullptr;
+    bool timing = false;
+    StageTimer tm;
+    bool phi_valid = false;
+};
+
+// ---- stage timing ------------------------------------------------------------------------------
+struct Stage {
+    gpz_ctx *c;
+    int idx = -1;
+    hipEvent_t e0{}, e1{};
+    Stage(gpz_ctx *c_, const char *name) : c(c_) {
+        if (!c->timing) return;
+        idx = c->tm.find(name);
+        e0 = c->tm.get();
+        e1 = c->tm.get();
+        (void)hipEventRecord(e0, c->st);
+    }
+    ~Stage() {
+        if (idx < 0) return;
+        (void)hipEventRecord(e1, c->st);
+        c->tm.pending.push_back({idx, {e0, e1}});
+    }
+};
+static void collect_timings(gpz_ctx *c) {
+    for (auto &pe : c->tm.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+            c->tm.ms[pe.first] += ms;
+            c->tm.calls[pe.first] += 1;
+        }
+    }
+    c->tm.pending.clear();
+    c->tm.pool_used = 0;
+}
+
+// ---- context creation ---------------------------------------------------------------------------
+static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X, const double *Y, const double *omega,
+                         const uint8_t *mask, bool need_xr) {
+    const int d = c->d, de = c->de, k = c->k;
+    std::vector<int64_t> idx;
+    idx.reserve((size_t)n_tot);
+    for (int64_t i = 0; i < n_tot; ++i)
+        if (!mask || mask[i]) idx.push_back(i);                            // X(selection,:)  getPHI.m:14
+    rs.n = (int)idx.size();
+    rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 512);
+    const size_t np = (size_t)rs.n_pad;
+    std::vector<double> h(np * (size_t)de, 0.0);
+    for (int c_ = 0; c_ < d; ++c_)
+        for (size_t r = 0; r < idx.size(); ++r) h[(size_t)c_ * np + r] = X[(size_t)c_ * n_tot + idx[r]];
+    if (int e = c->ar.alloc(&rs.Xc, np * de)) return e;
+    HIPCHK(hipMemcpy(rs.Xc, h.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
+    if (need_xr) {
+        std::fill(h.begin(), h.end(), 0.0);
+        for (size_t r = 0; r < idx.size(); ++r)
+            for (int c_ = 0; c_ < d; ++c_) h[r * de + c_] = X[(size_t)c_ * n_tot + idx[r]];
+        if (int e = c->ar.alloc(&rs.Xr, np * de)) return e;
+        HIPCHK(hipMemcpy(rs.Xr, h.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::vector<double> hy(np * (size_t)k, 0.0);
+    for (int o = 0; o < k; ++o)
+        for (size_t r = 0; r < idx.size(); ++r) hy[(size_t)o * np + r] = Y[(size_t)o * n_tot + idx[r]];
+    if (int e = c->ar.alloc(&rs.Y, np * k)) return e;
+    HIPCHK(hipMemcpy(rs.Y, hy.data(), np * k * sizeof(double), hipMemcpyHostToDevice));
+    if (omega) {
+        std::vector<double> ho(np, 0.0);
+        for (size_t r = 0; r < idx.size(); ++r) ho[r] = omega[idx[r]];
+        if (int e = c->ar.alloc(&rs.om, np)) return e;
+        HIPCHK(hipMemcpy(rs.om, ho.data(), np * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int has_nan(const double *X, int64_t count) {
+    for (int64_t i = 0; i < count; ++i)
+        if (X[i] != X[i]) return 1;
+    return 0;
+}
+
+static int setup_model(gpz_ctx *c, const gpz_desc *desc) {
+    c->desc = *desc;
+    c->mid = method_id_of(desc->method);
+    if (c->mid < 0) return fail(GPZ_ERR_ARG, "unknown method '%.2s'", desc->method);
+    if (desc->d < 1 || desc->m < 1 || desc->k < 1) return fail(GPZ_ERR_ARG, "d, m, k must be >= 1");
+    if (desc->k > 8) return fail(GPZ_ERR_UNSUPPORTED, "k > 8 outputs not supported");
+    c->kind = c->mid >= 4 ? GPZ_KIND_COV : GPZ_KIND_DIAG;
+    c->d = desc->d;
+    c->de = pad_dim(desc->d);
+    if (c->de < 0) return fail(GPZ_ERR_UNSUPPORTED, "d = %d > 20 not supported", desc->d);
+    c->m = desc->m;
+    c->k = desc->k;
+    c->hetero = desc->heteroscedastic ? 1 : 0;
+    c->g_dim = g_dim_of(c->mid, c->m, c->d);
+    c->p = (long)c->m * c->d + c->g_dim + (long)c->m * c->k + c->k + (c->hetero ? 2L * c->m * c->k : 0);
+    c->mp = rup(c->m + c->k, 16);
+    c->mq = rup(c->m, 32);
+    c->nm = (c->kind == GPZ_KIND_COV) ? c->de + c->de * (c->de + 1) / 2 : 2 * c->de;
+    c->device = desc->device;
+    c->st = (hipStream_t)desc->stream;
+    return 0;
+}
+
+static int alloc_params(gpz_ctx *c) {
+    const size_t m = c->m, de = c->de, k = c->k;
+    if (int e = c->ar.alloc(&c->theta_d, (size_t)c->p)) return e;
+    if (int e = c->ar.alloc(&c->pr.P, m * de)) return e;
+    if (int e = c->ar.alloc(&c->pr.G, c->kind == GPZ_KIND_COV ? m * de * de : m * de)) return e;
+    if (int e = c->ar.alloc(&c->pr.G2, m * de)) return e;
+    if (int e = c->ar.alloc(&c->pr.lnAlpha, m * k)) return e;
+    if (int e = c->ar.alloc(&c->pr.alpha, m * k)) return e;
+    if (int e = c->ar.alloc(&c->pr.b, k)) return e;
+    if (int e = c->ar.alloc(&c->pr.v, m * k)) return e;
+    if (int e = c->ar.alloc(&c->pr.lnTau, m * k)) return e;
+    if (int e = c->ar.alloc(&c->pr.tau, m * k)) return e;
+    return 0;
+}
+
+static int alloc_mm(gpz_ctx *c) {   // m x m stage buffers
+    const size_t mq2 = (size_t)c->mq * c->mq, m = c->m, k = c->k;
+    if (int e = c->ar.alloc(&c->A, mq2)) return e;
+    if (int e = c->ar.alloc(&c->Lm, mq2)) return e;
+    if (int e = c->ar.alloc(&c->Wm, mq2)) return e;
+    if (int e = c->ar.alloc(&c->Tmp, mq2)) return e;
+    if (int e = c->ar.alloc(&c->Sinv, mq2)) return e;
+    if (int e = c->ar.alloc(&c->Bext, (size_t)c->mp * c->mp)) return e;
+    if (int e = c->ar.alloc(&c->w, m * k)) return e;
+    if (int e = c->ar.alloc(&c->dwda, m * k)) return e;
+    if (int e = c->ar.alloc(&c->dgi, m * k)) return e;
+    if (int e = c->ar.alloc(&c->logdet, k)) return e;
+    if (int e = c->ar.alloc(&c->info, 2)) return e;
+    // LAUUM split: upper 128-tiles of an mq x mq product with mq rows
+    const int ntq = (c->mq + 127) / 128, npq = ntq * (ntq + 1) / 2;
+    int ns = (256 + npq - 1) / npq;
+    if (ns > c->mq / 32) ns = c->mq / 32;
+    if (ns < 1) ns = 1;
+    c->rows_per_split_l = rup((c->mq + ns - 1) / ns, 16);
+    c->nsplit_l = (c->mq + c->rows_per_split_l - 1) / c->rows_per_split_l;
+    return 0;
+}
+
+extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y, const double *Psi,
+                              int32_t psi_kind, const double *omega, const uint8_t *training,
+                              const uint8_t *validation, gpz_ctx **out) {
+    if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
+    *out = nullptr;
+    if (Psi || psi_kind != 0)
+        return fail(GPZ_ERR_UNSUPPORTED, "input-noise (Psi) paths (getPHI.m:78-89,100-106) are not built yet");
+    gpz_ctx *c = new gpz_ctx();
+    int rc = setup_model(c, desc);
+    if (rc) { delete c; return rc; }
+    if (has_nan(X, n_tot * (int64_t)c->d)) {
+        delete c;
+        return fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs are not built yet (getPHI.m:43-54 groups available via gpz_nan_groups)");
+    }
+    auto bail = [&](int code) {
+        c->ar.release();
+        if (c->out_h) (void)hipHostFree(c->out_h);
+        if (c->theta_h) (void)hipHostFree(c->theta_h);
+        delete c;
+        return code;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device));
+    if ((rc = upload_rowset(c, c->tr, n_tot, X, Y, omega, training, true))) return bail(rc);
+    if (c->tr.n < 1 && desc->world <= 1) return bail(fail(GPZ_ERR_ARG, "training mask selects no rows"));
+    bool any_valid = false;
+    if (validation)
+        for (int64_t i = 0; i < n_tot && !any_valid; ++i) any_valid = validation[i] != 0;
+    // with sharding a rank may hold no validation rows while others do: the caller signals "validation in use"
+    // by passing a non-NULL mask
+    if (validation && (any_valid || desc->world > 1)) {
+        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, false))) return bail(rc);
+        if (!omega) c->va.om = nullptr;
+    }
+    if ((rc = alloc_params(c))) return bail(rc);
+    if ((rc = alloc_mm(c))) return bail(rc);
+
+    const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
+    if ((rc = c->ar.alloc(&c->Phi, np * mp))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->T, np * mp))) return bail(rc);
+    if (k > 1 && (rc = c->ar.alloc(&c->dL, np * mp))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->lnbeta, np * k))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->wbeta, np * k))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->phiw, np * k))) return bail(rc);
+    if (c->va.n_pad) {
+        if ((rc = c->ar.alloc(&c->lnbeta_v, (size_t)c->va.n_pad * k))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->phiw_v, (size_t)c->va.n_pad * k))) return bail(rc);
+    }
+    // SYRK split over rows: aim at ~2048 workgroups
+    {
+        const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
+        int ns = (2048 + npairs - 1) / npairs;
+        const int max_ns = c->tr.n_pad / 64;
+        if (ns > max_ns) ns = max_ns;
+        if (ns < 1) ns = 1;
+        c->rows_per_split = rup((c->tr.n_pad + ns - 1) / ns, 16);
+        c->nsplit = (c->tr.n_pad + c->rows_per_split - 1) / c->rows_per_split;
+        size_t need = (size_t)c->nsplit * mp * mp;
+        size_t need_l = (size_t)c->nsplit_l * c->mq * c->mq;
+        c->slab_count = need > need_l ? need : need_l;
+        if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
+    }
+    c->comm1_count = k * mp * mp + GPZ_NS;
+    if ((rc = c->ar.alloc(&c->comm1, c->comm1_count))) return bail(rc);
+    c->comm2_count = m * c->nm + k * 2 * mp + k * 4 + GPZ_NS;
+    if ((rc = c->ar.alloc(&c->comm2, c->comm2_count))) return bail(rc);
+    c->nwg_rows = c->tr.n < 2048 ? (c->tr.n > 0 ? c->tr.n : 1) : 2048;
+    if ((rc = c->ar.alloc(&c->colslab, (size_t)c->nwg_rows * 2 * mp))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
+    {
+        const int ncg = (c->m + 255) / 256;
+        int nc = 2048 / ncg;
+        const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
+        if (nc > max_nc) nc = max_nc;
+        if (nc < 1) nc = 1;
+        c->rows_per_chunk = (c->tr.n + nc - 1) / nc;
+        if (c->rows_per_chunk < 1) c->rows_per_chunk = 1;
+        c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
+        if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * c->nm))) return bail(rc);
+    }
+    if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_SMALL_NWG * GPZ_NS))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->rstats, (size_t)GPZ_NS))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->spart, (size_t)8))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->dGfull, c->kind == GPZ_KIND_COV ? m * c->d * c->d : m * c->d))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->out_d, (size_t)c->p + 8))) return bail(rc);
+    if (hipHostMalloc((void **)&c->out_h, ((size_t)c->p + 8) * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&c->theta_h, (size_t)c->p * sizeof(double)) != hipSuccess)
+        return bail(fail(GPZ_ERR_ALLOC, "hipHostMalloc failed"));
+    *out = c;
+    return GPZ_OK;
+}
+
+extern "C" void gpz_ctx_destroy(gpz_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    c->ar.release();
+    if (c->out_h) (void)hipHostFree(c->out_h);
+    if (c->theta_h) (void)hipHostFree(c->theta_h);
+    for (hipEvent_t e : c->tm.pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int gpz_ctx_set_allreduce(gpz_ctx *c, gpz_allreduce_fn fn, void *user) {
+    if (!c) return fail(GPZ_ERR_ARG, "null context");
+    c->ar_fn = fn;
+    c->ar_user = user;
+    return GPZ_OK;
+}
+extern "C" int64_t gpz_theta_len(const gpz_ctx *c) { return c ? c->p : -1; }
+extern "C" int64_t gpz_n_train(const gpz_ctx *c) { return c ? c->tr.n : -1; }
+extern "C" int64_t gpz_n_valid(const gpz_ctx *c) { return c ? c->va.n : -1; }
+
+extern "C" int gpz_ctx_enable_timing(gpz_ctx *c, int enable) {
+    if (!c) return fail(GPZ_ERR_ARG, "null context");
+    c->timing = enable != 0;
+    return GPZ_OK;
+}
+extern "C" int gpz_ctx_reset_timings(gpz_ctx *c) {
+    if (!c) return fail(GPZ_ERR_ARG, "null context");
+    for (auto &v : c->tm.ms) v = 0.0;
+    for (auto &v : c->tm.calls) v = 0;
+    return GPZ_OK;
+}
+extern "C" int gpz_ctx_timings(gpz_ctx *c, const char **names, double *ms, int64_t *calls, int cap) {
+    if (!c) return fail(GPZ_ERR_ARG, "null context");
+    const int n = (int)c->tm.names.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = c->tm.names[i];
+        if (ms) ms[i] = c->tm.ms[i];
+        if (calls) calls[i] = c->tm.calls[i];
+    }
+    return n;
+}
+
+// ---- pipeline stages -----------------------------------------------------------------------------
+static int allreduce(gpz_ctx *c, double *buf, size_t count) {
+    if (c->desc.world <= 1) return 0;
+    if (!c->ar_fn) return fail(GPZ_ERR_COMM, "world=%d but no all-reduce hook set (gpz_ctx_set_allreduce)", c->desc.world);
+    if (c->ar_fn(c->ar_user, buf, count, (void *)c->st) != 0) return fail(GPZ_ERR_COMM, "all-reduce hook failed");
+    return 0;
+}
+
+// Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
+static int stage_a(gpz_ctx *c, const double *theta) {
+    memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
+    HIPCHK(hipMemcpyAsync(c->theta_d, c->theta_h, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+    {
+        Stage s(c, "unpack");
+        launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+    }
+    {
+        Stage s(c, "phi_build");
+        PhiArgs a{};
+        a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
+        a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = c->tr.Y;
+        a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
+        if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
+    }
+    double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
+    {
+        Stage s(c, "row_sums");
+        launch_sums1(c->st, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, sums1);
+    }
+    for (int o = 0; o < c->k; ++o) {
+        {
+            Stage s(c, "syrk");
+            launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
+                        c->rows_per_split, c->slab, false);
+        }
+        {
+            Stage s(c, "syrk_reduce");
+            launch_syrk_reduce(c->st, c->slab, c->nsplit, c->mp, c->comm1 + (size_t)o * c->mp * c->mp, c->mp);
+        }
+    }
+    {
+        Stage s(c, "allreduce1");
+        if (int e = allreduce(c, c->comm1, c->comm1_count)) return e;
+    }
+    c->phi_valid = true;
+    return 0;
+}
+
+// Stage B for one output: inv(SIGMA_o), logdet_o, w_o, dwda_o, diag; Bext = [inv | w].
+static void stage_b(gpz_ctx *c, int o) {
+    const int mq = c->mq, m = c->m;
+    const double *S = c->comm1 + (size_t)o * c->mp * c->mp;
+    {
+        Stage s(c, "chol");
+        launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq);
+        launch_zero(c->st, c->logdet + o, 1);
+        for (int k0 = 0; k0 < mq; k0 += 32) {
+            launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
+            launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, 32);
+        }
+    }
+    {
+        Stage s(c, "trtri");
+        launch_zero(c->st, c->Wm, (size_t)mq * mq);
+        launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
+        for (int gs = 32; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
+    }
+    {
+        Stage s(c, "lauum");
+        launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
+        launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
+    }
+    {
+        Stage s(c, "solve_vectors");
+        launch_post_inverse(c->st, c->Sinv, mq, S, c->mp, c->pr.alpha + (size_t)o * m, m, c->mp, o, c->Bext,
+                            c->w + (size_t)o * m, c->dwda + (size_t)o * m, c->dgi + (size_t)o * m, c->info, c->logdet);
+    }
+}
+
+extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, double stats[4], double diag[2]) {
+    if (!c || !theta || !f || !g) return fail(GPZ_ERR_ARG, "gpz_eval: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+    if (int e = stage_a(c, theta)) return e;
+    const size_t mp = c->mp, m = c->m, k = c->k;
+    double *mom = c->comm2;
+    double *cols = mom + m * c->nm;
+    double *scal = cols + k * 2 * mp;
+    double *vsums = scal + k * 4;
+    for (int o = 0; o < c->k; ++o) {
+        stage_b(c, o);
+        {
+            Stage s(c, "tgemm");
+            launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp);
+        }
+        {
+            Stage s(c, "row_epilogue");
+            RowArgs a{};
+            a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.n = c->tr.n; a.m = c->m; a.mp = c->mp; a.k = c->k; a.out = o;
+            a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.ldx = c->tr.n_pad;
+            a.w = c->w + (size_t)o * m; a.v = c->hetero ? c->pr.v + (size_t)o * m : nullptr;
+            a.dL = c->dL; a.colslab = c->colslab; a.scal = c->scal_slab; a.nwg = c->nwg_rows;
+            launch_row_epilogue(c->st, a);
+            launch_colslab_reduce(c->st, c->colslab, c->scal_slab, c->nwg_rows, c->mp, cols + (size_t)o * 2 * mp,
+                                  scal + (size_t)o * 4);
+        }
+    }
+    if (c->k > 1) {
+        Stage s(c, "mul_phi");
+        launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
+    }
+    {
+        Stage s(c, "moments");
+        MomentArgs a{};
+        a.dPhi = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.d = c->de;
+        a.kind = c->kind; a.P = c->pr.P; a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk;
+        a.slab = c->mom_slab; a.nm = c->nm;
+        if (launch_moments(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
+        launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * c->nm, mom);
+    }
+    const bool have_valid = c->va.n_pad > 0;
+    if (have_valid) {
+        Stage s(c, "validation");
+        PhiArgs a{};
+        a.Xc = c->va.Xc; a.ldx = c->va.n_pad; a.n = c->va.n; a.n_pad = c->va.n_pad;
+        a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.Y = nullptr;
+        a.Phi = nullptr; a.lnbeta = c->lnbeta_v; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw_v;
+        if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+    } else {
+        launch_zero(c->st, vsums, GPZ_NS);
+    }
+    {
+        Stage s(c, "allreduce2");
+        if (int e = allreduce(c, c->comm2, c->comm2_count)) return e;
+    }
+    {
+        Stage s(c, "finish");
+        FinishArgs a{};
+        a.method_id = c->mid; a.kind = c->kind; a.m = c->m; a.d = c->d; a.k = c->k; a.hetero = c->hetero;
+        a.g_dim = c->g_dim; a.pr = c->pr; a.mom = mom; a.nm = c->nm; a.cols = cols; a.scal = scal;
+        a.w = c->w; a.dwda = c->dwda; a.dgi = c->dgi; a.logdet = c->logdet;
+        a.sums1 = c->comm1 + k * mp * mp; a.vsums = have_valid ? vsums : nullptr; a.info = c->info;
+        a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de;
+        launch_finish(c->st, a);
+    }
+    HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 8) * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    if (c->timing) collect_timings(c);
+    *f = c->out_h[0];
+    memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
+    const double *st = c->out_h + 1 + c->p;
+    if (stats) {
+        stats[0] = st[0];
+        stats[1] = st[1];
+        if (have_valid) { stats[2] = st[2]; stats[3] = st[3]; }
+    }
+    if (diag) { diag[0] = st[4]; diag[1] = st[5]; }
+    return GPZ_OK;
+}
+
+extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSigma_w, double *nlogML_partial) {
+    if (!c || !theta || !w || !iSigma_w) return fail(GPZ_ERR_ARG, "gpz_solve: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+    if (int e = stage_a(c, theta)) return e;
+    const size_t m = c->m, mq = c->mq;
+    for (int o = 0; o < c->k; ++o) {
+        stage_b(c, o);
+        // inv(SIGMA) is symmetric: row-major == column-major
+        HIPCHK(hipMemcpy2DAsync(iSigma_w + (size_t)o * m * m, m * sizeof(double), c->Sinv, mq * sizeof(double),
+                                m * sizeof(double), m, hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(hipMemcpyAsync(w, c->w, m * c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    if (nlogML_partial) {
+        PhiArgs a{};
+        a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
+        a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = nullptr;
+        a.Phi = nullptr; a.lnbeta = c->lnbeta; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw;
+        if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
+        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
+        if (int e = allreduce(c, c->rstats, GPZ_NS)) return e;
+        launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
+                             c->k, c->spart);
+        HIPCHK(hipMemcpyAsync(nlogML_partial, c->spart, c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    }
+    int info_h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(info_h, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    if (c->timing) collect_timings(c);
+    if (info_h[0] != 0) {
+        for (size_t e = 0; e < m * c->k; ++e) w[e] = NAN;
+        for (size_t e = 0; e < m * m * c->k; ++e) iSigma_w[e] = NAN;
+        if (nlogML_partial)
+            for (int o = 0; o < c->k; ++o) nlogML_partial[o] = NAN;
+    }
+    return GPZ_OK;
+}
+
+extern "C" int gpz_get_phi(gpz_ctx *c, double *PHI) {
+    if (!c || !PHI) return fail(GPZ_ERR_ARG, "gpz_get_phi: null argument");
+    if (!c->phi_valid) return fail(GPZ_ERR_ARG, "gpz_get_phi: no evaluation has been run");
+    HIPCHK(hipSetDevice(c->device));
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, (size_t)c->tr.n * c->m * sizeof(double)));
+    launch_transpose_out(c->st, c->Phi, c->mp, c->tr.n, c->m, tmp);
+    hipError_t e = hipMemcpyAsync(PHI, tmp, (size_t)c->tr.n * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(GPZ_ERR_HIP, "gpz_get_phi copy: %s", hipGetErrorString(e));
+    return GPZ_OK;
+}
+
+// ---- stand-alone entry points --------------------------------------------------------------------
+// A throw-away context without training data: parameters + PHI on ns rows.
+static int make_eval_ctx(const gpz_desc *desc, const double *Xs, int64_t ns, gpz_ctx **out) {
+    gpz_ctx *c = new gpz_ctx();
+    int rc = setup_model(c, desc);
+    if (rc) { delete c; return rc; }
+    auto bail = [&](int code) { c->ar.release(); delete c; return code; };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device));
+    if (has_nan(Xs, ns * (int64_t)c->d)) return bail(fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs are not built yet"));
+    std::vector<double> y0((size_t)ns * c->k, 0.0);
+    if ((rc = upload_rowset(c, c->tr, ns, Xs, y0.data(), nullptr, nullptr, false))) return bail(rc);
+    if ((rc = alloc_params(c))) return bail(rc);
+    const size_t np = c->tr.n_pad;
+    if ((rc = c->ar.alloc(&c->Phi, np * c->mp))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->lnbeta, np * c->k))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->wbeta, np * c->k))) return bail(rc);
+    *out = c;
+    return 0;
+}
+static void free_eval_ctx(gpz_ctx *c) { c->ar.release(); delete c; }
+
+static int run_phi_only(gpz_ctx *c, const double *theta) {
+    HIPCHK(hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+    launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+    PhiArgs a{};
+    a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
+    a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
+    a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = nullptr; a.Y = nullptr;
+    a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
+    if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
+    return 0;
+}
+
+extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns, double *PHI,
+                       double *lnBeta_i) {
+    if (!desc || !theta || !Xs || ns < 1) return fail(GPZ_ERR_ARG, "gpz_phi: null argument");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, &c)) return e;
+    int rc = run_phi_only(c, theta);
+    double *tmp = nullptr;
+    if (!rc && PHI) {
+        rc = c->ar.alloc(&tmp, (size_t)ns * c->m);
+        if (!rc) {
+            launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+            if (hipMemcpyAsync(PHI, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+                rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
+        }
+    }
+    if (!rc && lnBeta_i) {
+        if (hipMemcpy2DAsync(lnBeta_i, (size_t)ns * sizeof(double), c->lnbeta, (size_t)c->tr.n_pad * sizeof(double),
+                             (size_t)ns * sizeof(double), c->k, hipMemcpyDeviceToHost, c->st) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
+    }
+    if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_phi: sync failed");
+    free_eval_ctx(c);
+    return rc;
+}
+
+extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                                const double *Xs, int64_t ns, double *mu, double *nu, double *beta_i, double *PHI) {
+    if (!desc || !theta || !w || !iSigma_w || !Xs || ns < 1 || !mu || !nu || !beta_i)
+        return fail(GPZ_ERR_ARG, "gpz_predict_full: null argument");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, &c)) return e;
+    const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
+    int rc = 0;
+    double *T = nullptr, *Bext = nullptr, *wd = nullptr, *Sd = nullptr, *nud = nullptr, *dgi = nullptr, *tmp = nullptr;
+    if (!rc) rc = c->ar.alloc(&T, np * mp);
+    if (!rc) rc = c->ar.alloc(&Bext, mp * mp);
+    if (!rc) rc = c->ar.alloc(&wd, m * k);
+    if (!rc) rc = c->ar.alloc(&Sd, m * m);
+    if (!rc) rc = c->ar.alloc(&nud, np);
+    if (!rc) rc = c->ar.alloc(&dgi, m);
+    if (!rc) rc = run_phi_only(c, theta);
+    std::vector<double> hbuf(np);
+    if (!rc && hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st) != hipSuccess)
+        rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+    for (int o = 0; o < (int)k && !rc; ++o) {
+        // iSigma_w(:,:,o) is m x m (symmetric up to rounding in the reference; used as given, B[k][j] = iS(k,j))
+        std::vector<double> rowmaj(m * m);
+        const double *src = iSigma_w + (size_t)o * m * m;
+        for (size_t a = 0; a < m; ++a)
+            for (size_t b = 0; b < m; ++b) rowmaj[a * m + b] = src[a + m * b];
+        if (hipMemcpy(Sd, rowmaj.data(), m * m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+            break;
+        }
+        launch_fill_bext(c->st, Sd, (int)m, wd + (size_t)o * m, (int)m, (int)mp, o, Bext, dgi);
+        launch_tgemm(c->st, c->Phi, (int)mp, Bext, (int)mp, T, (int)np, (int)mp);
+        launch_nu(c->st, c->Phi, T, (int)mp, (int)ns, (int)m, nud);                       // predictDiag.m:69-71
+        if (hipMemcpyAsync(nu + (size_t)o * ns, nud, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+        // mu(:,o) = PHI*w(:,o) = column m+o of T                                         // predictDiag.m:65
+        if (!rc && hipMemcpy2DAsync(mu + (size_t)o * ns, sizeof(double), T + m + o, mp * sizeof(double), sizeof(double),
+                                    (size_t)ns, hipMemcpyDeviceToHost, c->st) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+        if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "predict: sync failed");
+    }
+    if (!rc) {
+        // beta_i = exp(lnBeta_i)   (predictDiag.m:73): wbeta holds exp(-lnbeta) (omega = 1)
+        std::vector<double> lb((size_t)ns * k);
+        if (hipMemcpy2D(lb.data(), (size_t)ns * sizeof(double), c->wbeta, np * sizeof(double), (size_t)ns * sizeof(double), k,
+                        hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+        else
+            for (size_t e = 0; e < (size_t)ns * k; ++e) beta_i[e] = 1.0 / lb[e];
+    }
+    if (!rc && PHI) {
+        rc = c->ar.alloc(&tmp, (size_t)ns * m);
+        if (!rc) {
+            launch_transpose_out(c->st, c->Phi, (int)mp, ns, (int)m, tmp);
+            if (hipMemcpy(PHI, tmp, (size_t)ns * m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(GPZ_ERR_HIP, "predict: copy failed");
+        }
+    }
+    (void)hipStreamSynchronize(c->st);
+    free_eval_ctx(c);
+    return rc;
+}
+
+extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, double *Xi, double *logdet, int32_t *info) {
+    if (!Ain || m < 1 || !Xi || !logdet) return fail(GPZ_ERR_ARG, "gpz_inv_logdet: null argument");
+    gpz_ctx *c = new gpz_ctx();
+    c->device = device;
+    c->m = m; c->k = 1; c->mq = rup(m, 32); c->mp = rup(m + 1, 16);
+    auto bail = [&](int code) { c->ar.release(); delete c; return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", device));
+    int rc = alloc_mm(c);
+    if (rc) return bail(rc);
+    double *S = nullptr, *alpha0 = nullptr;
+    if ((rc = c->ar.alloc(&S, (size_t)m * m))) return bail(rc);
+    if ((rc = c->ar.alloc(&alpha0, (size_t)m))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->slab, (size_t)c->nsplit_l * c->mq * c->mq))) return bail(rc);
+    if (hipMemcpy(S, Ain, (size_t)m * m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(GPZ_ERR_HIP, "copy failed"));
+    (void)hipMemset(alpha0, 0, (size_t)m * sizeof(double));
+    (void)hipMemset(c->info, 0, 2 * sizeof(int));
+    const int mq = c->mq;
+    launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq);
+    launch_zero(c->st, c->logdet, 1);
+    for (int k0 = 0; k0 < mq; k0 += 32) {
+        launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
+        launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, 32);
+    }
+    launch_zero(c->st, c->Wm, (size_t)mq * mq);
+    launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
+    for (int gs = 32; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
+    launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
+    launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
+    int info_h[2] = {0, 0};
+    double ld = 0.0;
+    hipError_t e = hipMemcpy2D(Xi, (size_t)m * sizeof(double), c->Sinv, (size_t)mq * sizeof(double),
+                               (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&ld, c->logdet, sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(info_h, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(fail(GPZ_ERR_HIP, "gpz_inv_logdet: %s", hipGetErrorString(e)));
+    if (info_h[0] != 0) {
+        for (size_t q = 0; q < (size_t)m * m; ++q) Xi[q] = NAN;
+        ld = NAN;
+    }
+    *logdet = ld;
+    if (info) *info = info_h[0];
+    c->ar.release();
+    delete c;
+    return GPZ_OK;
+}
+
+extern "C" int gpz_dxy(const double *X, int64_t nx, const double *Y, int64_t ny, int32_t d, int32_t device, double *D) {
+    if (!X || !Y || !D || nx < 1 || ny < 1 || d < 1) return fail(GPZ_ERR_ARG, "gpz_dxy: bad argument");
+    HIPCHK(hipSetDevice(device));
+    Arena ar;
+    double *dx = nullptr, *dy = nullptr, *dd = nullptr;
+    int rc = ar.alloc(&dx, (size_t)nx * d);
+    if (!rc) rc = ar.alloc(&dy, (size_t)ny * d);
+    if (!rc) rc = ar.alloc(&dd, (size_t)nx * ny);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dx, X, (size_t)nx * d * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dy, Y, (size_t)ny * d * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_dxy(nullptr, dx, nx, dy, ny, d, dd);
+            e = hipMemcpy(D, dd, (size_t)nx * ny * sizeof(double), hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_dxy: %s", hipGetErrorString(e));
+    }
+    ar.release();
+    return rc;
+}
+
+extern "C" int gpz_nan_groups(const double *X, int64_t n, int32_t d, int32_t device, int32_t *group_id, int32_t *n_groups) {
+    if (!X || !group_id || !n_groups || n < 1 || d < 1) return fail(GPZ_ERR_ARG, "gpz_nan_groups: bad argument");
+    if (d > 64) return fail(GPZ_ERR_UNSUPPORTED, "gpz_nan_groups: d > 64");
+    HIPCHK(hipSetDevice(device));
+    Arena ar;
+    double *dx = nullptr;
+    unsigned long long *mask = nullptr, *uniq = nullptr;
+    int *ng = nullptr, *gid = nullptr;
+    int rc = ar.alloc(&dx, (size_t)n * d);
+    if (!rc) rc = ar.alloc(&mask, (size_t)n);
+    if (!rc) rc = ar.alloc(&uniq, (size_t)1024);
+    if (!rc) rc = ar.alloc(&ng, (size_t)1);
+    if (!rc) rc = ar.alloc(&gid, (size_t)n);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dx, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_nan_groups(nullptr, dx, n, d, mask, uniq, ng, gid, 1024);
+            e = hipMemcpy(group_id, gid, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        }
+        int g = 0;
+        if (e == hipSuccess) e = hipMemcpy(&g, ng, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_nan_groups: %s", hipGetErrorString(e));
+        else if (g > 1024) rc = fail(GPZ_ERR_UNSUPPORTED, "gpz_nan_groups: more than 1024 distinct NaN patterns");
+        else *n_groups = g;
+    }
+    ar.release();
+    return rc;
+}

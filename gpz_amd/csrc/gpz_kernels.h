@@ -1,0 +1,131 @@
+// Host-side launcher declarations shared by the translation units of libgpz_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- theta unpacking (getPHI.m:24-40,117,122; GPz.m:28,32,50,98-101) -------------------------
+// Device parameter block produced by k_unpack from the raw theta vector.
+struct GpzParams {
+    double *P;       // m x d row-major  P[j*d + c]
+    double *G;       // diag kinds: gamma[j*d + c];  cov kinds: Gamma_j row-major  G[j*d*d + a*d + b]
+    double *G2;      // diag kinds: gamma^2 [j*d + c]                       (unused for cov kinds)
+    double *lnAlpha; // m x k column-major (as in theta)
+    double *alpha;   // exp(lnAlpha)
+    double *b;       // k
+    double *v;       // m x k (zeros when homoscedastic)
+    double *lnTau;   // m x k
+    double *tau;     // exp(lnTau)
+};
+
+void launch_unpack(hipStream_t st, const double *theta, int method_id, int m, int d, int de, int k, int hetero,
+                   GpzParams pr);
+
+// ---- PHI build (getPHI.m:60-125) ---------------------------------------------------------------
+struct PhiArgs {
+    const double *Xc;    // d x ldx, column-major over rows: Xc[c*ldx + i]
+    long ldx;
+    int n;               // valid rows
+    int n_pad;           // rows written (rows >= n are zero-filled)
+    int m, mp, d, k;
+    int kind;            // GPZ_KIND_*
+    const double *P, *G; // see GpzParams (G = G2 for diag kinds)
+    const double *v;     // m x k or nullptr
+    const double *b;     // k
+    const double *omega; // n or nullptr (ones)
+    const double *Y;     // k x ldx (Y[o*ldx + i]) or nullptr: written into PHI columns m..m+k-1
+    double *Phi;         // n_pad x mp row-major, or nullptr (reduction-only mode)
+    double *lnbeta;      // k x ldx
+    double *wbeta;       // k x ldx  (omega .* exp(-lnbeta)), or nullptr
+    const double *w;     // m x k: when non-null, phiw[o*ldx + i] = sum_j PHI_ij w_jo
+    double *phiw;        // k x ldx
+};
+int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
+
+// ---- MFMA contractions (k_gemm.hip) ------------------------------------------------------------
+void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
+                 int nsplit, int rows_per_split, double *slab, bool tri);
+void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds);
+void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp);
+void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb);
+void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
+
+// ---- m x m factorisation pieces (k_chol.hip) -----------------------------------------------------
+// A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
+void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda);
+void launch_chol_panel(hipStream_t st, const double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
+void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq);
+void launch_zero(hipStream_t st, double *p, size_t count);
+// Bext (mp x mp) <- [inv | w column at m | 0]; iS (m x m col-major == row-major, symmetric) copy; w, dwda, diag.
+void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const double *S, int lds, const double *alpha,
+                         int m, int mp, int out, double *Bext, double *w, double *dwda, double *dgi, int *info,
+                         double *logdet);
+
+void launch_fill_bext(hipStream_t st, const double *Sinv, int ldsi, const double *w, int m, int mp, int out,
+                      double *Bext, double *dgi);
+
+// ---- row epilogue, moments, finish (k_rows.hip) --------------------------------------------------
+struct RowArgs {
+    const double *Phi; double *T; int ld;   // T is overwritten with dPHI (k==1) or accumulated into dL
+    int n, m, mp, k, out;                   // out = output index being processed
+    const double *y, *omega, *lnbeta, *wbeta; long ldx;
+    const double *w, *v;                    // column `out` of w (m), v (m) (v may be nullptr)
+    double *dL;                             // n_pad x ld accumulator when k>1 (else nullptr)
+    double *colslab;                        // [nwg][2][mp]: per-workgroup partial PHI'c, PHI'dbeta
+    double *scal;                           // [nwg][4]: sum c*delta, sum omega*delta^2, sum LL, sum dbeta
+    int nwg;
+};
+void launch_row_epilogue(hipStream_t st, const RowArgs &a);
+void launch_colslab_reduce(hipStream_t st, const double *colslab, const double *scal, int nwg, int mp, double *out_cols,
+                           double *out_scal);
+void launch_mul_phi(hipStream_t st, const double *dL, const double *Phi, double *T, size_t count);
+
+struct MomentArgs {
+    const double *dPhi; int ld;
+    const double *Xr;        // n_pad x d row-major
+    int n, n_pad, m, d, kind;
+    const double *P;
+    int nchunk, rows_per_chunk;
+    double *slab;            // [nchunk][m][nm]
+    int nm;                  // moments per basis: cov d + d(d+1)/2, diag 2d
+};
+int launch_moments(hipStream_t st, const MomentArgs &a);
+void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out);
+
+struct FinishArgs {
+    int method_id, kind, m, d, k, hetero, g_dim;
+    GpzParams pr;
+    const double *mom; int nm;            // reduced moments [m][nm]
+    const double *cols;                   // [k][2][mp]   PHI'(omega beta delta), PHI'dbeta
+    const double *scal;                   // [k][4]
+    const double *w, *dwda, *dgi;         // m x k each
+    const double *logdet;                 // k
+    const double *sums1;                  // [sum omega, sum_i omega_i lnbeta_io (8), n_train]       (GPZ_NS doubles)
+    const double *vsums;                  // [sum omega delta^2, sum LL, per-output (8), n_valid, 0]  or nullptr
+    const int *info;
+    double *out;                          // [f, grad(p), stats(4), info, n, logdet0, 0]   (p + 8 doubles)
+    double *dGfull;                       // scratch m*d or m*d*d
+    int p;
+    int nmp;                              // leading dimension of cols (= mp)
+    int de;                               // padded dimension of the parameter block / moments
+};
+void launch_finish(hipStream_t st, const FinishArgs &a);
+
+// Small row reductions; each writes GPZ_SMALL_NWG partial records of GPZ_NS doubles (sum them with launch_slab_sum).
+//   row_stats: [sum omega*delta^2, sum omega*(-0.5 beta delta^2 + 0.5 ln beta), sum omega*beta*delta^2 per output (8), rows, 0]
+//   sums1:     [sum omega, sum_i omega_i*lnbeta_io per output (8), 0, rows, 0]  -- rows at index 10 in both
+#define GPZ_NS 12
+#define GPZ_SMALL_NWG 128
+void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, const double *lnbeta,
+                      long ldx, int n, int k, double *partial);
+void launch_sums1(hipStream_t st, const double *omega, const double *lnbeta, long ldx, int n, int k, double *partial);
+// nlogML partial of the solve-only mode (GPz.m:81-82), one value per output.
+void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const double *logdet, const double *sums1,
+                          const double *rstats, int m, int k, double *out);
+// NaN-pattern grouping (getPHI.m:43-54): masks, first-occurrence unique list, ids.
+int launch_nan_groups(hipStream_t st, const double *X, long n, int d, unsigned long long *mask, unsigned long long *uniq,
+                      int *n_groups, int *group_id, int max_groups);
+
+// misc
+void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long ny, int d, double *D);
+void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst /* n x m col-major */);
+void launch_nu(hipStream_t st, const double *Phi, const double *T, int ld, int n, int m, double *nu);

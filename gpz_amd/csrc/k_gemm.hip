@@ -1,0 +1,362 @@
+// f64 MFMA contractions of the GPz objective/gradient path (gfx950, v_mfma_f64_16x16x4_f64).
+//
+//   k_syrk        S = PHI' * diag(w) * PHI   (GPz.m:63-65, upper 128x128 tiles, split over rows)
+//   k_syrk_reduce sum the row-split slabs, mirror to the lower triangle
+//   k_tgemm       T = PHI * B,  B = [inv(SIGMA) | w]   (GPz.m:69,72,77 in one product)
+//   k_gemm_small  generic strided C = beta*C + alpha*A*B for the m x m factorisation steps
+//
+// Tiling: a workgroup is 4 waves (2x2), each wave owns a 64x64 block of the 128x128 output tile as
+// 4x4 MFMA tiles (16 accumulators x 4 f64 = 128 accumulator registers).  Operands are staged
+// global -> registers -> LDS in 16-deep K slices, double buffered, one barrier per slice.
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// S = PHI' W PHI
+// ---------------------------------------------------------------------------------------------
+// PHI: n_rows x ld row-major.  Output slab[split] is mp x mp row-major; only tiles (ti <= tj) are written.
+// TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
+template <bool WEIGHTED, bool TRI>
+__global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi, int ld,
+                                                  const double *__restrict__ wgt, int n_rows, int mp,
+                                                  int ntile, int rows_per_split,
+                                                  double *__restrict__ slab) {
+    __shared__ double sA[2][16][LDS_LD128];
+    __shared__ double sB[2][16][LDS_LD128];
+    __shared__ double sW[2][16];
+
+    const int npairs = ntile * (ntile + 1) / 2;
+    const int pair = blockIdx.x % npairs;
+    const int split = blockIdx.x / npairs;
+    // decode pair -> (ti <= tj), row-major over the upper triangle
+    int ti = 0, rem = pair;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
+    const int tj = ti + rem;
+    const bool diag_tile = (ti == tj);
+    const int i0 = ti * 128, j0 = tj * 128;
+
+    int r_begin = split * rows_per_split;
+    int r_end = min(n_rows, r_begin + rows_per_split);
+    if (TRI) r_begin = max(r_begin, j0 & ~15);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    // staging map: 4 x double2 per thread per operand; a wave reads one full 1 KiB tile row per q
+    d2_t ra[4], rb[4];
+    double rw = 0.0;
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = q * 256 + tid;
+            int row = idx >> 6, c = (idx & 63) * 2;
+            const double *src = Phi + (size_t)(r0 + row) * ld;
+            ra[q] = (i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
+            if (!diag_tile)
+                rb[q] = (j0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + j0 + c) : (d2_t){0.0, 0.0};
+        }
+        if (WEIGHTED && tid < 16) rw = wgt[r0 + tid];
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = q * 256 + tid;
+            int row = idx >> 6, c = (idx & 63) * 2;
+            *reinterpret_cast<d2_t *>(&sA[buf][row][c]) = ra[q];
+            if (!diag_tile) *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
+        }
+        if (WEIGHTED && tid < 16) sW[buf][tid] = rw;
+    };
+
+    const int nstage = (r_end > r_begin) ? (r_end - r_begin) / 16 : 0;
+    if (nstage > 0) {
+        gload(r_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nstage) gload(r_begin + (s + 1) * 16);
+        const double(*tA)[LDS_LD128] = sA[cur];
+        const double(*tB)[LDS_LD128] = diag_tile ? sA[cur] : sB[cur];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int krow = kk * 4 + (lane >> 4);
+            double a[4], b[4];
+            const double wv = WEIGHTED ? sW[cur][krow] : 1.0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                double t = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
+                a[mi] = WEIGHTED ? t * wv : t;
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = tB[krow][wc * 64 + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+        }
+        if (s + 1 < nstage) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    double *out = slab + (size_t)split * mp * mp;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
+                if (row < mp && col < mp) out[(size_t)row * mp + col] = acc[mi][ni][r];
+            }
+        }
+}
+
+// S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
+__global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit, int mp, double *__restrict__ S, int lds) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= mp) return;
+    const int ti = i >> 7, tj = j >> 7;
+    const bool upper = (ti < tj) || (ti == tj && i <= j);
+    const size_t src = upper ? ((size_t)i * mp + j) : ((size_t)j * mp + i);
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * mp * mp + src];
+    S[(size_t)i * lds + j] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// T = PHI * B
+// ---------------------------------------------------------------------------------------------
+// PHI: n_pad x ld (row-major), B: mp x ldb (row-major), T: n_pad x ld.  n_pad % 128 == 0, mp % 16 == 0.
+__global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi, int ld,
+                                                   const double *__restrict__ B, int ldb,
+                                                   double *__restrict__ T, int mp, int nct) {
+    __shared__ double sA[2][128][18];
+    __shared__ double sB[2][16][LDS_LD128];
+
+    const int rt = blockIdx.x / nct, ct = blockIdx.x % nct;
+    const int i0 = rt * 128, j0 = ct * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    d2_t ra[4], rb[4];
+    const int arow = tid >> 1, ahalf = (tid & 1) * 8;
+    auto gload = [&](int k0) {
+        const double *src = Phi + (size_t)(i0 + arow) * ld + k0 + ahalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const d2_t *>(src + 2 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = q * 256 + tid;
+            int row = idx >> 6, c = (idx & 63) * 2;
+            rb[q] = (j0 + c < mp) ? *reinterpret_cast<const d2_t *>(B + (size_t)(k0 + row) * ldb + j0 + c)
+                                  : (d2_t){0.0, 0.0};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<d2_t *>(&sA[buf][arow][ahalf + 2 * q]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = q * 256 + tid;
+            int row = idx >> 6, c = (idx & 63) * 2;
+            *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
+        }
+    };
+
+    // number of valid 16-column MFMA tiles of this wave (last column tile may be partial)
+    int nvalid = (mp - (j0 + wc * 64) + 15) / 16;
+    nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
+
+    const int nstage = mp / 16;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nstage) gload((s + 1) * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kc = kk * 4 + (lane >> 4);
+            double a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = sB[cur][kc][wc * 64 + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                if (ni < nvalid) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+                }
+        }
+        if (s + 1 < nstage) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+            if (col < mp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
+                    T[(size_t)row * ld + col] = acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic strided tile GEMM for the m x m factorisation (sizes <= a few thousand; L2 resident)
+// ---------------------------------------------------------------------------------------------
+// C[M x N] (row stride sc, unit column stride) = beta*C + alpha * A[M x K] * B[K x N]
+// A element (i,k) at A[i*sa_r + k*sa_c];  B element (k,j) at B[k*sb_r + j*sb_c].
+// One workgroup computes the 64x64 tile (tm, tn).
+__device__ void gemm_tile_64(const double *__restrict__ A, long sa_r, long sa_c,
+                             const double *__restrict__ B, long sb_r, long sb_c,
+                             double *__restrict__ C, long sc, int M, int N, int K,
+                             double alpha, double beta, int tm, int tn) {
+    __shared__ double sA[16][LDS_LD64];
+    __shared__ double sB[16][LDS_LD64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i0 = tm * 64, j0 = tn * 64;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = (tid >> 6) + 4 * q, ii = tid & 63;
+            const int gi = i0 + ii, gj = j0 + ii, gk = k0 + kk;
+            sA[kk][ii] = (gi < M && gk < K) ? A[gi * sa_r + gk * sa_c] : 0.0;
+            sB[kk][ii] = (gj < N && gk < K) ? B[gk * sb_r + gj * sb_c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = kk * 4 + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = sA[kr][wr * 32 + mi * 16 + (lane & 15)];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = sB[kr][wc * 32 + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = j0 + wc * 32 + ni * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wr * 32 + mi * 16 + (lane >> 4) + 4 * r;
+                if (row < M && col < N) {
+                    double *p = C + row * sc + col;
+                    const double v = alpha * acc[mi][ni][r];
+                    *p = (beta == 0.0) ? v : (beta * (*p) + v);
+                }
+            }
+        }
+}
+
+// Trailing update of the right-looking Cholesky:  A22 -= L21 * L21'  (lower 64-tiles only).
+// A, Lm: mq x lda row-major; panel columns [k0, k0+nb) of the factor Lm; trailing rows/cols start at t0 = k0+nb.
+__global__ __launch_bounds__(256) void k_chol_trailing(double *__restrict__ A, const double *__restrict__ Lm, int lda,
+                                                        int mq, int k0, int nb) {
+    const int t0 = k0 + nb;
+    const int tm = blockIdx.y, tn = blockIdx.x;
+    if (tn > tm) return;
+    const int M = mq - t0;
+    const double *L21 = Lm + (size_t)t0 * lda + k0;
+    gemm_tile_64(L21, lda, 1, L21, 1, lda, A + (size_t)t0 * lda + t0, lda, M, M, nb, -1.0, 1.0, tm, tn);
+}
+
+// One level of the recursive triangular inverse W = inv(L) (both lower triangular, mq x ld):
+// for pair p with left block [a, a+gs) and right block [a+gs, a+2gs):
+//   phase 0:  Tmp(right,left) = L(right,left) * W(left,left)
+//   phase 1:  W(right,left)   = - W(right,right) * Tmp(right,left)
+__global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ L, double *__restrict__ W,
+                                                      double *__restrict__ Tmp, int ld, int mq, int gs, int phase) {
+    const int p = blockIdx.z;
+    const int a = p * 2 * gs;
+    const int rb = a + gs;
+    if (rb >= mq) return;
+    const int Mr = min(gs, mq - rb);
+    const int tm = blockIdx.y, tn = blockIdx.x;
+    if (tm * 64 >= Mr) return;
+    if (phase == 0) {
+        gemm_tile_64(L + (size_t)rb * ld + a, ld, 1, W + (size_t)a * ld + a, ld, 1,
+                     Tmp + (size_t)rb * ld + a, ld, Mr, gs, gs, 1.0, 0.0, tm, tn);
+    } else {
+        gemm_tile_64(W + (size_t)rb * ld + rb, ld, 1, Tmp + (size_t)rb * ld + a, ld, 1,
+                     W + (size_t)rb * ld + a, ld, Mr, gs, Mr, -1.0, 0.0, tm, tn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
+                 int nsplit, int rows_per_split, double *slab, bool tri) {
+    const int ntile = (mp + 127) / 128;
+    const int npairs = ntile * (ntile + 1) / 2;
+    dim3 grid(npairs * nsplit), block(256);
+    if (tri)
+        hipLaunchKernelGGL((k_syrk<false, true>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+    else if (wgt)
+        hipLaunchKernelGGL((k_syrk<true, false>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+    else
+        hipLaunchKernelGGL((k_syrk<false, false>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+}
+
+void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds) {
+    dim3 block(256), grid((mp + 255) / 256, mp);
+    hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, mp, S, lds);
+}
+
+void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp) {
+    const int nct = (mp + 127) / 128;
+    dim3 grid((n_pad / 128) * nct), block(256);
+    hipLaunchKernelGGL(k_tgemm, grid, block, 0, st, Phi, ld, B, ldb, T, mp, nct);
+}
+
+void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb) {
+    const int M = mq - k0 - nb;
+    if (M <= 0) return;
+    const int nt = (M + 63) / 64;
+    hipLaunchKernelGGL(k_chol_trailing, dim3(nt, nt), dim3(256), 0, st, A, Lm, lda, mq, k0, nb);
+}
+
+void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs) {
+    const int npair = (mq + 2 * gs - 1) / (2 * gs);
+    const int nt = (gs + 63) / 64;
+    hipLaunchKernelGGL(k_trtri_level, dim3(nt, nt, npair), dim3(256), 0, st, L, W, Tmp, ld, mq, gs, 0);
+    hipLaunchKernelGGL(k_trtri_level, dim3(nt, nt, npair), dim3(256), 0, st, L, W, Tmp, ld, mq, gs, 1);
+}

@@ -1,0 +1,665 @@
+// Row-local gradient epilogue, dP/dGamma moment accumulation, final packing (GPz.m:77-237).
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// Row epilogue: one workgroup per row (grid-stride), lanes along basis functions.
+//   nu_i    = sum_j PHI_ij T_ij                                   GPz.m:69
+//   delta_i = (PHI w)_i - y_i        ((PHI w)_i = T_i,m+out)      GPz.m:77
+//   dbeta_i = 0.5*(-beta)*(1/beta - (delta^2+nu))*omega           GPz.m:93
+//   dlnPHI  = -omega beta T - (omega beta delta) w' + dbeta v'    GPz.m:72,90,106
+//   dPHI    = dlnPHI .* PHI                                       GPz.m:113
+// plus the column sums PHI'(omega beta delta), PHI'dbeta (GPz.m:89,104) kept in registers and the
+// scalar sums of GPz.m:81,94,236,237.
+// ---------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(256) void k_row_epilogue(RowArgs a) {
+    __shared__ double sh4[4];
+    __shared__ double sh_phiw;
+    const int tid = threadIdx.x;
+    double wq[NJ], vq[NJ], r1[NJ], r2[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = tid + 256 * q;
+        wq[q] = (j < a.m) ? a.w[j] : 0.0;
+        vq[q] = (j < a.m && a.v) ? a.v[j] : 0.0;
+        r1[q] = 0.0;
+        r2[q] = 0.0;
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *yo = a.y + (size_t)a.out * a.ldx;
+    const double *lbo = a.lnbeta + (size_t)a.out * a.ldx;
+    const double *wbo = a.wbeta + (size_t)a.out * a.ldx;
+
+    for (int i = blockIdx.x; i < a.n; i += gridDim.x) {
+        const double *prow = a.Phi + (size_t)i * a.ld;
+        double *trow = a.T + (size_t)i * a.ld;
+        double ph[NJ], tt[NJ];
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int j = tid + 256 * q;
+            ph[q] = (j < a.mp) ? prow[j] : 0.0;
+            tt[q] = (j < a.mp) ? trow[j] : 0.0;
+            if (j < a.m) part = fma(ph[q], tt[q], part);
+            if (j == a.m + a.out) sh_phiw = tt[q];
+        }
+        const double nu = block_sum_256(part, sh4);        // barriers inside also publish sh_phiw
+        const double delta = sh_phiw - yo[i];
+        const double lb = lbo[i];
+        const double beta = exp(-lb);                                      // GPz.m:43
+        const double om = a.omega ? a.omega[i] : 1.0;
+        const double ob = wbo[i];                                          // omega*beta, GPz.m:48
+        const double dbeta = 0.5 * (-beta) * (1.0 / beta - (delta * delta + nu)) * om;   // GPz.m:93
+        const double c = ob * delta;                                       // GPz.m:79
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int j = tid + 256 * q;
+            if (j < a.mp) {
+                double dl = 0.0;
+                if (j < a.m) {
+                    dl = -ob * tt[q] - c * wq[q] + dbeta * vq[q];
+                    r1[q] = fma(ph[q], c, r1[q]);
+                    r2[q] = fma(ph[q], dbeta, r2[q]);
+                }
+                if (a.dL) {
+                    double *dp = a.dL + (size_t)i * a.ld + j;
+                    *dp = (a.out == 0) ? dl : (*dp + dl);
+                } else {
+                    trow[j] = dl * ph[q];
+                }
+            }
+        }
+        s0 = fma(c, delta, s0);
+        s1 = fma(om, delta * delta, s1);
+        s2 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));            // GPz.m:237  log(beta) = -lnBeta_i
+        s3 += dbeta;
+        __syncthreads();
+    }
+    double *cs = a.colslab + (size_t)blockIdx.x * 2 * a.mp;
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = tid + 256 * q;
+        if (j < a.mp) {
+            cs[j] = r1[q];
+            cs[a.mp + j] = r2[q];
+        }
+    }
+    if (tid == 0) {
+        double *sc = a.scal + (size_t)blockIdx.x * 4;
+        sc[0] = s0; sc[1] = s1; sc[2] = s2; sc[3] = s3;
+    }
+}
+
+void launch_row_epilogue(hipStream_t st, const RowArgs &a) {
+    const int nj = (a.mp + 255) / 256;
+    dim3 g(a.nwg), b(256);
+    if (nj <= 1) hipLaunchKernelGGL(k_row_epilogue<1>, g, b, 0, st, a);
+    else if (nj <= 2) hipLaunchKernelGGL(k_row_epilogue<2>, g, b, 0, st, a);
+    else if (nj <= 4) hipLaunchKernelGGL(k_row_epilogue<4>, g, b, 0, st, a);
+    else if (nj <= 8) hipLaunchKernelGGL(k_row_epilogue<8>, g, b, 0, st, a);
+    else hipLaunchKernelGGL(k_row_epilogue<16>, g, b, 0, st, a);
+}
+
+// out[e] = sum_s slab[s*count + e]   (fixed order: deterministic)
+__global__ void k_slab_sum(const double *__restrict__ slab, int nslab, size_t count, double *__restrict__ out) {
+    const size_t gs = (size_t)blockDim.x * gridDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gs) {
+        double s = 0.0;
+        for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * count + e];
+        out[e] = s;
+    }
+}
+
+void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out) {
+    size_t nb = (count + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb == 0) return;
+    hipLaunchKernelGGL(k_slab_sum, dim3((unsigned)nb), dim3(256), 0, st, slab, nslab, count, out);
+}
+
+void launch_colslab_reduce(hipStream_t st, const double *colslab, const double *scal, int nwg, int mp, double *out_cols,
+                           double *out_scal) {
+    launch_slab_sum(st, colslab, nwg, (size_t)2 * mp, out_cols);
+    launch_slab_sum(st, scal, nwg, 4, out_scal);
+}
+
+__global__ void k_mul_phi(const double *__restrict__ dL, const double *__restrict__ Phi, double *__restrict__ T,
+                          size_t count) {
+    const size_t gs = (size_t)blockDim.x * gridDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gs) T[e] = dL[e] * Phi[e];
+}
+
+void launch_mul_phi(hipStream_t st, const double *dL, const double *Phi, double *T, size_t count) {
+    hipLaunchKernelGGL(k_mul_phi, dim3(4096), dim3(256), 0, st, dL, Phi, T, count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dP / dGamma moments: lanes along basis functions, rows walked sequentially with x_i wave-uniform.
+//   cov kinds  (GPz.m:152-154):  M1_j[a] = sum_i dPHI_ij Delta_a ;  S_j[a][b] = sum_i dPHI_ij Delta_a Delta_b (a<=b)
+//   diag kinds (GPz.m:192-194):  A1_j[c] = sum_i dPHI_ij Delta_c ;  A2_j[c]   = sum_i dPHI_ij Delta_c^2
+// Rows [A0,A1) of S are handled per launch so the accumulators stay in registers for large d.
+// ---------------------------------------------------------------------------------------------
+template <int D, int A0, int A1>
+__global__ __launch_bounds__(256) void k_moments_cov(const double *__restrict__ dPhi, int ld,
+                                                      const double *__restrict__ Xr, int n, int m,
+                                                      const double *__restrict__ P, int rows_per_chunk,
+                                                      double *__restrict__ slab, int nm) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int chunk = blockIdx.x;
+    const bool act = j < m;
+    double p[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) p[c] = act ? P[(size_t)j * D + c] : 0.0;
+    constexpr int NS = (A1 - A0) * D - (A1 * (A1 - 1) / 2 - A0 * (A0 - 1) / 2);   // sum_{a=A0}^{A1-1} (D-a)
+    double M1[D], S[NS];
+#pragma unroll
+    for (int c = 0; c < D; ++c) M1[c] = 0.0;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) S[e] = 0.0;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(n, r0 + rows_per_chunk);
+    for (int i = r0; i < r1; ++i) {
+        const double dp = act ? dPhi[(size_t)i * ld + j] : 0.0;
+        const double *xi = Xr + (size_t)i * D;
+        double dl[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) dl[c] = xi[c] - p[c];
+        if (A0 == 0) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) M1[c] = fma(dp, dl[c], M1[c]);
+        }
+        int e = 0;
+#pragma unroll
+        for (int aa = A0; aa < A1; ++aa) {
+            const double t = dp * dl[aa];
+#pragma unroll
+            for (int bb = aa; bb < D; ++bb) { S[e] = fma(t, dl[bb], S[e]); ++e; }
+        }
+    }
+    if (act) {
+        double *o = slab + ((size_t)chunk * m + j) * nm;
+        if (A0 == 0) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] = M1[c];
+        }
+        // S stored upper row-major after M1: offset of row aa is D + sum_{q<aa}(D-q)
+        int e = 0;
+#pragma unroll
+        for (int aa = A0; aa < A1; ++aa) {
+            const int roff = D + aa * D - aa * (aa - 1) / 2;
+#pragma unroll
+            for (int bb = aa; bb < D; ++bb) { o[roff + (bb - aa)] = S[e]; ++e; }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__ dPhi, int ld,
+                                                       const double *__restrict__ Xr, int n, int m,
+                                                       const double *__restrict__ P, int rows_per_chunk,
+                                                       double *__restrict__ slab, int nm) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int chunk = blockIdx.x;
+    const bool act = j < m;
+    double p[D], A1v[D], A2v[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { p[c] = act ? P[(size_t)j * D + c] : 0.0; A1v[c] = 0.0; A2v[c] = 0.0; }
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(n, r0 + rows_per_chunk);
+    for (int i = r0; i < r1; ++i) {
+        const double dp = act ? dPhi[(size_t)i * ld + j] : 0.0;
+        const double *xi = Xr + (size_t)i * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double dl = xi[c] - p[c];
+            const double t = dp * dl;
+            A1v[c] += t;
+            A2v[c] = fma(t, dl, A2v[c]);
+        }
+    }
+    if (act) {
+        double *o = slab + ((size_t)chunk * m + j) * nm;
+#pragma unroll
+        for (int c = 0; c < D; ++c) { o[c] = A1v[c]; o[D + c] = A2v[c]; }
+    }
+}
+
+#define MOM_COV(D, A0, A1) \
+    hipLaunchKernelGGL((k_moments_cov<D, A0, A1>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm)
+#define MOM_DIAG(D) \
+    hipLaunchKernelGGL((k_moments_diag<D>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm)
+
+int launch_moments(hipStream_t st, const MomentArgs &a) {
+    dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
+    if (a.kind == GPZ_KIND_COV) {
+        switch (a.d) {
+            case 1: MOM_COV(1, 0, 1); break;
+            case 2: MOM_COV(2, 0, 2); break;
+            case 3: MOM_COV(3, 0, 3); break;
+            case 4: MOM_COV(4, 0, 4); break;
+            case 5: MOM_COV(5, 0, 5); break;
+            case 6: MOM_COV(6, 0, 6); break;
+            case 8: MOM_COV(8, 0, 8); break;
+            case 10: MOM_COV(10, 0, 10); break;
+            case 12: MOM_COV(12, 0, 5); MOM_COV(12, 5, 12); break;
+            case 16: MOM_COV(16, 0, 4); MOM_COV(16, 4, 9); MOM_COV(16, 9, 16); break;
+            case 20: MOM_COV(20, 0, 3); MOM_COV(20, 3, 7); MOM_COV(20, 7, 12); MOM_COV(20, 12, 20); break;
+            default: return -1;
+        }
+    } else {
+        switch (a.d) {
+            case 1: MOM_DIAG(1); break;
+            case 2: MOM_DIAG(2); break;
+            case 3: MOM_DIAG(3); break;
+            case 4: MOM_DIAG(4); break;
+            case 5: MOM_DIAG(5); break;
+            case 6: MOM_DIAG(6); break;
+            case 8: MOM_DIAG(8); break;
+            case 10: MOM_DIAG(10); break;
+            case 12: MOM_DIAG(12); break;
+            case 16: MOM_DIAG(16); break;
+            case 20: MOM_DIAG(20); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finish: chain the moments to dP/dGamma (GPz.m:146-159,189-194), method reduction (:215-225),
+// the m-sized gradient blocks (:73,89,94,104,105), the objective (:81-82,103,110,233) and the
+// statistics (:236-237,258-259).  p_e = padded dimension of the parameter block.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_finish_a(FinishArgs a, int de) {
+    const int gs = blockDim.x * gridDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = a.m, d = a.d, k = a.k;
+    const double nk = a.sums1[10] * (double)k;
+    double *grad = a.out + 1;
+    const int md = m * d;
+    if (a.kind == GPZ_KIND_COV) {
+        // dP(j,:) = M1_j * (Gamma_j' Gamma_j)      (GPz.m:146,151-152)
+        for (int e = t0; e < m * d; e += gs) {
+            const int j = e / d, c = e % d;
+            const double *Gj = a.pr.G + (size_t)j * de * de;
+            const double *M1 = a.mom + (size_t)j * a.nm;
+            double s = 0.0;
+            for (int aa = 0; aa < d; ++aa) {
+                double is = 0.0;
+                for (int q = 0; q < d; ++q) is = fma(Gj[q * de + aa], Gj[q * de + c], is);
+                s = fma(M1[aa], is, s);
+            }
+            grad[j + m * c] = -s / nk;
+        }
+        // dGamma_j = 2*Gamma_j*(-0.5*S_j) = -Gamma_j S_j     (GPz.m:154,157-158)
+        for (int e = t0; e < m * d * d; e += gs) {
+            const int j = e / (d * d), aa = (e / d) % d, bb = e % d;
+            const double *Gj = a.pr.G + (size_t)j * de * de;
+            const double *Sj = a.mom + (size_t)j * a.nm + de;
+            double s = 0.0;
+            for (int q = 0; q < d; ++q) {
+                const int lo = q < bb ? q : bb, hi = q < bb ? bb : q;
+                const double sv = Sj[lo * de - lo * (lo - 1) / 2 + (hi - lo)];
+                s = fma(Gj[aa * de + q], sv, s);
+            }
+            const double val = -s;
+            if (a.method_id == 5) grad[md + aa + d * bb + d * d * j] = -val / nk;   // VC
+            else a.dGfull[e] = val;                                                   // GC: summed in k_finish_b
+        }
+    } else {
+        for (int e = t0; e < m * d; e += gs) {
+            const int j = e / d, c = e % d;
+            const double *mo = a.mom + (size_t)j * a.nm;
+            const double g = a.pr.G[(size_t)j * de + c];
+            grad[j + m * c] = -(mo[c] * (g * g)) / nk;                     // GPz.m:192  ./Sigma, Sigma = gamma^-2
+            const double dg = -g * mo[de + c];                             // GPz.m:194
+            if (a.method_id == 3) grad[md + j + m * c] = -dg / nk;         // VD
+            else a.dGfull[e] = dg;
+        }
+    }
+    const int off = md + a.g_dim;
+    for (int e = t0; e < m * k; e += gs) {
+        const int j = e % m, o = e / m;
+        const double al = a.pr.alpha[e], w = a.w[e], dw = a.dwda[e];
+        const double r1 = a.cols[(size_t)o * 2 * a.nmp + j];
+        const double r2 = a.cols[(size_t)o * 2 * a.nmp + a.nmp + j];
+        // GPz.m:73,89
+        const double dla = -0.5 * a.dgi[e] * al - r1 * dw - al * w * dw - 0.5 * al * w * w + 0.5;
+        grad[off + e] = -dla / nk;
+        if (a.hetero) {
+            const double v = a.pr.v[e], tau = a.pr.tau[e];
+            grad[off + m * k + k + e] = -(r2 - v * tau) / nk;              // GPz.m:104
+            grad[off + m * k + k + m * k + e] = -(-0.5 * tau * v * v + 0.5) / nk;   // GPz.m:105
+        }
+    }
+    for (int o = t0; o < k; o += gs) grad[off + m * k + o] = -a.scal[o * 4 + 3] / nk;   // db, GPz.m:94
+}
+
+__global__ __launch_bounds__(256) void k_finish_b(FinishArgs a, int de) {
+    __shared__ double sh4[4];
+    const int tid = threadIdx.x;
+    const int m = a.m, d = a.d, k = a.k;
+    const double n = a.sums1[10];
+    const double nk = n * (double)k;
+    double *grad = a.out + 1;
+    const int md = m * d;
+    // method reductions of dGamma (GPz.m:215-225)
+    if (a.method_id == 0) {
+        double s = 0.0;
+        for (int e = tid; e < m * d; e += 256) s += a.dGfull[e];
+        s = block_sum_256(s, sh4);
+        if (tid == 0) grad[md] = -s / nk;
+    } else if (a.method_id == 1) {
+        for (int j = tid; j < m; j += 256) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) s += a.dGfull[j * d + c];
+            grad[md + j] = -s / nk;
+        }
+    } else if (a.method_id == 2) {
+        for (int c = tid; c < d; c += 256) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += a.dGfull[j * d + c];
+            grad[md + c] = -s / nk;
+        }
+    } else if (a.method_id == 4) {
+        for (int e = tid; e < d * d; e += 256) {
+            const int aa = e / d, bb = e % d;
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += a.dGfull[(size_t)j * d * d + e];
+            grad[md + aa + d * bb] = -s / nk;
+        }
+    }
+    // objective (GPz.m:81-82,103,110,233)
+    double L = 0.0;
+    for (int o = 0; o < k; ++o) {
+        double part = 0.0;
+        for (int j = tid; j < m; j += 256) {
+            const int e = j + m * o;
+            const double w = a.w[e];
+            part += -0.5 * a.pr.alpha[e] * w * w + 0.5 * a.pr.lnAlpha[e];
+            if (a.hetero) {
+                const double v = a.pr.v[e];
+                part += -0.5 * v * v * a.pr.tau[e] + 0.5 * a.pr.lnTau[e];
+            }
+        }
+        part = block_sum_256(part, sh4);
+        double Lo = part - 0.5 * a.scal[o * 4 + 0] - 0.5 * a.logdet[o] + 0.5 * (-a.sums1[1 + o]);
+        if (a.hetero) Lo -= 0.5 * (double)m * (double)k * GPZ_LOG2PI;
+        L += Lo;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        L -= 0.5 * GPZ_LOG2PI * a.sums1[0];
+        const bool bad = (*a.info != 0);
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+        double s1 = 0.0, s2 = 0.0;
+        for (int o = 0; o < k; ++o) { s1 += a.scal[o * 4 + 1]; s2 += a.scal[o * 4 + 2]; }
+        a.out[0] = bad ? nanv : -L / nk;
+        double *st = a.out + 1 + a.p;
+        st[0] = sqrt(s1 / nk);                                             // GPz.m:236
+        st[1] = s2 / nk - 0.5 * GPZ_LOG2PI;                                // GPz.m:237
+        if (a.vsums) {
+            const double nvk = a.vsums[10] * (double)k;
+            st[2] = sqrt(a.vsums[0] / nvk);                                // GPz.m:258
+            st[3] = a.vsums[1] / nvk - 0.5 * GPZ_LOG2PI;                   // GPz.m:259
+        }
+        st[4] = (double)(*a.info);
+        st[5] = n;
+        st[6] = a.logdet[0];
+    }
+    if (*a.info != 0) {
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+        __syncthreads();
+        for (int e = tid; e < a.p; e += 256) grad[e] = nanv;
+    }
+}
+
+void launch_finish(hipStream_t st, const FinishArgs &a) {
+    hipLaunchKernelGGL(k_finish_a, dim3(256), dim3(256), 0, st, a, a.de);
+    hipLaunchKernelGGL(k_finish_b, dim3(1), dim3(256), 0, st, a, a.de);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small row reductions
+// ---------------------------------------------------------------------------------------------
+// partial[wg][0] = sum omega*delta^2 (all outputs), [1] = sum omega*(-0.5 beta delta^2 + 0.5 ln beta),
+// [2+o] = sum omega*beta*delta^2 for output o, with delta = phiw - y.   (GPz.m:81,236-237,258-259)
+__global__ __launch_bounds__(256) void k_row_stats(const double *__restrict__ phiw, const double *__restrict__ y,
+                                                    const double *__restrict__ omega,
+                                                    const double *__restrict__ lnbeta, long ldx, int n, int k,
+                                                    double *__restrict__ partial) {
+    __shared__ double sh4[4];
+    double s0 = 0.0, s1 = 0.0, cnt = 0.0;
+    double so[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double om = omega ? omega[i] : 1.0;
+        cnt += 1.0;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (o < k) {
+                const double delta = phiw[(size_t)o * ldx + i] - y[(size_t)o * ldx + i];
+                const double lb = lnbeta[(size_t)o * ldx + i];
+                const double beta = exp(-lb);
+                s0 = fma(om, delta * delta, s0);
+                s1 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
+                so[o] = fma(om * beta, delta * delta, so[o]);
+            }
+        }
+    }
+    s0 = block_sum_256(s0, sh4);
+    __syncthreads();
+    s1 = block_sum_256(s1, sh4);
+    __syncthreads();
+    cnt = block_sum_256(cnt, sh4);
+    double *pw = partial + (size_t)blockIdx.x * GPZ_NS;
+    if (threadIdx.x == 0) { pw[0] = s0; pw[1] = s1; pw[10] = cnt; pw[11] = 0.0; }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        __syncthreads();
+        const double t = block_sum_256(so[o], sh4);
+        if (threadIdx.x == 0) pw[2 + o] = t;
+    }
+}
+
+// partial[wg][0] = sum omega, [1+o] = sum_i omega_i lnbeta_io      (GPz.m:82,110)
+__global__ __launch_bounds__(256) void k_sums1(const double *__restrict__ omega, const double *__restrict__ lnbeta,
+                                                long ldx, int n, int k, double *__restrict__ partial) {
+    __shared__ double sh4[4];
+    double s0 = 0.0, cnt = 0.0;
+    double so[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double om = omega ? omega[i] : 1.0;
+        s0 += om;
+        cnt += 1.0;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < k) so[o] = fma(om, lnbeta[(size_t)o * ldx + i], so[o]);
+    }
+    s0 = block_sum_256(s0, sh4);
+    __syncthreads();
+    cnt = block_sum_256(cnt, sh4);
+    double *pw = partial + (size_t)blockIdx.x * GPZ_NS;
+    if (threadIdx.x == 0) { pw[0] = s0; pw[9] = 0.0; pw[10] = cnt; pw[11] = 0.0; }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        __syncthreads();
+        const double t = block_sum_256(so[o], sh4);
+        if (threadIdx.x == 0) pw[1 + o] = t;
+    }
+}
+
+// nlogML(o) of GPz.m:81-82 (solve-only mode returns it un-normalised)
+__global__ __launch_bounds__(256) void k_solve_partial(GpzParams pr, const double *__restrict__ w,
+                                                        const double *__restrict__ logdet,
+                                                        const double *__restrict__ sums1,
+                                                        const double *__restrict__ rstats, int m, int k,
+                                                        double *__restrict__ out) {
+    __shared__ double sh4[4];
+    for (int o = 0; o < k; ++o) {
+        double part = 0.0;
+        for (int j = threadIdx.x; j < m; j += 256) {
+            const int e = j + m * o;
+            part += -0.5 * pr.alpha[e] * w[e] * w[e] + 0.5 * pr.lnAlpha[e];
+        }
+        part = block_sum_256(part, sh4);
+        if (threadIdx.x == 0) out[o] = part - 0.5 * rstats[2 + o] - 0.5 * logdet[o] + 0.5 * (-sums1[1 + o]);
+        __syncthreads();
+    }
+}
+
+void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const double *logdet, const double *sums1,
+                          const double *rstats, int m, int k, double *out) {
+    hipLaunchKernelGGL(k_solve_partial, dim3(1), dim3(256), 0, st, pr, w, logdet, sums1, rstats, m, k, out);
+}
+
+#define SMALL_NWG GPZ_SMALL_NWG
+void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, const double *lnbeta,
+                      long ldx, int n, int k, double *partial) {
+    hipLaunchKernelGGL(k_row_stats, dim3(SMALL_NWG), dim3(256), 0, st, phiw, y, omega, lnbeta, ldx, n, k, partial);
+}
+void launch_sums1(hipStream_t st, const double *omega, const double *lnbeta, long ldx, int n, int k, double *partial) {
+    hipLaunchKernelGGL(k_sums1, dim3(SMALL_NWG), dim3(256), 0, st, omega, lnbeta, ldx, n, k, partial);
+}
+
+// ---------------------------------------------------------------------------------------------
+// misc entry points
+// ---------------------------------------------------------------------------------------------
+// D = | |x|^2 + |y|^2 - 2 x.y |   (Dxy.m:3-7); X nx x d, Y ny x d, D nx x ny, all column-major.
+__global__ void k_dxy(const double *__restrict__ X, long nx, const double *__restrict__ Y, long ny, int d,
+                      double *__restrict__ D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long j = blockIdx.y;
+    if (i >= nx) return;
+    double xx = 0.0, yy = 0.0, xy = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const double xv = X[c * nx + i], yv = Y[c * ny + j];
+        xx = fma(xv, xv, xx);
+        yy = fma(yv, yv, yy);
+        xy = fma(xv, yv, xy);
+    }
+    D[j * nx + i] = fabs(fabs(yy + (xx - 2.0 * xy)));
+}
+
+void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long ny, int d, double *D) {
+    hipLaunchKernelGGL(k_dxy, dim3((unsigned)((nx + 255) / 256), (unsigned)ny), dim3(256), 0, st, X, nx, Y, ny, d, D);
+}
+
+// dst (n x m column-major) = src (row-major, leading dimension ld), tiled through LDS.
+__global__ __launch_bounds__(256) void k_transpose_out(const double *__restrict__ src, int ld, long n, int m,
+                                                        double *__restrict__ dst) {
+    __shared__ double t[32][33];
+    const long i0 = (long)blockIdx.x * 32;
+    const int j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long i = i0 + r;
+        const int j = j0 + tx;
+        t[r][tx] = (i < n && j < m) ? src[(size_t)i * ld + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r;
+        const long i = i0 + tx;
+        if (i < n && j < m) dst[(size_t)j * n + i] = t[tx][r];
+    }
+}
+
+void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst) {
+    hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, st, src,
+                       ld, n, m, dst);
+}
+
+// nu_i = sum_j PHI_ij T_ij, one wave per row (predictDiag.m:69-71).
+__global__ __launch_bounds__(256) void k_nu(const double *__restrict__ Phi, const double *__restrict__ T, int ld, int n,
+                                             int m, double *__restrict__ nu) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < m; j += 64) s = fma(Phi[(size_t)i * ld + j], T[(size_t)i * ld + j], s);
+    s = wave_sum(s);
+    if (lane == 0) nu[i] = s;
+}
+
+void launch_nu(hipStream_t st, const double *Phi, const double *T, int ld, int n, int m, double *nu) {
+    hipLaunchKernelGGL(k_nu, dim3((n + 3) / 4), dim3(256), 0, st, Phi, T, ld, n, m, nu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NaN-pattern grouping (getPHI.m:43-54, duplicated at GPz.m:118-129, predict.m:45-56):
+// group id of a row = rank, by first occurrence, of its isnan() bit pattern.  Integer work, bit-exact.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_nan_mask(const double *__restrict__ X, long n, int d, unsigned long long *__restrict__ mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long b = 0ULL;
+    for (int c = 0; c < d; ++c) {
+        const double v = X[(size_t)c * n + i];
+        if (v != v) b |= (1ULL << c);
+    }
+    mask[i] = b;
+}
+
+// One workgroup walks the rows in order and appends every pattern not seen before.
+__global__ __launch_bounds__(256) void k_nan_unique(const unsigned long long *__restrict__ mask, long n,
+                                                     unsigned long long *__restrict__ uniq, int *__restrict__ n_groups,
+                                                     int max_groups) {
+    __shared__ unsigned long long su[1024];
+    __shared__ int sn;
+    __shared__ long first;
+    const int tid = threadIdx.x;
+    const int cap = max_groups < 1024 ? max_groups : 1024;
+    if (tid == 0) sn = 0;
+    __syncthreads();
+    for (long base = 0; base < n; base += 256) {
+        const long i = base + tid;
+        const bool have = i < n;
+        const unsigned long long mk = have ? mask[i] : 0ULL;
+        while (true) {
+            bool known = !have;
+            const int cnt = sn;
+            for (int g = 0; g < cnt && !known; ++g) known = (su[g] == mk);
+            if (tid == 0) first = n;
+            __syncthreads();
+            if (!known) atomicMin((unsigned long long *)&first, (unsigned long long)i);
+            __syncthreads();
+            const long f = first;
+            if (f >= n) break;                       // nothing new in this chunk
+            if (i == f) {
+                if (sn < cap) su[sn] = mk;
+                sn = sn + 1;
+            }
+            __syncthreads();
+            if (sn > cap) break;
+        }
+        __syncthreads();
+        if (sn > cap) break;
+    }
+    __syncthreads();
+    const int total = sn;
+    for (int g = tid; g < total && g < cap; g += 256) uniq[g] = su[g];
+    if (tid == 0) *n_groups = total;
+}
+
+__global__ void k_nan_ids(const unsigned long long *__restrict__ mask, long n, const unsigned long long *__restrict__ uniq,
+                          const int *__restrict__ n_groups, int *__restrict__ gid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long mk = mask[i];
+    const int G = *n_groups;
+    int id = -1;
+    for (int g = 0; g < G; ++g)
+        if (uniq[g] == mk) { id = g; break; }
+    gid[i] = id;
+}
+
+int launch_nan_groups(hipStream_t st, const double *X, long n, int d, unsigned long long *mask, unsigned long long *uniq,
+                      int *n_groups, int *group_id, int max_groups) {
+    if (d > 64) return -1;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_nan_mask, dim3(nb), dim3(256), 0, st, X, n, d, mask);
+    hipLaunchKernelGGL(k_nan_unique, dim3(1), dim3(256), 0, st, (const unsigned long long *)mask, n, uniq, n_groups, max_groups);
+    hipLaunchKernelGGL(k_nan_ids, dim3(nb), dim3(256), 0, st, (const unsigned long long *)mask, n,
+                       (const unsigned long long *)uniq, (const int *)n_groups, group_id);
+    return 0;
+}

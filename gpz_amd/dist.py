@@ -1,0 +1,81 @@
+"""Row sharding across GPUs (one process per GPU) and the all-reduce hook of the C ABI.
+
+The evaluation is data-parallel over samples: every n-indexed quantity of GPz.m is row-local and rows couple
+only through sums.  Each rank owns a contiguous block of the training-selected rows; per
+evaluation the library calls the hook twice, on [PHI'W PHI | PHI'W y | scalar sums] (m x m) and on
+[dP/dGamma moments | PHI'(..) vectors | scalar sums] (m x (d^2+d)), and every rank finishes the m-sized work
+redundantly so no broadcast is needed.  The hook is ``torch.distributed.all_reduce`` — RCCL over xGMI for
+device buffers ("nccl" backend), gloo for the host-buffer tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block [lo, hi) of rank ``rank`` out of ``world`` over n rows: ceil(n/world) rows per rank,
+    the last ranks may be short or empty."""
+    per = -(-n // world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def shard_rows(rank, world, X, Y, omega=None, training=None, validation=None):
+    """Split the TRAINING-selected rows (and, independently, the validation rows) into contiguous blocks and
+    return this rank's (X, Y, omega, training, validation) slices.  Rows selected by neither mask are dropped:
+    the path never reads them (getPHI.m:14)."""
+    X = np.asarray(X)
+    Y = np.asarray(Y)
+    n = X.shape[0]
+    tr = np.ones(n, dtype=bool) if training is None else np.asarray(training, dtype=bool)
+    idx_t = np.flatnonzero(tr)
+    lo, hi = shard_bounds(idx_t.size, rank, world)
+    keep = [idx_t[lo:hi]]
+    if validation is not None:
+        idx_v = np.flatnonzero(np.asarray(validation, dtype=bool))
+        lv, hv = shard_bounds(idx_v.size, rank, world)
+        keep.append(idx_v[lv:hv])
+    rows = np.concatenate(keep)
+    Xs, Ys = X[rows], Y[rows]
+    oms = None if omega is None else np.asarray(omega)[rows]
+    trs = np.zeros(rows.size, dtype=bool)
+    trs[:hi - lo] = True
+    vas = None
+    if validation is not None:
+        vas = np.zeros(rows.size, dtype=bool)
+        vas[hi - lo:] = True
+    return Xs, Ys, oms, trs, vas
+
+
+class _CudaBuf:
+    """Minimal __cuda_array_interface__ view of a raw device pointer (float64, 1-D)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def make_allreduce(group=None, device="cuda"):
+    """Build the C-ABI all-reduce hook (gpz_allreduce_fn) on top of torch.distributed.
+
+    device "cuda": ``buf`` is a device pointer; the tensor view is all-reduced with the process group's
+    backend (RCCL) on the current stream — the library runs on the same stream, so ordering is implicit.
+    device "cpu": ``buf`` is a host pointer (used by the gloo tests)."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(user, buf, count, stream):
+        try:
+            if device == "cpu":
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                t = torch.from_numpy(arr)
+            else:
+                t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:  # never unwind through the C frame
+            print("gpz_amd.dist allreduce hook failed:", repr(e), flush=True)
+            return 1
+
+    return hook

@@ -1,0 +1,138 @@
+/*
+ * gpz_hip.h — C ABI of libgpz_hip.so: the MI355X (gfx950) implementation of GPz's
+ * marginal-likelihood objective/gradient path.
+ *
+ * Every entry point replaces one reference interface (paths relative to the
+ * OxfordML/GPz tree); INTEGRATION.md shows the MEX / ctypes binding for each.
+ *
+ *   gpz_ctx_create      the closure  f = @(params) GPz(params,model,X,Y,Psi,omega,training,validation)
+ *                       GPz/train.m:40, GPz/init.m:89  (data captured once; row selection of
+ *                       GPz/getPHI.m:14-22 is done here, once, instead of on every call)
+ *   gpz_eval            [nlogML,grad] = GPz(theta,...)      GPz/GPz.m:1  (nargout<=2 mode, :89-261)
+ *                       + globals trainRMSE/trainLL/validRMSE/validLL   GPz/GPz.m:3-7,236-259
+ *   gpz_solve           [~,~,w,iSigma_w] = GPz(theta,...)   GPz/GPz.m:84-87 (nargout>2 mode)
+ *   gpz_phi             [PHI,Gamma,lnBeta_i] = getPHI(X,[],theta,model,[])   GPz/getPHI.m:1
+ *   gpz_predict_full    predictFull(X,theta,w,iSigma_w,model) GPz/predictDiag.m:58-74, predictCov.m:53-69
+ *   gpz_inv_logdet      [Xi,logdet] = inv_logdet(X)         GPz/inv_logdet.m:1
+ *   gpz_dxy             D = Dxy(X,Y)                        GPz/Dxy.m:1
+ *   gpz_nan_groups      the NaN-pattern grouping loop       GPz/getPHI.m:43-54 (== GPz.m:118-129)
+ *
+ * Conventions (MATLAB's, so a MEX shim is pure marshalling):
+ *   - all matrices are column-major double; masks are 1 byte per row (MATLAB logical);
+ *     a NULL pointer plays MATLAB's [].
+ *   - theta / grad use the reference packing [P(:);Gamma(:);lnAlpha(:);b(:);v(:);lnTau(:)]
+ *     (GPz/GPz.m:227-231, GPz/init.m:87-97).
+ *   - host pointers are never retained after a call returns; outputs are caller-allocated.
+ *   - return value: 0 ok; <0 error (text via gpz_last_error()).  Numerical breakdown
+ *     (non-positive-definite or non-finite SIGMA) is NOT an error: f and g come back NaN so the
+ *     caller's line search backs off (minFunc/WolfeLineSearch.m:53-70, isLegal.m); this is a
+ *     documented deviation — the reference would raise from svd().
+ *   - no torch types, no C++ in the signatures.  The library owns its device memory
+ *     (hipMalloc) and runs on the HIP stream given at context creation (NULL = the null stream).
+ */
+#ifndef GPZ_HIP_H
+#define GPZ_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPZ_OK               0
+#define GPZ_ERR_ARG         -1   /* bad argument / unsupported combination */
+#define GPZ_ERR_HIP         -2   /* HIP runtime failure */
+#define GPZ_ERR_ALLOC       -3
+#define GPZ_ERR_COMM        -4   /* the all-reduce hook failed */
+#define GPZ_ERR_UNSUPPORTED -5   /* valid in the reference, not built yet (see DESIGN.md scope table) */
+
+#define GPZ_VERSION 1
+
+typedef struct gpz_ctx gpz_ctx;
+
+/* model.{d,k,m,method,heteroscedastic} (GPz/init.m:16-20) + placement. */
+typedef struct gpz_desc {
+    int32_t d;                /* input dimension */
+    int32_t m;                /* number of basis functions */
+    int32_t k;                /* number of outputs */
+    char    method[4];        /* "GL","VL","GD","VD","GC","VC" (NUL padded) */
+    int32_t heteroscedastic;  /* model.heteroscedastic */
+    int32_t device;           /* HIP device ordinal */
+    void   *stream;           /* hipStream_t to run on; NULL = null stream */
+    int32_t rank;             /* this shard's rank (0 when unsharded) */
+    int32_t world;            /* number of row shards (1 when unsharded) */
+    int32_t reserved[4];
+} gpz_desc;
+
+/* In-place SUM all-reduce over ranks of `count` doubles at device pointer `buf`, ordered on
+ * `stream`.  Return 0 on success.  The Python host wires this to torch.distributed (RCCL);
+ * a single-process caller leaves it unset. */
+typedef int (*gpz_allreduce_fn)(void *user, void *buf, size_t count, void *stream);
+
+/* Build the evaluation context.  X is n_tot x d, Y n_tot x k, omega n_tot x 1 (NULL = ones),
+ * training/validation n_tot x 1 logical (NULL = all rows / no validation), all HOST pointers,
+ * column-major.  psi_kind: 0 none; 1 = n_tot x d (after fixPsi, diag kinds); 2 = d x d x n_tot cube.
+ * When world>1 the arrays hold only this rank's row shard. */
+int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot,
+                   const double *X, const double *Y,
+                   const double *Psi, int32_t psi_kind,
+                   const double *omega,
+                   const uint8_t *training, const uint8_t *validation,
+                   gpz_ctx **out);
+void gpz_ctx_destroy(gpz_ctx *ctx);
+int  gpz_ctx_set_allreduce(gpz_ctx *ctx, gpz_allreduce_fn fn, void *user);
+
+/* numel(theta) for this context's model. */
+int64_t gpz_theta_len(const gpz_ctx *ctx);
+/* rows selected by the training / validation mask on this rank. */
+int64_t gpz_n_train(const gpz_ctx *ctx);
+int64_t gpz_n_valid(const gpz_ctx *ctx);
+
+/* [f,g] = GPz(theta,...).  stats[0..3] = trainRMSE, trainLL, validRMSE, validLL (the last two
+ * untouched when there is no validation mask).  diag (optional, may be NULL) receives
+ * diag[0] = Cholesky info (0 ok, j>0: pivot j not positive), diag[1] = global n. */
+int gpz_eval(gpz_ctx *ctx, const double *theta, double *f, double *g, double stats[4], double diag[2]);
+
+/* [~,~,w,iSigma_w] = GPz(theta,...): w is m x k, iSigma_w m x m x k; nlogML_partial (optional)
+ * is the un-normalised 1 x k vector of GPz.m:81-82. */
+int gpz_solve(gpz_ctx *ctx, const double *theta, double *w, double *iSigma_w, double *nlogML_partial);
+
+/* Copy PHI (n_train x m, column-major) of the last gpz_eval/gpz_solve back to the host
+ * (5th output of GPz.m:1). */
+int gpz_get_phi(gpz_ctx *ctx, double *PHI);
+
+/* Per-stage GPU time (HIP events on the context's stream).  enable!=0 turns recording on;
+ * gpz_ctx_timings copies up to `cap` accumulated stage times in ms and the call counts, returns
+ * the number of stages; names are static strings. */
+int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);
+int gpz_ctx_timings(gpz_ctx *ctx, const char **names, double *ms, int64_t *calls, int cap);
+int gpz_ctx_reset_timings(gpz_ctx *ctx);
+
+/* getPHI(X,[],theta,model,[]) on ns rows: PHI ns x m, lnBeta_i ns x k (column-major, host). */
+int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns,
+            double *PHI, double *lnBeta_i);
+
+/* predictFull: mu = PHI*w (muY NOT added, as in predictDiag.m:65), nu, beta_i; PHI optional. */
+int gpz_predict_full(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                     const double *Xs, int64_t ns,
+                     double *mu, double *nu, double *beta_i, double *PHI);
+
+/* Inverse and log-determinant of a symmetric positive-definite m x m matrix.  info (optional):
+ * 0 ok, j>0 not positive definite at pivot j (Xi, logdet are NaN then). */
+int gpz_inv_logdet(const double *A, int32_t m, int32_t device, double *Xi, double *logdet, int32_t *info);
+
+/* D = | |x|^2 + |y|^2 - 2 x y' |, X nx x d, Y ny x d, D nx x ny. */
+int gpz_dxy(const double *X, int64_t nx, const double *Y, int64_t ny, int32_t d, int32_t device, double *D);
+
+/* Group id per row = rank (by first occurrence) of the row's NaN pattern; returns the number of
+ * groups in *n_groups.  Bit-exact with the greedy loop of getPHI.m:43-54. */
+int gpz_nan_groups(const double *X, int64_t n, int32_t d, int32_t device, int32_t *group_id, int32_t *n_groups);
+
+const char *gpz_last_error(void);
+int gpz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPZ_HIP_H */
