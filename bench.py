@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Benchmark of the GPz objective+gradient evaluation on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2]
+
+A "step" is one gpz_eval: theta on the host -> [f, grad, 4 statistics] on the host, data resident in HBM.
+Metric (BASELINE.json): objective+gradient evaluations per second, whole job.  With N>1 the script is
+launched by torch.distributed.run, one rank per GPU; the n rows of the SAME problem are sharded across ranks
+(strong scaling) and the m x m / m x d partials are all-reduced over RCCL (gpz_amd/dist.py).
+
+Workloads (synthetic data per SURVEY.md §8d):
+    c4  n=1e6 d=10 m=1000 VC heteroscedastic fp64   <- the configuration the metric's target is quoted on (default)
+    c3  n=1e5 d=10 m=500  VC heteroscedastic + cost-sensitive omega
+    c2  n=1e5 d=10 m=200  VD heteroscedastic
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "c4": dict(n=1_000_000, d=10, m=1000, method="VC", omega=None),
+    "c3": dict(n=100_000, d=10, m=500, method="VC", omega="normalized"),
+    "c2": dict(n=100_000, d=10, m=200, method="VD", omega=None),
+}
+F64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (datasheet f64 matrix = f64 vector rate)
+F64_MFMA_UBENCH_TFLOPS = 47.5  # tools/mfma_f64_bench.hip on this pool's MI355X (back-to-back v_mfma_f64_16x16x4_f64)
+
+
+def synth(cfg, n=None):
+    """Synthetic problem of SURVEY.md §8d: default_rng(1) data, default_rng(2) theta perturbation."""
+    from gpz_amd.api import Model
+    n = n or cfg["n"]
+    d, m, method = cfg["d"], cfg["m"], cfg["method"]
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, d))
+    a = rng.standard_normal(d) / math.sqrt(d)
+    c = rng.standard_normal(d) / math.sqrt(d)
+    y = np.sin(X @ a) + 0.1 * (1.0 + np.abs(X @ c)) * rng.standard_normal(n)
+    y = (y - y.mean())[:, None]
+    omega = None
+    if cfg["omega"] == "normalized":
+        omega = ((1.0 + y - y.min()) ** -2.0)           # getOmega.m:19 on a shifted target
+    model = Model(m=m, d=d, k=1, method=method, heteroscedastic=True)
+    P = X[rng.choice(n, m, replace=False)] + 0.1 * rng.standard_normal((m, d))
+    sub = X[rng.choice(n, min(n, 20000), replace=False)]  # init.m:62 heuristic on a row subsample
+    D = ((sub ** 2).sum(1)[:, None] + (P ** 2).sum(1)[None, :] - 2.0 * sub @ P.T)
+    gam = np.sqrt(0.5 * m ** (1.0 / d) / np.mean(np.abs(D), axis=0))
+    if method == "VC":
+        G = np.zeros((d, d, m))
+        for j in range(m):
+            G[:, :, j] = np.eye(d) * gam[j]
+    else:
+        G = np.tile(gam[:, None], (1, d))
+    vy = float(np.var(y, ddof=1))
+    theta = np.concatenate([P.ravel(order="F"), G.ravel(order="F"), np.full(m, -math.log(vy)), [math.log(vy)],
+                            0.01 * rng.standard_normal(m), np.zeros(m)])
+    theta = theta + 0.05 * np.random.default_rng(2).standard_normal(theta.size)
+    return model, theta, X, y, omega
+
+
+def cpu_baseline(cfg, model, theta, X, y, omega, rows):
+    """The oracle (as-written NumPy restatement of the reference path) timed on a bounded row sample."""
+    from oracle import gpz_oracle as O
+    om = Omodel = None
+    Omodel = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
+    Xs, ys = X[:rows], y[:rows]
+    oms = None if omega is None else omega[:rows]
+    t0 = time.perf_counter()
+    ref = O.GPz(theta, Omodel, Xs, ys, None, oms)
+    t_all = time.perf_counter() - t0
+    # the m^3 part does not scale with n: time it alone
+    S = np.eye(model.m) + np.ones((model.m, model.m)) * 1e-3
+    t0 = time.perf_counter()
+    O.inv_logdet(S)
+    t_svd = time.perf_counter() - t0
+    scale = cfg["n"] / rows
+    t_full = (t_all - t_svd) * scale + t_svd
+    try:
+        import threadpoolctl
+        nthreads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        nthreads = os.cpu_count()
+    return ref, dict(value=1.0 / t_full, unit="evals/s", cores=int(nthreads), kind="port",
+                     sample=f"oracle GPz() as-written on the first {rows} of {cfg['n']} rows: {t_all:.1f} s measured "
+                            f"(of which {t_svd:.2f} s is the m^3 SVD inverse), row-dependent part scaled x{scale:.1f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--n", type=int, default=None, help="override the row count (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gpz_amd
+    from gpz_amd import dist as gdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(CONFIGS[args.config])
+    if args.n:
+        cfg["n"] = args.n
+    model, theta0, X, y, omega = synth(cfg)
+    n = cfg["n"]
+    stream = torch.cuda.current_stream().cuda_stream
+    if use_dist:
+        Xs, ys, oms, trs, _ = gdist.shard_rows(rank, world, X, y, omega)
+        ctx = gpz_amd.GPzContext(model, Xs, ys, None, oms, trs, None, device=local_rank, stream=stream or None,
+                                 rank=rank, world=world, allreduce=gdist.make_allreduce())
+    else:
+        ctx = gpz_amd.GPzContext(model, X, y, None, omega, None, None, device=local_rank, stream=stream or None)
+    n_local = ctx.n_train
+
+    prng = np.random.default_rng(3)
+    thetas = [theta0 + 1e-3 * prng.standard_normal(theta0.size) for _ in range(args.steps + args.warmup)]
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        ctx.eval(thetas[i])
+    ctx.enable_timing(True)
+    ctx.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    fs = []
+    for i in range(args.steps):
+        f, g = ctx.eval(thetas[args.warmup + i])
+        fs.append(f)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tim = ctx.timings()
+    finite = bool(np.isfinite(fs).all() and np.isfinite(g).all())
+
+    out = None
+    if rank == 0:
+        m = cfg["m"]
+        ms_per_step = elapsed / args.steps * 1e3
+        tg_ms, tg_calls = tim.get("tgemm", (0.0, 0))
+        tg_avg = tg_ms / max(1, tg_calls)
+        flops_tg = 2.0 * n_local * m * m              # algorithmic flops of PHI*inv(SIGMA) per launch (SURVEY §8d F_T)
+        ach = flops_tg / (tg_avg * 1e-3) / 1e12 if tg_avg > 0 else 0.0
+        sy_ms, sy_calls = tim.get("syrk", (0.0, 0))
+        sy_avg = sy_ms / max(1, sy_calls)
+        ach_sy = (n_local * m * (m + 1.0)) / (sy_avg * 1e-3) / 1e12 if sy_avg > 0 else 0.0
+        ph_ms, ph_calls = tim.get("phi_build", (0.0, 0))
+        ph_avg = ph_ms / max(1, ph_calls)
+        phi_gbs = 8.0 * (n_local * cfg["d"] + n_local * m) / (ph_avg * 1e-3) / 1e9 if ph_avg > 0 else 0.0
+        out = {
+            "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: n={n} d={cfg['d']} m={m} method={cfg['method']} heteroscedastic k=1"
+                                   + (" omega=(1+y-min y)^-2" if cfg["omega"] else ""),
+                       "rows_per_gpu": n_local, "sharding": f"rows/{world} + RCCL all-reduce of m x m and m x d partials"
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)",
+                         "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_ms": tg_avg, "ubench_ceiling": F64_MFMA_UBENCH_TFLOPS,
+                         "frac_of_ubench": ach / F64_MFMA_UBENCH_TFLOPS},
+            "kernels": {"syrk_tflops_algorithmic": ach_sy, "syrk_avg_ms": sy_avg,
+                        "phi_build_GBs_algorithmic": phi_gbs, "phi_build_avg_ms": ph_avg,
+                        "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
+            "finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rows = max(2000, min(n, n // 16 if n >= 200000 else n // 4))
+            ref, cb = cpu_baseline(cfg, model, theta0, X, y, omega, rows)
+            out["cpu_baseline"] = cb
+            # parity gate on the same sample through the HIP path
+            c2 = gpz_amd.GPzContext(model, X[:rows], y[:rows], None, None if omega is None else omega[:rows],
+                                    device=local_rank)
+            f2, g2 = c2.eval(theta0)
+            c2.close()
+            out["parity"] = {"rows": rows, "rel_f": abs(f2 - ref.nlogML) / abs(ref.nlogML),
+                             "rel_g_max": float(np.max(np.abs(g2 - ref.grad)) / np.max(np.abs(ref.grad))),
+                             "cond_sigma": ref.cond, "tol_g": max(1e-8, 50 * ref.cond * 2.2e-16)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Shared helpers for the test-suite."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import gpz_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    model = O.Model(m=int(g["m"]), d=int(g["d"]), k=int(g["k"]), method=str(g["method"]),
+                    heteroscedastic=bool(int(g["heteroscedastic"])))
+    Psi = g["Psi"] if int(g["has_psi"]) else None
+    if int(g["has_masks"]):
+        omega, training, validation = g["omega"], g["training"], g["validation"]
+    else:
+        omega = training = validation = None
+    return g, model, Psi, omega, training, validation
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def make_problem(n, d, m, k, method, hetero, seed, psi=False, nanfrac=0.0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    A = rng.standard_normal((d, k)) / np.sqrt(d)
+    Y = np.sin(X @ A) + 0.1 * rng.standard_normal((n, k))
+    Y -= Y.mean(0)
+    model, theta = O.init_theta(X, Y, method, m, hetero, rng)
+    theta = theta + 0.05 * rng.standard_normal(theta.size)
+    if hetero:
+        o = theta.size - 2 * m * k
+        theta[o:o + m * k] = 0.05 * rng.standard_normal(m * k)
+    Psi = None
+    if psi:
+        if model.method[1] == "C":
+            Psi = np.zeros((d, d, n))
+            for i in range(n):
+                B = 0.3 * rng.standard_normal((d, d))
+                Psi[:, :, i] = B @ B.T
+        else:
+            Psi = rng.gamma(1.0, 0.2, (n, d))
+    if nanfrac > 0 and d > 1:
+        rows = rng.random(n) < nanfrac
+        X[rows, rng.integers(0, d, n)[rows]] = np.nan
+    return model, theta, X, Y, Psi, rng
+
+
+def grad_tol(cond):
+    """Parity gate of BASELINE.md §6."""
+    return max(1e-8, 50.0 * cond * 2.2e-16)

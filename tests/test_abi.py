@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/gpz_hip.h
+declares, fails loudly without a GPU (no CPU fallback), and the product package never touches the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gpz_amd
+from gpz_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gpz_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(gpz_[a-z_0-9]+)\s*\(", src))
+    names.discard("gpz_allreduce_fn")
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gpz_hip.h but not exported"
+    assert set(declared) == set(_lib.SYMBOLS), "ctypes table and header disagree"
+    assert lib.gpz_version() == 1
+
+
+def _no_gpu():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(_lib.GpzError):
+        gpz_amd.Dxy(np.zeros((3, 2)), np.zeros((2, 2)))
+    model = gpz_amd.Model(m=3, d=2)
+    with pytest.raises(_lib.GpzError):
+        gpz_amd.GPzContext(model, np.zeros((8, 2)), np.zeros((8, 1)))
+
+
+def test_product_package_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gpz_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), f"{fn} mentions the oracle"
+
+
+def test_argument_validation_is_host_side():
+    model = gpz_amd.Model(m=3, d=2)
+    with pytest.raises(ValueError):
+        gpz_amd.GPzContext(model, np.zeros((8, 3)), np.zeros((8, 1)))      # wrong d
+    with pytest.raises(ValueError):
+        gpz_amd.GPzContext(model, np.zeros((8, 2)), np.zeros((8, 1)), training=np.ones(5, bool))
+
+
+def test_theta_layout_matches_reference():
+    # g_dim per method (init.m:65-86) and p = m*d + g_dim + m*k + k + 2*m*k
+    for method, g in (("GL", 1), ("VL", 7), ("GD", 3), ("VD", 21), ("GC", 9), ("VC", 63)):
+        assert gpz_amd.Model(m=7, d=3, method=method).g_dim == g

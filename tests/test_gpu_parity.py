@@ -1,0 +1,250 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Gates: |f - f_ref|/|f_ref| <= 1e-8; max|g - g_ref|/max|g_ref| <= max(1e-8, 50*cond(SIGMA)*2.2e-16)
+with cond reported by the oracle; w, inv(SIGMA), mu, sigma under the same rule; the four statistics to 1e-10;
+NaN-pattern group ids bit-exact.  Full-size cases use size-independent properties (directional finite
+differences with the reference's derivative-check step, method-nesting identities).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import gpz_amd
+from gpz_amd import _lib
+from oracle import gpz_oracle as O
+from helpers import golden_names, grad_tol, load_golden, make_problem, rel
+
+pytestmark = pytest.mark.gpu
+METHODS = ["GL", "VL", "GD", "VD", "GC", "VC"]
+FTOL = 1e-8
+
+
+def _check_eval(model, theta, X, Y, omega=None, training=None, validation=None):
+    ref = O.GPz(theta, model, X, Y, None, omega, training, validation)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, omega, training, validation)
+    try:
+        f, g = ctx.eval(theta)
+        tol = grad_tol(ref.cond)
+        assert ctx.info == 0
+        assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+        assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+        for key, val in ref.stats.items():
+            assert abs(ctx.stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+        r4 = O.GPz(theta, model, X, Y, None, omega, training, validation, nargout=4)
+        w, iS, part = ctx.solve(theta)
+        assert rel(w, r4.w) <= tol and rel(iS, r4.iSigma_w) <= tol
+        assert rel(part, r4.nlogML) <= FTOL
+        PHI = ctx.phi()
+        assert rel(PHI, r4.PHI) <= 1e-12
+    finally:
+        ctx.close()
+    return ref
+
+
+GOLD_OK = [n for n in golden_names() if "_p1" not in n and "_n1" not in n]
+GOLD_UNSUPPORTED = [n for n in golden_names() if "_p1" in n or "_n1" in n]
+
+
+@pytest.mark.parametrize("name", GOLD_OK)
+def test_golden_through_c_abi(name):
+    g, model, Psi, omega, training, validation = load_golden(name)
+    ctx = gpz_amd.GPzContext(model, g["X"], g["Y"], None, omega, training, validation)
+    try:
+        f, grad = ctx.eval(g["theta"])
+        tol = grad_tol(float(g["cond"]))
+        assert abs(f - float(g["nlogML"])) <= FTOL * abs(float(g["nlogML"]))
+        assert rel(grad, g["grad"]) <= tol
+        assert abs(ctx.stats["trainRMSE"] - float(g["trainRMSE"])) <= 1e-10
+        assert abs(ctx.stats["trainLL"] - float(g["trainLL"])) <= 1e-10
+        if validation is not None:
+            assert abs(ctx.stats["validRMSE"] - float(g["validRMSE"])) <= 1e-10
+            assert abs(ctx.stats["validLL"] - float(g["validLL"])) <= 1e-10
+        w, iS, part = ctx.solve(g["theta"])
+        assert rel(w, g["w"]) <= tol and rel(iS, g["iSigma_w"]) <= tol and rel(part, g["nlogML_partial"]) <= FTOL
+    finally:
+        ctx.close()
+    PHI, Gamma, lnB = gpz_amd.getPHI(g["X"], None, g["theta"], model, training)
+    assert rel(lnB, g["lnBeta_i"]) <= 1e-12
+    if "PHI" in g:
+        assert rel(PHI, g["PHI"]) <= 1e-12
+    if "Xs" in g:
+        model.sets["best"] = {"theta": g["theta"], "w": g["w"], "iSigma_w": g["iSigma_w"]}
+        mu, sigma, nu, beta_i, gamma, PHIs, _, _ = gpz_amd.predict(g["Xs"], model)
+        assert rel(mu, g["mu"]) <= tol and rel(sigma, g["sigma"]) <= tol and rel(nu, g["nu"]) <= tol
+        assert rel(beta_i, g["beta_i"]) <= 1e-12 and rel(PHIs, g["PHIs"]) <= 1e-12 and not gamma.any()
+
+
+@pytest.mark.parametrize("name", GOLD_UNSUPPORTED[:6])
+def test_unbuilt_branches_refuse_loudly(name):
+    """Psi / missing-value branches are in the oracle but not yet in the HIP path: the library must say so
+    (GPZ_ERR_UNSUPPORTED), never silently compute something else."""
+    g, model, Psi, omega, training, validation = load_golden(name)
+    with pytest.raises(_lib.GpzError) as ei:
+        gpz_amd.GPzContext(model, g["X"], g["Y"], Psi, omega, training, validation)
+    assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("hetero", [True, False])
+@pytest.mark.parametrize("shape", [(300, 3, 7, 1), (2000, 10, 64, 1), (600, 5, 20, 2), (1031, 7, 33, 1)])
+def test_random_problems(method, hetero, shape):
+    n, d, m, k = shape
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, hetero, seed=n + m)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    _check_eval(model, theta, X, Y, om, tr, ~tr)
+
+
+@pytest.mark.parametrize("shape", [(5, 1, 1, 1), (17, 2, 1, 1), (64, 1, 16, 1), (513, 4, 17, 1), (129, 20, 9, 1),
+                                   (700, 12, 40, 1), (90, 16, 6, 3), (400, 9, 250, 1)])
+def test_edge_shapes(shape):
+    n, d, m, k = shape
+    for method in ("VD", "VC"):
+        model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=17 * n + d)
+        _check_eval(model, theta, X, Y)
+
+
+def test_defaults_and_masks_equivalence():
+    model, theta, X, Y, _, rng = make_problem(500, 4, 12, 1, "VC", True, seed=2)
+    a = gpz_amd.GPzContext(model, X, Y)
+    b = gpz_amd.GPzContext(model, X, Y, None, np.ones((500, 1)), np.ones(500, bool), None)
+    fa, ga = a.eval(theta); fb, gb = b.eval(theta)
+    a.close(); b.close()
+    assert fa == fb and np.array_equal(ga, gb)          # omega = 1 / mask = all are bit-identical to the defaults
+
+
+def test_repeatable_bitwise():
+    model, theta, X, Y, _, rng = make_problem(3000, 10, 100, 1, "VC", True, seed=8)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f1, g1 = ctx.eval(theta); f2, g2 = ctx.eval(theta + 0.0)
+    ctx.close()
+    assert f1 == f2 and np.array_equal(g1, g2)          # fixed reduction order: no atomics on the data path
+
+
+def test_nan_theta_gives_nan_not_error():
+    model, theta, X, Y, _, rng = make_problem(300, 3, 8, 1, "VD", True, seed=1)
+    th = theta.copy(); th[3] = np.nan
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f, g = ctx.eval(th)
+    ctx.close()
+    assert math.isnan(f) and np.isnan(g).all()          # the caller's line search backs off (WolfeLineSearch.m:53-70)
+
+
+def test_matlab_style_entry_and_globals():
+    model, theta, X, Y, _, rng = make_problem(400, 3, 9, 1, "GC", True, seed=12)
+    tr = rng.random(400) < 0.75
+    va = ~tr
+    ref = O.GPz(theta, model, X, Y, None, None, tr, va)
+    gpz_amd.reset()
+    f, g = gpz_amd.GPz(theta, model, X, Y, None, None, tr, va)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert abs(gpz_amd.globals_["validLL"] - ref.stats["validLL"]) <= 1e-10
+    before = dict(gpz_amd.globals_)
+    part, zero, w, iS = gpz_amd.GPz(theta * 1.01, model, X, Y, None, None, tr, va, nargout=4)
+    assert zero == 0.0 and gpz_amd.globals_ == before   # 4-output calls leave the statistics alone (GPz.m:84-87)
+    assert gpz_amd.GPz(theta, model, X, None) == (0.0, 0.0, 0.0, 0.0)
+    gpz_amd.reset()
+
+
+@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 100, 257, 1000])
+def test_inv_logdet(m):
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((m, 2 * m + 3)); S = A @ A.T + 0.5 * np.eye(m)
+    Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
+    Ri, rl = O.inv_logdet(S)
+    cond = O.cond_of(S)
+    assert info == 0 and rel(Xi, Ri) <= 50 * cond * 2.2e-16 and abs(ld - rl) <= 1e-12 * max(1.0, abs(rl))
+
+
+def test_inv_logdet_not_positive_definite():
+    S = np.array([[1.0, 2.0], [2.0, 1.0]])
+    Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
+    assert info > 0 and np.isnan(Xi).all() and math.isnan(ld)
+
+
+def test_dxy():
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((1000, 10)); P = rng.standard_normal((77, 10))
+    assert rel(gpz_amd.Dxy(X, P), O.Dxy(X, P)) <= 1e-13
+
+
+@pytest.mark.parametrize("n,d,frac", [(1, 1, 0.0), (1000, 1, 0.3), (5000, 6, 0.15), (20000, 10, 0.05), (300, 64, 0.01),
+                                      (4097, 3, 0.0)])
+def test_nan_groups_bit_exact(n, d, frac):
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    X[rng.random((n, d)) < frac] = np.nan
+    gid, ng = gpz_amd.nan_groups(X)
+    rg, pats = O.nan_groups(X)
+    assert ng == pats.shape[0] and np.array_equal(gid, rg)
+
+
+def test_stage_timings_api():
+    model, theta, X, Y, _, rng = make_problem(2000, 5, 30, 1, "VD", True, seed=3)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    ctx.enable_timing(True)
+    ctx.eval(theta); ctx.eval(theta)
+    t = ctx.timings()
+    ctx.close()
+    assert t["tgemm"][1] == 2 and t["syrk"][0] > 0 and t["phi_build"][0] > 0
+
+
+# ---- full-size cases: properties that do not need the oracle at size ---------------------------------
+def _bench_problem(name, n=None):
+    import bench
+    cfg = dict(bench.CONFIGS[name])
+    if n:
+        cfg["n"] = n
+    return bench.synth(cfg)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_full_size_directional_derivative(name):
+    """At BASELINE.json's sizes: the gradient must be the derivative of the objective along random
+    directions, with the reference's derivative-check step (autoDif/autoGrad.m:34-45)."""
+    model, theta, X, Y, omega = _bench_problem(name)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, omega)
+    try:
+        f0, g = ctx.eval(theta)
+        assert ctx.info == 0 and np.isfinite(f0) and np.isfinite(g).all()
+        rng = np.random.default_rng(0)
+        h = 2.0 * math.sqrt(1e-12) * (1.0 + np.linalg.norm(theta))
+        for _ in range(2):
+            u = rng.standard_normal(theta.size); u /= np.linalg.norm(u)
+            fp, _ = ctx.eval(theta + h * u)
+            fm, _ = ctx.eval(theta - h * u)
+            fd = (fp - fm) / (2 * h)
+            assert abs(fd - g @ u) <= 1e-6 * max(abs(g @ u), np.linalg.norm(g) / math.sqrt(theta.size))
+    finally:
+        ctx.close()
+
+
+def test_full_size_nesting_identity_c2():
+    """GL(gamma) == VD(gamma*1) at n = 1e5, m = 200 (getPHI.m:26-40): same objective, gradients related by the
+    sums of GPz.m:215-225."""
+    import bench
+    model_vd, theta_vd, X, Y, omega = _bench_problem("c2")
+    m, d = model_vd.m, model_vd.d
+    md = m * d
+    gam = 0.7
+    th_vd = theta_vd.copy(); th_vd[md:2 * md] = gam
+    model_gl = gpz_amd.Model(m=m, d=d, k=1, method="GL", heteroscedastic=True)
+    th_gl = np.concatenate([th_vd[:md], [gam], th_vd[2 * md:]])
+    a = gpz_amd.GPzContext(model_vd, X, Y); fa, ga = a.eval(th_vd); a.close()
+    b = gpz_amd.GPzContext(model_gl, X, Y); fb, gb = b.eval(th_gl); b.close()
+    assert abs(fa - fb) <= 1e-12 * abs(fa)
+    assert rel(gb[:md], ga[:md]) <= 1e-9 and rel(gb[md + 1:], ga[2 * md:]) <= 1e-9
+    assert abs(ga[md:2 * md].sum() - gb[md]) <= 1e-9 * max(1.0, abs(gb[md]))
+
+
+def test_c4_shape_against_oracle_subsample():
+    """c4's shape (d=10, m=1000, VC, heteroscedastic) at n = 20000 rows, against the oracle."""
+    model, theta, X, Y, omega = _bench_problem("c4", n=20000)
+    om = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
+    ref = O.GPz(theta, om, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f, g = ctx.eval(theta)
+    ctx.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= grad_tol(ref.cond)
