@@ -259,3 +259,57 @@ def test_c4_shape_against_oracle_subsample():
     ctx.close()
     assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
     assert rel(g, ref.grad) <= grad_tol(ref.cond)
+
+
+# ---- sharded evaluation: two ranks on one GPU (gloo moves the CUDA buffers; RCCL needs distinct devices) ----
+def _shard_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from gpz_amd import dist as gdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model, theta, X, Y, _, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33)
+    r2 = np.random.default_rng(1)
+    om = r2.random((3001, 1)) + 0.5
+    tr = r2.random(3001) < 0.8
+    va = ~tr
+    Xs, Ys, oms, trs, vas = gdist.shard_rows(rank, world, X, Y, om, tr, va)
+    ctx = gpz_amd.GPzContext(model, Xs, Ys, None, oms, trs, vas, rank=rank, world=world,
+                             allreduce=gdist.make_allreduce())
+    f, g = ctx.eval(theta)
+    w, iS, part = ctx.solve(theta)
+    q.put((rank, f, g, dict(ctx.stats), w, part, ctx.n_global))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_eval_world2_matches_unsharded():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    model, theta, X, Y, _, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33)
+    r2 = np.random.default_rng(1)
+    om = r2.random((3001, 1)) + 0.5
+    tr = r2.random(3001) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    r4 = O.GPz(theta, model, X, Y, None, om, tr, ~tr, nargout=4)
+    tol = grad_tol(ref.cond)
+    for rank, f, g, stats, w, part, n_global in res:
+        assert n_global == int(tr.sum())
+        assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+        assert rel(g, ref.grad) <= tol
+        for key, val in ref.stats.items():
+            assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+        assert rel(w, r4.w) <= tol and rel(part, r4.nlogML) <= FTOL
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])   # ranks finish identically (no broadcast)
