@@ -155,6 +155,8 @@ struct gpz_ctx {
     double *mom_slab = nullptr;
     int nchunk = 1, rows_per_chunk = 1;
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
+    double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused single-output path
+    int nslots = 0;
     double *out_d = nullptr;
     double *out_h = nullptr, *theta_h = nullptr;   // pinned
     gpz_allreduce_fn ar_fn = nullptr;
@@ -203,7 +205,7 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
     for (int64_t i = 0; i < n_tot; ++i)
         if (!mask || mask[i]) idx.push_back(i);                            // X(selection,:)  getPHI.m:14
     rs.n = (int)idx.size();
-    rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 512);
+    rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 1024);   // multiple of the PHI kernel's rows per workgroup (4 waves x 64 lanes x 4 rows)
     const size_t np = (size_t)rs.n_pad;
     std::vector<double> h(np * (size_t)de, 0.0);
     for (int c_ = 0; c_ < d; ++c_)
@@ -266,6 +268,7 @@ static int alloc_params(gpz_ctx *c) {
     if (int e = c->ar.alloc(&c->pr.P, m * de)) return e;
     if (int e = c->ar.alloc(&c->pr.G, c->kind == GPZ_KIND_COV ? m * de * de : m * de)) return e;
     if (int e = c->ar.alloc(&c->pr.G2, m * de)) return e;
+    if (int e = c->ar.alloc(&c->pr.Rc, m * (de * (de + 1) / 2 + de))) return e;
     if (int e = c->ar.alloc(&c->pr.lnAlpha, m * k)) return e;
     if (int e = c->ar.alloc(&c->pr.alpha, m * k)) return e;
     if (int e = c->ar.alloc(&c->pr.b, k)) return e;
@@ -364,8 +367,15 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     c->comm2_count = m * c->nm + k * 2 * mp + k * 4 + GPZ_NS;
     if ((rc = c->ar.alloc(&c->comm2, c->comm2_count))) return bail(rc);
     c->nwg_rows = c->tr.n < 2048 ? (c->tr.n > 0 ? c->tr.n : 1) : 2048;
-    if ((rc = c->ar.alloc(&c->colslab, (size_t)c->nwg_rows * 2 * mp))) return bail(rc);
-    if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
+    if (k > 1) {
+        if ((rc = c->ar.alloc(&c->colslab, (size_t)c->nwg_rows * 2 * mp))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
+    } else {
+        c->nslots = 2 * ((c->mp + 127) / 128);
+        if ((rc = c->ar.alloc(&c->nupart, (size_t)c->nslots * np))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->rowscal, (size_t)4 * np))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->frec, (size_t)m * (c->nm + 2)))) return bail(rc);
+    }
     {
         const int ncg = (c->m + 255) / 256;
         int nc = 2048 / ncg;
@@ -375,7 +385,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         c->rows_per_chunk = (c->tr.n + nc - 1) / nc;
         if (c->rows_per_chunk < 1) c->rows_per_chunk = 1;
         c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
-        if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * c->nm))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * (c->nm + 2)))) return bail(rc);
     }
     if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_SMALL_NWG * GPZ_NS))) return bail(rc);
     if ((rc = c->ar.alloc(&c->rstats, (size_t)GPZ_NS))) return bail(rc);
@@ -447,13 +457,14 @@ static int stage_a(gpz_ctx *c, const double *theta) {
     {
         Stage s(c, "unpack");
         launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+        if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
     }
     {
         Stage s(c, "phi_build");
         PhiArgs a{};
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
-        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = c->tr.Y;
         a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
@@ -524,11 +535,32 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
     double *cols = mom + m * c->nm;
     double *scal = cols + k * 2 * mp;
     double *vsums = scal + k * 4;
+    const bool fused = (c->k == 1);
     for (int o = 0; o < c->k; ++o) {
         stage_b(c, o);
         {
             Stage s(c, "tgemm");
-            launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp);
+            launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
+                         c->phiw, c->m, c->m + o);
+        }
+        if (fused) {
+            {
+                Stage s(c, "row_scalars");
+                launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->wbeta,
+                                   c->tr.n_pad, c->tr.n, c->rowscal, c->partial);
+                launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
+                HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+            }
+            Stage s(c, "moments");
+            FusedMomentArgs a{};
+            a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.rowscal = c->rowscal; a.n = c->tr.n; a.m = c->m;
+            a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w; a.v = c->hetero ? c->pr.v : nullptr;
+            a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk; a.slab = c->mom_slab; a.nm = c->nm;
+            if (launch_moments_fused(c->st, a))
+                return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
+            launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * (c->nm + 2), c->frec);
+            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols);
+            continue;
         }
         {
             Stage s(c, "row_epilogue");
@@ -543,10 +575,10 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         }
     }
     if (c->k > 1) {
-        Stage s(c, "mul_phi");
-        launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
-    }
-    {
+        {
+            Stage s(c, "mul_phi");
+            launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
+        }
         Stage s(c, "moments");
         MomentArgs a{};
         a.dPhi = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.d = c->de;
@@ -561,7 +593,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         PhiArgs a{};
         a.Xc = c->va.Xc; a.ldx = c->va.n_pad; a.n = c->va.n; a.n_pad = c->va.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
-        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta_v; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw_v;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
@@ -617,7 +649,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         PhiArgs a{};
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
-        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+        a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
@@ -680,10 +712,11 @@ static void free_eval_ctx(gpz_ctx *c) { c->ar.release(); delete c; }
 static int run_phi_only(gpz_ctx *c, const double *theta) {
     HIPCHK(hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+    if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
     PhiArgs a{};
     a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
     a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
-    a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.G : c->pr.G2;
+    a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
     a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = nullptr; a.Y = nullptr;
     a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
     if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
@@ -745,7 +778,7 @@ extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const
             break;
         }
         launch_fill_bext(c->st, Sd, (int)m, wd + (size_t)o * m, (int)m, (int)mp, o, Bext, dgi);
-        launch_tgemm(c->st, c->Phi, (int)mp, Bext, (int)mp, T, (int)np, (int)mp);
+        launch_tgemm(c->st, c->Phi, (int)mp, Bext, (int)mp, T, (int)np, (int)mp, nullptr, nullptr, (int)m, -1);
         launch_nu(c->st, c->Phi, T, (int)mp, (int)ns, (int)m, nud);                       // predictDiag.m:69-71
         if (hipMemcpyAsync(nu + (size_t)o * ns, nud, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
             rc = fail(GPZ_ERR_HIP, "predict: copy failed");

@@ -9,6 +9,7 @@ struct GpzParams {
     double *P;       // m x d row-major  P[j*d + c]
     double *G;       // diag kinds: gamma[j*d + c];  cov kinds: Gamma_j row-major  G[j*d*d + a*d + b]
     double *G2;      // diag kinds: gamma^2 [j*d + c]                       (unused for cov kinds)
+    double *Rc;      // cov kinds: [R_j packed upper | c_j = R_j p_j], R_j = QR triangular factor of Gamma_j
     double *lnAlpha; // m x k column-major (as in theta)
     double *alpha;   // exp(lnAlpha)
     double *b;       // k
@@ -28,7 +29,7 @@ struct PhiArgs {
     int n_pad;           // rows written (rows >= n are zero-filled)
     int m, mp, d, k;
     int kind;            // GPZ_KIND_*
-    const double *P, *G; // see GpzParams (G = G2 for diag kinds)
+    const double *P, *G; // see GpzParams (G = G2 for diag kinds, Rc for cov kinds)
     const double *v;     // m x k or nullptr
     const double *b;     // k
     const double *omega; // n or nullptr (ones)
@@ -39,13 +40,16 @@ struct PhiArgs {
     const double *w;     // m x k: when non-null, phiw[o*ldx + i] = sum_j PHI_ij w_jo
     double *phiw;        // k x ldx
 };
+void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
 
 // ---- MFMA contractions (k_gemm.hip) ------------------------------------------------------------
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
                  int nsplit, int rows_per_split, double *slab, bool tri);
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds);
-void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp);
+// nupart (optional): [2*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
+void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
+                  double *nupart, double *phiw, int m, int mcol);
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
@@ -89,6 +93,25 @@ struct MomentArgs {
     int nm;                  // moments per basis: cov d + d(d+1)/2, diag 2d
 };
 int launch_moments(hipStream_t st, const MomentArgs &a);
+
+// Fused single-output path: row scalars from the T-GEMM epilogue, then moments with dPHI formed on the fly.
+//   rowscal[i*4 + {0,1,2}] = omega*beta, omega*beta*delta, dbeta   (GPz.m:48,79,93)
+//   partial: GPZ_SMALL_NWG records of GPZ_NS doubles [sum c*delta, sum omega*delta^2, sum LL, sum dbeta, ...]
+void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
+                        const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
+                        double *rowscal, double *partial);
+struct FusedMomentArgs {
+    const double *Phi, *T; int ld;
+    const double *Xr, *rowscal;
+    int n, m, d, kind;
+    const double *P, *w, *v;   // v may be nullptr
+    int nchunk, rows_per_chunk;
+    double *slab;              // [nchunk][m][nm + 2]: moments, then PHI'(omega beta delta), PHI'dbeta
+    int nm;
+};
+int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a);
+// split the reduced [m][nm+2] records into mom [m][nm] and cols [2][mp]
+void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols);
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out);
 
 struct FinishArgs {

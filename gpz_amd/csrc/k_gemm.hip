@@ -16,29 +16,11 @@
 // ---------------------------------------------------------------------------------------------
 // PHI: n_rows x ld row-major.  Output slab[split] is mp x mp row-major; only tiles (ti <= tj) are written.
 // TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
-template <bool WEIGHTED, bool TRI>
-__global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi, int ld,
-                                                  const double *__restrict__ wgt, int n_rows, int mp,
-                                                  int ntile, int rows_per_split,
-                                                  double *__restrict__ slab) {
-    __shared__ double sA[2][16][LDS_LD128];
-    __shared__ double sB[2][16][LDS_LD128];
-    __shared__ double sW[2][16];
-
-    const int npairs = ntile * (ntile + 1) / 2;
-    const int pair = blockIdx.x % npairs;
-    const int split = blockIdx.x / npairs;
-    // decode pair -> (ti <= tj), row-major over the upper triangle
-    int ti = 0, rem = pair;
-    while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
-    const int tj = ti + rem;
-    const bool diag_tile = (ti == tj);
-    const int i0 = ti * 128, j0 = tj * 128;
-
-    int r_begin = split * rows_per_split;
-    int r_end = min(n_rows, r_begin + rows_per_split);
-    if (TRI) r_begin = max(r_begin, j0 & ~15);
-
+template <bool WEIGHTED, bool EDGE>
+__device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld, const double *__restrict__ wgt,
+                                          int mp, int i0, int j0, bool diag_tile, int r_begin, int r_end,
+                                          double *__restrict__ out, double (*sA)[16][LDS_LD128],
+                                          double (*sB)[16][LDS_LD128], double (*sW)[16]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -57,9 +39,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi,
             int idx = q * 256 + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
             const double *src = Phi + (size_t)(r0 + row) * ld;
-            ra[q] = (i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
+            ra[q] = (!EDGE || i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
             if (!diag_tile)
-                rb[q] = (j0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + j0 + c) : (d2_t){0.0, 0.0};
+                rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + j0 + c) : (d2_t){0.0, 0.0};
         }
         if (WEIGHTED && tid < 16) rw = wgt[r0 + tid];
     };
@@ -106,7 +88,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi,
         __syncthreads();
     }
 
-    double *out = slab + (size_t)split * mp * mp;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -115,9 +96,39 @@ __global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
-                if (row < mp && col < mp) out[(size_t)row * mp + col] = acc[mi][ni][r];
+                if (!EDGE || (row < mp && col < mp)) out[(size_t)row * mp + col] = acc[mi][ni][r];
             }
         }
+}
+
+template <bool WEIGHTED, bool TRI>
+__global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi, int ld,
+                                                  const double *__restrict__ wgt, int n_rows, int mp,
+                                                  int ntile, int rows_per_split,
+                                                  double *__restrict__ slab) {
+    __shared__ double sA[2][16][LDS_LD128];
+    __shared__ double sB[2][16][LDS_LD128];
+    __shared__ double sW[2][16];
+
+    const int npairs = ntile * (ntile + 1) / 2;
+    const int pair = blockIdx.x % npairs;
+    const int split = blockIdx.x / npairs;
+    // decode pair -> (ti <= tj), row-major over the upper triangle
+    int ti = 0, rem = pair;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
+    const int tj = ti + rem;
+    const bool diag_tile = (ti == tj);
+    const int i0 = ti * 128, j0 = tj * 128;
+
+    int r_begin = split * rows_per_split;
+    int r_end = min(n_rows, r_begin + rows_per_split);
+    if (TRI) r_begin = max(r_begin, j0 & ~15);
+    double *out = slab + (size_t)split * mp * mp;
+    // interior tiles take the guard-free body (no exec-mask branches in the K loop)
+    if (j0 + 128 <= mp)
+        syrk_body<WEIGHTED, false>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
+    else
+        syrk_body<WEIGHTED, true>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
 }
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
@@ -137,14 +148,15 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit, int m
 // T = PHI * B
 // ---------------------------------------------------------------------------------------------
 // PHI: n_pad x ld (row-major), B: mp x ldb (row-major), T: n_pad x ld.  n_pad % 128 == 0, mp % 16 == 0.
-__global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi, int ld,
-                                                   const double *__restrict__ B, int ldb,
-                                                   double *__restrict__ T, int mp, int nct) {
-    __shared__ double sA[2][128][18];
-    __shared__ double sB[2][16][LDS_LD128];
-
-    const int rt = blockIdx.x / nct, ct = blockIdx.x % nct;
-    const int i0 = rt * 128, j0 = ct * 128;
+// Optional fused epilogue (nupart != nullptr):
+//   nupart[(ct*2 + wc)*n_pad + row] = sum over this wave's 64 columns (< m) of PHI[row][col]*T[row][col]   (GPz.m:69)
+//   phiw[row] = T[row][mcol]  (= (PHI w)_row, GPz.m:77)
+template <bool EDGE>
+__device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int ld, const double *__restrict__ B,
+                                           int ldb, double *__restrict__ T, int mp, int i0, int j0,
+                                           double (*sA)[128][18], double (*sB)[16][LDS_LD128],
+                                           double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
+                                           long n_pad, int ct) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -164,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi
         for (int q = 0; q < 4; ++q) {
             int idx = q * 256 + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
-            rb[q] = (j0 + c < mp) ? *reinterpret_cast<const d2_t *>(B + (size_t)(k0 + row) * ldb + j0 + c)
-                                  : (d2_t){0.0, 0.0};
+            rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(B + (size_t)(k0 + row) * ldb + j0 + c)
+                                           : (d2_t){0.0, 0.0};
         }
     };
     auto lstore = [&](int buf) {
@@ -179,9 +191,12 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi
         }
     };
 
-    // number of valid 16-column MFMA tiles of this wave (last column tile may be partial)
-    int nvalid = (mp - (j0 + wc * 64) + 15) / 16;
-    nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
+    // number of valid 16-column MFMA tiles of this wave (only the last column tile can be partial)
+    int nvalid = 4;
+    if (EDGE) {
+        nvalid = (mp - (j0 + wc * 64) + 15) / 16;
+        nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
+    }
 
     const int nstage = mp / 16;
     gload(0);
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi
             for (int ni = 0; ni < 4; ++ni) b[ni] = sB[cur][kc][wc * 64 + ni * 16 + (lane & 15)];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                if (ni < nvalid) {
+                if (!EDGE || ni < nvalid) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
                 }
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
-            if (col < mp) {
+            if (!EDGE || col < mp) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
@@ -222,6 +237,41 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi
                 }
             }
         }
+    if (nupart) {
+        double *slot = nupart + (size_t)(ct * 2 + wc) * n_pad;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
+                double p = 0.0;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+                    if (col < m) p = fma(Phi[(size_t)row * ld + col], acc[mi][ni][r], p);
+                    if (col == mcol) phiw[row] = acc[mi][ni][r];
+                }
+                // sum over the 16 lanes that share this row (lane & 15 runs over columns)
+                p += __shfl_xor(p, 1, 64);
+                p += __shfl_xor(p, 2, 64);
+                p += __shfl_xor(p, 4, 64);
+                p += __shfl_xor(p, 8, 64);
+                if ((lane & 15) == 0) slot[row] = p;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi, int ld,
+                                                   const double *__restrict__ B, int ldb,
+                                                   double *__restrict__ T, int mp, int nct,
+                                                   double *__restrict__ nupart, double *__restrict__ phiw, int m,
+                                                   int mcol, long n_pad) {
+    __shared__ double sA[2][128][18];
+    __shared__ double sB[2][16][LDS_LD128];
+    const int rt = blockIdx.x / nct, ct = blockIdx.x % nct;
+    const int i0 = rt * 128, j0 = ct * 128;
+    if (j0 + 128 <= mp) tgemm_body<false>(Phi, ld, B, ldb, T, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+    else tgemm_body<true>(Phi, ld, B, ldb, T, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,10 +391,11 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, 
     hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, mp, S, lds);
 }
 
-void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp) {
+void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
+                  double *nupart, double *phiw, int m, int mcol) {
     const int nct = (mp + 127) / 128;
     dim3 grid((n_pad / 128) * nct), block(256);
-    hipLaunchKernelGGL(k_tgemm, grid, block, 0, st, Phi, ld, B, ldb, T, mp, nct);
+    hipLaunchKernelGGL(k_tgemm, grid, block, 0, st, Phi, ld, B, ldb, T, mp, nct, nupart, phiw, m, mcol, (long)n_pad);
 }
 
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb) {

@@ -82,14 +82,61 @@ void launch_unpack(hipStream_t st, const double *theta, int method_id, int m, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Covariance kinds: R_j = triangular factor of Gamma_j (Householder QR), c_j = R_j p_j.
+// |Gamma_j (x - p_j)|^2 = |R_j x - c_j|^2 exactly (orthogonal invariance), with d(d+1)/2 instead of d^2
+// multiply-adds per (sample, basis) pair and no loss of conditioning (no Gamma'Gamma is formed).
+// Rc[j] = [R packed upper row-major: row a holds b = a..de-1 | c (de)], stride de(de+1)/2 + de.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_prep_cov(const double *__restrict__ G, const double *__restrict__ P, int m, int de,
+                           double *__restrict__ Rc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double A[20 * 20], v[20];
+    const double *Gj = G + (size_t)j * de * de;
+    for (int e = 0; e < de * de; ++e) A[e] = Gj[e];          // A[r*de + c] = Gamma_j(r, c)
+    for (int c = 0; c < de; ++c) {
+        double n2 = 0.0;
+        for (int r = c; r < de; ++r) n2 = fma(A[r * de + c], A[r * de + c], n2);
+        if (n2 == 0.0) continue;
+        const double nrm = sqrt(n2);
+        const double acc = A[c * de + c];
+        const double alpha = (acc > 0.0) ? -nrm : nrm;
+        for (int r = c; r < de; ++r) v[r] = A[r * de + c];
+        v[c] -= alpha;
+        const double vn2 = n2 - acc * acc + v[c] * v[c];
+        for (int cc = c + 1; cc < de; ++cc) {
+            double dot = 0.0;
+            for (int r = c; r < de; ++r) dot = fma(v[r], A[r * de + cc], dot);
+            const double f = 2.0 * dot / vn2;
+            for (int r = c; r < de; ++r) A[r * de + cc] = fma(-f, v[r], A[r * de + cc]);
+        }
+        A[c * de + c] = alpha;
+        for (int r = c + 1; r < de; ++r) A[r * de + c] = 0.0;
+    }
+    const int nt = de * (de + 1) / 2;
+    double *o = Rc + (size_t)j * (nt + de);
+    const double *pj = P + (size_t)j * de;
+    int e = 0;
+    for (int a = 0; a < de; ++a) {
+        double s = 0.0;
+        for (int b = a; b < de; ++b) {
+            const double r = A[a * de + b];
+            o[e++] = r;
+            s = fma(r, pj[b], s);
+        }
+        o[nt + a] = s;
+    }
+}
+
+void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc) {
+    hipLaunchKernelGGL(k_prep_cov, dim3((m + 63) / 64), dim3(64), 0, st, G, P, m, de, Rc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // PHI build
 // ---------------------------------------------------------------------------------------------
-#define PHI_R 2   // rows per thread
-#ifndef PHI_UA
-#define PHI_UA 1  // unroll of the Gamma-row loop (keeps the scalar-load working set to one row)
-#endif
-
-template <int KIND, int D, bool KGEN>
+// R rows per thread, JB basis functions per LDS transposition block.
+template <int KIND, int D, bool KGEN, int R, int JB>
 __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
                                               const double *__restrict__ P, const double *__restrict__ G,
                                               const double *__restrict__ v, const double *__restrict__ bvec,
@@ -98,71 +145,69 @@ __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long
                                               double *__restrict__ wbeta, const double *__restrict__ wv,
                                               double *__restrict__ phiw) {
     constexpr int KM = KGEN ? 8 : 1;
-    __shared__ double tile[4][PHI_R][64][17];
+    constexpr int NT = D * (D + 1) / 2;
+    __shared__ double tile[4][R][64][JB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * PHI_R);
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
 
-    double x[PHI_R][D];
-    bool valid[PHI_R];
+    double x[R][D];
+    bool valid[R];
 #pragma unroll
-    for (int r = 0; r < PHI_R; ++r) {
+    for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
         valid[r] = i < n;
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[r][c] = valid[r] ? Xc[c * ldx + i] : 0.0;
+        for (int c = 0; c < D; ++c) x[r][c] = Xc[c * ldx + i];   // rows >= n are zero-padded
     }
-    double sv[PHI_R][KM], sw[PHI_R][KM];
+    double sv[R][KM], sw[R][KM];
 #pragma unroll
-    for (int r = 0; r < PHI_R; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int o = 0; o < KM; ++o) { sv[r][o] = 0.0; sw[r][o] = 0.0; }
 
-    for (int j0 = 0; j0 < mp; j0 += 16) {
+    for (int j0 = 0; j0 < mp; j0 += JB) {
 #pragma unroll 1
-        for (int jj = 0; jj < 16; ++jj) {
+        for (int jj = 0; jj < JB; ++jj) {
             const int j = j0 + jj;
-            double ph[PHI_R];
+            double ph[R];
             if (j < m) {
-                double q[PHI_R];
+                double q[R];
 #pragma unroll
-                for (int r = 0; r < PHI_R; ++r) q[r] = 0.0;
+                for (int r = 0; r < R; ++r) q[r] = 0.0;
                 if (KIND == GPZ_KIND_DIAG) {
                     const double *pj = P + (size_t)j * D, *gj = G + (size_t)j * D;   // G = gamma^2
 #pragma unroll
                     for (int c = 0; c < D; ++c) {
                         const double pc = pj[c], gc = gj[c];
 #pragma unroll
-                        for (int r = 0; r < PHI_R; ++r) {
+                        for (int r = 0; r < R; ++r) {
                             const double dl = x[r][c] - pc;
                             q[r] = fma(dl * dl, gc, q[r]);                 // getPHI.m:97  Delta.^2 ./ Sigma
                         }
                     }
                 } else {
-                    const double *pj = P + (size_t)j * D, *gj = G + (size_t)j * D * D;
-                    double dl[PHI_R][D];
+                    const double *rj = G + (size_t)j * (NT + D);                     // G = Rc (see k_prep_cov)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        const double pc = pj[c];
-#pragma unroll
-                        for (int r = 0; r < PHI_R; ++r) dl[r][c] = x[r][c] - pc;
-                    }
-#pragma unroll 2
                     for (int a = 0; a < D; ++a) {
-                        double s[PHI_R];
+                        double s[R];
+                        const double ca = rj[NT + a];
 #pragma unroll
-                        for (int r = 0; r < PHI_R; ++r) s[r] = 0.0;
+                        for (int r = 0; r < R; ++r) s[r] = -ca;
 #pragma unroll
-                        for (int b = 0; b < D; ++b) {
-                            const double g = gj[a * D + b];
+                        for (int b = a; b < D; ++b) {
+                            const double g = rj[a * D - a * (a - 1) / 2 + (b - a)];
 #pragma unroll
-                            for (int r = 0; r < PHI_R; ++r) s[r] = fma(g, dl[r][b], s[r]);
+                            for (int r = 0; r < R; ++r) s[r] = fma(g, x[r][b], s[r]);
                         }
 #pragma unroll
-                        for (int r = 0; r < PHI_R; ++r) q[r] = fma(s[r], s[r], q[r]);   // |Gamma_j Delta'|^2  (getPHI.m:73,76)
+                        for (int r = 0; r < R; ++r) q[r] = fma(s[r], s[r], q[r]);   // |R_j x - c_j|^2  (getPHI.m:73,76)
+                        // keep the scalar loads of later rows from being hoisted above this row: the whole factor
+                        // (d(d+1)/2 doubles) does not fit the SGPR file and would be spilled to VGPR lanes
+                        if ((a & 1) == 1) asm volatile("" ::: "memory");
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < PHI_R; ++r) {
+                for (int r = 0; r < R; ++r) {
                     ph[r] = valid[r] ? exp(-0.5 * q[r]) : 0.0;             // getPHI.m:113
 #pragma unroll
                     for (int o = 0; o < KM; ++o) {
@@ -175,32 +220,34 @@ __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long
             } else {
                 // padding columns: y in columns m..m+k-1 (the SYRK then yields PHI' W y for free), zeros after
 #pragma unroll
-                for (int r = 0; r < PHI_R; ++r) {
+                for (int r = 0; r < R; ++r) {
                     const long i = row0 + r * 64 + lane;
-                    ph[r] = (Y != nullptr && (j - m) < k && valid[r]) ? Y[(size_t)(j - m) * ldx + i] : 0.0;
+                    ph[r] = (Y != nullptr && (j - m) < k) ? Y[(size_t)(j - m) * ldx + i] : 0.0;   // zero-padded rows
                 }
             }
             if (Phi) {
 #pragma unroll
-                for (int r = 0; r < PHI_R; ++r) tile[wave][r][lane][jj] = ph[r];
+                for (int r = 0; r < R; ++r) tile[wave][r][lane][jj] = ph[r];
             }
         }
         if (Phi) {
             __syncthreads();
-            // wave-uniform base + 32-bit lane offset keeps the 32 stores from each holding a 64-bit address
+            // wave-uniform base + 32-bit lane offset; each store instruction covers 64/JB rows x JB columns
+            constexpr int RPI = 64 / JB;                    // rows per store instruction
             double *base = Phi + (size_t)row0 * mp + j0;
-            const unsigned loff = (unsigned)(lane >> 4) * (unsigned)mp + (unsigned)(lane & 15);
+            const int lr = lane / JB, lc = lane % JB;
+            const unsigned loff = (unsigned)lr * (unsigned)mp + (unsigned)lc;
 #pragma unroll 4
-            for (int q = 0; q < PHI_R * 16; ++q) {
-                const int r = q >> 4, it = q & 15;
-                base[loff + (unsigned)(r * 64 + it * 4) * (unsigned)mp] = tile[wave][r][it * 4 + (lane >> 4)][lane & 15];
+            for (int qq = 0; qq < R * JB; ++qq) {
+                const int r = qq / JB, it = qq % JB;
+                base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
             }
             __syncthreads();
         }
     }
 
 #pragma unroll
-    for (int r = 0; r < PHI_R; ++r) {
+    for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
 #pragma unroll
         for (int o = 0; o < KM; ++o) {
@@ -208,7 +255,7 @@ __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long
                 const double lb = bvec[o] + sv[r][o];                      // getPHI.m:119,124
                 lnbeta[(size_t)o * ldx + i] = valid[r] ? lb : 0.0;
                 if (wbeta) {
-                    const double om = omega ? (valid[r] ? omega[i] : 0.0) : 1.0;
+                    const double om = omega ? omega[i] : 1.0;
                     wbeta[(size_t)o * ldx + i] = valid[r] ? om * exp(-lb) : 0.0;   // GPz.m:43,48
                 }
                 if (phiw) phiw[(size_t)o * ldx + i] = sw[r][o];
@@ -217,16 +264,201 @@ __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long
     }
 }
 
-template <int KIND, int D>
-static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
-    const int rows_per_wg = 4 * 64 * PHI_R;
+// ---------------------------------------------------------------------------------------------
+// PHI build, covariance kinds.  Same thread mapping (lanes along rows, R rows per thread) but the per-basis
+// parameters [R_j | c_j] are staged once per workgroup into LDS for JB basis functions at a time and read back
+// as wave-uniform (broadcast) ds_reads: d(d+1)/2 + d doubles per basis do not fit the SGPR file, and each
+// LDS operand feeds R = 4 multiply-adds, so the LDS pipe stays well below the VALU time.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool KGEN, int R, int JB>
+__global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
+                                                  const double *__restrict__ Rc,
+                                                  const double *__restrict__ v, const double *__restrict__ bvec,
+                                                  const double *__restrict__ omega, const double *__restrict__ Y,
+                                                  double *__restrict__ Phi, double *__restrict__ lnbeta,
+                                                  double *__restrict__ wbeta, const double *__restrict__ wv,
+                                                  double *__restrict__ phiw) {
+    constexpr int KM = KGEN ? 8 : 1;
+    constexpr int NT = D * (D + 1) / 2;
+    constexpr int NP = NT + D;                       // doubles per basis function
+    constexpr int NPB = JB * NP;                     // doubles per parameter block
+    constexpr int NLD = (NPB + 255) / 256;           // staging loads per thread
+    __shared__ double tile[4][R][64][JB + 1];
+    __shared__ double prm[NPB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
+
+    double x[R][D];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long i = row0 + r * 64 + lane;
+        valid[r] = i < n;
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[r][c] = Xc[c * ldx + i];   // rows >= n are zero-padded
+    }
+    double sv[R][KM], sw[R][KM];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int o = 0; o < KM; ++o) { sv[r][o] = 0.0; sw[r][o] = 0.0; }
+
+    // parameters of block 0
+    double stg[NLD];
+    const size_t prm_total = (size_t)m * NP;
+    auto pload = [&](int j0) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 256 * q;
+            const size_t ge = (size_t)j0 * NP + e;
+            stg[q] = (e < NPB && ge < prm_total) ? Rc[ge] : 0.0;
+        }
+    };
+    auto pstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 256 * q;
+            if (e < NPB) prm[e] = stg[q];
+        }
+    };
+    pload(0);
+    pstore();
+    __syncthreads();
+
+    for (int j0 = 0; j0 < mp; j0 += JB) {
+        if (j0 + JB < m) pload(j0 + JB);             // in flight during the compute phase
+#pragma unroll 1
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            double ph[R];
+            if (j < m) {
+                const double *rj = prm + jj * NP;
+                double q[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) q[r] = 0.0;
+                // software-pipelined over the rows of R_j: the LDS (broadcast) reads of row a+1 are issued before
+                // the multiply-adds of row a, and sched_barrier keeps the compiler from hoisting every read of
+                // the factor to the top (which needs d(d+1) VGPRs and spills)
+                double gc[D + 1], gn[D + 1];
+#pragma unroll
+                for (int b = 0; b < D; ++b) gc[b] = rj[b];
+                gc[D] = rj[NT];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    if (a + 1 < D) {
+#pragma unroll
+                        for (int b = a + 1; b < D; ++b) gn[b] = rj[(a + 1) * D - (a + 1) * a / 2 + (b - a - 1)];
+                        gn[D] = rj[NT + a + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double s[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) s[r] = -gc[D];
+#pragma unroll
+                    for (int b = a; b < D; ++b) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) s[r] = fma(gc[b], x[r][b], s[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) q[r] = fma(s[r], s[r], q[r]);       // |R_j x - c_j|^2  (getPHI.m:73,76)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = a + 1; b <= D; ++b) gc[b] = gn[b];
+                }
+                double vj[KM], wj[KM];
+#pragma unroll
+                for (int o = 0; o < KM; ++o) {
+                    vj[o] = (v && o < k) ? v[j + (size_t)m * o] : 0.0;
+                    wj[o] = (wv && o < k) ? wv[j + (size_t)m * o] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double e = exp(-0.5 * q[r]);                             // getPHI.m:113
+                    ph[r] = valid[r] ? e : 0.0;
+#pragma unroll
+                    for (int o = 0; o < KM; ++o) {
+                        sv[r][o] = fma(ph[r], vj[o], sv[r][o]);                    // getPHI.m:124
+                        sw[r][o] = fma(ph[r], wj[o], sw[r][o]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const long i = row0 + r * 64 + lane;
+                    ph[r] = (Y != nullptr && (j - m) < k) ? Y[(size_t)(j - m) * ldx + i] : 0.0;   // zero-padded rows
+                }
+            }
+            if (Phi) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) tile[wave][r][lane][jj] = ph[r];
+            }
+        }
+        __syncthreads();                             // tile complete; every wave is done with prm
+        if (Phi) {
+            constexpr int RPI = 64 / JB;
+            double *base = Phi + (size_t)row0 * mp + j0;
+            const int lr = lane / JB, lc = lane % JB;
+            const unsigned loff = (unsigned)lr * (unsigned)mp + (unsigned)lc;
+#pragma unroll 4
+            for (int qq = 0; qq < R * JB; ++qq) {
+                const int r = qq / JB, it = qq % JB;
+                base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
+            }
+        }
+        if (j0 + JB < m) pstore();
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long i = row0 + r * 64 + lane;
+#pragma unroll
+        for (int o = 0; o < KM; ++o) {
+            if (o < k && i < ldx) {
+                const double lb = bvec[o] + sv[r][o];                      // getPHI.m:119,124
+                lnbeta[(size_t)o * ldx + i] = valid[r] ? lb : 0.0;
+                if (wbeta) {
+                    const double om = omega ? omega[i] : 1.0;
+                    wbeta[(size_t)o * ldx + i] = valid[r] ? om * exp(-lb) : 0.0;   // GPz.m:43,48
+                }
+                if (phiw) phiw[(size_t)o * ldx + i] = sw[r][o];
+            }
+        }
+    }
+}
+
+template <int D>
+static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
+    // 4 rows per thread and 8-wide blocks while [tile | params] fits twice in a CU's LDS; else 2 rows
+    constexpr int NP = D * (D + 1) / 2 + D;
+    constexpr bool BIG = (4 * 4 * 64 * 9 + 8 * NP) * 8 * 2 <= 160 * 1024;
+    constexpr int R = BIG ? 4 : 2;
+    constexpr int JB = 8;
+    const int rows_per_wg = 4 * 64 * R;
     const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
     if (a.k == 1)
-        hipLaunchKernelGGL((k_phi<KIND, D, false>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,
+        hipLaunchKernelGGL((k_phi_cov<D, false, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
                            a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
     else
-        hipLaunchKernelGGL((k_phi<KIND, D, true>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,
+        hipLaunchKernelGGL((k_phi_cov<D, true, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
                            a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
+}
+
+template <int KIND, int D>
+static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
+    if (KIND == GPZ_KIND_COV) {
+        launch_phi_cov_d<D>(st, a);
+        return;
+    }
+    constexpr int R = 2, JB = 16;                    // diagonal kinds are store-bound
+    const int rows_per_wg = 4 * 64 * R;
+    const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
+    if (a.k == 1)
+        hipLaunchKernelGGL((k_phi<GPZ_KIND_DIAG, D, false, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m,
+                           a.mp, a.k, a.P, a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
+    else
+        hipLaunchKernelGGL((k_phi<GPZ_KIND_DIAG, D, true, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m,
+                           a.mp, a.k, a.P, a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
 }
 
 template <int KIND>

@@ -267,6 +267,206 @@ int launch_moments(hipStream_t st, const MomentArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused single-output path (k == 1): no dPHI matrix is ever written.
+// ---------------------------------------------------------------------------------------------
+// Row scalars from the T-GEMM epilogue's partial sums (GPz.m:69,77-79,93) + the scalar sums of GPz.m:81,94,236-237.
+__global__ __launch_bounds__(256) void k_row_scalars(const double *__restrict__ nupart, int nslots,
+                                                      const double *__restrict__ phiw, const double *__restrict__ y,
+                                                      const double *__restrict__ omega,
+                                                      const double *__restrict__ lnbeta,
+                                                      const double *__restrict__ wbeta, long n_pad, int n,
+                                                      double *__restrict__ rowscal, double *__restrict__ partial) {
+    __shared__ double sh4[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double nu = 0.0;
+        for (int q = 0; q < nslots; ++q) nu += nupart[(size_t)q * n_pad + i];
+        const double delta = phiw[i] - y[i];
+        const double lb = lnbeta[i];
+        const double beta = exp(-lb);
+        const double om = omega ? omega[i] : 1.0;
+        const double ob = wbeta[i];
+        const double dbeta = 0.5 * (-beta) * (1.0 / beta - (delta * delta + nu)) * om;   // GPz.m:93
+        const double c = ob * delta;
+        double *rs = rowscal + (size_t)i * 4;
+        rs[0] = ob; rs[1] = c; rs[2] = dbeta; rs[3] = 0.0;
+        s0 = fma(c, delta, s0);
+        s1 = fma(om, delta * delta, s1);
+        s2 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
+        s3 += dbeta;
+    }
+    s0 = block_sum_256(s0, sh4); __syncthreads();
+    s1 = block_sum_256(s1, sh4); __syncthreads();
+    s2 = block_sum_256(s2, sh4); __syncthreads();
+    s3 = block_sum_256(s3, sh4);
+    if (threadIdx.x == 0) {
+        double *pw = partial + (size_t)blockIdx.x * GPZ_NS;
+        pw[0] = s0; pw[1] = s1; pw[2] = s2; pw[3] = s3;
+        for (int q = 4; q < GPZ_NS; ++q) pw[q] = 0.0;
+    }
+}
+
+void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
+                        const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
+                        double *rowscal, double *partial) {
+    hipLaunchKernelGGL(k_row_scalars, dim3(GPZ_SMALL_NWG), dim3(256), 0, st, nupart, nslots, phiw, y, omega, lnbeta, wbeta,
+                       n_pad, n, rowscal, partial);
+}
+
+// Moments with dPHI_ij = (-omega beta_i T_ij - c_i w_j + dbeta_i v_j) * PHI_ij formed on the fly (GPz.m:72,90,106,113),
+// plus the column sums PHI'c and PHI'dbeta (GPz.m:89,104).  Lanes along basis functions; row data (x_i, row scalars)
+// are wave-uniform.  UR rows are in flight per thread to cover the HBM latency.
+template <int KIND, int D, int A0, int A1, int UR>
+__global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict__ Phi, const double *__restrict__ T,
+                                                        int ld, const double *__restrict__ Xr,
+                                                        const double *__restrict__ rowscal, int n, int m,
+                                                        const double *__restrict__ P, const double *__restrict__ w,
+                                                        const double *__restrict__ v, int rows_per_chunk,
+                                                        double *__restrict__ slab, int nm) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int chunk = blockIdx.x;
+    const bool act = j < m;
+    const int jc = act ? j : 0;
+    double p[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) p[c] = P[(size_t)jc * D + c];
+    const double wj = w[jc], vj = v ? v[jc] : 0.0;
+    constexpr int NS = (KIND == GPZ_KIND_COV) ? ((A1 - A0) * D - (A1 * (A1 - 1) / 2 - A0 * (A0 - 1) / 2)) : D;
+    double M1[D], S[NS];
+    double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) M1[c] = 0.0;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) S[e] = 0.0;
+    const int r0 = chunk * rows_per_chunk;
+    const int rend = min(n, r0 + rows_per_chunk);
+    for (int ib = r0; ib < rend; ib += UR) {
+        double ph[UR], tt[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int i = min(ib + u, rend - 1);
+            ph[u] = Phi[(size_t)i * ld + jc];
+            tt[u] = T[(size_t)i * ld + jc];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int i = ib + u;
+            if (i < rend) {
+                const double *rs = rowscal + (size_t)i * 4;
+                const double ob = rs[0], cc = rs[1], db = rs[2];
+                const double dp = (-ob * tt[u] - cc * wj + db * vj) * ph[u];
+                if (A0 == 0) {
+                    r1 = fma(ph[u], cc, r1);
+                    r2 = fma(ph[u], db, r2);
+                }
+                const double *xi = Xr + (size_t)i * D;
+                if (KIND == GPZ_KIND_COV) {
+                    double dl[D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dl[c] = xi[c] - p[c];
+                    if (A0 == 0) {
+#pragma unroll
+                        for (int c = 0; c < D; ++c) M1[c] = fma(dp, dl[c], M1[c]);
+                    }
+                    int e = 0;
+#pragma unroll
+                    for (int aa = A0; aa < A1; ++aa) {
+                        const double t = dp * dl[aa];
+#pragma unroll
+                        for (int bb = aa; bb < D; ++bb) { S[e] = fma(t, dl[bb], S[e]); ++e; }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        const double dl = xi[c] - p[c];
+                        const double t = dp * dl;
+                        M1[c] += t;
+                        S[c] = fma(t, dl, S[c]);
+                    }
+                }
+            }
+        }
+    }
+    if (act) {
+        double *o = slab + ((size_t)chunk * m + j) * (nm + 2);
+        if (A0 == 0) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] = M1[c];
+            o[nm] = r1;
+            o[nm + 1] = r2;
+        }
+        if (KIND == GPZ_KIND_COV) {
+            int e = 0;
+#pragma unroll
+            for (int aa = A0; aa < A1; ++aa) {
+                const int roff = D + aa * D - aa * (aa - 1) / 2;
+#pragma unroll
+                for (int bb = aa; bb < D; ++bb) { o[roff + (bb - aa)] = S[e]; ++e; }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[D + c] = S[c];
+        }
+    }
+}
+
+#define MOMF(KIND, D, A0, A1) \
+    hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, 4>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, a.m, \
+                       a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm)
+
+int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
+    dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
+    if (a.kind == GPZ_KIND_COV) {
+        switch (a.d) {
+            case 1: MOMF(GPZ_KIND_COV, 1, 0, 1); break;
+            case 2: MOMF(GPZ_KIND_COV, 2, 0, 2); break;
+            case 3: MOMF(GPZ_KIND_COV, 3, 0, 3); break;
+            case 4: MOMF(GPZ_KIND_COV, 4, 0, 4); break;
+            case 5: MOMF(GPZ_KIND_COV, 5, 0, 5); break;
+            case 6: MOMF(GPZ_KIND_COV, 6, 0, 6); break;
+            case 8: MOMF(GPZ_KIND_COV, 8, 0, 8); break;
+            case 10: MOMF(GPZ_KIND_COV, 10, 0, 10); break;
+            case 12: MOMF(GPZ_KIND_COV, 12, 0, 5); MOMF(GPZ_KIND_COV, 12, 5, 12); break;
+            case 16: MOMF(GPZ_KIND_COV, 16, 0, 4); MOMF(GPZ_KIND_COV, 16, 4, 9); MOMF(GPZ_KIND_COV, 16, 9, 16); break;
+            case 20: MOMF(GPZ_KIND_COV, 20, 0, 3); MOMF(GPZ_KIND_COV, 20, 3, 7); MOMF(GPZ_KIND_COV, 20, 7, 12);
+                     MOMF(GPZ_KIND_COV, 20, 12, 20); break;
+            default: return -1;
+        }
+    } else {
+        switch (a.d) {
+            case 1: MOMF(GPZ_KIND_DIAG, 1, 0, 1); break;
+            case 2: MOMF(GPZ_KIND_DIAG, 2, 0, 2); break;
+            case 3: MOMF(GPZ_KIND_DIAG, 3, 0, 3); break;
+            case 4: MOMF(GPZ_KIND_DIAG, 4, 0, 4); break;
+            case 5: MOMF(GPZ_KIND_DIAG, 5, 0, 5); break;
+            case 6: MOMF(GPZ_KIND_DIAG, 6, 0, 6); break;
+            case 8: MOMF(GPZ_KIND_DIAG, 8, 0, 8); break;
+            case 10: MOMF(GPZ_KIND_DIAG, 10, 0, 10); break;
+            case 12: MOMF(GPZ_KIND_DIAG, 12, 0, 12); break;
+            case 16: MOMF(GPZ_KIND_DIAG, 16, 0, 16); break;
+            case 20: MOMF(GPZ_KIND_DIAG, 20, 0, 20); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+__global__ void k_split_fused(const double *__restrict__ rec, int m, int nm, int mp, double *__restrict__ mom,
+                              double *__restrict__ cols) {
+    const int gs = blockDim.x * gridDim.x;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * (nm + 2); e += gs) {
+        const int j = e / (nm + 2), q = e % (nm + 2);
+        const double v = rec[e];
+        if (q < nm) mom[(size_t)j * nm + q] = v;
+        else cols[(size_t)(q - nm) * mp + j] = v;
+    }
+}
+
+void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols) {
+    hipLaunchKernelGGL(k_split_fused, dim3(256), dim3(256), 0, st, rec, m, nm, mp, mom, cols);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Finish: chain the moments to dP/dGamma (GPz.m:146-159,189-194), method reduction (:215-225),
 // the m-sized gradient blocks (:73,89,94,104,105), the objective (:81-82,103,110,233) and the
 // statistics (:236-237,258-259).  p_e = padded dimension of the parameter block.

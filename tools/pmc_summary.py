@@ -1,0 +1,43 @@
+"""Summarise the counter passes written by tools/pmc_run.sh into a text file under profiles/.
+usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/<name>.txt"""
+import collections
+import csv
+import sys
+
+base, dst = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+data = {}
+for f in ("sq", "sq2", "fetch", "write"):
+    for k, cs in load(base + f + "/p_counter_collection.csv").items():
+        for c, v in cs.items():
+            data.setdefault(k, {})[c] = sum(v) / len(v)
+keys = [k for k in data if k.startswith(("k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue"))]
+with open(dst, "w") as out:
+    out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
+              "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X; one counter group per pass; tools/pmc_run.sh)\n"
+              "# per-launch averages.  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles;\n"
+              "# SQ_VALU_MFMA_BUSY_CYCLES in cycles (= 64 x N_mfma for v_mfma_f64_16x16x4_f64); GRBM_GUI_ACTIVE is summed over\n"
+              "# the 8 XCDs (divide by 8 for kernel cycles); FETCH_SIZE / WRITE_SIZE in KB at the L2 fabric side; FETCH_SIZE reads\n"
+              "# 1/2 of the bytes of wide streaming loads on gfx950 (MI355X_MICROARCH.md, HBM section) -> 'x2 corrected'.\n")
+    for k in sorted(keys):
+        d = data[k]
+        out.write("\n%s\n" % k)
+        for c in sorted(d):
+            out.write("   %-30s %.6g\n" % (c, d[c]))
+        cyc = d.get("GRBM_GUI_ACTIVE", 0) / 8
+        if d.get("SQ_INSTS_MFMA", 0) > 0 and cyc > 0:
+            util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
+            out.write("   -> kernel cycles (GRBM/8) %.4g; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) = %.1f %%\n"
+                      % (cyc, 100 * util))
+        if "FETCH_SIZE" in d:
+            out.write("   -> fabric-side bytes per launch: fetch %.2f GB (x2 corrected %.2f GB), write %.2f GB\n"
+                      % (d["FETCH_SIZE"] * 1024 / 1e9, 2 * d["FETCH_SIZE"] * 1024 / 1e9, d.get("WRITE_SIZE", 0) * 1024 / 1e9))
+print(open(dst).read())
