@@ -93,6 +93,10 @@ struct RowSet {          // a device-resident row selection of the data
     double *Xr = nullptr;   // n_pad x de
     double *Y = nullptr;    // k x n_pad
     double *om = nullptr;   // n_pad (nullptr => ones)
+    // diagonal kinds only: input-noise variances and the observed-dimension mask (nullptr => absent)
+    double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)
+    double *Mc = nullptr, *Mr = nullptr;       // 1.0 observed / 0.0 missing
+    double *ucnt = nullptr;                    // number of missing dimensions per row
 };
 
 struct StageTimer {
@@ -164,6 +168,7 @@ struct gpz_ctx {
     bool timing = false;
     StageTimer tm;
     bool phi_valid = false;
+    bool has_psi = false, has_missing = false;
 };
 
 // ---- stage timing ------------------------------------------------------------------------------
@@ -198,7 +203,7 @@ static void collect_timings(gpz_ctx *c) {
 
 // ---- context creation ---------------------------------------------------------------------------
 static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X, const double *Y, const double *omega,
-                         const uint8_t *mask, bool need_xr) {
+                         const uint8_t *mask, bool need_xr, const double *Psi = nullptr) {
     const int d = c->d, de = c->de, k = c->k;
     std::vector<int64_t> idx;
     idx.reserve((size_t)n_tot);
@@ -207,17 +212,49 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
     rs.n = (int)idx.size();
     rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 1024);   // multiple of the PHI kernel's rows per workgroup (4 waves x 64 lanes x 4 rows)
     const size_t np = (size_t)rs.n_pad;
-    std::vector<double> h(np * (size_t)de, 0.0);
+    // column-layout (de x n_pad) and row-layout (n_pad x de) uploads of a per-(row, dim) quantity
+    auto up2 = [&](const std::vector<double> &cm, double **dc, double **dr, bool want_r) -> int {
+        if (int e = c->ar.alloc(dc, np * de)) return e;
+        HIPCHK(hipMemcpy(*dc, cm.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
+        if (want_r) {
+            std::vector<double> rm(np * (size_t)de, 0.0);
+            for (int c_ = 0; c_ < de; ++c_)
+                for (size_t r = 0; r < idx.size(); ++r) rm[r * de + c_] = cm[(size_t)c_ * np + r];
+            if (int e = c->ar.alloc(dr, np * de)) return e;
+            HIPCHK(hipMemcpy(*dr, rm.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return 0;
+    };
+    std::vector<double> h(np * (size_t)de, 0.0), hm;
+    bool any_missing = false;
     for (int c_ = 0; c_ < d; ++c_)
-        for (size_t r = 0; r < idx.size(); ++r) h[(size_t)c_ * np + r] = X[(size_t)c_ * n_tot + idx[r]];
-    if (int e = c->ar.alloc(&rs.Xc, np * de)) return e;
-    HIPCHK(hipMemcpy(rs.Xc, h.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
-    if (need_xr) {
-        std::fill(h.begin(), h.end(), 0.0);
-        for (size_t r = 0; r < idx.size(); ++r)
-            for (int c_ = 0; c_ < d; ++c_) h[r * de + c_] = X[(size_t)c_ * n_tot + idx[r]];
-        if (int e = c->ar.alloc(&rs.Xr, np * de)) return e;
-        HIPCHK(hipMemcpy(rs.Xr, h.data(), np * de * sizeof(double), hipMemcpyHostToDevice));
+        for (size_t r = 0; r < idx.size(); ++r) {
+            const double xv = X[(size_t)c_ * n_tot + idx[r]];
+            if (xv != xv) any_missing = true;                              // isnan(X)  getPHI.m:43
+            h[(size_t)c_ * np + r] = (xv != xv) ? 0.0 : xv;
+        }
+    if (int e = up2(h, &rs.Xc, &rs.Xr, need_xr)) return e;
+    if (any_missing || c->has_missing) {
+        c->has_missing = true;
+        hm.assign(np * (size_t)de, 1.0);
+        std::vector<double> hu(np, 0.0);
+        for (int c_ = 0; c_ < d; ++c_)
+            for (size_t r = 0; r < idx.size(); ++r) {
+                const double xv = X[(size_t)c_ * n_tot + idx[r]];
+                if (xv != xv) { hm[(size_t)c_ * np + r] = 0.0; hu[r] += 1.0; }
+            }
+        if (int e = up2(hm, &rs.Mc, &rs.Mr, need_xr)) return e;
+        if (int e = c->ar.alloc(&rs.ucnt, np)) return e;
+        HIPCHK(hipMemcpy(rs.ucnt, hu.data(), np * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (Psi) {   // n_tot x d (fixPsi.m:42-53); entries of missing dimensions are never read by the reference
+        std::vector<double> hp(np * (size_t)de, 0.0);
+        for (int c_ = 0; c_ < d; ++c_)
+            for (size_t r = 0; r < idx.size(); ++r) {
+                const double xv = X[(size_t)c_ * n_tot + idx[r]];
+                hp[(size_t)c_ * np + r] = (xv != xv) ? 0.0 : Psi[(size_t)c_ * n_tot + idx[r]];
+            }
+        if (int e = up2(hp, &rs.Psic, &rs.Psir, need_xr)) return e;
     }
     std::vector<double> hy(np * (size_t)k, 0.0);
     for (int o = 0; o < k; ++o)
@@ -306,15 +343,23 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
                               const uint8_t *validation, gpz_ctx **out) {
     if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
     *out = nullptr;
-    if (Psi || psi_kind != 0)
-        return fail(GPZ_ERR_UNSUPPORTED, "input-noise (Psi) paths (getPHI.m:78-89,100-106) are not built yet");
     gpz_ctx *c = new gpz_ctx();
     int rc = setup_model(c, desc);
     if (rc) { delete c; return rc; }
-    if (has_nan(X, n_tot * (int64_t)c->d)) {
+    if ((Psi != nullptr) != (psi_kind != 0)) { delete c; return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree"); }
+    if (Psi && c->kind == GPZ_KIND_COV) {
         delete c;
-        return fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs are not built yet (getPHI.m:43-54 groups available via gpz_nan_groups)");
+        return fail(GPZ_ERR_UNSUPPORTED, "input noise with GC/VC (getPHI.m:78-89, GPz.m:164-185) is not built yet");
     }
+    if (Psi && psi_kind != 1) { delete c; return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)"); }
+    if (c->kind == GPZ_KIND_COV && has_nan(X, n_tot * (int64_t)c->d)) {
+        delete c;
+        return fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs with GC/VC (getPHI.m:76, GPz.m:151-159) are not built yet");
+    }
+    c->has_psi = Psi != nullptr;
+    if (c->has_psi) c->nm = 3 * c->de;
+    // one missing value anywhere (training or validation rows) switches the mask arrays on for both row sets
+    c->has_missing = has_nan(X, n_tot * (int64_t)c->d) != 0;
     auto bail = [&](int code) {
         c->ar.release();
         if (c->out_h) (void)hipHostFree(c->out_h);
@@ -323,7 +368,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         return code;
     };
     if (hipSetDevice(c->device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device));
-    if ((rc = upload_rowset(c, c->tr, n_tot, X, Y, omega, training, true))) return bail(rc);
+    if ((rc = upload_rowset(c, c->tr, n_tot, X, Y, omega, training, true, Psi))) return bail(rc);
     if (c->tr.n < 1 && desc->world <= 1) return bail(fail(GPZ_ERR_ARG, "training mask selects no rows"));
     bool any_valid = false;
     if (validation)
@@ -331,7 +376,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     // with sharding a rank may hold no validation rows while others do: the caller signals "validation in use"
     // by passing a non-NULL mask
     if (validation && (any_valid || desc->world > 1)) {
-        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, false))) return bail(rc);
+        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, false, Psi))) return bail(rc);
         if (!omega) c->va.om = nullptr;
     }
     if ((rc = alloc_params(c))) return bail(rc);
@@ -467,6 +512,7 @@ static int stage_a(gpz_ctx *c, const double *theta) {
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = c->tr.Y;
         a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
+        a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
     }
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
@@ -556,6 +602,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
             a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.rowscal = c->rowscal; a.n = c->tr.n; a.m = c->m;
             a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w; a.v = c->hetero ? c->pr.v : nullptr;
             a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk; a.slab = c->mom_slab; a.nm = c->nm;
+            a.Psir = c->tr.Psir; a.Mr = c->tr.Mr; a.G2 = c->pr.G2;
             if (launch_moments_fused(c->st, a))
                 return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
             launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * (c->nm + 2), c->frec);
@@ -584,6 +631,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         a.dPhi = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.d = c->de;
         a.kind = c->kind; a.P = c->pr.P; a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk;
         a.slab = c->mom_slab; a.nm = c->nm;
+        a.Psir = c->tr.Psir; a.Mr = c->tr.Mr; a.G2 = c->pr.G2;
         if (launch_moments(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
         launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * c->nm, mom);
     }
@@ -596,6 +644,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta_v; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw_v;
+        a.Psic = c->va.Psic; a.Mc = c->va.Mc; a.ucnt = c->va.ucnt;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
@@ -613,7 +662,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         a.g_dim = c->g_dim; a.pr = c->pr; a.mom = mom; a.nm = c->nm; a.cols = cols; a.scal = scal;
         a.w = c->w; a.dwda = c->dwda; a.dgi = c->dgi; a.logdet = c->logdet;
         a.sums1 = c->comm1 + k * mp * mp; a.vsums = have_valid ? vsums : nullptr; a.info = c->info;
-        a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de;
+        a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de; a.psi = c->has_psi ? 1 : 0;
         launch_finish(c->st, a);
     }
     HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 8) * sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -652,6 +701,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw;
+        a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);

@@ -39,6 +39,10 @@ struct PhiArgs {
     double *wbeta;       // k x ldx  (omega .* exp(-lnbeta)), or nullptr
     const double *w;     // m x k: when non-null, phiw[o*ldx + i] = sum_j PHI_ij w_jo
     double *phiw;        // k x ldx
+    // diagonal kinds only (nullptr = absent): input-noise variances, observed mask (1/0), missing count per row
+    const double *Psic;  // d x ldx   (fixPsi.m layout n x d, zero where missing)
+    const double *Mc;    // d x ldx
+    const double *ucnt;  // ldx
 };
 void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
@@ -90,7 +94,8 @@ struct MomentArgs {
     const double *P;
     int nchunk, rows_per_chunk;
     double *slab;            // [nchunk][m][nm]
-    int nm;                  // moments per basis: cov d + d(d+1)/2, diag 2d
+    int nm;                  // moments per basis: cov d + d(d+1)/2, diag 2d (3d with Psi)
+    const double *Psir, *Mr, *G2;   // diag kinds: Psi rows (n_pad x d), observed mask rows, gamma^2 (nullptr = absent)
 };
 int launch_moments(hipStream_t st, const MomentArgs &a);
 
@@ -108,6 +113,7 @@ struct FusedMomentArgs {
     int nchunk, rows_per_chunk;
     double *slab;              // [nchunk][m][nm + 2]: moments, then PHI'(omega beta delta), PHI'dbeta
     int nm;
+    const double *Psir, *Mr, *G2;   // as in MomentArgs
 };
 int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a);
 // split the reduced [m][nm+2] records into mom [m][nm] and cols [2][mp]
@@ -130,6 +136,7 @@ struct FinishArgs {
     int p;
     int nmp;                              // leading dimension of cols (= mp)
     int de;                               // padded dimension of the parameter block / moments
+    int psi;                              // diag kinds with input noise: moments are [A1|A2|A3]
 };
 void launch_finish(hipStream_t st, const FinishArgs &a);
 

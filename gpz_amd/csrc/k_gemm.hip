@@ -56,19 +56,21 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         if (WEIGHTED && tid < 16) sW[buf][tid] = rw;
     };
 
+    // Software pipeline: the global loads of slice s+2 are issued in the middle of slice s, right after slice s+1
+    // has been written to the other LDS buffer, so every load has a full slice of MFMA work to land and the
+    // LDS writes sit between the two MFMA halves instead of in front of the barrier.
     const int nstage = (r_end > r_begin) ? (r_end - r_begin) / 16 : 0;
     if (nstage > 0) {
         gload(r_begin);
         lstore(0);
+        if (nstage > 1) gload(r_begin + 16);
     }
     __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nstage) gload(r_begin + (s + 1) * 16);
+    auto mfma_half = [&](int cur, int kk0) {
         const double(*tA)[LDS_LD128] = sA[cur];
         const double(*tB)[LDS_LD128] = diag_tile ? sA[cur] : sB[cur];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int krow = kk * 4 + (lane >> 4);
             double a[4], b[4];
             const double wv = WEIGHTED ? sW[cur][krow] : 1.0;
@@ -84,7 +86,15 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
         }
-        if (s + 1 < nstage) lstore(cur ^ 1);
+    };
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        mfma_half(cur, 0);
+        if (s + 1 < nstage) {
+            lstore(cur ^ 1);
+            if (s + 2 < nstage) gload(r_begin + (s + 2) * 16);
+        }
+        mfma_half(cur, 2);
         __syncthreads();
     }
 
@@ -198,15 +208,15 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
     }
 
+    // Software pipeline as in syrk_body: loads of slice s+2 issued mid-slice s, LDS writes between the MFMA halves.
     const int nstage = mp / 16;
     gload(0);
     lstore(0);
+    if (nstage > 1) gload(16);
     __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nstage) gload((s + 1) * 16);
+    auto mfma_half = [&](int cur, int kk0) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int kc = kk * 4 + (lane >> 4);
             double a[4], b[4];
 #pragma unroll
@@ -220,7 +230,15 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                     for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
                 }
         }
-        if (s + 1 < nstage) lstore(cur ^ 1);
+    };
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        mfma_half(cur, 0);
+        if (s + 1 < nstage) {
+            lstore(cur ^ 1);
+            if (s + 2 < nstage) gload((s + 2) * 16);
+        }
+        mfma_half(cur, 2);
         __syncthreads();
     }
 

@@ -135,29 +135,38 @@ void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, in
 // ---------------------------------------------------------------------------------------------
 // PHI build
 // ---------------------------------------------------------------------------------------------
-// R rows per thread, JB basis functions per LDS transposition block.
-template <int KIND, int D, bool KGEN, int R, int JB>
-__global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
-                                              const double *__restrict__ P, const double *__restrict__ G,
-                                              const double *__restrict__ v, const double *__restrict__ bvec,
-                                              const double *__restrict__ omega, const double *__restrict__ Y,
-                                              double *__restrict__ Phi, double *__restrict__ lnbeta,
-                                              double *__restrict__ wbeta, const double *__restrict__ wv,
-                                              double *__restrict__ phiw) {
+// Diagonal kinds (GL, VL, GD, VD).  R rows per thread, JB basis functions per LDS transposition block.
+//   no Psi  (getPHI.m:97):   ln PHI = -1/2 sum_c Delta_c^2 gamma_c^2
+//   Psi     (getPHI.m:104):  ln PHI = -1/2 sum_c Delta_c^2/(psi_c + sigma_c) - 1/2 sum_c ln(1 + psi_c/sigma_c),  sigma = gamma^-2
+//   missing dimensions (NaN in X; getPHI.m:64-69,97,104): dropped from the sums, minus 1/2 |u_i| ln 2.
+// Mc (optional) is the observed-mask (1.0 / 0.0) in the layout of Xc; X and Psi hold 0 at missing entries.
+template <int D, bool KGEN, bool PSI, int R, int JB>
+__global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
+                                                   const double *__restrict__ P, const double *__restrict__ G,
+                                                   const double *__restrict__ v, const double *__restrict__ bvec,
+                                                   const double *__restrict__ omega, const double *__restrict__ Y,
+                                                   double *__restrict__ Phi, double *__restrict__ lnbeta,
+                                                   double *__restrict__ wbeta, const double *__restrict__ wv,
+                                                   double *__restrict__ phiw, const double *__restrict__ Psic,
+                                                   const double *__restrict__ Mc, const double *__restrict__ ucnt) {
     constexpr int KM = KGEN ? 8 : 1;
-    constexpr int NT = D * (D + 1) / 2;
     __shared__ double tile[4][R][64][JB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
 
-    double x[R][D];
+    double x[R][D], ps[PSI ? R : 1][PSI ? D : 1], mk[R][D], q0[R];
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
         valid[r] = i < n;
+        q0[r] = ucnt ? ucnt[i] * GPZ_LOG2 : 0.0;                          // |u_i| ln 2
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[r][c] = Xc[c * ldx + i];   // rows >= n are zero-padded
+        for (int c = 0; c < D; ++c) {
+            x[r][c] = Xc[c * ldx + i];                                     // rows >= n are zero-padded
+            mk[r][c] = Mc ? Mc[c * ldx + i] : 1.0;
+            if (PSI) ps[r][c] = Psic[c * ldx + i];
+        }
     }
     double sv[R][KM], sw[R][KM];
 #pragma unroll
@@ -171,43 +180,28 @@ __global__ __launch_bounds__(256) void k_phi(const double *__restrict__ Xc, long
             const int j = j0 + jj;
             double ph[R];
             if (j < m) {
-                double q[R];
+                double q[R], pr[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) q[r] = 0.0;
-                if (KIND == GPZ_KIND_DIAG) {
-                    const double *pj = P + (size_t)j * D, *gj = G + (size_t)j * D;   // G = gamma^2
+                for (int r = 0; r < R; ++r) { q[r] = q0[r]; pr[r] = 1.0; }
+                const double *pj = P + (size_t)j * D, *gj = G + (size_t)j * D;   // G = gamma^2 = 1/sigma
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        const double pc = pj[c], gc = gj[c];
+                for (int c = 0; c < D; ++c) {
+                    const double pc = pj[c], gc = gj[c];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const double dl = x[r][c] - pc;
+                    for (int r = 0; r < R; ++r) {
+                        const double dl = (x[r][c] - pc) * mk[r][c];
+                        if (PSI) {
+                            const double u = fma(ps[r][c], gc, 1.0);       // 1 + psi/sigma  (psi = 0 where missing)
+                            q[r] = fma(dl * dl, gc / u, q[r]);             // Delta^2/(psi+sigma)
+                            pr[r] *= u;
+                        } else {
                             q[r] = fma(dl * dl, gc, q[r]);                 // getPHI.m:97  Delta.^2 ./ Sigma
                         }
-                    }
-                } else {
-                    const double *rj = G + (size_t)j * (NT + D);                     // G = Rc (see k_prep_cov)
-#pragma unroll
-                    for (int a = 0; a < D; ++a) {
-                        double s[R];
-                        const double ca = rj[NT + a];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) s[r] = -ca;
-#pragma unroll
-                        for (int b = a; b < D; ++b) {
-                            const double g = rj[a * D - a * (a - 1) / 2 + (b - a)];
-#pragma unroll
-                            for (int r = 0; r < R; ++r) s[r] = fma(g, x[r][b], s[r]);
-                        }
-#pragma unroll
-                        for (int r = 0; r < R; ++r) q[r] = fma(s[r], s[r], q[r]);   // |R_j x - c_j|^2  (getPHI.m:73,76)
-                        // keep the scalar loads of later rows from being hoisted above this row: the whole factor
-                        // (d(d+1)/2 doubles) does not fit the SGPR file and would be spilled to VGPR lanes
-                        if ((a & 1) == 1) asm volatile("" ::: "memory");
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    if (PSI) q[r] += log(pr[r]);                           // sum_c ln(1 + psi/sigma)
                     ph[r] = valid[r] ? exp(-0.5 * q[r]) : 0.0;             // getPHI.m:113
 #pragma unroll
                     for (int o = 0; o < KM; ++o) {
@@ -453,12 +447,12 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     constexpr int R = 2, JB = 16;                    // diagonal kinds are store-bound
     const int rows_per_wg = 4 * 64 * R;
     const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
-    if (a.k == 1)
-        hipLaunchKernelGGL((k_phi<GPZ_KIND_DIAG, D, false, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m,
-                           a.mp, a.k, a.P, a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
-    else
-        hipLaunchKernelGGL((k_phi<GPZ_KIND_DIAG, D, true, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m,
-                           a.mp, a.k, a.P, a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
+#define PHI_DIAG(KG, PS) \
+    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P, \
+                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt)
+    if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
+    else { if (a.Psic) PHI_DIAG(true, true); else PHI_DIAG(true, false); }
+#undef PHI_DIAG
 }
 
 template <int KIND>

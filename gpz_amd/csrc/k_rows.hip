@@ -194,17 +194,25 @@ __global__ __launch_bounds__(256) void k_moments_cov(const double *__restrict__ 
     }
 }
 
-template <int D>
+// PSI (GPz.m:198-206): A1 = sum dPHI Delta/(psi+sigma), A2 = sum dPHI (Delta r)^2, A3 = sum dPHI (r sigma - sigma),
+// r = sigma/(sigma+psi) = 1/u, u = 1 + psi gamma^2;  note r sigma - sigma = -psi/u.
+template <int D, bool PSI>
 __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__ dPhi, int ld,
                                                        const double *__restrict__ Xr, int n, int m,
                                                        const double *__restrict__ P, int rows_per_chunk,
-                                                       double *__restrict__ slab, int nm) {
+                                                       double *__restrict__ slab, int nm,
+                                                       const double *__restrict__ Psir, const double *__restrict__ Mr,
+                                                       const double *__restrict__ G2) {
     const int j = blockIdx.y * 256 + threadIdx.x;
     const int chunk = blockIdx.x;
     const bool act = j < m;
-    double p[D], A1v[D], A2v[D];
+    const int jc = act ? j : 0;
+    double p[D], g2[PSI ? D : 1], A1v[D], A2v[D], A3v[PSI ? D : 1];
 #pragma unroll
-    for (int c = 0; c < D; ++c) { p[c] = act ? P[(size_t)j * D + c] : 0.0; A1v[c] = 0.0; A2v[c] = 0.0; }
+    for (int c = 0; c < D; ++c) {
+        p[c] = P[(size_t)jc * D + c]; A1v[c] = 0.0; A2v[c] = 0.0;
+        if (PSI) { g2[c] = G2[(size_t)jc * D + c]; A3v[c] = 0.0; }
+    }
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(n, r0 + rows_per_chunk);
     for (int i = r0; i < r1; ++i) {
@@ -212,23 +220,41 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
         const double *xi = Xr + (size_t)i * D;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const double dl = xi[c] - p[c];
-            const double t = dp * dl;
-            A1v[c] += t;
-            A2v[c] = fma(t, dl, A2v[c]);
+            const double mk = Mr ? Mr[(size_t)i * D + c] : 1.0;
+            const double dl = (xi[c] - p[c]) * mk;
+            if (PSI) {
+                const double psi = Psir[(size_t)i * D + c];
+                const double iu = 1.0 / fma(psi, g2[c], 1.0);
+                const double dr = dl * iu;
+                A1v[c] = fma(dp * dl, g2[c] * iu, A1v[c]);
+                A2v[c] = fma(dp * dr, dr, A2v[c]);
+                A3v[c] = fma(dp, -psi * iu, A3v[c]);
+            } else {
+                const double t = dp * dl;
+                A1v[c] += t;
+                A2v[c] = fma(t, dl, A2v[c]);
+            }
         }
     }
     if (act) {
         double *o = slab + ((size_t)chunk * m + j) * nm;
 #pragma unroll
-        for (int c = 0; c < D; ++c) { o[c] = A1v[c]; o[D + c] = A2v[c]; }
+        for (int c = 0; c < D; ++c) {
+            o[c] = A1v[c]; o[D + c] = A2v[c];
+            if (PSI) o[2 * D + c] = A3v[c];
+        }
     }
 }
 
 #define MOM_COV(D, A0, A1) \
     hipLaunchKernelGGL((k_moments_cov<D, A0, A1>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm)
 #define MOM_DIAG(D) \
-    hipLaunchKernelGGL((k_moments_diag<D>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm)
+    do { \
+        if (a.Psir) hipLaunchKernelGGL((k_moments_diag<D, true>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
+                                       a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2); \
+        else hipLaunchKernelGGL((k_moments_diag<D, false>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
+                                a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2); \
+    } while (0)
 
 int launch_moments(hipStream_t st, const MomentArgs &a) {
     dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
@@ -316,13 +342,15 @@ void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const 
 // Moments with dPHI_ij = (-omega beta_i T_ij - c_i w_j + dbeta_i v_j) * PHI_ij formed on the fly (GPz.m:72,90,106,113),
 // plus the column sums PHI'c and PHI'dbeta (GPz.m:89,104).  Lanes along basis functions; row data (x_i, row scalars)
 // are wave-uniform.  UR rows are in flight per thread to cover the HBM latency.
-template <int KIND, int D, int A0, int A1, int UR>
+template <int KIND, int D, int A0, int A1, int UR, bool PSI>
 __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict__ Phi, const double *__restrict__ T,
                                                         int ld, const double *__restrict__ Xr,
                                                         const double *__restrict__ rowscal, int n, int m,
                                                         const double *__restrict__ P, const double *__restrict__ w,
                                                         const double *__restrict__ v, int rows_per_chunk,
-                                                        double *__restrict__ slab, int nm) {
+                                                        double *__restrict__ slab, int nm,
+                                                        const double *__restrict__ Psir, const double *__restrict__ Mr,
+                                                        const double *__restrict__ G2) {
     const int j = blockIdx.y * 256 + threadIdx.x;
     const int chunk = blockIdx.x;
     const bool act = j < m;
@@ -332,22 +360,30 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
     for (int c = 0; c < D; ++c) p[c] = P[(size_t)jc * D + c];
     const double wj = w[jc], vj = v ? v[jc] : 0.0;
     constexpr int NS = (KIND == GPZ_KIND_COV) ? ((A1 - A0) * D - (A1 * (A1 - 1) / 2 - A0 * (A0 - 1) / 2)) : D;
-    double M1[D], S[NS];
+    double M1[D], S[NS], S3[PSI ? D : 1], g2[PSI ? D : 1];
     double r1 = 0.0, r2 = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) M1[c] = 0.0;
+    for (int c = 0; c < D; ++c) {
+        M1[c] = 0.0;
+        if (PSI) { S3[c] = 0.0; g2[c] = G2[(size_t)jc * D + c]; }
+    }
 #pragma unroll
     for (int e = 0; e < NS; ++e) S[e] = 0.0;
     const int r0 = chunk * rows_per_chunk;
     const int rend = min(n, r0 + rows_per_chunk);
-    for (int ib = r0; ib < rend; ib += UR) {
-        double ph[UR], tt[UR];
+    // register double buffering: the loads of the next UR rows are in flight while this batch is consumed
+    double ph[UR], tt[UR], phn[UR], ttn[UR];
+    auto rload = [&](int ib, double *a, double *b) {
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const int i = min(ib + u, rend - 1);
-            ph[u] = Phi[(size_t)i * ld + jc];
-            tt[u] = T[(size_t)i * ld + jc];
+            a[u] = Phi[(size_t)i * ld + jc];
+            b[u] = T[(size_t)i * ld + jc];
         }
+    };
+    if (r0 < rend) rload(r0, ph, tt);
+    for (int ib = r0; ib < rend; ib += UR) {
+        if (ib + UR < rend) rload(ib + UR, phn, ttn);
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const int i = ib + u;
@@ -378,14 +414,26 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                 } else {
 #pragma unroll
                     for (int c = 0; c < D; ++c) {
-                        const double dl = xi[c] - p[c];
-                        const double t = dp * dl;
-                        M1[c] += t;
-                        S[c] = fma(t, dl, S[c]);
+                        const double mk = Mr ? Mr[(size_t)i * D + c] : 1.0;
+                        const double dl = (xi[c] - p[c]) * mk;
+                        if (PSI) {
+                            const double psi = Psir[(size_t)i * D + c];
+                            const double iu = 1.0 / fma(psi, g2[c], 1.0);
+                            const double dr = dl * iu;
+                            M1[c] = fma(dp * dl, g2[c] * iu, M1[c]);
+                            S[c] = fma(dp * dr, dr, S[c]);
+                            S3[c] = fma(dp, -psi * iu, S3[c]);
+                        } else {
+                            const double t = dp * dl;
+                            M1[c] += t;
+                            S[c] = fma(t, dl, S[c]);
+                        }
                     }
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) { ph[u] = phn[u]; tt[u] = ttn[u]; }
     }
     if (act) {
         double *o = slab + ((size_t)chunk * m + j) * (nm + 2);
@@ -405,14 +453,22 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < D; ++c) o[D + c] = S[c];
+            for (int c = 0; c < D; ++c) {
+                o[D + c] = S[c];
+                if (PSI) o[2 * D + c] = S3[c];
+            }
         }
     }
 }
 
+#define MOMF_(KIND, D, A0, A1, PS) \
+    hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, 4, PS>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, \
+                       a.m, a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2)
 #define MOMF(KIND, D, A0, A1) \
-    hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, 4>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, a.m, \
-                       a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm)
+    do { \
+        if (KIND == GPZ_KIND_DIAG && a.Psir) MOMF_(KIND, D, A0, A1, true); \
+        else MOMF_(KIND, D, A0, A1, false); \
+    } while (0)
 
 int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
     dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
@@ -511,8 +567,15 @@ __global__ void k_finish_a(FinishArgs a, int de) {
             const int j = e / d, c = e % d;
             const double *mo = a.mom + (size_t)j * a.nm;
             const double g = a.pr.G[(size_t)j * de + c];
-            grad[j + m * c] = -(mo[c] * (g * g)) / nk;                     // GPz.m:192  ./Sigma, Sigma = gamma^-2
-            const double dg = -g * mo[de + c];                             // GPz.m:194
+            double dpv, dg;
+            if (a.psi) {
+                dpv = mo[c];                                               // GPz.m:202  (1/(psi+sigma) applied per pair)
+                dg = -g * (mo[de + c] - mo[2 * de + c]);                   // GPz.m:206
+            } else {
+                dpv = mo[c] * (g * g);                                     // GPz.m:192  ./Sigma, Sigma = gamma^-2
+                dg = -g * mo[de + c];                                      // GPz.m:194
+            }
+            grad[j + m * c] = -dpv / nk;
             if (a.method_id == 3) grad[md + j + m * c] = -dg / nk;         // VD
             else a.dGfull[e] = dg;
         }

@@ -53,14 +53,20 @@ def _check_eval(model, theta, X, Y, omega=None, training=None, validation=None):
     return ref
 
 
-GOLD_OK = [n for n in golden_names() if "_p1" not in n and "_n1" not in n]
-GOLD_UNSUPPORTED = [n for n in golden_names() if "_p1" in n or "_n1" in n]
+def _built(name):
+    """Input noise / missing values are built for the diagonal kinds; GC/VC with Psi or NaN still refuse."""
+    plain = "_p1" not in name and "_n1" not in name
+    return plain or name.split("_")[1] in ("GL", "VL", "GD", "VD")
+
+
+GOLD_OK = [n for n in golden_names() if _built(n)]
+GOLD_UNSUPPORTED = [n for n in golden_names() if not _built(n)]
 
 
 @pytest.mark.parametrize("name", GOLD_OK)
 def test_golden_through_c_abi(name):
     g, model, Psi, omega, training, validation = load_golden(name)
-    ctx = gpz_amd.GPzContext(model, g["X"], g["Y"], None, omega, training, validation)
+    ctx = gpz_amd.GPzContext(model, g["X"], g["Y"], Psi, omega, training, validation)
     try:
         f, grad = ctx.eval(g["theta"])
         tol = grad_tol(float(g["cond"]))
@@ -75,10 +81,16 @@ def test_golden_through_c_abi(name):
         assert rel(w, g["w"]) <= tol and rel(iS, g["iSigma_w"]) <= tol and rel(part, g["nlogML_partial"]) <= FTOL
     finally:
         ctx.close()
-    PHI, Gamma, lnB = gpz_amd.getPHI(g["X"], None, g["theta"], model, training)
-    assert rel(lnB, g["lnBeta_i"]) <= 1e-12
-    if "PHI" in g:
-        assert rel(PHI, g["PHI"]) <= 1e-12
+    if Psi is None and not np.isnan(g["X"]).any():
+        PHI, Gamma, lnB = gpz_amd.getPHI(g["X"], None, g["theta"], model, training)
+        assert rel(lnB, g["lnBeta_i"]) <= 1e-12
+        if "PHI" in g:
+            assert rel(PHI, g["PHI"]) <= 1e-12
+    elif "PHI" in g:
+        ctx = gpz_amd.GPzContext(model, g["X"], g["Y"], Psi, omega, training, validation)
+        ctx.solve(g["theta"])
+        assert rel(ctx.phi(), g["PHI"]) <= 1e-12                      # 5th output of GPz.m:1 with Psi / missing dims
+        ctx.close()
     if "Xs" in g:
         model.sets["best"] = {"theta": g["theta"], "w": g["w"], "iSigma_w": g["iSigma_w"]}
         mu, sigma, nu, beta_i, gamma, PHIs, _, _ = gpz_amd.predict(g["Xs"], model)
@@ -86,7 +98,7 @@ def test_golden_through_c_abi(name):
         assert rel(beta_i, g["beta_i"]) <= 1e-12 and rel(PHIs, g["PHIs"]) <= 1e-12 and not gamma.any()
 
 
-@pytest.mark.parametrize("name", GOLD_UNSUPPORTED[:6])
+@pytest.mark.parametrize("name", GOLD_UNSUPPORTED)
 def test_unbuilt_branches_refuse_loudly(name):
     """Psi / missing-value branches are in the oracle but not yet in the HIP path: the library must say so
     (GPZ_ERR_UNSUPPORTED), never silently compute something else."""
@@ -105,6 +117,30 @@ def test_random_problems(method, hetero, shape):
     om = rng.random((n, 1)) + 0.5
     tr = rng.random(n) < 0.8
     _check_eval(model, theta, X, Y, om, tr, ~tr)
+
+
+@pytest.mark.parametrize("method", ["GL", "VL", "GD", "VD"])
+@pytest.mark.parametrize("psi,nanfrac", [(True, 0.0), (False, 0.3), (True, 0.3)])
+@pytest.mark.parametrize("shape", [(700, 4, 12, 1), (1500, 10, 40, 2)])
+def test_diag_kinds_with_input_noise_and_missing(method, psi, nanfrac, shape):
+    n, d, m, k = shape
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=3 * n + d, psi=psi, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        tol = grad_tol(ref.cond)
+        assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+        assert rel(g, ref.grad) <= tol
+        for key, val in ref.stats.items():
+            assert abs(ctx.stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+        r4 = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr, nargout=4)
+        w, iS, part = ctx.solve(theta)
+        assert rel(w, r4.w) <= tol and rel(ctx.phi(), r4.PHI) <= 1e-12
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 1, 1), (17, 2, 1, 1), (64, 1, 16, 1), (513, 4, 17, 1), (129, 20, 9, 1),
