@@ -416,7 +416,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         if ((rc = c->ar.alloc(&c->colslab, (size_t)c->nwg_rows * 2 * mp))) return bail(rc);
         if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
     } else {
-        c->nslots = 2 * ((c->mp + 127) / 128);
+        c->nslots = gpz_gemm_wave_cols() * ((c->mp + 127) / 128);
         if ((rc = c->ar.alloc(&c->nupart, (size_t)c->nslots * np))) return bail(rc);
         if ((rc = c->ar.alloc(&c->rowscal, (size_t)4 * np))) return bail(rc);
         if ((rc = c->ar.alloc(&c->frec, (size_t)m * (c->nm + 2)))) return bail(rc);
@@ -524,7 +524,9 @@ static int stage_a(gpz_ctx *c, const double *theta) {
     for (int o = 0; o < c->k; ++o) {
         {
             Stage s(c, "syrk");
-            launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
+            // GPZ_DEBUG_LD0 (timing experiment only): collapse every PHI row onto row 0 so the operand is cache-resident
+            static const int dbg_ld0 = getenv("GPZ_DEBUG_LD0") ? 1 : 0;
+            launch_syrk(c->st, c->Phi, dbg_ld0 ? 0 : c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
                         c->rows_per_split, c->slab, false);
         }
         {
@@ -586,8 +588,9 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         stage_b(c, o);
         {
             Stage s(c, "tgemm");
+            static const int dbg_ld0 = getenv("GPZ_DEBUG_LD0") ? atoi(getenv("GPZ_DEBUG_LD0")) : 0;
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
-                         c->phiw, c->m, c->m + o);
+                         c->phiw, c->m, c->m + o, dbg_ld0);
         }
         if (fused) {
             {

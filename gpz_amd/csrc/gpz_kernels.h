@@ -51,9 +51,10 @@ int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is 
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
                  int nsplit, int rows_per_split, double *slab, bool tri);
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds);
-// nupart (optional): [2*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
+int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
+// nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol);
+                  double *nupart, double *phiw, int m, int mcol, int debug_ld0 = 0);
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 

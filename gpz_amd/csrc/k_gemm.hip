@@ -16,27 +16,32 @@
 // ---------------------------------------------------------------------------------------------
 // PHI: n_rows x ld row-major.  Output slab[split] is mp x mp row-major; only tiles (ti <= tj) are written.
 // TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
-template <bool WEIGHTED, bool EDGE>
+// WC = wave columns of the 2 x WC wave grid: WC = 2 -> 4 waves of 64x64 each, WC = 4 -> 8 waves of 64x32 each
+// (64 accumulator registers per wave, 4 waves per SIMD with two workgroups per CU).
+template <bool WEIGHTED, bool EDGE, int WC>
 __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld, const double *__restrict__ wgt,
                                           int mp, int i0, int j0, bool diag_tile, int r_begin, int r_end,
                                           double *__restrict__ out, double (*sA)[16][LDS_LD128],
                                           double (*sB)[16][LDS_LD128], double (*sW)[16]) {
+    constexpr int NT = 128 * WC;          // threads
+    constexpr int NI = 8 / WC;            // 16-column MFMA tiles per wave
+    constexpr int Q = 1024 / NT;          // double2 per thread per operand slice (16 x 128 doubles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
 
-    d4_t acc[4][4];
+    d4_t acc[4][NI];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NI; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    // staging map: 4 x double2 per thread per operand; a wave reads one full 1 KiB tile row per q
-    d2_t ra[4], rb[4];
+    // staging map: a wave reads one full 1 KiB tile row per q
+    d2_t ra[Q], rb[Q];
     double rw = 0.0;
     auto gload = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = q * 256 + tid;
+        for (int q = 0; q < Q; ++q) {
+            int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
             const double *src = Phi + (size_t)(r0 + row) * ld;
             ra[q] = (!EDGE || i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
@@ -47,8 +52,8 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = q * 256 + tid;
+        for (int q = 0; q < Q; ++q) {
+            int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
             *reinterpret_cast<d2_t *>(&sA[buf][row][c]) = ra[q];
             if (!diag_tile) *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
@@ -72,7 +77,7 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 #pragma unroll
         for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int krow = kk * 4 + (lane >> 4);
-            double a[4], b[4];
+            double a[4], b[NI];
             const double wv = WEIGHTED ? sW[cur][krow] : 1.0;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
@@ -80,11 +85,11 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
                 a[mi] = WEIGHTED ? t * wv : t;
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = tB[krow][wc * 64 + ni * 16 + (lane & 15)];
+            for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
         }
     };
     for (int s = 0; s < nstage; ++s) {
@@ -101,8 +106,8 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
@@ -111,11 +116,11 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         }
 }
 
-template <bool WEIGHTED, bool TRI>
-__global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi, int ld,
-                                                  const double *__restrict__ wgt, int n_rows, int mp,
-                                                  int ntile, int rows_per_split,
-                                                  double *__restrict__ slab) {
+template <bool WEIGHTED, bool TRI, int WC>
+__global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict__ Phi, int ld,
+                                                       const double *__restrict__ wgt, int n_rows, int mp,
+                                                       int ntile, int rows_per_split,
+                                                       double *__restrict__ slab) {
     __shared__ double sA[2][16][LDS_LD128];
     __shared__ double sB[2][16][LDS_LD128];
     __shared__ double sW[2][16];
@@ -136,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk(const double *__restrict__ Phi,
     double *out = slab + (size_t)split * mp * mp;
     // interior tiles take the guard-free body (no exec-mask branches in the K loop)
     if (j0 + 128 <= mp)
-        syrk_body<WEIGHTED, false>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
+        syrk_body<WEIGHTED, false, WC>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
     else
-        syrk_body<WEIGHTED, true>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
+        syrk_body<WEIGHTED, true, WC>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
 }
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
@@ -159,32 +164,34 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit, int m
 // ---------------------------------------------------------------------------------------------
 // PHI: n_pad x ld (row-major), B: mp x ldb (row-major), T: n_pad x ld.  n_pad % 128 == 0, mp % 16 == 0.
 // Optional fused epilogue (nupart != nullptr):
-//   nupart[(ct*2 + wc)*n_pad + row] = sum over this wave's 64 columns (< m) of PHI[row][col]*T[row][col]   (GPz.m:69)
+//   nupart[(ct*WC + wc)*n_pad + row] = sum over this wave's columns (< m) of PHI[row][col]*T[row][col]   (GPz.m:69)
 //   phiw[row] = T[row][mcol]  (= (PHI w)_row, GPz.m:77)
-template <bool EDGE>
+template <bool EDGE, int WC>
 __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int ld, const double *__restrict__ B,
-                                           int ldb, double *__restrict__ T, int mp, int i0, int j0,
+                                           int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            double (*sA)[128][18], double (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
-                                           long n_pad, int ct) {
+                                           long n_pad, int ct, int dbg) {
+    constexpr int NT = 128 * WC;
+    constexpr int NI = 8 / WC;
+    constexpr int Q = 1024 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
 
-    d4_t acc[4][4];
+    d4_t acc[4][NI];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NI; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    d2_t ra[4], rb[4];
-    const int arow = tid >> 1, ahalf = (tid & 1) * 8;
+    // A slice: 128 rows x 16 doubles, 8 consecutive lanes cover one 128-byte row segment
+    d2_t ra[Q], rb[Q];
     auto gload = [&](int k0) {
-        const double *src = Phi + (size_t)(i0 + arow) * ld + k0 + ahalf;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const d2_t *>(src + 2 * q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = q * 256 + tid;
+        for (int q = 0; q < Q; ++q) {
+            int idx = q * NT + tid;
+            int arow = idx >> 3, ac = (idx & 7) * 2;
+            ra[q] = *reinterpret_cast<const d2_t *>(Phi + (size_t)(i0 + arow) * ld + k0 + ac);
             int row = idx >> 6, c = (idx & 63) * 2;
             rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(B + (size_t)(k0 + row) * ldb + j0 + c)
                                            : (d2_t){0.0, 0.0};
@@ -192,20 +199,20 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<d2_t *>(&sA[buf][arow][ahalf + 2 * q]) = ra[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = q * 256 + tid;
+        for (int q = 0; q < Q; ++q) {
+            int idx = q * NT + tid;
+            int arow = idx >> 3, ac = (idx & 7) * 2;
+            *reinterpret_cast<d2_t *>(&sA[buf][arow][ac]) = ra[q];
             int row = idx >> 6, c = (idx & 63) * 2;
             *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
         }
     };
 
     // number of valid 16-column MFMA tiles of this wave (only the last column tile can be partial)
-    int nvalid = 4;
+    int nvalid = NI;
     if (EDGE) {
-        nvalid = (mp - (j0 + wc * 64) + 15) / 16;
-        nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
+        nvalid = (mp - (j0 + wc * (16 * NI)) + 15) / 16;
+        nvalid = nvalid < 0 ? 0 : (nvalid > NI ? NI : nvalid);
     }
 
     // Software pipeline as in syrk_body: loads of slice s+2 issued mid-slice s, LDS writes between the MFMA halves.
@@ -218,13 +225,20 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 #pragma unroll
         for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int kc = kk * 4 + (lane >> 4);
-            double a[4], b[4];
+            double a[4], b[NI];
+            if (dbg & 1) {   // ablation: operands from registers instead of LDS
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) a[mi] = 1e-3 * (lane + mi + kk);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = 1e-3 * (lane - ni + kk);
+            } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = sB[cur][kc][wc * 64 + ni * 16 + (lane & 15)];
+            for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
+            }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
                 if (!EDGE || ni < nvalid) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
@@ -234,29 +248,31 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
         mfma_half(cur, 0);
+        if (!(dbg & 2)) {   // ablation bit 1: no staging, no barrier
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
             if (s + 2 < nstage) gload((s + 2) * 16);
         }
+        }
         mfma_half(cur, 2);
-        __syncthreads();
+        if (!(dbg & 2)) __syncthreads();
     }
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
             if (!EDGE || col < mp) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
-                    T[(size_t)row * ld + col] = acc[mi][ni][r];
+                    T[(size_t)row * ldt + col] = acc[mi][ni][r];
                 }
             }
         }
     if (nupart) {
-        double *slot = nupart + (size_t)(ct * 2 + wc) * n_pad;
+        double *slot = nupart + (size_t)(ct * WC + wc) * n_pad;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -264,8 +280,8 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                 const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
                 double p = 0.0;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int col = j0 + wc * 64 + ni * 16 + (lane & 15);
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
                     if (col < m) p = fma(Phi[(size_t)row * ld + col], acc[mi][ni][r], p);
                     if (col == mcol) phiw[row] = acc[mi][ni][r];
                 }
@@ -279,17 +295,20 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_tgemm(const double *__restrict__ Phi, int ld,
-                                                   const double *__restrict__ B, int ldb,
-                                                   double *__restrict__ T, int mp, int nct,
-                                                   double *__restrict__ nupart, double *__restrict__ phiw, int m,
-                                                   int mcol, long n_pad) {
+template <int WC>
+__global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict__ Phi, int ld,
+                                                        const double *__restrict__ B, int ldb,
+                                                        double *__restrict__ T, int ldt, int mp, int nct,
+                                                        double *__restrict__ nupart, double *__restrict__ phiw, int m,
+                                                        int mcol, long n_pad, int dbg) {
     __shared__ double sA[2][128][18];
     __shared__ double sB[2][16][LDS_LD128];
     const int rt = blockIdx.x / nct, ct = blockIdx.x % nct;
     const int i0 = rt * 128, j0 = ct * 128;
-    if (j0 + 128 <= mp) tgemm_body<false>(Phi, ld, B, ldb, T, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
-    else tgemm_body<true>(Phi, ld, B, ldb, T, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+    if (j0 + 128 <= mp)
+        tgemm_body<false, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, dbg);
+    else
+        tgemm_body<true, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, dbg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,17 +410,23 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+#ifndef GPZ_GEMM_WC
+#define GPZ_GEMM_WC 4   // 8 waves per workgroup (gpz_gemm_wave_cols() reports it to the host code)
+#endif
+int gpz_gemm_wave_cols() { return GPZ_GEMM_WC; }
+
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
                  int nsplit, int rows_per_split, double *slab, bool tri) {
+    constexpr int WC = GPZ_GEMM_WC;
     const int ntile = (mp + 127) / 128;
     const int npairs = ntile * (ntile + 1) / 2;
-    dim3 grid(npairs * nsplit), block(256);
+    dim3 grid(npairs * nsplit), block(128 * WC);
     if (tri)
-        hipLaunchKernelGGL((k_syrk<false, true>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<false, true, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
     else if (wgt)
-        hipLaunchKernelGGL((k_syrk<true, false>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<true, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
     else
-        hipLaunchKernelGGL((k_syrk<false, false>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<false, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
 }
 
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds) {
@@ -410,10 +435,14 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, 
 }
 
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol) {
+                  double *nupart, double *phiw, int m, int mcol, int debug_ld0) {
+    constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
-    dim3 grid((n_pad / 128) * nct), block(256);
-    hipLaunchKernelGGL(k_tgemm, grid, block, 0, st, Phi, ld, B, ldb, T, mp, nct, nupart, phiw, m, mcol, (long)n_pad);
+    dim3 grid((n_pad / 128) * nct), block(128 * WC);
+    const int dbg = debug_ld0 >> 1;   // ablation bits (timing experiments only)
+    const int l0 = debug_ld0 & 1;
+    hipLaunchKernelGGL(k_tgemm<WC>, grid, block, 0, st, Phi, l0 ? 0 : ld, B, ldb, T, l0 ? 0 : ld, mp, nct,
+                       nupart, phiw, m, mcol, (long)n_pad, dbg);
 }
 
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb) {
