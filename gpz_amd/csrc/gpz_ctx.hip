@@ -160,6 +160,8 @@ struct gpz_ctx {
     int nchunk = 1, rows_per_chunk = 1;
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
     double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused single-output path
+    double *phipart = nullptr;   // PHI-build column-group partial sums (small row counts)
+    int phipart_groups = 0;
     int nslots = 0;
     double *out_d = nullptr;
     double *out_h = nullptr, *theta_h = nullptr;   // pinned
@@ -393,10 +395,10 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         if ((rc = c->ar.alloc(&c->lnbeta_v, (size_t)c->va.n_pad * k))) return bail(rc);
         if ((rc = c->ar.alloc(&c->phiw_v, (size_t)c->va.n_pad * k))) return bail(rc);
     }
-    // SYRK split over rows: aim at ~2048 workgroups
+    // SYRK split over rows: aim at ~1024 workgroups (two resident rounds of 2 per CU; the slab sum costs nsplit*mp^2 reads)
     {
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
-        int ns = (2048 + npairs - 1) / npairs;
+        int ns = 1024 / npairs;   // floor: npairs*ns workgroups fill at most two full rounds of 512 resident slots
         const int max_ns = c->tr.n_pad / 64;
         if (ns > max_ns) ns = max_ns;
         if (ns < 1) ns = 1;
@@ -406,6 +408,11 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         size_t need_l = (size_t)c->nsplit_l * c->mq * c->mq;
         c->slab_count = need > need_l ? need : need_l;
         if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
+    }
+    if (c->kind == GPZ_KIND_COV && np < 1024 * 1024) {
+        c->phipart_groups = 16;
+        size_t rows = np > (size_t)c->va.n_pad ? np : (size_t)c->va.n_pad;
+        if ((rc = c->ar.alloc(&c->phipart, (size_t)c->phipart_groups * 2 * k * rows))) return bail(rc);
     }
     c->comm1_count = k * mp * mp + GPZ_NS;
     if ((rc = c->ar.alloc(&c->comm1, c->comm1_count))) return bail(rc);
@@ -513,6 +520,7 @@ static int stage_a(gpz_ctx *c, const double *theta) {
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = c->tr.Y;
         a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
         a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
+        a.part = c->phipart; a.part_groups = c->phipart_groups;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
     }
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;

@@ -43,6 +43,9 @@ struct PhiArgs {
     const double *Psic;  // d x ldx   (fixPsi.m layout n x d, zero where missing)
     const double *Mc;    // d x ldx
     const double *ucnt;  // ldx
+    // cov kinds: scratch for the column-group split used at small row counts ([part_groups][2][k][ldx]); nullptr disables it
+    double *part;
+    int part_groups;
 };
 void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported

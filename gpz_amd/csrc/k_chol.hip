@@ -26,49 +26,68 @@ __global__ void k_build_sigma(const double *__restrict__ S, int lds, const doubl
     A[(size_t)i * lda + j] = v;
 }
 
-// Factor the 32x32 diagonal block at k0 (every workgroup does it redundantly in LDS, workgroup 0
-// writes it back) and solve the panel rows below it:  L21 = A21 * inv(L11)'.
+// Cholesky of a 32x32 block held one row per lane (lanes 0..31 of one wave), fully unrolled so every index is a
+// compile-time register index.  Column c: the pivot and the multipliers l_cc',c travel between lanes through
+// v_readlane (wave-uniform broadcasts), no LDS round trips and no barriers.  Returns the first bad pivot (1-based, 0 = ok).
+__device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        const double piv = __shfl(a[c], c, 64);                 // a_cc lives in lane c
+        if (!(piv > 0.0) && bad == 0) bad = c + 1;
+        const double d = sqrt(piv);
+        const double l = a[c] / d;                              // l_rc for this lane's row r (meaningful for r >= c)
+        a[c] = (lane == c) ? d : l;
+#pragma unroll
+        for (int cc = c + 1; cc < CH_NB; ++cc) {
+            const double lcc = __shfl(l, cc, 64);               // l_cc,c
+            a[cc] = fma(-l, lcc, a[cc]);                        // a_r,cc -= l_rc * l_cc,c   (used for r >= cc)
+        }
+    }
+    return bad;
+}
+
+// Factor the 32x32 diagonal block at k0 (wave 0 of every workgroup does it redundantly in registers and publishes
+// it through LDS; workgroup 0 writes it back) and solve the panel rows below it:  L21 = A21 * inv(L11)'.
 // Reads A, writes the factor to Lm (a separate buffer: the redundant per-workgroup factorisation must
 // never observe another workgroup's write-back).
 __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A, double *__restrict__ Lm, int lda,
                                                      int mq, int k0, double *__restrict__ logdet,
                                                      int *__restrict__ info) {
     __shared__ double D[CH_NB][CH_NB + 1];
-    __shared__ int bad;
     const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        const int r = e / CH_NB, c = e % CH_NB;
-        D[r][c] = A[(size_t)(k0 + r) * lda + k0 + c];
+    if (tid < 64) {
+        const int lane = tid;
+        const int r = lane & (CH_NB - 1);
+        double a[CH_NB];
+        const double *ar = A + (size_t)(k0 + r) * lda + k0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) a[c] = ar[c];
+        const int bad = chol32_rows(a, lane);
+        if (lane < CH_NB) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) D[lane][c] = (c <= lane) ? a[c] : 0.0;
+            if (blockIdx.x == 0) {
+                double *lr = Lm + (size_t)(k0 + lane) * lda + k0;
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) lr[c] = (c <= lane) ? a[c] : 0.0;
+            }
+        }
+        if (blockIdx.x == 0) {
+            // log-determinant contribution: 2*sum(log(diag))   (inv_logdet.m:15, sum of logs)
+            double ld = 0.0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                const double dcc = __shfl(a[c], c, 64);
+                ld += log(dcc);
+            }
+            if (lane == 0) {
+                *logdet += 2.0 * ld;
+                if (bad && *info == 0) *info = k0 + bad;
+            }
+        }
     }
     __syncthreads();
-    for (int c = 0; c < CH_NB; ++c) {
-        if (tid == 0) {
-            const double p = D[c][c];
-            if (!(p > 0.0)) { if (bad == 0) bad = k0 + c + 1; }
-            D[c][c] = sqrt(p);
-        }
-        __syncthreads();
-        if (tid > c && tid < CH_NB) D[tid][c] /= D[c][c];
-        __syncthreads();
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int r = e / CH_NB, cc = e % CH_NB;
-            if (cc > c && r >= cc) D[r][cc] -= D[r][c] * D[cc][c];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int r = e / CH_NB, c = e % CH_NB;
-            Lm[(size_t)(k0 + r) * lda + k0 + c] = (c <= r) ? D[r][c] : 0.0;
-        }
-        if (tid == 0) {
-            double s = 0.0;
-            for (int c = 0; c < CH_NB; ++c) s += log(D[c][c]);
-            *logdet += 2.0 * s;                                            // inv_logdet.m:15 (sum of logs)
-            if (bad && *info == 0) *info = bad;
-        }
-    }
     const int row = k0 + CH_NB + blockIdx.x * 256 + tid;
     if (row < mq) {
         double x[CH_NB];

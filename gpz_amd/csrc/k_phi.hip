@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                                                   const double *__restrict__ omega, const double *__restrict__ Y,
                                                   double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                   double *__restrict__ wbeta, const double *__restrict__ wv,
-                                                  double *__restrict__ phiw) {
+                                                  double *__restrict__ phiw, int jgroup, double *__restrict__ part) {
     constexpr int KM = KGEN ? 8 : 1;
     constexpr int NT = D * (D + 1) / 2;
     constexpr int NP = NT + D;                       // doubles per basis function
@@ -315,12 +315,16 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
             if (e < NPB) prm[e] = stg[q];
         }
     };
-    pload(0);
+    // column group of this workgroup: [jlo, jhi) in steps of JB (small row counts are split over basis functions
+    // as well so the grid still fills the chip; the per-row sums are then combined by k_phi_finalize)
+    const int jlo = blockIdx.y * jgroup;
+    const int jhi = min(mp, jlo + jgroup);
+    pload(jlo);
     pstore();
     __syncthreads();
 
-    for (int j0 = 0; j0 < mp; j0 += JB) {
-        if (j0 + JB < m) pload(j0 + JB);             // in flight during the compute phase
+    for (int j0 = jlo; j0 < jhi; j0 += JB) {
+        if (j0 + JB < m && j0 + JB < jhi) pload(j0 + JB);   // in flight during the compute phase
 #pragma unroll 1
         for (int jj = 0; jj < JB; ++jj) {
             const int j = j0 + jj;
@@ -399,10 +403,23 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                 base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
             }
         }
-        if (j0 + JB < m) pstore();
+        if (j0 + JB < m && j0 + JB < jhi) pstore();
         __syncthreads();
     }
 
+    if (part) {   // column-split launch: partial sums [group][2][k][ldx]; k_phi_finalize combines them in fixed order
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long i = row0 + r * 64 + lane;
+#pragma unroll
+            for (int o = 0; o < KM; ++o)
+                if (o < k && i < ldx) {
+                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldx + i] = sv[r][o];
+                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldx + i] = sw[r][o];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
@@ -421,6 +438,29 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
     }
 }
 
+// lnbeta = b + sum_g part_v[g], omega*beta, PHI*w from the column-group partial sums (fixed order: repeatable)
+__global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long ldx, int n, int k,
+                               const double *__restrict__ bvec, const double *__restrict__ omega,
+                               double *__restrict__ lnbeta, double *__restrict__ wbeta, double *__restrict__ phiw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldx) return;
+    for (int o = 0; o < k; ++o) {
+        double sv = 0.0, sw = 0.0;
+        for (int g = 0; g < ngroup; ++g) {
+            sv += part[(((size_t)g * 2 + 0) * k + o) * ldx + i];
+            sw += part[(((size_t)g * 2 + 1) * k + o) * ldx + i];
+        }
+        const bool valid = i < n;
+        const double lb = bvec[o] + sv;
+        lnbeta[(size_t)o * ldx + i] = valid ? lb : 0.0;
+        if (wbeta) {
+            const double om = omega ? omega[i] : 1.0;
+            wbeta[(size_t)o * ldx + i] = valid ? om * exp(-lb) : 0.0;
+        }
+        if (phiw) phiw[(size_t)o * ldx + i] = sw;
+    }
+}
+
 template <int D>
 static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     // 4 rows per thread and 8-wide blocks while [tile | params] fits twice in a CU's LDS; else 2 rows
@@ -430,12 +470,28 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     constexpr int JB = 8;
     const int rows_per_wg = 4 * 64 * R;
     const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
+    // few rows: split the basis functions into groups (multiples of JB) until ~1024 workgroups exist
+    int ngroup = 1;
+    if (a.part && nwg < 1024) {
+        ngroup = (1024 + nwg - 1) / nwg;
+        const int maxg = (a.mp + 63) / 64;
+        if (ngroup > maxg) ngroup = maxg;
+        if (ngroup > a.part_groups) ngroup = a.part_groups;
+        if (ngroup < 1) ngroup = 1;
+    }
+    int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
+    ngroup = (a.mp + jgroup - 1) / jgroup;
+    double *part = ngroup > 1 ? a.part : nullptr;
+    dim3 grid(nwg, ngroup);
     if (a.k == 1)
-        hipLaunchKernelGGL((k_phi_cov<D, false, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
-                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
+        hipLaunchKernelGGL((k_phi_cov<D, false, R, JB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
+                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part);
     else
-        hipLaunchKernelGGL((k_phi_cov<D, true, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
-                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw);
+        hipLaunchKernelGGL((k_phi_cov<D, true, R, JB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
+                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part);
+    if (part)
+        hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.ldx + 255) / 256)), dim3(256), 0, st, (const double *)part,
+                           ngroup, a.ldx, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
 template <int KIND, int D>
