@@ -97,6 +97,10 @@ struct RowSet {          // a device-resident row selection of the data
     double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)
     double *Mc = nullptr, *Mr = nullptr;       // 1.0 observed / 0.0 missing
     double *ucnt = nullptr;                    // number of missing dimensions per row
+    // covariance kinds, general path (Psi cube and/or missing dimensions)
+    int *gid = nullptr, *rows_by_group = nullptr;
+    double *Psi3 = nullptr;                    // n_pad x d*d
+    std::vector<int> group_begin;              // offsets into rows_by_group (size G+1)
 };
 
 struct StageTimer {
@@ -171,6 +175,13 @@ struct gpz_ctx {
     StageTimer tm;
     bool phi_valid = false;
     bool has_psi = false, has_missing = false;
+    // general covariance-kind path
+    bool gen = false;
+    int ngroups = 0, nrec = 0;
+    std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
+    unsigned char *pat_d = nullptr;
+    double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr;
+    int gen_nchunk = 1;
 };
 
 // ---- stage timing ------------------------------------------------------------------------------
@@ -249,7 +260,38 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
         if (int e = c->ar.alloc(&rs.ucnt, np)) return e;
         HIPCHK(hipMemcpy(rs.ucnt, hu.data(), np * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (Psi) {   // n_tot x d (fixPsi.m:42-53); entries of missing dimensions are never read by the reference
+    if (c->gen) {
+        // pattern id per row (global table c->pats, first-occurrence order over the rows seen so far; getPHI.m:43-54)
+        std::vector<int> hg(np, 0);
+        for (size_t r = 0; r < idx.size(); ++r) {
+            std::vector<unsigned char> pt(d);
+            for (int c_ = 0; c_ < d; ++c_) { const double xv = X[(size_t)c_ * n_tot + idx[r]]; pt[c_] = (xv != xv) ? 0 : 1; }
+            int g = -1;
+            for (size_t q = 0; q < c->pats.size(); ++q)
+                if (c->pats[q] == pt) { g = (int)q; break; }
+            if (g < 0) { c->pats.push_back(pt); g = (int)c->pats.size() - 1; }
+            hg[r] = g;
+        }
+        if (int e = c->ar.alloc(&rs.gid, np)) return e;
+        HIPCHK(hipMemcpy(rs.gid, hg.data(), np * sizeof(int), hipMemcpyHostToDevice));
+        const int G = (int)c->pats.size();
+        std::vector<int> cnt(G + 1, 0), order(idx.size());
+        for (size_t r = 0; r < idx.size(); ++r) cnt[hg[r] + 1]++;
+        for (int g = 0; g < G; ++g) cnt[g + 1] += cnt[g];
+        rs.group_begin = cnt;
+        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+        for (size_t r = 0; r < idx.size(); ++r) order[pos[hg[r]]++] = (int)r;
+        if (int e = c->ar.alloc(&rs.rows_by_group, idx.size() ? idx.size() : 1)) return e;
+        if (!idx.empty()) HIPCHK(hipMemcpy(rs.rows_by_group, order.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (Psi) {   // d x d x n_tot cube (fixPsi.m:22-38): Psi(:,:,i) is contiguous
+            std::vector<double> hp(np * (size_t)d * d, 0.0);
+            for (size_t r = 0; r < idx.size(); ++r)
+                memcpy(&hp[r * d * d], Psi + (size_t)idx[r] * d * d, (size_t)d * d * sizeof(double));
+            if (int e = c->ar.alloc(&rs.Psi3, np * d * d)) return e;
+            HIPCHK(hipMemcpy(rs.Psi3, hp.data(), np * d * d * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    if (Psi && !c->gen) {   // n_tot x d (fixPsi.m:42-53); entries of missing dimensions are never read by the reference
         std::vector<double> hp(np * (size_t)de, 0.0);
         for (int c_ = 0; c_ < d; ++c_)
             for (size_t r = 0; r < idx.size(); ++r) {
@@ -349,19 +391,25 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     int rc = setup_model(c, desc);
     if (rc) { delete c; return rc; }
     if ((Psi != nullptr) != (psi_kind != 0)) { delete c; return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree"); }
-    if (Psi && c->kind == GPZ_KIND_COV) {
-        delete c;
-        return fail(GPZ_ERR_UNSUPPORTED, "input noise with GC/VC (getPHI.m:78-89, GPz.m:164-185) is not built yet");
+    const bool xnan = has_nan(X, n_tot * (int64_t)c->d) != 0;
+    if (c->kind == GPZ_KIND_COV && (Psi || xnan)) {
+        // general path: per-pair d x d factorisations (k_gen.hip)
+        if (Psi && psi_kind != 2) { delete c; return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)"); }
+        if (desc->world > 1) {
+            delete c;
+            return fail(GPZ_ERR_UNSUPPORTED, "row-sharded runs of the general GC/VC path (Psi / missing values) are not built yet");
+        }
+        if (c->d > 20) { delete c; return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20"); }
+        c->gen = true;
     }
-    if (Psi && psi_kind != 1) { delete c; return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)"); }
-    if (c->kind == GPZ_KIND_COV && has_nan(X, n_tot * (int64_t)c->d)) {
+    if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1) {
         delete c;
-        return fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs with GC/VC (getPHI.m:76, GPz.m:151-159) are not built yet");
+        return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)");
     }
     c->has_psi = Psi != nullptr;
-    if (c->has_psi) c->nm = 3 * c->de;
+    if (c->has_psi && !c->gen) c->nm = 3 * c->de;
     // one missing value anywhere (training or validation rows) switches the mask arrays on for both row sets
-    c->has_missing = has_nan(X, n_tot * (int64_t)c->d) != 0;
+    c->has_missing = xnan;
     auto bail = [&](int code) {
         c->ar.release();
         if (c->out_h) (void)hipHostFree(c->out_h);
@@ -378,8 +426,23 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     // with sharding a rank may hold no validation rows while others do: the caller signals "validation in use"
     // by passing a non-NULL mask
     if (validation && (any_valid || desc->world > 1)) {
-        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, false, Psi))) return bail(rc);
+        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, c->gen, Psi))) return bail(rc);
         if (!omega) c->va.om = nullptr;
+    }
+    if (c->gen) {
+        c->ngroups = (int)c->pats.size();
+        c->nrec = 3 + c->d + c->d * c->d;
+        c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
+        std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
+        for (int g = 0; g < c->ngroups; ++g) memcpy(&hp[(size_t)g * c->d], c->pats[g].data(), c->d);
+        if ((rc = c->ar.alloc(&c->pat_d, hp.size()))) return bail(rc);
+        if (hipMemcpy(c->pat_d, hp.data(), hp.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "copy failed"));
+        if ((rc = c->ar.alloc(&c->Sig, (size_t)c->m * c->d * c->d))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->iSig, (size_t)c->m * c->d * c->d))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->lnS, (size_t)c->ngroups * c->m))) return bail(rc);
+        c->gen_nchunk = 64;
+        if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * c->nrec))) return bail(rc);
+        if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
     }
     if ((rc = alloc_params(c))) return bail(rc);
     if ((rc = alloc_mm(c))) return bail(rc);
@@ -434,6 +497,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
         if (nc > max_nc) nc = max_nc;
         if (nc < 1) nc = 1;
+        if (c->gen) nc = 1;   // the general path has its own slabs
         c->rows_per_chunk = (c->tr.n + nc - 1) / nc;
         if (c->rows_per_chunk < 1) c->rows_per_chunk = 1;
         c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
@@ -495,6 +559,12 @@ extern "C" int gpz_ctx_timings(gpz_ctx *c, const char **names, double *ms, int64
 }
 
 // ---- pipeline stages -----------------------------------------------------------------------------
+static GenRows gen_rows(const RowSet &rs) {
+    GenRows r{};
+    r.Xr = rs.Xr; r.gid = rs.gid; r.Psi3 = rs.Psi3; r.rows_by_group = rs.rows_by_group; r.n = rs.n; r.n_pad = rs.n_pad;
+    return r;
+}
+
 static int allreduce(gpz_ctx *c, double *buf, size_t count) {
     if (c->desc.world <= 1) return 0;
     if (!c->ar_fn) return fail(GPZ_ERR_COMM, "world=%d but no all-reduce hook set (gpz_ctx_set_allreduce)", c->desc.world);
@@ -511,7 +581,14 @@ static int stage_a(gpz_ctx *c, const double *theta) {
         launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
         if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
     }
-    {
+    if (c->gen) {
+        Stage s(c, "phi_build");
+        launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+        launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d, c->Phi,
+                       c->tr.Y);
+        launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
+                          c->tr.om, nullptr, c->lnbeta, c->wbeta, nullptr);
+    } else {
         Stage s(c, "phi_build");
         PhiArgs a{};
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
@@ -609,6 +686,22 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
                 HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");
+            if (c->gen) {
+                const GenRows gr = gen_rows(c->tr);
+                for (int g = 0; g < c->ngroups; ++g) {
+                    const int rb = c->tr.group_begin[g], nr = c->tr.group_begin[g + 1] - rb;
+                    double *recs_g = mom + (size_t)g * m * c->nrec;
+                    if (nr <= 0) { launch_zero(c->st, recs_g, m * c->nrec); continue; }
+                    int nch = c->gen_nchunk;
+                    if (nch > nr) nch = nr;
+                    const int rpc = (nr + nch - 1) / nch;
+                    nch = (nr + rpc - 1) / rpc;
+                    launch_gen_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, gr, g, rb,
+                                       nr, c->pat_d, c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                    launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, recs_g);
+                }
+                continue;
+            }
             FusedMomentArgs a{};
             a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.rowscal = c->rowscal; a.n = c->tr.n; a.m = c->m;
             a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w; a.v = c->hetero ? c->pr.v : nullptr;
@@ -638,6 +731,21 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
             launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
         }
         Stage s(c, "moments");
+        if (c->gen) {
+            const GenRows gr = gen_rows(c->tr);
+            for (int g = 0; g < c->ngroups; ++g) {
+                const int rb = c->tr.group_begin[g], nr = c->tr.group_begin[g + 1] - rb;
+                double *recs_g = mom + (size_t)g * m * c->nrec;
+                if (nr <= 0) { launch_zero(c->st, recs_g, m * c->nrec); continue; }
+                int nch = c->gen_nchunk;
+                if (nch > nr) nch = nr;
+                const int rpc = (nr + nch - 1) / nch;
+                nch = (nr + rpc - 1) / rpc;
+                launch_gen_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gr, g, rb, nr, c->pat_d, c->m, c->d,
+                                   c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, recs_g);
+            }
+        } else {
         MomentArgs a{};
         a.dPhi = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.d = c->de;
         a.kind = c->kind; a.P = c->pr.P; a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk;
@@ -645,9 +753,18 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         a.Psir = c->tr.Psir; a.Mr = c->tr.Mr; a.G2 = c->pr.G2;
         if (launch_moments(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
         launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * c->nm, mom);
+        }
     }
     const bool have_valid = c->va.n_pad > 0;
-    if (have_valid) {
+    if (have_valid && c->gen) {
+        Stage s(c, "validation");
+        launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d, c->Phi_v,
+                       nullptr);
+        launch_gen_rowdot(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
+                          nullptr, c->w, c->lnbeta_v, nullptr, c->phiw_v);
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+    } else if (have_valid) {
         Stage s(c, "validation");
         PhiArgs a{};
         a.Xc = c->va.Xc; a.ldx = c->va.n_pad; a.n = c->va.n; a.n_pad = c->va.n_pad;
@@ -673,7 +790,11 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         a.g_dim = c->g_dim; a.pr = c->pr; a.mom = mom; a.nm = c->nm; a.cols = cols; a.scal = scal;
         a.w = c->w; a.dwda = c->dwda; a.dgi = c->dgi; a.logdet = c->logdet;
         a.sums1 = c->comm1 + k * mp * mp; a.vsums = have_valid ? vsums : nullptr; a.info = c->info;
-        a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de; a.psi = c->has_psi ? 1 : 0;
+        a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de;
+        a.psi = (c->has_psi && !c->gen) ? 1 : 0; a.gen = c->gen ? 1 : 0;
+        if (c->gen)
+            launch_gen_finish(c->st, mom, c->ngroups, c->pat_d, c->m, c->d, c->de, c->pr.G, c->Sig, c->iSig, c->mid, a.sums1,
+                              c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         launch_finish(c->st, a);
     }
     HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 8) * sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -705,7 +826,15 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
                                 m * sizeof(double), m, hipMemcpyDeviceToHost, c->st));
     }
     HIPCHK(hipMemcpyAsync(w, c->w, m * c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
-    if (nlogML_partial) {
+    if (nlogML_partial && c->gen) {
+        launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
+                          nullptr, c->w, c->lnbeta, nullptr, c->phiw);
+        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
+        launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
+                             c->k, c->spart);
+        HIPCHK(hipMemcpyAsync(nlogML_partial, c->spart, c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    } else if (nlogML_partial) {
         PhiArgs a{};
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;

@@ -141,6 +141,7 @@ struct FinishArgs {
     int nmp;                              // leading dimension of cols (= mp)
     int de;                               // padded dimension of the parameter block / moments
     int psi;                              // diag kinds with input noise: moments are [A1|A2|A3]
+    int gen;                              // cov kinds, general path: dP/dGamma already written by k_gen_finish
 };
 void launch_finish(hipStream_t st, const FinishArgs &a);
 
@@ -158,6 +159,29 @@ void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const d
 // NaN-pattern grouping (getPHI.m:43-54): masks, first-occurrence unique list, ids.
 int launch_nan_groups(hipStream_t st, const double *X, long n, int d, unsigned long long *mask, unsigned long long *uniq,
                       int *n_groups, int *group_id, int max_groups);
+
+// ---- general covariance-kind path: input noise and/or missing dimensions (k_gen.hip) ---------------
+struct GenRows {
+    const double *Xr;          // n_pad x de, 0 at missing entries
+    const int *gid;            // pattern id per row
+    const double *Psi3;        // n_pad x d*d (Psi(:,:,i) column-major) or nullptr
+    const int *rows_by_group;  // row indices sorted by pattern id
+    int n, n_pad;
+};
+void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
+                     const unsigned char *pat, int ngroups, double *lnS);
+void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
+                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y);
+void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
+                       const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
+                       double *phiw);
+void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                        const double *v, const GenRows &r, int g, int row_begin, int nrows, const unsigned char *pat, int m,
+                        int d, int de, const double *P, const double *Sig, int nchunk, int rows_per_chunk, double *slab,
+                        int nrec);
+void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
+                       const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
+                       double *grad, double *dGfull, double *cols, int mp, int nrec);
 
 // misc
 void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long ny, int d, double *D);

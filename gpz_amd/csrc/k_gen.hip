@@ -1,0 +1,381 @@
+// General covariance-kind path: input noise Psi (d x d per sample) and/or missing input dimensions.
+//
+//   getPHI.m:73-89   ln PHI_ij = -1/2 Delta_o' M^-1 Delta_o + 1/2 ln|Sigma_oo| - 1/2 ln|M| - 1/2 |u| ln 2,
+//                    M = Psi_i,oo + Sigma_j,oo,  Sigma_j = inv(Gamma_j' Gamma_j)       (without Psi the two log-dets cancel)
+//   GPz.m:146-185    dP(j,o) += dPHI_ij Delta_o' M^-1;  dSoo = 1/2 (Sigma_oo^-1 - M^-1 + M^-1 Delta Delta' M^-1);
+//                    diSoo = -Sigma_oo dSoo Sigma_oo;  dGo = 2 (Gamma(:,o) - Gamma(:,u) GuuGuo) diSoo;
+//                    dGamma(:,o,j) += dPHI_ij dGo;  dGamma(:,u,j) -= dPHI_ij dGo GuuGuo'   (GuuGuo = iSigma_uu^-1 iSigma_uo).
+//   With Psi = 0 this reduces to the no-noise branch GPz.m:151-159 (M^-1 Delta = Sigma_oo^-1 Delta, diSoo = -1/2 Delta Delta').
+//
+// These are per-(sample, basis) d x d factorisations (SURVEY.md §8a rows a7, a22 and the missing-value branches of
+// a5, a21): not MFMA-shaped.  This first version is a straightforward correctness path — runtime d <= 20, the small
+// matrices live in per-thread scratch — used only when Psi is given or X has NaNs with GC/VC; everything around it
+// (SYRK, factorisation, T-GEMM, row scalars) is the regular pipeline.
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+#define GDM 20   // maximum d of the general path
+
+// Cholesky of the leading no x no block of M (row-major, leading dimension GDM), lower factor in place.
+__device__ inline bool chol_small(double *M, int no) {
+    bool ok = true;
+    for (int c = 0; c < no; ++c) {
+        double p = M[c * GDM + c];
+        for (int q = 0; q < c; ++q) p = fma(-M[c * GDM + q], M[c * GDM + q], p);
+        if (!(p > 0.0)) ok = false;
+        const double dd = sqrt(p);
+        M[c * GDM + c] = dd;
+        for (int r = c + 1; r < no; ++r) {
+            double s = M[r * GDM + c];
+            for (int q = 0; q < c; ++q) s = fma(-M[r * GDM + q], M[c * GDM + q], s);
+            M[r * GDM + c] = s / dd;
+        }
+    }
+    return ok;
+}
+
+// W = inv(L) (lower), then Minv = W' W; L in M (lower), result symmetric full in Minv.
+__device__ inline void inv_from_chol(const double *L, int no, double *W, double *Minv) {
+    for (int c = 0; c < no; ++c) {
+        W[c * GDM + c] = 1.0 / L[c * GDM + c];
+        for (int r = c + 1; r < no; ++r) {
+            double s = 0.0;
+            for (int q = c; q < r; ++q) s = fma(L[r * GDM + q], W[q * GDM + c], s);
+            W[r * GDM + c] = -s / L[r * GDM + r];
+        }
+    }
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double s = 0.0;
+            for (int q = a; q < no; ++q) s = fma(W[q * GDM + a], W[q * GDM + b], s);
+            Minv[a * GDM + b] = s;
+            Minv[b * GDM + a] = s;
+        }
+}
+
+// Sigma_j = inv(Gamma_j' Gamma_j), iSigma_j = Gamma_j' Gamma_j   (getPHI.m:73, GPz.m:146-147); d x d row-major, stride d*d.
+__global__ void k_gen_prep(const double *__restrict__ G, int m, int d, int de, double *__restrict__ Sig,
+                           double *__restrict__ iSig) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double A[GDM * GDM], W[GDM * GDM], Ai[GDM * GDM];
+    const double *Gj = G + (size_t)j * de * de;
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) {
+            double s = 0.0;
+            for (int q = 0; q < d; ++q) s = fma(Gj[q * de + a], Gj[q * de + b], s);
+            A[a * GDM + b] = s;
+            iSig[(size_t)j * d * d + a * d + b] = s;
+        }
+    chol_small(A, d);
+    inv_from_chol(A, d, W, Ai);
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) Sig[(size_t)j * d * d + a * d + b] = Ai[a * GDM + b];
+}
+
+// ln|Sigma_j,oo| for every (pattern g, basis j):  lnS[g*m + j]
+__global__ void k_gen_lndet(const double *__restrict__ Sig, const unsigned char *__restrict__ pat, int G, int m, int d,
+                            double *__restrict__ lnS) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G * m) return;
+    const int g = e / m, j = e % m;
+    int o[GDM], no = 0;
+    for (int c = 0; c < d; ++c)
+        if (pat[g * d + c]) o[no++] = c;
+    double M[GDM * GDM];
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b < no; ++b) M[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
+    chol_small(M, no);
+    double s = 0.0;
+    for (int a = 0; a < no; ++a) s += log(M[a * GDM + a]);
+    lnS[e] = 2.0 * s;
+}
+
+// PHI build, one thread per row, loop over basis functions.  Xr: n_pad x de (0 at missing), gid: pattern per row,
+// Psi3: n_pad x d*d (nullptr without input noise).  Writes columns [0, m) of PHI.
+__global__ __launch_bounds__(64) void k_gen_phi(const double *__restrict__ Xr, int de, const int *__restrict__ gid,
+                                                 const unsigned char *__restrict__ pat, const double *__restrict__ Psi3,
+                                                 int n, int m, int d, const double *__restrict__ P,
+                                                 const double *__restrict__ Sig, const double *__restrict__ lnS,
+                                                 double *__restrict__ Phi, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = gid[i];
+    int o[GDM], no = 0;
+    for (int c = 0; c < d; ++c)
+        if (pat[g * d + c]) o[no++] = c;
+    const double cmiss = -0.5 * (double)(d - no) * GPZ_LOG2;               // -1/2 |u| ln 2
+    double x[GDM], M[GDM * GDM], y[GDM];
+    for (int a = 0; a < no; ++a) x[a] = Xr[(size_t)i * de + o[a]];
+    for (int j = 0; j < m; ++j) {
+        const double *Sj = Sig + (size_t)j * d * d;
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double v = Sj[o[a] * d + o[b]];
+                if (Psi3) v += Psi3[(size_t)i * d * d + o[a] + d * o[b]];   // Psi(o,o,i)   getPHI.m:84
+                M[a * GDM + b] = v;
+            }
+        chol_small(M, no);
+        double quad = 0.0, ldM = 0.0;
+        for (int a = 0; a < no; ++a) {                                      // y = L^-1 Delta_o
+            double s = x[a] - P[(size_t)j * de + o[a]];
+            for (int q = 0; q < a; ++q) s = fma(-M[a * GDM + q], y[q], s);
+            y[a] = s / M[a * GDM + a];
+            quad = fma(y[a], y[a], quad);
+            ldM += log(M[a * GDM + a]);
+        }
+        double lp = -0.5 * quad + cmiss;                                    // getPHI.m:76
+        if (Psi3) lp += 0.5 * lnS[(size_t)g * m + j] - ldM;                 // getPHI.m:86  (+1/2 ln|S_oo| - 1/2 ln|M|)
+        Phi[(size_t)i * ld + j] = exp(lp);
+    }
+}
+
+// Columns m..mp-1 of PHI: y in m..m+k-1, zero after; rows >= n zero everywhere.
+__global__ void k_gen_fill(double *__restrict__ Phi, int ld, int n, int n_pad, int m, int mp, int k,
+                           const double *__restrict__ Y, long ldx) {
+    const size_t gs = (size_t)blockDim.x * gridDim.x;
+    const size_t tot = (size_t)n_pad * mp;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gs) {
+        const size_t i = e / mp;
+        const int j = (int)(e % mp);
+        if ((int)i >= n) Phi[i * ld + j] = 0.0;
+        else if (j >= m) Phi[i * ld + j] = (Y && j - m < k) ? Y[(size_t)(j - m) * ldx + i] : 0.0;
+    }
+}
+
+// lnbeta = b + PHI v, omega*beta, PHI w: one wave per row over an existing PHI (getPHI.m:116-125, GPz.m:43-48).
+__global__ __launch_bounds__(256) void k_gen_rowdot(const double *__restrict__ Phi, int ld, int n, long ldx, int m, int k,
+                                                     const double *__restrict__ v, const double *__restrict__ bvec,
+                                                     const double *__restrict__ omega, const double *__restrict__ wv,
+                                                     double *__restrict__ lnbeta, double *__restrict__ wbeta,
+                                                     double *__restrict__ phiw) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= ldx) return;
+    for (int o = 0; o < k; ++o) {
+        double sv = 0.0, sw = 0.0;
+        if (i < n) {
+            for (int j = lane; j < m; j += 64) {
+                const double ph = Phi[(size_t)i * ld + j];
+                if (v) sv = fma(ph, v[j + (size_t)m * o], sv);
+                if (wv) sw = fma(ph, wv[j + (size_t)m * o], sw);
+            }
+        }
+        sv = wave_sum(sv);
+        sw = wave_sum(sw);
+        if (lane == 0) {
+            const bool valid = i < n;
+            const double lb = bvec[o] + sv;
+            lnbeta[(size_t)o * ldx + i] = valid ? lb : 0.0;
+            if (wbeta) wbeta[(size_t)o * ldx + i] = valid ? (omega ? omega[i] : 1.0) * exp(-lb) : 0.0;
+            if (phiw) phiw[(size_t)o * ldx + i] = sw;
+        }
+    }
+}
+
+// Moment accumulation for one pattern group: thread per basis j, rows of the group given by an index list.
+//   rec[j] = [A0 = sum dp | Acc1 (d) = sum dp * embed(M^-1 Delta) | Cacc (d*d) = sum dp * embed(-M^-1 + u u') | r1 | r2]
+// dp = dPHI_ij from T, PHI and the row scalars (single-output fused form) or read from dPhi (multi-output).
+__global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ Phi, const double *__restrict__ T, int ld,
+                                                     const double *__restrict__ rowscal, const double *__restrict__ w,
+                                                     const double *__restrict__ v, const double *__restrict__ Xr, int de,
+                                                     const int *__restrict__ rows, int nrows,
+                                                     const unsigned char *__restrict__ pat, int g,
+                                                     const double *__restrict__ Psi3, int m, int d,
+                                                     const double *__restrict__ P, const double *__restrict__ Sig,
+                                                     int rows_per_chunk, double *__restrict__ slab, int nrec) {
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int chunk = blockIdx.x;
+    int o[GDM], no = 0;
+    for (int c = 0; c < d; ++c)
+        if (pat[g * d + c]) o[no++] = c;
+    double M[GDM * GDM], W[GDM * GDM], Mi[GDM * GDM], u[GDM], dl[GDM];
+    double acc1[GDM], cacc[GDM * GDM];
+    double a0 = 0.0, r1 = 0.0, r2 = 0.0;
+    for (int a = 0; a < no; ++a) acc1[a] = 0.0;
+    for (int a = 0; a < no * GDM; ++a) cacc[a] = 0.0;
+    const double wj = w ? w[j] : 0.0, vj = v ? v[j] : 0.0;
+    const double *Sj = Sig + (size_t)j * d * d;
+    const int r0 = chunk * rows_per_chunk, rend = min(nrows, r0 + rows_per_chunk);
+    for (int rr = r0; rr < rend; ++rr) {
+        const int i = rows[rr];
+        const double ph = Phi[(size_t)i * ld + j];
+        double dp;
+        if (rowscal) {
+            const double *rs = rowscal + (size_t)i * 4;
+            dp = (-rs[0] * T[(size_t)i * ld + j] - rs[1] * wj + rs[2] * vj) * ph;   // GPz.m:72,90,106,113
+            r1 = fma(ph, rs[1], r1);
+            r2 = fma(ph, rs[2], r2);
+        } else {
+            dp = T[(size_t)i * ld + j];                                     // dPHI already formed (k > 1)
+        }
+        for (int a = 0; a < no; ++a) {
+            dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
+            for (int b = 0; b <= a; ++b) {
+                double s = Sj[o[a] * d + o[b]];
+                if (Psi3) s += Psi3[(size_t)i * d * d + o[a] + d * o[b]];
+                M[a * GDM + b] = s;
+            }
+        }
+        chol_small(M, no);
+        inv_from_chol(M, no, W, Mi);                                        // iPSoo   GPz.m:170
+        for (int a = 0; a < no; ++a) {
+            double s = 0.0;
+            for (int b = 0; b < no; ++b) s = fma(Mi[a * GDM + b], dl[b], s);
+            u[a] = s;
+        }
+        a0 += dp;
+        for (int a = 0; a < no; ++a) {
+            acc1[a] = fma(dp, u[a], acc1[a]);                               // GPz.m:152,172
+            for (int b = 0; b < no; ++b) cacc[a * GDM + b] = fma(dp, u[a] * u[b] - Mi[a * GDM + b], cacc[a * GDM + b]);
+        }
+    }
+    double *rec = slab + ((size_t)chunk * m + j) * nrec;
+    for (int q = 0; q < nrec; ++q) rec[q] = 0.0;
+    rec[0] = a0;
+    for (int a = 0; a < no; ++a) {
+        rec[1 + o[a]] = acc1[a];
+        for (int b = 0; b < no; ++b) rec[1 + d + o[a] * d + o[b]] = cacc[a * GDM + b];
+    }
+    rec[1 + d + d * d] = r1;
+    rec[2 + d + d * d] = r2;
+}
+
+// Chain the per-(pattern, basis) records to dP, dGamma (GPz.m:151-159,174-181) and the column sums.
+// recs: [G][m][nrec] reduced over chunks.  Writes grad dP (scaled), dGamma into grad (VC) or dGfull (GC), cols[2][mp].
+__global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ recs, int G,
+                                                    const unsigned char *__restrict__ pat, int m, int d, int de,
+                                                    const double *__restrict__ Gam, const double *__restrict__ Sig,
+                                                    const double *__restrict__ iSig, int method_id,
+                                                    const double *__restrict__ sums1, int k, double *__restrict__ grad,
+                                                    double *__restrict__ dGfull, double *__restrict__ cols, int mp,
+                                                    int nrec) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double nk = sums1[10] * (double)k;
+    double dP[GDM], dG[GDM * GDM];
+    for (int c = 0; c < d; ++c) dP[c] = 0.0;
+    for (int e = 0; e < d * GDM; ++e) dG[e] = 0.0;
+    double r1 = 0.0, r2 = 0.0;
+    const double *Sj = Sig + (size_t)j * d * d, *iSj = iSig + (size_t)j * d * d;
+    const double *Gj = Gam + (size_t)j * de * de;
+    double Soo[GDM * GDM], W[GDM * GDM], Sinv[GDM * GDM], dS[GDM * GDM], tmp[GDM * GDM], Kuo[GDM * GDM], Aeff[GDM * GDM];
+    for (int g = 0; g < G; ++g) {
+        const double *rec = recs + ((size_t)g * m + j) * nrec;
+        int o[GDM], uix[GDM], no = 0, nu = 0;
+        for (int c = 0; c < d; ++c) {
+            if (pat[g * d + c]) o[no++] = c; else uix[nu++] = c;
+        }
+        r1 += rec[1 + d + d * d];
+        r2 += rec[2 + d + d * d];
+        for (int a = 0; a < no; ++a) dP[o[a]] += rec[1 + o[a]];
+        // Sigma_oo^-1
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b < no; ++b) Soo[a * GDM + b] = Sj[o[a] * d + o[b]];
+        for (int e = 0; e < no * GDM; ++e) tmp[e] = Soo[e];
+        chol_small(tmp, no);
+        inv_from_chol(tmp, no, W, Sinv);
+        // dSoo = 1/2 (A0 Sigma_oo^-1 + Cacc)       GPz.m:174
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b < no; ++b)
+                dS[a * GDM + b] = 0.5 * (rec[0] * Sinv[a * GDM + b] + rec[1 + d + o[a] * d + o[b]]);
+        // diSoo = -Soo dSoo Soo                    GPz.m:176
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b < no; ++b) {
+                double s = 0.0;
+                for (int q = 0; q < no; ++q) s = fma(Soo[a * GDM + q], dS[q * GDM + b], s);
+                tmp[a * GDM + b] = s;
+            }
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b < no; ++b) {
+                double s = 0.0;
+                for (int q = 0; q < no; ++q) s = fma(tmp[a * GDM + q], Soo[q * GDM + b], s);
+                dS[a * GDM + b] = -s;                                       // now diSoo
+            }
+        // GuuGuo = iSigma_uu^-1 iSigma_uo  (nu x no)   GPz.m:156,178
+        if (nu > 0) {
+            for (int a = 0; a < nu; ++a)
+                for (int b = 0; b < nu; ++b) tmp[a * GDM + b] = iSj[uix[a] * d + uix[b]];
+            chol_small(tmp, nu);
+            inv_from_chol(tmp, nu, W, Sinv);                                // Sinv = iSigma_uu^-1
+            for (int a = 0; a < nu; ++a)
+                for (int b = 0; b < no; ++b) {
+                    double s = 0.0;
+                    for (int q = 0; q < nu; ++q) s = fma(Sinv[a * GDM + q], iSj[uix[q] * d + o[b]], s);
+                    Kuo[a * GDM + b] = s;
+                }
+        }
+        // Aeff = Gamma(:,o) - Gamma(:,u) GuuGuo  (d x no);  dGo = 2 Aeff diSoo     GPz.m:157,179
+        for (int r = 0; r < d; ++r)
+            for (int b = 0; b < no; ++b) {
+                double s = Gj[r * de + o[b]];
+                for (int q = 0; q < nu; ++q) s = fma(-Gj[r * de + uix[q]], Kuo[q * GDM + b], s);
+                Aeff[r * GDM + b] = s;
+            }
+        for (int r = 0; r < d; ++r) {
+            double dgo[GDM];
+            for (int b = 0; b < no; ++b) {
+                double s = 0.0;
+                for (int q = 0; q < no; ++q) s = fma(Aeff[r * GDM + q], dS[q * GDM + b], s);
+                dgo[b] = 2.0 * s;
+                dG[r * GDM + o[b]] += dgo[b];                               // dGamma(:,o,j) += dGo     GPz.m:158,180
+            }
+            for (int a = 0; a < nu; ++a) {
+                double s = 0.0;
+                for (int b = 0; b < no; ++b) s = fma(dgo[b], Kuo[a * GDM + b], s);
+                dG[r * GDM + uix[a]] -= s;                                  // dGamma(:,u,j) -= dGo GuuGuo'   GPz.m:159,181
+            }
+        }
+    }
+    const int md = m * d;
+    for (int c = 0; c < d; ++c) grad[j + m * c] = -dP[c] / nk;
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) {
+            const double val = dG[a * GDM + b];
+            if (method_id == 5) grad[md + a + d * b + d * d * j] = -val / nk;
+            else dGfull[(size_t)j * d * d + a * d + b] = val;
+        }
+    if (cols) {
+        cols[j] = r1;
+        cols[mp + j] = r2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
+                     const unsigned char *pat, int ngroups, double *lnS) {
+    hipLaunchKernelGGL(k_gen_prep, dim3((m + 63) / 64), dim3(64), 0, st, G, m, d, de, Sig, iSig);
+    hipLaunchKernelGGL(k_gen_lndet, dim3((ngroups * m + 63) / 64), dim3(64), 0, st, (const double *)Sig, pat, ngroups, m, d,
+                       lnS);
+}
+
+void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
+                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y) {
+    hipLaunchKernelGGL(k_gen_phi, dim3((r.n + 63) / 64), dim3(64), 0, st, r.Xr, de, r.gid, pat, r.Psi3, r.n, m, d, P, Sig, lnS,
+                       Phi, mp);
+    hipLaunchKernelGGL(k_gen_fill, dim3(1024), dim3(256), 0, st, Phi, mp, r.n, r.n_pad, m, mp, k, Y, (long)r.n_pad);
+}
+
+void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
+                       const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
+                       double *phiw) {
+    hipLaunchKernelGGL(k_gen_rowdot, dim3((unsigned)((ldx + 3) / 4)), dim3(256), 0, st, Phi, ld, n, ldx, m, k, v, b, omega, w,
+                       lnbeta, wbeta, phiw);
+}
+
+void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                        const double *v, const GenRows &r, int g, int row_begin, int nrows, const unsigned char *pat, int m,
+                        int d, int de, const double *P, const double *Sig, int nchunk, int rows_per_chunk, double *slab,
+                        int nrec) {
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_gen_moments, dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, w, v, r.Xr, de,
+                       r.rows_by_group + row_begin, nrows, pat, g, r.Psi3, m, d, P, Sig, rows_per_chunk, slab, nrec);
+}
+
+void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
+                       const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
+                       double *grad, double *dGfull, double *cols, int mp, int nrec) {
+    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, method_id,
+                       sums1, k, grad, dGfull, cols, mp, nrec);
+}

@@ -533,7 +533,9 @@ __global__ void k_finish_a(FinishArgs a, int de) {
     const double nk = a.sums1[10] * (double)k;
     double *grad = a.out + 1;
     const int md = m * d;
-    if (a.kind == GPZ_KIND_COV) {
+    if (a.kind == GPZ_KIND_COV && a.gen) {
+        // dP / dGamma were chained by k_gen_finish (general path)
+    } else if (a.kind == GPZ_KIND_COV) {
         // dP(j,:) = M1_j * (Gamma_j' Gamma_j)      (GPz.m:146,151-152)
         for (int e = t0; e < m * d; e += gs) {
             const int j = e / d, c = e % d;

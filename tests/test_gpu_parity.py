@@ -53,14 +53,7 @@ def _check_eval(model, theta, X, Y, omega=None, training=None, validation=None):
     return ref
 
 
-def _built(name):
-    """Input noise / missing values are built for the diagonal kinds; GC/VC with Psi or NaN still refuse."""
-    plain = "_p1" not in name and "_n1" not in name
-    return plain or name.split("_")[1] in ("GL", "VL", "GD", "VD")
-
-
-GOLD_OK = [n for n in golden_names() if _built(n)]
-GOLD_UNSUPPORTED = [n for n in golden_names() if not _built(n)]
+GOLD_OK = golden_names()          # every method x {Psi, missing values} combination is built
 
 
 @pytest.mark.parametrize("name", GOLD_OK)
@@ -98,14 +91,43 @@ def test_golden_through_c_abi(name):
         assert rel(beta_i, g["beta_i"]) <= 1e-12 and rel(PHIs, g["PHIs"]) <= 1e-12 and not gamma.any()
 
 
-@pytest.mark.parametrize("name", GOLD_UNSUPPORTED)
-def test_unbuilt_branches_refuse_loudly(name):
-    """Psi / missing-value branches are in the oracle but not yet in the HIP path: the library must say so
-    (GPZ_ERR_UNSUPPORTED), never silently compute something else."""
-    g, model, Psi, omega, training, validation = load_golden(name)
-    with pytest.raises(_lib.GpzError) as ei:
-        gpz_amd.GPzContext(model, g["X"], g["Y"], Psi, omega, training, validation)
+def test_unbuilt_combinations_refuse_loudly():
+    """What is not built must say so (GPZ_ERR_UNSUPPORTED / GPZ_ERR_ARG), never silently compute something else."""
+    model, theta, X, Y, Psi, rng = make_problem(64, 3, 4, 1, "VC", True, seed=5, psi=True)
+    with pytest.raises(_lib.GpzError) as ei:          # row-sharded general GC/VC path
+        gpz_amd.GPzContext(model, X, Y, Psi, rank=0, world=2)
     assert ei.value.code == -5
+    with pytest.raises(_lib.GpzError) as ei:          # wrong Psi layout for the method (fixPsi.m)
+        gpz_amd.GPzContext(model, X, Y, np.abs(X))
+    assert ei.value.code == -1
+    big = gpz_amd.Model(m=3, d=21, method="VD")
+    with pytest.raises(_lib.GpzError) as ei:          # d beyond the instantiated kernels
+        gpz_amd.GPzContext(big, np.zeros((8, 21)), np.zeros((8, 1)))
+    assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("method", ["GC", "VC"])
+@pytest.mark.parametrize("psi,nanfrac", [(True, 0.0), (False, 0.3), (True, 0.3)])
+@pytest.mark.parametrize("shape", [(300, 3, 8, 1), (500, 5, 12, 2), (400, 10, 10, 1)])
+def test_cov_kinds_with_input_noise_and_missing(method, psi, nanfrac, shape):
+    n, d, m, k = shape
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=7 * n + d, psi=psi, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        tol = max(grad_tol(ref.cond), phi_tol(model, theta))
+        assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
+        assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+        for key, val in ref.stats.items():
+            assert abs(ctx.stats[key] - val) <= max(1e-10, phi_tol(model, theta)) * max(1.0, abs(val)), key
+        r4 = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr, nargout=4)
+        w, iS, part = ctx.solve(theta)
+        assert rel(w, r4.w) <= tol and rel(ctx.phi(), r4.PHI) <= max(1e-12, phi_tol(model, theta))
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("method", METHODS)
