@@ -126,8 +126,12 @@ __global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict_
     __shared__ double sW[2][16];
 
     const int npairs = ntile * (ntile + 1) / 2;
-    const int pair = blockIdx.x % npairs;
-    const int split = blockIdx.x / npairs;
+    // XCD-aware remap (see k_tgemm): the tiles of one row split run on one XCD and walk the same 16-row slices of
+    // PHI at the same time, so a slice is fetched once per split instead of once per tile.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int pair = lb % npairs;
+    const int split = lb / npairs;
     // decode pair -> (ti <= tj), row-major over the upper triangle
     int ti = 0, rem = pair;
     while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
@@ -303,7 +307,12 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
                                                         int mcol, long n_pad, int dbg) {
     __shared__ double sA[2][128][18];
     __shared__ double sB[2][16][LDS_LD128];
-    const int rt = blockIdx.x / nct, ct = blockIdx.x % nct;
+    // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
+    // logical tiles, so the 8 column tiles of a row panel run back to back on one XCD and the 1 MB PHI panel is
+    // fetched from HBM once instead of once per XCD.  Bijective for any grid size; affects speed only.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
         tgemm_body<false, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, dbg);
