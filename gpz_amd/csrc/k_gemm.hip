@@ -71,7 +71,11 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         if (nstage > 1) gload(r_begin + 16);
     }
     __syncthreads();
+    // diagonal tiles: the wave blocks strictly below the diagonal (rows 64..127 x columns 0..63) are never read by
+    // the slab reduction; their waves only take part in the staging, which frees MFMA slots for the other workgroup
+    const bool skip = diag_tile && wr == 1 && wc < WC / 2;
     auto mfma_half = [&](int cur, int kk0) {
+        if (skip) return;
         const double(*tA)[LDS_LD128] = sA[cur];
         const double(*tB)[LDS_LD128] = diag_tile ? sA[cur] : sB[cur];
 #pragma unroll
