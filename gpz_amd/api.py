@@ -234,23 +234,33 @@ def GPz(theta, model, X, Y, Psi=None, omega=None, training=None, validation=None
     return out
 
 
-def getPHI(X, Psi, theta, model, selection=None, device=0):
-    """[PHI,Gamma,lnBeta_i] = getPHI(X,Psi,theta,model,selection)   (getPHI.m:1); Gamma is the expanded
-    parameter array of getPHI.m:26-40 (pure reshaping of theta, done on the host)."""
-    if Psi is not None:
-        raise _lib.GpzError(-5, "input-noise (Psi) paths are not built yet")
+def getPHI(X, Psi, theta, model, selection=None, device=0, want_N=False):
+    """[PHI,Gamma,lnBeta_i,N] = getPHI(X,Psi,theta,model,selection)   (getPHI.m:1); Gamma is the expanded
+    parameter array of getPHI.m:26-40 (pure reshaping of theta, done on the host).  Psi: n x d for the diagonal
+    kinds, d x d x n for GC/VC (the layouts fixPsi.m produces); X may contain NaN (missing inputs)."""
     lib = _lib.load()
     X = np.asarray(X, dtype=np.float64)
+    psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)
     if selection is not None:
-        X = X[np.asarray(selection, dtype=bool)]
+        sel = np.asarray(selection, dtype=bool)
+        X = X[sel]                                                     # getPHI.m:14
+        if psi is not None:
+            psi = psi[:, :, sel] if psi.ndim == 3 else psi[sel]        # getPHI.m:16-22
     X = _f64(X, 2)
+    psi_kind = 0
+    if psi is not None:
+        psi = np.asfortranarray(psi)
+        psi_kind = 2 if psi.ndim == 3 else 1
     theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
     ns = X.shape[0]
     PHI = np.empty((ns, model.m), order="F")
     lnB = np.empty((ns, model.k), order="F")
+    N = np.empty((ns, model.m), order="F") if want_N else None
     ds = _desc(model, device)
-    _lib.check(lib.gpz_phi(C.byref(ds), _lib.dptr(theta), _lib.dptr(X), ns, _lib.dptr(PHI), _lib.dptr(lnB)))
-    return PHI, _expand_gamma(theta, model), lnB
+    _lib.check(lib.gpz_phi(C.byref(ds), _lib.dptr(theta), _lib.dptr(X), ns, _lib.dptr(psi), psi_kind, _lib.dptr(PHI),
+                           _lib.dptr(lnB), _lib.dptr(N)))
+    out = (PHI, _expand_gamma(theta, model), lnB)
+    return out + (N,) if want_N else out
 
 
 def _expand_gamma(theta, model):

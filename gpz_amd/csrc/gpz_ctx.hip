@@ -382,51 +382,37 @@ static int alloc_mm(gpz_ctx *c) {   // m x m stage buffers
     return 0;
 }
 
-extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y, const double *Psi,
-                              int32_t psi_kind, const double *omega, const uint8_t *training,
-                              const uint8_t *validation, gpz_ctx **out) {
-    if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
-    *out = nullptr;
-    gpz_ctx *c = new gpz_ctx();
-    int rc = setup_model(c, desc);
-    if (rc) { delete c; return rc; }
-    if ((Psi != nullptr) != (psi_kind != 0)) { delete c; return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree"); }
+// Data-dependent part of a context: path selection (tuned / general), row sets, pattern table, parameter block.
+static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *Y, const double *Psi, int32_t psi_kind,
+                      const double *omega, const uint8_t *training, const uint8_t *validation) {
+    const gpz_desc *desc = &c->desc;
+    int rc = 0;
+    if ((Psi != nullptr) != (psi_kind != 0)) return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree");
     const bool xnan = has_nan(X, n_tot * (int64_t)c->d) != 0;
     if (c->kind == GPZ_KIND_COV && (Psi || xnan)) {
         // general path: per-pair d x d factorisations (k_gen.hip)
-        if (Psi && psi_kind != 2) { delete c; return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)"); }
-        if (desc->world > 1) {
-            delete c;
+        if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
+        if (desc->world > 1)
             return fail(GPZ_ERR_UNSUPPORTED, "row-sharded runs of the general GC/VC path (Psi / missing values) are not built yet");
-        }
-        if (c->d > 20) { delete c; return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20"); }
+        if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
     }
-    if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1) {
-        delete c;
+    if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1)
         return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)");
-    }
     c->has_psi = Psi != nullptr;
     if (c->has_psi && !c->gen) c->nm = 3 * c->de;
     // one missing value anywhere (training or validation rows) switches the mask arrays on for both row sets
     c->has_missing = xnan;
-    auto bail = [&](int code) {
-        c->ar.release();
-        if (c->out_h) (void)hipHostFree(c->out_h);
-        if (c->theta_h) (void)hipHostFree(c->theta_h);
-        delete c;
-        return code;
-    };
-    if (hipSetDevice(c->device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device));
-    if ((rc = upload_rowset(c, c->tr, n_tot, X, Y, omega, training, true, Psi))) return bail(rc);
-    if (c->tr.n < 1 && desc->world <= 1) return bail(fail(GPZ_ERR_ARG, "training mask selects no rows"));
+    if (hipSetDevice(c->device) != hipSuccess) return fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if ((rc = upload_rowset(c, c->tr, n_tot, X, Y, omega, training, true, Psi))) return rc;
+    if (c->tr.n < 1 && desc->world <= 1) return fail(GPZ_ERR_ARG, "training mask selects no rows");
     bool any_valid = false;
     if (validation)
         for (int64_t i = 0; i < n_tot && !any_valid; ++i) any_valid = validation[i] != 0;
     // with sharding a rank may hold no validation rows while others do: the caller signals "validation in use"
     // by passing a non-NULL mask
     if (validation && (any_valid || desc->world > 1)) {
-        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, c->gen, Psi))) return bail(rc);
+        if ((rc = upload_rowset(c, c->va, n_tot, X, Y, omega, validation, c->gen, Psi))) return rc;
         if (!omega) c->va.om = nullptr;
     }
     if (c->gen) {
@@ -435,16 +421,36 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
         for (int g = 0; g < c->ngroups; ++g) memcpy(&hp[(size_t)g * c->d], c->pats[g].data(), c->d);
-        if ((rc = c->ar.alloc(&c->pat_d, hp.size()))) return bail(rc);
-        if (hipMemcpy(c->pat_d, hp.data(), hp.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "copy failed"));
-        if ((rc = c->ar.alloc(&c->Sig, (size_t)c->m * c->d * c->d))) return bail(rc);
-        if ((rc = c->ar.alloc(&c->iSig, (size_t)c->m * c->d * c->d))) return bail(rc);
-        if ((rc = c->ar.alloc(&c->lnS, (size_t)c->ngroups * c->m))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->pat_d, hp.size()))) return rc;
+        if (hipMemcpy(c->pat_d, hp.data(), hp.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(GPZ_ERR_HIP, "copy failed");
+        if ((rc = c->ar.alloc(&c->Sig, (size_t)c->m * c->d * c->d))) return rc;
+        if ((rc = c->ar.alloc(&c->iSig, (size_t)c->m * c->d * c->d))) return rc;
+        if ((rc = c->ar.alloc(&c->lnS, (size_t)c->ngroups * c->m))) return rc;
+    }
+    return alloc_params(c);
+}
+
+extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y, const double *Psi,
+                              int32_t psi_kind, const double *omega, const uint8_t *training,
+                              const uint8_t *validation, gpz_ctx **out) {
+    if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
+    *out = nullptr;
+    gpz_ctx *c = new gpz_ctx();
+    int rc = setup_model(c, desc);
+    if (rc) { delete c; return rc; }
+    auto bail = [&](int code) {
+        c->ar.release();
+        if (c->out_h) (void)hipHostFree(c->out_h);
+        if (c->theta_h) (void)hipHostFree(c->theta_h);
+        delete c;
+        return code;
+    };
+    if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation))) return bail(rc);
+    if (c->gen) {
         c->gen_nchunk = 64;
         if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * c->nrec))) return bail(rc);
         if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
     }
-    if ((rc = alloc_params(c))) return bail(rc);
     if ((rc = alloc_mm(c))) return bail(rc);
 
     const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
@@ -572,15 +578,8 @@ static int allreduce(gpz_ctx *c, double *buf, size_t count) {
     return 0;
 }
 
-// Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
-static int stage_a(gpz_ctx *c, const double *theta) {
-    memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
-    HIPCHK(hipMemcpyAsync(c->theta_d, c->theta_h, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
-    {
-        Stage s(c, "unpack");
-        launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
-        if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
-    }
+// PHI, ln beta and omega*beta of the training row set from the unpacked parameters (getPHI.m:60-125, GPz.m:43-48).
+static int build_phi(gpz_ctx *c) {
     if (c->gen) {
         Stage s(c, "phi_build");
         launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
@@ -600,6 +599,19 @@ static int stage_a(gpz_ctx *c, const double *theta) {
         a.part = c->phipart; a.part_groups = c->phipart_groups;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
     }
+    return 0;
+}
+
+// Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
+static int stage_a(gpz_ctx *c, const double *theta) {
+    memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
+    HIPCHK(hipMemcpyAsync(c->theta_d, c->theta_h, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+    {
+        Stage s(c, "unpack");
+        launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+        if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
+    }
+    if (int e = build_phi(c)) return e;
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
     {
         Stage s(c, "row_sums");
@@ -879,17 +891,16 @@ extern "C" int gpz_get_phi(gpz_ctx *c, double *PHI) {
 }
 
 // ---- stand-alone entry points --------------------------------------------------------------------
-// A throw-away context without training data: parameters + PHI on ns rows.
-static int make_eval_ctx(const gpz_desc *desc, const double *Xs, int64_t ns, gpz_ctx **out) {
+// A throw-away context without targets: parameters + PHI on ns rows (all rows selected).
+static int make_eval_ctx(const gpz_desc *desc, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
+                         gpz_ctx **out) {
     gpz_ctx *c = new gpz_ctx();
     int rc = setup_model(c, desc);
     if (rc) { delete c; return rc; }
     auto bail = [&](int code) { c->ar.release(); delete c; return code; };
-    if (hipSetDevice(c->device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", c->device));
-    if (has_nan(Xs, ns * (int64_t)c->d)) return bail(fail(GPZ_ERR_UNSUPPORTED, "missing (NaN) inputs are not built yet"));
+    c->desc.world = 1;
     std::vector<double> y0((size_t)ns * c->k, 0.0);
-    if ((rc = upload_rowset(c, c->tr, ns, Xs, y0.data(), nullptr, nullptr, false))) return bail(rc);
-    if ((rc = alloc_params(c))) return bail(rc);
+    if ((rc = setup_data(c, ns, Xs, y0.data(), Psi, psi_kind, nullptr, nullptr, nullptr))) return bail(rc);
     const size_t np = c->tr.n_pad;
     if ((rc = c->ar.alloc(&c->Phi, np * c->mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->lnbeta, np * c->k))) return bail(rc);
@@ -903,28 +914,32 @@ static int run_phi_only(gpz_ctx *c, const double *theta) {
     HIPCHK(hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
     if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
-    PhiArgs a{};
-    a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
-    a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
-    a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
-    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = nullptr; a.Y = nullptr;
-    a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
-    if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
-    return 0;
+    return build_phi(c);
 }
 
-extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns, double *PHI,
-                       double *lnBeta_i) {
+extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns, const double *Psi,
+                       int32_t psi_kind, double *PHI, double *lnBeta_i, double *N) {
     if (!desc || !theta || !Xs || ns < 1) return fail(GPZ_ERR_ARG, "gpz_phi: null argument");
     gpz_ctx *c = nullptr;
-    if (int e = make_eval_ctx(desc, Xs, ns, &c)) return e;
+    if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     int rc = run_phi_only(c, theta);
-    double *tmp = nullptr;
+    double *tmp = nullptr, *nd = nullptr;
+    if (!rc && (PHI || N)) rc = c->ar.alloc(&tmp, (size_t)ns * c->m);
     if (!rc && PHI) {
-        rc = c->ar.alloc(&tmp, (size_t)ns * c->m);
+        launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+        if (hipMemcpyAsync(PHI, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
+    }
+    if (!rc && N) {   // N = exp(lnN), lnN = lnPHI - 1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2   (getPHI.m:77,87,98,105,114)
+        rc = c->ar.alloc(&nd, (size_t)c->tr.n_pad * c->mp);
         if (!rc) {
-            launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
-            if (hipMemcpyAsync(PHI, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+            NormArgs a{};
+            a.Phi = c->Phi; a.ld = c->mp; a.n = (int)ns; a.m = c->m; a.d = c->d; a.de = c->de; a.kind = c->kind;
+            a.gen = c->gen ? 1 : 0; a.G = c->pr.G; a.Rc = c->pr.Rc; a.Mr = c->tr.Mr; a.ucnt = c->tr.ucnt;
+            a.gid = c->tr.gid; a.pat = c->pat_d; a.lnS = c->lnS; a.N = nd;
+            launch_phi_norm(c->st, a);
+            launch_transpose_out(c->st, nd, c->mp, ns, c->m, tmp);
+            if (hipMemcpyAsync(N, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
                 rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
         }
     }
@@ -943,7 +958,9 @@ extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const
     if (!desc || !theta || !w || !iSigma_w || !Xs || ns < 1 || !mu || !nu || !beta_i)
         return fail(GPZ_ERR_ARG, "gpz_predict_full: null argument");
     gpz_ctx *c = nullptr;
-    if (int e = make_eval_ctx(desc, Xs, ns, &c)) return e;
+    if (has_nan(Xs, ns * (int64_t)desc->d))
+        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values (predictMissing, predictDiag.m:127) is not built");
+    if (int e = make_eval_ctx(desc, Xs, ns, nullptr, 0, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
     int rc = 0;
     double *T = nullptr, *Bext = nullptr, *wd = nullptr, *Sd = nullptr, *nud = nullptr, *dgi = nullptr, *tmp = nullptr;

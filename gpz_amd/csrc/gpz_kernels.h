@@ -183,6 +183,17 @@ void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
                        double *grad, double *dGfull, double *cols, int mp, int nrec);
 
+// N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
+struct NormArgs {
+    const double *Phi; int ld; int n, m, d, de, kind, gen;
+    const double *G;        // diag kinds: gamma [m][de]
+    const double *Rc;       // cov kinds, tuned path: QR factor records
+    const double *Mr, *ucnt;// diag kinds with missing values (row-major mask, missing count) or nullptr
+    const int *gid; const unsigned char *pat; const double *lnS;   // general cov path
+    double *N;              // n_pad x ld row-major
+};
+void launch_phi_norm(hipStream_t st, const NormArgs &a);
+
 // misc
 void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long ny, int d, double *D);
 void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst /* n x m col-major */);

@@ -342,6 +342,43 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
     }
 }
 
+// N_ij = PHI_ij * exp(cn), cn = -1/2 ln|Sigma_j,oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2      (getPHI.m:77,87,98,105)
+__global__ void k_phi_norm(NormArgs a) {
+    const size_t gs = (size_t)blockDim.x * gridDim.x;
+    const size_t tot = (size_t)a.n * a.m;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gs) {
+        const size_t i = e / a.m;
+        const int j = (int)(e % a.m);
+        double cn;
+        if (a.kind == GPZ_KIND_DIAG) {
+            // -1/2 sum_o ln sigma = sum_o ln|gamma|
+            double s = 0.0, nu = a.ucnt ? a.ucnt[i] : 0.0;
+            for (int c = 0; c < a.d; ++c) {
+                const double mk = a.Mr ? a.Mr[i * a.de + c] : 1.0;
+                if (mk != 0.0) s += log(fabs(a.G[(size_t)j * a.de + c]));
+            }
+            cn = s - 0.5 * ((double)a.d - nu) * GPZ_LOG2PI + 0.5 * nu * GPZ_LOG2;
+        } else if (a.gen) {
+            const int g = a.gid[i];
+            int no = 0;
+            for (int c = 0; c < a.d; ++c) no += a.pat[g * a.d + c] ? 1 : 0;
+            cn = -0.5 * a.lnS[(size_t)g * a.m + j] - 0.5 * no * GPZ_LOG2PI + 0.5 * (a.d - no) * GPZ_LOG2;
+        } else {
+            // -1/2 ln|Sigma_j| = ln|det Gamma_j| = sum ln|R_aa|
+            const int nt = a.de * (a.de + 1) / 2;
+            const double *rj = a.Rc + (size_t)j * (nt + a.de);
+            double s = 0.0;
+            for (int q = 0; q < a.d; ++q) s += log(fabs(rj[q * a.de - q * (q - 1) / 2]));
+            cn = s - 0.5 * a.d * GPZ_LOG2PI;
+        }
+        a.N[i * a.ld + j] = a.Phi[i * a.ld + j] * exp(cn);
+    }
+}
+
+void launch_phi_norm(hipStream_t st, const NormArgs &a) {
+    hipLaunchKernelGGL(k_phi_norm, dim3(1024), dim3(256), 0, st, a);
+}
+
 // ---------------------------------------------------------------------------------------------
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
                      const unsigned char *pat, int ngroups, double *lnS) {

@@ -11,7 +11,7 @@
  *   gpz_eval            [nlogML,grad] = GPz(theta,...)      GPz/GPz.m:1  (nargout<=2 mode, :89-261)
  *                       + globals trainRMSE/trainLL/validRMSE/validLL   GPz/GPz.m:3-7,236-259
  *   gpz_solve           [~,~,w,iSigma_w] = GPz(theta,...)   GPz/GPz.m:84-87 (nargout>2 mode)
- *   gpz_phi             [PHI,Gamma,lnBeta_i] = getPHI(X,[],theta,model,[])   GPz/getPHI.m:1
+ *   gpz_phi             [PHI,Gamma,lnBeta_i,N] = getPHI(X,Psi,theta,model,[]) GPz/getPHI.m:1
  *   gpz_predict_full    predictFull(X,theta,w,iSigma_w,model) GPz/predictDiag.m:58-74, predictCov.m:53-69
  *   gpz_inv_logdet      [Xi,logdet] = inv_logdet(X)         GPz/inv_logdet.m:1
  *   gpz_dxy             D = Dxy(X,Y)                        GPz/Dxy.m:1
@@ -109,9 +109,10 @@ int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);
 int gpz_ctx_timings(gpz_ctx *ctx, const char **names, double *ms, int64_t *calls, int cap);
 int gpz_ctx_reset_timings(gpz_ctx *ctx);
 
-/* getPHI(X,[],theta,model,[]) on ns rows: PHI ns x m, lnBeta_i ns x k (column-major, host). */
+/* [PHI,~,lnBeta_i,N] = getPHI(X,Psi,theta,model,[]) on ns rows: PHI ns x m, lnBeta_i ns x k, N ns x m
+ * (column-major, host; any output may be NULL).  Psi / psi_kind as in gpz_ctx_create; X may contain NaN. */
 int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns,
-            double *PHI, double *lnBeta_i);
+            const double *Psi, int32_t psi_kind, double *PHI, double *lnBeta_i, double *N);
 
 /* predictFull: mu = PHI*w (muY NOT added, as in predictDiag.m:65), nu, beta_i; PHI optional. */
 int gpz_predict_full(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,

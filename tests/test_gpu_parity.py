@@ -74,16 +74,15 @@ def test_golden_through_c_abi(name):
         assert rel(w, g["w"]) <= tol and rel(iS, g["iSigma_w"]) <= tol and rel(part, g["nlogML_partial"]) <= FTOL
     finally:
         ctx.close()
-    if Psi is None and not np.isnan(g["X"]).any():
-        PHI, Gamma, lnB = gpz_amd.getPHI(g["X"], None, g["theta"], model, training)
-        assert rel(lnB, g["lnBeta_i"]) <= 1e-12
-        if "PHI" in g:
-            assert rel(PHI, g["PHI"]) <= 1e-12
-    elif "PHI" in g:
-        ctx = gpz_amd.GPzContext(model, g["X"], g["Y"], Psi, omega, training, validation)
-        ctx.solve(g["theta"])
-        assert rel(ctx.phi(), g["PHI"]) <= 1e-12                      # 5th output of GPz.m:1 with Psi / missing dims
-        ctx.close()
+    # getPHI as a stand-alone call: every branch (Psi, missing values), all four outputs
+    PHI, Gamma, lnB, N = gpz_amd.getPHI(g["X"], Psi, g["theta"], model, training, want_N=True)
+    ptol = phi_tol(model, g["theta"])
+    assert rel(lnB, g["lnBeta_i"]) <= ptol
+    if "PHI" in g:
+        assert rel(PHI, g["PHI"]) <= ptol
+        assert rel(N, g["N"]) <= max(ptol, 1e-11)
+    P_, G_, *_ = O.unpack_theta(g["theta"], model)
+    assert np.array_equal(Gamma, O.expand_gamma(G_, model))
     if "Xs" in g:
         model.sets["best"] = {"theta": g["theta"], "w": g["w"], "iSigma_w": g["iSigma_w"]}
         mu, sigma, nu, beta_i, gamma, PHIs, _, _ = gpz_amd.predict(g["Xs"], model)
