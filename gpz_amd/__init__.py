@@ -6,3 +6,4 @@ The numeric work lives in ``lib/libgpz_hip.so`` (hand-written HIP, built by ``./
 """
 from .api import (GPz, GPzContext, Model, getPHI, inv_logdet, Dxy, nan_groups, predict, reset, globals_)  # noqa: F401
 from . import dist  # noqa: F401
+from .host import init, train, fixPsi, getOmega, sample, metrics, minfunc_lbfgs  # noqa: F401

@@ -621,9 +621,7 @@ static int stage_a(gpz_ctx *c, const double *theta) {
     for (int o = 0; o < c->k; ++o) {
         {
             Stage s(c, "syrk");
-            // GPZ_DEBUG_LD0 (timing experiment only): collapse every PHI row onto row 0 so the operand is cache-resident
-            static const int dbg_ld0 = getenv("GPZ_DEBUG_LD0") ? 1 : 0;
-            launch_syrk(c->st, c->Phi, dbg_ld0 ? 0 : c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
+            launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
                         c->rows_per_split, c->slab, false);
         }
         {
@@ -685,9 +683,8 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
         stage_b(c, o);
         {
             Stage s(c, "tgemm");
-            static const int dbg_ld0 = getenv("GPZ_DEBUG_LD0") ? atoi(getenv("GPZ_DEBUG_LD0")) : 0;
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
-                         c->phiw, c->m, c->m + o, dbg_ld0);
+                         c->phiw, c->m, c->m + o);
         }
         if (fused) {
             {

@@ -179,7 +179,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            double (*sA)[128][18], double (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
-                                           long n_pad, int ct, int dbg) {
+                                           long n_pad, int ct) {
     constexpr int NT = 128 * WC;
     constexpr int NI = 8 / WC;
     constexpr int Q = 1024 / NT;
@@ -234,17 +234,10 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int kc = kk * 4 + (lane >> 4);
             double a[4], b[NI];
-            if (dbg & 1) {   // ablation: operands from registers instead of LDS
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) a[mi] = 1e-3 * (lane + mi + kk);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni] = 1e-3 * (lane - ni + kk);
-            } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
-            }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 if (!EDGE || ni < nvalid) {
@@ -256,14 +249,12 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
         mfma_half(cur, 0);
-        if (!(dbg & 2)) {   // ablation bit 1: no staging, no barrier
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
             if (s + 2 < nstage) gload((s + 2) * 16);
         }
-        }
         mfma_half(cur, 2);
-        if (!(dbg & 2)) __syncthreads();
+        __syncthreads();
     }
 
 #pragma unroll
@@ -308,7 +299,7 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
                                                         const double *__restrict__ B, int ldb,
                                                         double *__restrict__ T, int ldt, int mp, int nct,
                                                         double *__restrict__ nupart, double *__restrict__ phiw, int m,
-                                                        int mcol, long n_pad, int dbg) {
+                                                        int mcol, long n_pad) {
     __shared__ double sA[2][128][18];
     __shared__ double sB[2][16][LDS_LD128];
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
@@ -319,9 +310,9 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
-        tgemm_body<false, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, dbg);
+        tgemm_body<false, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
     else
-        tgemm_body<true, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, dbg);
+        tgemm_body<true, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -448,14 +439,12 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, 
 }
 
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol, int debug_ld0) {
+                  double *nupart, double *phiw, int m, int mcol) {
     constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
     dim3 grid((n_pad / 128) * nct), block(128 * WC);
-    const int dbg = debug_ld0 >> 1;   // ablation bits (timing experiments only)
-    const int l0 = debug_ld0 & 1;
-    hipLaunchKernelGGL(k_tgemm<WC>, grid, block, 0, st, Phi, l0 ? 0 : ld, B, ldb, T, l0 ? 0 : ld, mp, nct,
-                       nupart, phiw, m, mcol, (long)n_pad, dbg);
+    hipLaunchKernelGGL(k_tgemm<WC>, grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
+                       (long)n_pad);
 }
 
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb) {

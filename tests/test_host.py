@@ -1,0 +1,124 @@
+"""Host-side callers of the path (gpz_amd/host.py): the L-BFGS / strong-Wolfe driver mirrors minFunc's 'lbfgs'
+method (minFunc.m:544-582,968-1150; WolfeLineSearch.m; polyinterp.m; lbfgsAdd.m; lbfgsProd.m).  CPU tests use
+analytic objectives and the oracle; the GPU tests run init -> train -> predict through the HIP path."""
+import math
+
+import numpy as np
+import pytest
+
+from gpz_amd import host
+from oracle import gpz_oracle as O
+from helpers import make_problem, rel
+
+
+def rosenbrock(x):
+    f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+    g = np.zeros_like(x)
+    g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+    g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+    return float(f), g
+
+
+def test_polyinterp_cubic_closed_form():
+    # f(x) = x^3 - 3x  -> minimum at x = 1; points at 0 and 2
+    t = host._polyinterp([(0.0, 0.0, -3.0), (2.0, 2.0, 9.0)])
+    assert abs(t - 1.0) < 1e-14
+    # quadratic from one value+slope and one value: f = (x-0.3)^2
+    t = host._polyinterp([(0.0, 0.09, -0.6), (1.0, 0.49, None)], 0.0, 1.0)
+    assert abs(t - 0.3) < 1e-12
+
+
+def test_lbfgs_converges_on_rosenbrock():
+    x0 = np.full(10, -1.2)
+    x, f, flag, evals, msg = host.minfunc_lbfgs(rosenbrock, x0, max_iter=500)
+    assert flag in (1, 2) and f < 1e-8 and np.max(np.abs(x - 1.0)) < 1e-3   # stops on progTol/optTol like minFunc
+
+
+def test_wolfe_conditions_hold():
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((8, 8)); A = A @ A.T + np.eye(8)
+    b = rng.standard_normal(8)
+    fun = lambda x: (0.5 * x @ A @ x - b @ x, A @ x - b)
+    x = rng.standard_normal(8)
+    f, g = fun(x)
+    d = -g
+    gtd = g @ d
+    t, fn, gn, ev = host._wolfe(fun, x, 1.0, d, f, g, gtd, 1e-4, 0.9, 25, 1e-9)
+    assert fn <= f + 1e-4 * t * gtd and abs(gn @ d) <= -0.9 * gtd
+
+
+def test_lbfgs_memory_is_circular_and_skips_bad_pairs():
+    mem = host._LBFGS(3, 2)
+    assert not mem.add(np.array([1.0, 0, 0]), np.array([-1.0, 0, 0]))         # y's <= 1e-10: skipped (lbfgsAdd.m:5)
+    for q in range(3):
+        assert mem.add(np.eye(3)[q] * (q + 1.0), np.eye(3)[q])
+    assert mem.count == 2 and mem.hdiag == pytest.approx(1.0 / 3.0)
+    d = mem.direction(np.ones(3))
+    assert np.all(np.isfinite(d)) and d @ np.ones(3) < 0                      # a descent direction
+
+
+def test_nonfinite_objective_backs_off():
+    def fun(x):
+        if abs(x[0]) > 2.0:
+            return float("nan"), np.full_like(x, np.nan)
+        return float((x[0] - 1.5) ** 2), np.array([2 * (x[0] - 1.5)])
+    x, f, flag, evals, msg = host.minfunc_lbfgs(fun, np.array([-1.9]), max_iter=50)
+    assert abs(x[0] - 1.5) < 1e-5
+
+
+def test_lbfgs_on_oracle_objective_decreases():
+    model, theta, X, Y, _, rng = make_problem(120, 2, 6, 1, "VD", True, seed=4)
+    fun = lambda t: (lambda r: (r.nlogML, r.grad))(O.GPz(t, model, X, Y))
+    f0, g0 = fun(theta)
+    x, f, flag, evals, msg = host.minfunc_lbfgs(fun, theta, max_iter=15)
+    assert f < f0 - 1e-3
+
+
+def test_input_helpers_match_oracle():
+    sd = np.array([2.0, 4.0])
+    for psi in (np.array([1.0, 2.0, 3.0]), np.abs(np.random.default_rng(0).standard_normal((3, 2)))):
+        for method in ("VD", "VC"):
+            assert rel(host.fixPsi(psi, 3, sd, method), O.fixPsi(psi, 3, sd, method)) < 1e-15
+    tr, va, te = host.sample(100, 0.7, 0.15, 0.15, np.random.default_rng(1))
+    assert tr.sum() == 70 and va.sum() == 15 and te.sum() == 15 and not (tr & va).any() and (tr | va | te).all()
+
+
+# ---- through the HIP path -------------------------------------------------------------------------
+def _sinc_data(n=3000, seed=1):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-10, 10, (n, 1))
+    noise = 0.05 + 0.2 * (1 + np.sin(X[:, 0] / 3)) / 2
+    Y = (np.sinc(X[:, 0] / np.pi) + noise * rng.standard_normal(n))[:, None]
+    return X, Y
+
+
+@pytest.mark.gpu
+def test_init_train_predict_sinc():
+    import gpz_amd
+    X, Y = _sinc_data()
+    rng = np.random.default_rng(0)
+    tr, va, te = gpz_amd.sample(X.shape[0], 0.7, 0.15, 0.15, rng)
+    model = gpz_amd.init(X, Y, "VL", 30, training=tr, rng=rng)
+    assert model.method == "VL" and model.sets["last"]["w"].shape == (30, 1)
+    model = gpz_amd.train(model, X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False)
+    mu, sigma, nu, beta_i, gamma, PHI, w, iS = gpz_amd.predict(X, model, selection=te)
+    rmse = math.sqrt(np.mean((mu[:, 0] - Y[te, 0]) ** 2))
+    assert rmse < 0.2 and np.all(sigma > 0)
+    # heteroscedastic noise model picked up the input-dependent noise: predicted variance correlates with it
+    noise = 0.05 + 0.2 * (1 + np.sin(X[te, 0] / 3)) / 2
+    assert np.corrcoef(np.sqrt(sigma[:, 0]), noise)[0, 1] > 0.5
+
+
+@pytest.mark.gpu
+def test_training_trajectory_matches_oracle_objective():
+    """Same optimiser, objective from the HIP path vs the oracle: the first iterations must coincide."""
+    import gpz_amd
+    model, theta, X, Y, _, rng = make_problem(400, 2, 8, 1, "VC", True, seed=6)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    fs_gpu, fs_cpu = [], []
+    rec = lambda store: (lambda x, kind, i, ev, f, *a: store.append(f) or False)
+    host.minfunc_lbfgs(ctx.eval, theta, max_iter=6, output_fcn=rec(fs_gpu))
+    ctx.close()
+    host.minfunc_lbfgs(lambda t: (lambda r: (r.nlogML, r.grad))(O.GPz(t, model, X, Y)), theta, max_iter=6,
+                       output_fcn=rec(fs_cpu))
+    assert len(fs_gpu) == len(fs_cpu) and rel(np.array(fs_gpu), np.array(fs_cpu)) < 1e-7
