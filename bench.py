@@ -213,7 +213,7 @@ def main():
             "finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rows = max(2000, min(n, n // 16 if n >= 200000 else n // 4))
+            rows = max(2000, min(n, n // 32 if n >= 200000 else n // 4))   # ~20 s of CPU work at c4
             ref, cb = cpu_baseline(cfg, model, theta0, X, y, omega, rows)
             out["cpu_baseline"] = cb
             # parity gate on the same sample through the HIP path

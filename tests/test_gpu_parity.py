@@ -370,3 +370,26 @@ def test_sharded_eval_world2_matches_unsharded():
             assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
         assert rel(w, r4.w) <= tol and rel(part, r4.nlogML) <= FTOL
     assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])   # ranks finish identically (no broadcast)
+
+
+def test_c5_shape_fp64_small_n():
+    """c5's shape (d=20, m large, VC) in fp64 at a row count the oracle can do: exercises the d=20 kernel
+    instantiations (split moment passes, 4-row PHI kernel at the LDS limit) and a 16-tile SYRK."""
+    model, theta, X, Y, _, rng = make_problem(2500, 20, 300, 1, "VC", True, seed=55)
+    ref = O.GPz(theta, model, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f, g = ctx.eval(theta)
+    ctx.close()
+    tol = max(grad_tol(ref.cond), phi_tol(model, theta))
+    assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol
+
+
+def test_large_m_tiles():
+    """m = 2050 (17 column tiles, partial edge tile, 65 Cholesky panels) against the oracle."""
+    model, theta, X, Y, _, rng = make_problem(6000, 3, 2050, 1, "VD", True, seed=56)
+    ref = O.GPz(theta, model, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f, g = ctx.eval(theta)
+    ctx.close()
+    assert ctx.info == 0 and abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
