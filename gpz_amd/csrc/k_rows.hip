@@ -101,19 +101,33 @@ void launch_row_epilogue(hipStream_t st, const RowArgs &a) {
     else hipLaunchKernelGGL(k_row_epilogue<16>, g, b, 0, st, a);
 }
 
-// out[e] = sum_s slab[s*count + e]   (fixed order: deterministic)
-__global__ void k_slab_sum(const double *__restrict__ slab, int nslab, size_t count, double *__restrict__ out) {
-    const size_t gs = (size_t)blockDim.x * gridDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gs) {
+// out[e] = sum_s slab[s*count + e].  16 elements x 16 slab lanes per workgroup: lane q adds slabs q, q+16, ... and the
+// 16 partial sums are combined in a fixed order through LDS, so the result is deterministic but the chain of
+// dependent loads per thread is nslab/16 instead of nslab (many small slabs used to make this latency-bound).
+__global__ __launch_bounds__(256) void k_slab_sum(const double *__restrict__ slab, int nslab, size_t count,
+                                                   double *__restrict__ out) {
+    __shared__ double part[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (size_t e0 = (size_t)blockIdx.x * 16; e0 < count; e0 += (size_t)gridDim.x * 16) {
+        const size_t e = e0 + el;
         double s = 0.0;
-        for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * count + e];
-        out[e] = s;
+        if (e < count)
+            for (int k = sl; k < nslab; k += 16) s += slab[(size_t)k * count + e];
+        part[sl][el] = s;
+        __syncthreads();
+        if (sl == 0 && e < count) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][el];
+            out[e] = t;
+        }
+        __syncthreads();
     }
 }
 
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out) {
-    size_t nb = (count + 255) / 256;
-    if (nb > 2048) nb = 2048;
+    size_t nb = (count + 15) / 16;
+    if (nb > 8192) nb = 8192;
     if (nb == 0) return;
     hipLaunchKernelGGL(k_slab_sum, dim3((unsigned)nb), dim3(256), 0, st, slab, nslab, count, out);
 }
