@@ -87,49 +87,86 @@ void launch_unpack(hipStream_t st, const double *theta, int method_id, int m, in
 // multiply-adds per (sample, basis) pair and no loss of conditioning (no Gamma'Gamma is formed).
 // Rc[j] = [R packed upper row-major: row a holds b = a..de-1 | c (de)], stride de(de+1)/2 + de.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_prep_cov(const double *__restrict__ G, const double *__restrict__ P, int m, int de,
+// DE > 0: compile-time dimension, the matrix lives in registers (fully unrolled); DE == 0: runtime de, scratch.
+template <int DE>
+__global__ __launch_bounds__(64) void k_prep_cov(const double *__restrict__ G, const double *__restrict__ P, int m, int de_rt,
                            double *__restrict__ Rc) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    double A[20 * 20], v[20];
+    constexpr int CAP = DE > 0 ? DE : 20;
+    const int de = DE > 0 ? DE : de_rt;
+    double A[CAP * CAP], v[CAP];
     const double *Gj = G + (size_t)j * de * de;
-    for (int e = 0; e < de * de; ++e) A[e] = Gj[e];          // A[r*de + c] = Gamma_j(r, c)
-    for (int c = 0; c < de; ++c) {
+#pragma unroll
+    for (int r = 0; r < CAP; ++r)
+#pragma unroll
+        for (int c = 0; c < CAP; ++c)
+            if (r < de && c < de) A[r * CAP + c] = Gj[r * de + c];          // A[r][c] = Gamma_j(r, c)
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) {
+        if (c >= de) break;
         double n2 = 0.0;
-        for (int r = c; r < de; ++r) n2 = fma(A[r * de + c], A[r * de + c], n2);
+#pragma unroll
+        for (int r = 0; r < CAP; ++r)
+            if (r >= c && r < de) n2 = fma(A[r * CAP + c], A[r * CAP + c], n2);
         if (n2 == 0.0) continue;
         const double nrm = sqrt(n2);
-        const double acc = A[c * de + c];
+        const double acc = A[c * CAP + c];
         const double alpha = (acc > 0.0) ? -nrm : nrm;
-        for (int r = c; r < de; ++r) v[r] = A[r * de + c];
+#pragma unroll
+        for (int r = 0; r < CAP; ++r)
+            if (r >= c && r < de) v[r] = A[r * CAP + c];
         v[c] -= alpha;
         const double vn2 = n2 - acc * acc + v[c] * v[c];
-        for (int cc = c + 1; cc < de; ++cc) {
+#pragma unroll
+        for (int cc = 0; cc < CAP; ++cc) {
+            if (cc <= c || cc >= de) continue;
             double dot = 0.0;
-            for (int r = c; r < de; ++r) dot = fma(v[r], A[r * de + cc], dot);
+#pragma unroll
+            for (int r = 0; r < CAP; ++r)
+                if (r >= c && r < de) dot = fma(v[r], A[r * CAP + cc], dot);
             const double f = 2.0 * dot / vn2;
-            for (int r = c; r < de; ++r) A[r * de + cc] = fma(-f, v[r], A[r * de + cc]);
+#pragma unroll
+            for (int r = 0; r < CAP; ++r)
+                if (r >= c && r < de) A[r * CAP + cc] = fma(-f, v[r], A[r * CAP + cc]);
         }
-        A[c * de + c] = alpha;
-        for (int r = c + 1; r < de; ++r) A[r * de + c] = 0.0;
+        A[c * CAP + c] = alpha;
+#pragma unroll
+        for (int r = 0; r < CAP; ++r)
+            if (r > c && r < de) A[r * CAP + c] = 0.0;
     }
     const int nt = de * (de + 1) / 2;
     double *o = Rc + (size_t)j * (nt + de);
     const double *pj = P + (size_t)j * de;
-    int e = 0;
-    for (int a = 0; a < de; ++a) {
+#pragma unroll
+    for (int a = 0; a < CAP; ++a) {
+        if (a >= de) break;
         double s = 0.0;
-        for (int b = a; b < de; ++b) {
-            const double r = A[a * de + b];
-            o[e++] = r;
-            s = fma(r, pj[b], s);
-        }
+        const int roff = a * de - a * (a - 1) / 2;
+#pragma unroll
+        for (int b = 0; b < CAP; ++b)
+            if (b >= a && b < de) {
+                const double r = A[a * CAP + b];
+                o[roff + (b - a)] = r;
+                s = fma(r, pj[b], s);
+            }
         o[nt + a] = s;
     }
 }
 
 void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc) {
-    hipLaunchKernelGGL(k_prep_cov, dim3((m + 63) / 64), dim3(64), 0, st, G, P, m, de, Rc);
+    dim3 g((m + 63) / 64), b(64);
+    switch (de) {
+        case 1: hipLaunchKernelGGL(k_prep_cov<1>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 2: hipLaunchKernelGGL(k_prep_cov<2>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 3: hipLaunchKernelGGL(k_prep_cov<3>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 4: hipLaunchKernelGGL(k_prep_cov<4>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 5: hipLaunchKernelGGL(k_prep_cov<5>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 6: hipLaunchKernelGGL(k_prep_cov<6>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 8: hipLaunchKernelGGL(k_prep_cov<8>, g, b, 0, st, G, P, m, de, Rc); break;
+        case 10: hipLaunchKernelGGL(k_prep_cov<10>, g, b, 0, st, G, P, m, de, Rc); break;
+        default: hipLaunchKernelGGL(k_prep_cov<0>, g, b, 0, st, G, P, m, de, Rc); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
