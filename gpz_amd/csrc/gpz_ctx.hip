@@ -336,7 +336,7 @@ static int setup_model(gpz_ctx *c, const gpz_desc *desc) {
     c->g_dim = g_dim_of(c->mid, c->m, c->d);
     c->p = (long)c->m * c->d + c->g_dim + (long)c->m * c->k + c->k + (c->hetero ? 2L * c->m * c->k : 0);
     c->mp = rup(c->m + c->k, 16);
-    c->mq = rup(c->m, 32);
+    c->mq = rup(c->m, GPZ_CH_NB);
     c->nm = (c->kind == GPZ_KIND_COV) ? c->de + c->de * (c->de + 1) / 2 : 2 * c->de;
     c->device = desc->device;
     c->st = (hipStream_t)desc->stream;
@@ -645,16 +645,16 @@ static void stage_b(gpz_ctx *c, int o) {
         Stage s(c, "chol");
         launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq);
         launch_zero(c->st, c->logdet + o, 1);
-        for (int k0 = 0; k0 < mq; k0 += 32) {
+        for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
             launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
-            launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, 32);
+            launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, GPZ_CH_NB);
         }
     }
     {
         Stage s(c, "trtri");
         launch_zero(c->st, c->Wm, (size_t)mq * mq);
         launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
-        for (int gs = 32; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
+        for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     }
     {
         Stage s(c, "lauum");
@@ -1018,7 +1018,7 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     if (!Ain || m < 1 || !Xi || !logdet) return fail(GPZ_ERR_ARG, "gpz_inv_logdet: null argument");
     gpz_ctx *c = new gpz_ctx();
     c->device = device;
-    c->m = m; c->k = 1; c->mq = rup(m, 32); c->mp = rup(m + 1, 16);
+    c->m = m; c->k = 1; c->mq = rup(m, GPZ_CH_NB); c->mp = rup(m + 1, 16);
     auto bail = [&](int code) { c->ar.release(); delete c; return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", device));
     int rc = alloc_mm(c);
@@ -1034,13 +1034,13 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     const int mq = c->mq;
     launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq);
     launch_zero(c->st, c->logdet, 1);
-    for (int k0 = 0; k0 < mq; k0 += 32) {
+    for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
         launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
-        launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, 32);
+        launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, GPZ_CH_NB);
     }
     launch_zero(c->st, c->Wm, (size_t)mq * mq);
     launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
-    for (int gs = 32; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
+    for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
     launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
     int info_h[2] = {0, 0};

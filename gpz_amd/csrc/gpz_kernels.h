@@ -61,6 +61,9 @@ void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, in
 void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
+#ifndef GPZ_CH_NB
+#define GPZ_CH_NB 32   // Cholesky panel width / diagonal block of the triangular inverse (64 measured 1.6x slower)
+#endif
 // ---- m x m factorisation pieces (k_chol.hip) -----------------------------------------------------
 // A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda);

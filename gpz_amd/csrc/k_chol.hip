@@ -10,7 +10,7 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
-#define CH_NB 32
+#define CH_NB GPZ_CH_NB
 
 __global__ void k_build_sigma(const double *__restrict__ S, int lds, const double *__restrict__ alpha, int m, int mq,
                               double *__restrict__ A, int lda) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A
     const int tid = threadIdx.x;
     if (tid < 64) {
         const int lane = tid;
-        const int r = lane & (CH_NB - 1);
+        const int r = lane & (CH_NB - 1);   // CH_NB = 32: lanes 32..63 duplicate rows 0..31; CH_NB = 64: one row per lane
         double a[CH_NB];
         const double *ar = A + (size_t)(k0 + r) * lda + k0;
 #pragma unroll
