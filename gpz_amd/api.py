@@ -316,14 +316,16 @@ def nan_groups(X, device=0):
 
 
 def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
-    """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1), branch without input
-    noise and without missing values (predict.m:60-73 -> predictFull)."""
-    if Psi is not None:
-        raise _lib.GpzError(-5, "predict with input noise is not built yet")
+    """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1).  Built branches: no input
+    noise (predictFull) and input noise without missing values (predictNoisy); inputs with NaN refuse."""
     lib = _lib.load()
     X = np.asarray(X, dtype=np.float64)
+    psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)
     if selection is not None:
-        X = X[np.asarray(selection, dtype=bool)]                     # predict.m:25
+        sel = np.asarray(selection, dtype=bool)
+        X = X[sel]                                                   # predict.m:25
+        if psi is not None:                                          # predict.m:27-33
+            psi = psi[:, :, sel] if (model.method[1] == "C" and psi.ndim == 3) else psi[sel]
     st = model.sets[whichSet]                                        # predict.m:10-14
     Xn = _f64((X - model.muX) / model.sdX, 2)                        # predict.m:35-36
     theta = np.ascontiguousarray(np.asarray(st["theta"], dtype=np.float64).ravel())
@@ -333,9 +335,41 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
     mu = np.empty((ns, k), order="F"); nu = np.empty((ns, k), order="F"); beta_i = np.empty((ns, k), order="F")
     PHI = np.empty((ns, model.m), order="F")
     ds = _desc(model, device)
-    _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
-                                    _lib.dptr(mu), _lib.dptr(nu), _lib.dptr(beta_i), _lib.dptr(PHI)))
-    gamma = np.zeros((ns, k))                                        # predictDiag.m:74
+    if psi is None:
+        _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
+                                        _lib.dptr(mu), _lib.dptr(nu), _lib.dptr(beta_i), _lib.dptr(PHI)))
+        gamma = np.zeros((ns, k))                                    # predictDiag.m:74
+    else:
+        from .host import fixPsi
+        psin = np.asfortranarray(fixPsi(psi, ns, model.sdX, model.method))   # predict.m:43
+        gamma = np.empty((ns, k), order="F")
+        _lib.check(lib.gpz_predict_noisy(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
+                                         _lib.dptr(psin), 2 if psin.ndim == 3 else 1, _lib.dptr(mu), _lib.dptr(nu),
+                                         _lib.dptr(beta_i), _lib.dptr(gamma), _lib.dptr(PHI)))
     sigma = nu + beta_i + gamma                                      # predict.m:72
     mu = mu + model.muY                                              # predict.m:73
     return mu, sigma, nu, beta_i, gamma, PHI, w, iS
+
+
+def getPrior(X, Psi, theta, model, selection=None, device=0, return_iterations=False):
+    """prior = getPrior(X,Sx,theta,model,set)   (getPrior.m:1); X / Psi already normalised as train.m passes them."""
+    lib = _lib.load()
+    X = np.asarray(X, dtype=np.float64)
+    psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)
+    if selection is not None:
+        sel = np.asarray(selection, dtype=bool)
+        X = X[sel]
+        if psi is not None:
+            psi = psi[:, :, sel] if psi.ndim == 3 else psi[sel]
+    X = _f64(X, 2)
+    psi_kind = 0
+    if psi is not None:
+        psi = np.asfortranarray(psi)
+        psi_kind = 2 if psi.ndim == 3 else 1
+    theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+    prior = np.empty(model.m)
+    it = C.c_int32()
+    ds = _desc(model, device)
+    _lib.check(lib.gpz_prior(C.byref(ds), _lib.dptr(theta), _lib.dptr(X), X.shape[0], _lib.dptr(psi), psi_kind,
+                             _lib.dptr(prior), C.byref(it)))
+    return (prior, int(it.value)) if return_iterations else prior

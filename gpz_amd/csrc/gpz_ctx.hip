@@ -1014,6 +1014,125 @@ extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const
     return rc;
 }
 
+// predictNoisy (predictDiag.m:75-125, predictCov.m:70-132): inputs with noise Psi, no missing values.
+extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                                 const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind, double *mu,
+                                 double *nu, double *beta_i, double *gamma, double *PHI) {
+    if (!desc || !theta || !w || !iSigma_w || !Xs || !Psi || ns < 1 || !mu || !nu || !beta_i || !gamma)
+        return fail(GPZ_ERR_ARG, "gpz_predict_noisy: null argument");
+    if (has_nan(Xs, ns * (int64_t)desc->d))
+        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values (predictNoisyMissing, predictDiag.m:211) is not built");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    const size_t m = c->m, np = c->tr.n_pad, k = c->k;
+    const int d = c->d;
+    int rc = run_phi_only(c, theta);
+    double *wd = nullptr, *iSd = nullptr, *phiw = nullptr, *tab = nullptr, *part = nullptr, *sums = nullptr, *outb = nullptr,
+           *tmp = nullptr;
+    const long npair = (long)m * (m + 1) / 2;
+    const int rec = 1 + d + (c->kind == GPZ_KIND_COV ? d * d : d);
+    // split the pairs so that ~1024 workgroups exist
+    int nchunk = (int)((1024 + (ns + 63) / 64 - 1) / ((ns + 63) / 64));
+    if (nchunk > npair) nchunk = (int)npair;
+    if (nchunk > 256) nchunk = 256;
+    if (nchunk < 1) nchunk = 1;
+    const long ppc = (npair + nchunk - 1) / nchunk;
+    nchunk = (int)((npair + ppc - 1) / ppc);
+    if (!rc) rc = c->ar.alloc(&wd, m * k);
+    if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
+    if (!rc) rc = c->ar.alloc(&phiw, np * k);
+    if (!rc) rc = c->ar.alloc(&tab, (size_t)npair * rec);
+    if (!rc) rc = c->ar.alloc(&part, (size_t)nchunk * 3 * k * np);
+    if (!rc) rc = c->ar.alloc(&sums, (size_t)3 * k * np);
+    if (!rc) rc = c->ar.alloc(&outb, (size_t)3 * k * np);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(iSd, iSigma_w, m * m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_noisy: copy failed");
+    }
+    if (!rc) {
+        // mu = PHI*w (lnbeta = ElnS is already there)                                       predictDiag.m:82
+        launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
+                          nullptr, wd, c->lnbeta, nullptr, phiw);
+        launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
+        launch_pair_table(c->st, c->kind, c->m, d, c->de, c->pr.P, c->pr.G, c->Sig, c->iSig, tab, rec);
+        launch_predict_noisy(c->st, c->kind, c->tr.n, (long)np, c->m, d, c->de, c->k, c->tr.Xr, c->tr.Psir, c->tr.Psi3, tab,
+                             rec, wd, c->hetero ? c->pr.v : nullptr, iSd, nchunk, ppc, part);
+        launch_slab_sum(c->st, part, nchunk, (size_t)3 * k * np, sums);
+        launch_predict_noisy_final(c->st, sums, (long)np, c->tr.n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
+                                   outb + 2 * k * np);
+        auto down = [&](double *dst, const double *src) {
+            return hipMemcpy2DAsync(dst, (size_t)ns * sizeof(double), src, np * sizeof(double), (size_t)ns * sizeof(double), k,
+                                    hipMemcpyDeviceToHost, c->st);
+        };
+        hipError_t e = down(gamma, outb);
+        if (e == hipSuccess) e = down(nu, outb + k * np);
+        if (e == hipSuccess) e = down(beta_i, outb + 2 * k * np);
+        if (e == hipSuccess) e = down(mu, phiw);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_noisy: copy failed");
+    }
+    if (!rc && PHI) {
+        rc = c->ar.alloc(&tmp, (size_t)ns * m);
+        if (!rc) {
+            launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+            if (hipMemcpyAsync(PHI, tmp, (size_t)ns * m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+                rc = fail(GPZ_ERR_HIP, "gpz_predict_noisy: copy failed");
+        }
+    }
+    if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_predict_noisy: sync failed");
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_noisy: kernel failed");
+    free_eval_ctx(c);
+    return rc;
+}
+
+// prior = getPrior(X,Psi,theta,model,[])   (getPrior.m): N once, then the fixed point on the device; the convergence
+// test on the m-vector (getPrior.m:18) runs on the host between iterations.
+extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns, const double *Psi,
+                         int32_t psi_kind, double *prior, int32_t *iterations) {
+    if (!desc || !theta || !Xs || ns < 1 || !prior) return fail(GPZ_ERR_ARG, "gpz_prior: null argument");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    const int m = c->m;
+    int rc = run_phi_only(c, theta);
+    double *nd = nullptr, *pd = nullptr, *slab = nullptr, *colsum = nullptr;
+    const int nwg = ns < 1024 ? (int)ns : 1024;
+    if (!rc) rc = c->ar.alloc(&nd, (size_t)c->tr.n_pad * c->mp);
+    if (!rc) rc = c->ar.alloc(&pd, (size_t)m);
+    if (!rc) rc = c->ar.alloc(&slab, (size_t)nwg * m);
+    if (!rc) rc = c->ar.alloc(&colsum, (size_t)m);
+    std::vector<double> pr(m, 1.0 / m), old(m), cs(m);                     // getPrior.m:5
+    int it = 0;
+    if (!rc) {
+        NormArgs a{};
+        a.Phi = c->Phi; a.ld = c->mp; a.n = (int)ns; a.m = c->m; a.d = c->d; a.de = c->de; a.kind = c->kind;
+        a.gen = c->gen ? 1 : 0; a.G = c->pr.G; a.Rc = c->pr.Rc; a.Mr = c->tr.Mr; a.ucnt = c->tr.ucnt;
+        a.gid = c->tr.gid; a.pat = c->pat_d; a.lnS = c->lnS; a.N = nd;
+        launch_phi_norm(c->st, a);
+        for (it = 1; it <= 100 && !rc; ++it) {                             // getPrior.m:7
+            old = pr;
+            hipError_t e = hipMemcpyAsync(pd, pr.data(), m * sizeof(double), hipMemcpyHostToDevice, c->st);
+            launch_prior_iter(c->st, nd, c->mp, (int)ns, m, pd, slab, nwg);
+            launch_slab_sum(c->st, slab, nwg, (size_t)m, colsum);
+            if (e == hipSuccess) e = hipMemcpyAsync(cs.data(), colsum, m * sizeof(double), hipMemcpyDeviceToHost, c->st);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+            if (e != hipSuccess) { rc = fail(GPZ_ERR_HIP, "gpz_prior: %s", hipGetErrorString(e)); break; }
+            double num = 0.0, den = 0.0;
+            for (int j = 0; j < m; ++j) {
+                pr[j] = cs[j] / (double)ns;                                // mean(w)   getPrior.m:15
+                num += (old[j] - pr[j]) * (old[j] - pr[j]);
+                den += (old[j] + pr[j]) * (old[j] + pr[j]);
+            }
+            if (sqrt(num) / sqrt(den) < 1e-10) break;                      // getPrior.m:17-19
+        }
+    }
+    if (!rc) {
+        memcpy(prior, pr.data(), m * sizeof(double));
+        if (iterations) *iterations = it > 100 ? 100 : it;
+    }
+    free_eval_ctx(c);
+    return rc;
+}
+
 extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, double *Xi, double *logdet, int32_t *info) {
     if (!Ain || m < 1 || !Xi || !logdet) return fail(GPZ_ERR_ARG, "gpz_inv_logdet: null argument");
     gpz_ctx *c = new gpz_ctx();

@@ -186,6 +186,17 @@ void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
                        double *grad, double *dGfull, double *cols, int mp, int nrec);
 
+// prediction with input noise (predictDiag.m:75-125 / predictCov.m:70-132) and the getPrior iteration (getPrior.m:7-20)
+void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,
+                       const double *iSig, double *tab, int rec);
+void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
+                          const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
+                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part);
+void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
+                                const double *lnbeta, const double *b, double *gamma, double *nu, double *beta_i);
+void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
+                       int nwg);
+
 // N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
 struct NormArgs {
     const double *Phi; int ld; int n, m, d, de, kind, gen;

@@ -342,6 +342,224 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prediction with input noise, no missing values (predictDiag.m:75-125, predictCov.m:70-132):
+//   gamma_i = sum_ab w_a w_b E[phi_a phi_b] - mu_i^2,  nu_i = sum_ab iSigma_w(a,b) E[phi_a phi_b],
+//   VlnS_i = sum_ab v_a v_b E[phi_a phi_b] - (ElnS_i - b)^2,  E[phi_a phi_b](x_i) = Z_ab N(x_i | c_ab, C_ab + Psi_i).
+// Pair table: one record per (a >= b): [lnZ_ab | c_ab (d) | C_ab (d diag or d*d)].
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pair_table(int kind, int m, int d, int de, const double *__restrict__ P, const double *__restrict__ G,
+                             const double *__restrict__ Sig, const double *__restrict__ iSig, double *__restrict__ tab,
+                             int rec) {
+    const long npair = (long)m * (m + 1) / 2;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npair) return;
+    // e -> (a >= b): a = floor((sqrt(8e+1)-1)/2)
+    long a = (long)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > e) --a;
+    while ((a + 1) * (a + 2) / 2 <= e) ++a;
+    const long b = e - a * (a + 1) / 2;
+    double *o = tab + (size_t)e * rec;
+    if (kind == GPZ_KIND_DIAG) {
+        double lnz = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double ga = G[a * de + c], gb = G[b * de + c];
+            const double isa = ga * ga, isb = gb * gb;            // iSigma = Gamma.^2      predictDiag.m:89
+            const double sa = 1.0 / isa, sb = 1.0 / isb;          // Sigma = Gamma.^-2
+            const double icij = isa + isb;
+            const double pa = P[a * de + c], pb = P[b * de + c];
+            o[1 + c] = (pa * isa + pb * isb) / icij;              // cij                    :98
+            o[1 + d + c] = 1.0 / icij;                            // Cij                    :97
+            lnz += -0.5 * log(isa) - 0.5 * log(isb) - 0.5 * (pa - pb) * (pa - pb) / (sa + sb) - 0.5 * log(sa + sb);   // :101
+        }
+        o[0] = lnz;
+    } else {
+        double A[GDM * GDM], W[GDM * GDM], Ci[GDM * GDM], S2[GDM * GDM], S2i[GDM * GDM], rhs[GDM];
+        const double *iSa = iSig + (size_t)a * d * d, *iSb = iSig + (size_t)b * d * d;
+        const double *Sa = Sig + (size_t)a * d * d, *Sb = Sig + (size_t)b * d * d;
+        double lnz = 0.0;
+        // lnz(a) = -1/2 ln|iSigma_a| = +1/2 ln|Sigma_a|           predictCov.m:91
+        for (int pass = 0; pass < 2; ++pass) {
+            const double *S = pass ? Sb : Sa;
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c <= r; ++c) A[r * GDM + c] = S[r * d + c];
+            chol_small(A, d);
+            for (int r = 0; r < d; ++r) lnz += log(A[r * GDM + r]);          // 1/2 ln|Sigma| = sum ln L_rr
+        }
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c <= r; ++c) A[r * GDM + c] = iSa[r * d + c] + iSb[r * d + c];    // iCij          :100
+        chol_small(A, d);
+        inv_from_chol(A, d, W, Ci);                                                            // Cij = inv(iCij)
+        for (int c = 0; c < d; ++c) {
+            double s = 0.0;
+            for (int r = 0; r < d; ++r) s += P[a * de + r] * iSa[r * d + c] + P[b * de + r] * iSb[r * d + c];
+            rhs[c] = s;
+        }
+        for (int c = 0; c < d; ++c) {                                                          // cij = rhs * Cij   :102
+            double s = 0.0;
+            for (int r = 0; r < d; ++r) s = fma(rhs[r], Ci[r * GDM + c], s);
+            o[1 + c] = s;
+        }
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c < d; ++c) o[1 + d + r * d + c] = Ci[r * GDM + c];
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c <= r; ++c) S2[r * GDM + c] = Sa[r * d + c] + Sb[r * d + c];
+        chol_small(S2, d);
+        double ld = 0.0;
+        for (int r = 0; r < d; ++r) ld += log(S2[r * GDM + r]);
+        inv_from_chol(S2, d, W, S2i);
+        double q = 0.0;
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c < d; ++c) q += (P[a * de + r] - P[b * de + r]) * S2i[r * GDM + c] * (P[a * de + c] - P[b * de + c]);
+        o[0] = lnz - 0.5 * q - ld;                                                             // :105  (-1/2 ln|Sa+Sb| = -ld)
+    }
+}
+
+// One thread per sample, pairs [p0, p1) of this chunk; partial sums part[chunk][3][k][n_pad].
+__global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx, int m, int d, int de, int k,
+                                                       const double *__restrict__ Xr, const double *__restrict__ Psir,
+                                                       const double *__restrict__ Psi3, const double *__restrict__ tab,
+                                                       int rec, const double *__restrict__ w, const double *__restrict__ v,
+                                                       const double *__restrict__ iS, long pairs_per_chunk,
+                                                       double *__restrict__ part) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long npair = (long)m * (m + 1) / 2;
+    const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
+    double x[GDM], ps[GDM], M[GDM * GDM], y[GDM];
+    double ga[8], vl[8], nu[8];
+    for (int o = 0; o < 8; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    for (int c = 0; c < d; ++c) {
+        x[c] = Xr[(size_t)i * de + c];
+        if (kind == GPZ_KIND_DIAG) ps[c] = Psir[(size_t)i * de + c];
+    }
+    // recover (a, b) of the first pair, then walk
+    long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > p0) --a;
+    while ((a + 1) * (a + 2) / 2 <= p0) ++a;
+    long b = p0 - a * (a + 1) / 2;
+    for (long e = p0; e < p1; ++e) {
+        const double *t = tab + (size_t)e * rec;
+        double ln;
+        if (kind == GPZ_KIND_DIAG) {
+            double q = 0.0, pr = 1.0;
+            for (int c = 0; c < d; ++c) {
+                const double cp = t[1 + d + c] + ps[c];                     // Cij + Psi          :105
+                const double dl = x[c] - t[1 + c];
+                q = fma(dl * dl, 1.0 / cp, q);
+                pr *= cp;
+            }
+            ln = -0.5 * q - 0.5 * log(pr);                                  // :107
+        } else {
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c <= r; ++c) M[r * GDM + c] = t[1 + d + r * d + c] + Psi3[(size_t)i * d * d + r + d * c];
+            chol_small(M, d);
+            double q = 0.0, ld = 0.0;
+            for (int r = 0; r < d; ++r) {
+                double s = x[r] - t[1 + r];
+                for (int c = 0; c < r; ++c) s = fma(-M[r * GDM + c], y[c], s);
+                y[r] = s / M[r * GDM + r];
+                q = fma(y[r], y[r], q);
+                ld += log(M[r * GDM + r]);
+            }
+            ln = -0.5 * q - ld;                                             // predictCov.m:111
+        }
+        const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] + ln);           // 2x in the loop, -1x for a == b  (:113-119)
+        for (int o = 0; o < k; ++o) {
+            ga[o] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o]);
+            vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o]);
+            nu[o] = fma(z, iS[a + (size_t)m * b + (size_t)m * m * o], nu[o]);
+        }
+        if (++b > a) { ++a; b = 0; }
+    }
+    for (int o = 0; o < k; ++o) {
+        part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
+        part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
+        part[(((size_t)blockIdx.y * 3 + 2) * k + o) * ldx + i] = nu[o];
+    }
+}
+
+// sums[3][k][ldx] (gamma, VlnS, nu raw) -> gamma, nu, beta_i   (predictDiag.m:121-125)
+__global__ void k_predict_noisy_final(const double *__restrict__ sums, long ldx, int n, int k,
+                                      const double *__restrict__ mu, const double *__restrict__ lnbeta,
+                                      const double *__restrict__ bvec, double *__restrict__ gamma,
+                                      double *__restrict__ nu, double *__restrict__ beta_i) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int o = 0; o < k; ++o) {
+        const double muv = mu[(size_t)o * ldx + i], els = lnbeta[(size_t)o * ldx + i];
+        const double vl = sums[((size_t)1 * k + o) * ldx + i] - (els - bvec[o]) * (els - bvec[o]);
+        gamma[(size_t)o * ldx + i] = sums[((size_t)0 * k + o) * ldx + i] - muv * muv;
+        nu[(size_t)o * ldx + i] = sums[((size_t)2 * k + o) * ldx + i];
+        beta_i[(size_t)o * ldx + i] = exp(els) * (1.0 + 0.5 * vl);
+    }
+}
+
+// getPrior.m:7-20: one fixed-point iteration  prior <- mean_i( N_i. .* prior / sum_j N_ij prior_j ).
+// Workgroup per row (grid-stride), lanes along basis functions; per-workgroup column sums in colslab[wg][mp].
+template <int NJ>
+__global__ __launch_bounds__(256) void k_prior_iter(const double *__restrict__ N, int ld, int n, int m,
+                                                     const double *__restrict__ prior, double *__restrict__ colslab) {
+    __shared__ double sh4[4];
+    const int tid = threadIdx.x;
+    double pq[NJ], acc[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = tid + 256 * q;
+        pq[q] = (j < m) ? prior[j] : 0.0;
+        acc[q] = 0.0;
+    }
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        double wv[NJ], part = 0.0;
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int j = tid + 256 * q;
+            wv[q] = (j < m) ? N[(size_t)i * ld + j] * pq[q] : 0.0;
+            part += wv[q];
+        }
+        const double tot = block_sum_256(part, sh4);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) acc[q] += wv[q] / tot;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = tid + 256 * q;
+        if (j < m) colslab[(size_t)blockIdx.x * m + j] = acc[q];
+    }
+}
+
+void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
+                       int nwg) {
+    const int nj = (m + 255) / 256;
+    dim3 g(nwg), b(256);
+    if (nj <= 1) hipLaunchKernelGGL(k_prior_iter<1>, g, b, 0, st, N, ld, n, m, prior, colslab);
+    else if (nj <= 2) hipLaunchKernelGGL(k_prior_iter<2>, g, b, 0, st, N, ld, n, m, prior, colslab);
+    else if (nj <= 4) hipLaunchKernelGGL(k_prior_iter<4>, g, b, 0, st, N, ld, n, m, prior, colslab);
+    else if (nj <= 8) hipLaunchKernelGGL(k_prior_iter<8>, g, b, 0, st, N, ld, n, m, prior, colslab);
+    else hipLaunchKernelGGL(k_prior_iter<16>, g, b, 0, st, N, ld, n, m, prior, colslab);
+}
+
+void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,
+                       const double *iSig, double *tab, int rec) {
+    const long npair = (long)m * (m + 1) / 2;
+    hipLaunchKernelGGL(k_pair_table, dim3((unsigned)((npair + 63) / 64)), dim3(64), 0, st, kind, m, d, de, P, G, Sig, iSig,
+                       tab, rec);
+}
+
+void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
+                          const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
+                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part) {
+    hipLaunchKernelGGL(k_predict_noisy, dim3((n + 63) / 64, nchunk), dim3(64), 0, st, kind, n, ldx, m, d, de, k, Xr, Psir,
+                       Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);
+}
+
+void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
+                                const double *lnbeta, const double *b, double *gamma, double *nu, double *beta_i) {
+    hipLaunchKernelGGL(k_predict_noisy_final, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sums, ldx, n, k, mu, lnbeta,
+                       b, gamma, nu, beta_i);
+}
+
 // N_ij = PHI_ij * exp(cn), cn = -1/2 ln|Sigma_j,oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2      (getPHI.m:77,87,98,105)
 __global__ void k_phi_norm(NormArgs a) {
     const size_t gs = (size_t)blockDim.x * gridDim.x;

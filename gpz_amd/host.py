@@ -10,8 +10,7 @@ argument plumbing.  Semantics follow
     lbfgsAdd.m, lbfgsProd.m, WolfeLineSearch.m, ArmijoBacktrack.m, polyinterp.m
 
 with minFunc's defaults for 'lbfgs' (corrections 100, c1 1e-4, c2 0.9, cubic interpolation, optTol 1e-5,
-progTol 1e-9, 25 line-search iterations).  ``getPrior`` (mixture priors for prediction with missing values) is
-not built.
+progTol 1e-9, 25 line-search iterations).
 """
 from __future__ import annotations
 
@@ -480,7 +479,7 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
         for name, th in (("last", theta), ("best", state["best_theta"])):          # train.m:53-80
             w, iS, _ = ctx.solve(th)
             st = {"theta": th.copy(), "w": w, "iSigma_w": iS, "P": th[:m * d].reshape((m, d), order="F"),
-                  "priors": np.ones(m) / m}
+                  "priors": api.getPrior(Xn, PsiN, th, model, training, device=device)}   # train.m:59,74
             if model.heteroscedastic:
                 o = m * d + g_dim + m * k + k
                 st["v"] = th[o:o + m * k].reshape((m, k), order="F")

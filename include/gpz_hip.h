@@ -13,6 +13,8 @@
  *   gpz_solve           [~,~,w,iSigma_w] = GPz(theta,...)   GPz/GPz.m:84-87 (nargout>2 mode)
  *   gpz_phi             [PHI,Gamma,lnBeta_i,N] = getPHI(X,Psi,theta,model,[]) GPz/getPHI.m:1
  *   gpz_predict_full    predictFull(X,theta,w,iSigma_w,model) GPz/predictDiag.m:58-74, predictCov.m:53-69
+ *   gpz_predict_noisy   predictNoisy(X,Psi,...)               GPz/predictDiag.m:75-125, predictCov.m:70-132
+ *   gpz_prior           prior = getPrior(X,Psi,theta,model,set) GPz/getPrior.m:1
  *   gpz_inv_logdet      [Xi,logdet] = inv_logdet(X)         GPz/inv_logdet.m:1
  *   gpz_dxy             D = Dxy(X,Y)                        GPz/Dxy.m:1
  *   gpz_nan_groups      the NaN-pattern grouping loop       GPz/getPHI.m:43-54 (== GPz.m:118-129)
@@ -118,6 +120,16 @@ int gpz_phi(const gpz_desc *desc, const double *theta, const double *Xs, int64_t
 int gpz_predict_full(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
                      const double *Xs, int64_t ns,
                      double *mu, double *nu, double *beta_i, double *PHI);
+
+/* predictNoisy (inputs with noise Psi, no missing values): also returns gamma; mu without muY. */
+int gpz_predict_noisy(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                      const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
+                      double *mu, double *nu, double *beta_i, double *gamma, double *PHI);
+
+/* prior = getPrior(X,Psi,theta,model,[]): mixture weights (1 x m) of the normalised basis densities;
+ * iterations (optional) receives the number of fixed-point iterations used (<= 100). */
+int gpz_prior(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns,
+              const double *Psi, int32_t psi_kind, double *prior, int32_t *iterations);
 
 /* Inverse and log-determinant of a symmetric positive-definite m x m matrix.  info (optional):
  * 0 ok, j>0 not positive definite at pivot j (Xi, logdet are NaN then). */

@@ -14,6 +14,8 @@ A NumPy fp64 restatement of the reference's MATLAB code, written from reading
     GPz/inv_logdet.m:1-15  -> :func:`inv_logdet`
     GPz/Dxy.m:1-9          -> :func:`Dxy`
     GPz/predict.m:1-76 + predictDiag.m:58-74 / predictCov.m:53-69 -> :func:`predict`
+    predictDiag.m:75-125 / predictCov.m:70-132 (predictNoisy) -> :func:`predict_noisy`
+    GPz/getPrior.m:1-22    -> :func:`getPrior`
     GPz/fixPsi.m:1-55      -> :func:`fixPsi`
     GPz/getOmega.m:1-23    -> :func:`getOmega`
     GPz/init.m:54-98       -> :func:`init_theta` (theta layout + heuristics)
@@ -472,6 +474,93 @@ def predict(X, model: Model, whichSet="best", selection=None):
     sigma = nu + beta_i + gamma                              # predict.m:72
     mu = mu + model.muY                                      # predict.m:73
     return mu, sigma, nu, beta_i, gamma, PHI, w, iSigma_w
+
+
+def predict_noisy(X, Psi, model: Model, whichSet="best"):
+    """predict() with input noise and no missing values: predict.m:25-43,60-73 -> predictNoisy
+    (predictDiag.m:75-125 for GL/VL/GD/VD, predictCov.m:70-132 for GC/VC).  X raw (n x d), Psi raw in any layout
+    fixPsi.m accepts.  Returns (mu, sigma, nu, beta_i, gamma, PHI)."""
+    X = np.asarray(X, dtype=np.float64)
+    n, d = X.shape
+    st = model.sets[whichSet]
+    Xn = (X - model.muX) / model.sdX                          # predict.m:35-36
+    PsiN = fixPsi(Psi, n, model.sdX, model.method)            # predict.m:43
+    theta, w, iSigma_w = st["theta"], st["w"], st["iSigma_w"]
+    m, k = model.m, model.k
+    P, G, lnAlpha, b, v, lnTau = unpack_theta(theta, model)
+    if v is None:
+        v = np.zeros((m, k))                                  # predictDiag.m:17-21
+    Gamma = expand_gamma(G, model)
+    PHI, _, ElnS = getPHI(Xn, PsiN, theta, model, None)       # predictDiag.m:80
+    mu = PHI @ w
+    nu = np.zeros((n, k)); gamma = np.zeros((n, k)); VlnS = np.zeros((n, k))
+    if model.method[1] != "C":
+        iSigma = Gamma ** 2.0                                 # :89-91
+        Sigma = Gamma ** -2.0
+        lnz = -0.5 * np.sum(np.log(iSigma), axis=1)
+        for i in range(m):
+            Z = None
+            for j in range(i + 1):                            # :93-94
+                iCij = iSigma[i] + iSigma[j]
+                Cij = 1.0 / iCij
+                cij = (P[i] * iSigma[i] + P[j] * iSigma[j]) / iCij
+                lnZij = (lnz[i] + lnz[j] - 0.5 * np.sum((P[i] - P[j]) ** 2 / (Sigma[i] + Sigma[j]))
+                         - 0.5 * np.sum(np.log(Sigma[i] + Sigma[j])))          # :101
+                Delta = Xn - cij
+                CpP = PsiN + Cij
+                lnNxc = -0.5 * np.sum(Delta ** 2 / CpP, axis=1) - 0.5 * np.sum(np.log(CpP), axis=1)   # :107
+                Z = np.exp(lnZij + lnNxc)[:, None]
+                gamma = gamma + 2.0 * Z * (w[i] * w[j])
+                VlnS = VlnS + 2.0 * Z * (v[i] * v[j])
+                nu = nu + 2.0 * Z * iSigma_w[i, j, :]
+            # the loop variable j is still i here (:117-119): the diagonal term is counted once
+            gamma = gamma - Z * (w[i] * w[i])
+            VlnS = VlnS - Z * (v[i] * v[i])
+            nu = nu - Z * iSigma_w[i, i, :]
+    else:
+        iSigma = np.zeros((d, d, m)); Sigma = np.zeros((d, d, m)); lnz = np.zeros(m)
+        for i in range(m):                                    # predictCov.m:86-92
+            iSigma[:, :, i] = Gamma[:, :, i].T @ Gamma[:, :, i]
+            Sigma[:, :, i] = np.linalg.inv(iSigma[:, :, i])
+            lnz[i] = -0.5 * _sum_log_svd(iSigma[:, :, i])
+        for i in range(m):
+            for j in range(i + 1):
+                iCij = iSigma[:, :, i] + iSigma[:, :, j]
+                Cij = np.linalg.inv(iCij)
+                cij = _mrdivide((P[i] @ iSigma[:, :, i] + P[j] @ iSigma[:, :, j])[None, :], iCij)[0]
+                Dl = (P[i] - P[j])[None, :]
+                Sij = Sigma[:, :, i] + Sigma[:, :, j]
+                lnZij = lnz[i] + lnz[j] - 0.5 * float((_mrdivide(Dl, Sij) @ Dl.T)[0, 0]) - 0.5 * _sum_log_svd(Sij)   # :105
+                for r in range(n):                            # the reference loops samples outermost (:94); same sums
+                    Dx = (Xn[r] - cij)[None, :]
+                    CpP = PsiN[:, :, r] + Cij
+                    lnNxc = -0.5 * float((_mrdivide(Dx, CpP) @ Dx.T)[0, 0]) - 0.5 * _sum_log_svd(CpP)                # :111
+                    Z = math.exp(lnZij + lnNxc)
+                    c2 = 2.0 if j < i else 1.0                # 2x in the loop, minus 1x for j == i (:123-125)
+                    gamma[r] += c2 * Z * (w[i] * w[j])
+                    VlnS[r] += c2 * Z * (v[i] * v[j])
+                    nu[r] += c2 * Z * iSigma_w[i, j, :]
+    VlnS = VlnS - (ElnS - b) ** 2                             # predictDiag.m:123
+    gamma = gamma - mu ** 2
+    beta_i = np.exp(ElnS) * (1.0 + 0.5 * VlnS)
+    sigma = nu + beta_i + gamma                               # predict.m:72
+    return mu + model.muY, sigma, nu, beta_i, gamma, PHI
+
+
+def getPrior(X, Psi, theta, model: Model, selection=None):
+    """prior = getPrior(X,Sx,theta,model,set)   (getPrior.m:1-22): EM-style fixed point on the mixture weights of
+    the normalised basis densities N (N is loop-invariant; the reference recomputes it every iteration)."""
+    m = model.m
+    prior = np.ones(m) / m
+    N = getPHI(X, Psi, theta, model, selection, want_N=True)[3]
+    for _ in range(100):
+        old = prior
+        wgt = N * prior
+        wgt = wgt / wgt.sum(axis=1, keepdims=True)
+        prior = wgt.mean(axis=0)
+        if np.linalg.norm(old - prior) / np.linalg.norm(old + prior) < 1e-10:
+            break
+    return prior
 
 
 # --------------------------------------------------------------------------

@@ -393,3 +393,32 @@ def test_large_m_tiles():
     f, g = ctx.eval(theta)
     ctx.close()
     assert ctx.info == 0 and abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+
+
+@pytest.mark.parametrize("method,d,k", [("VD", 3, 2), ("GL", 2, 1), ("VL", 1, 1), ("VC", 3, 2), ("GC", 2, 1)])
+def test_predict_with_input_noise(method, d, k):
+    """predict.m -> predictNoisy (predictDiag.m:75-125 / predictCov.m:70-132) against the oracle, and its Psi -> 0
+    limit against predictFull."""
+    model, theta, X, Y, _, rng = make_problem(300, d, 9, k, method, True, seed=31 + d)
+    model.muX = rng.standard_normal(d) * 0.1; model.sdX = 1.0 + rng.random(d); model.muY = rng.standard_normal(k)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w}
+    Xs = rng.standard_normal((57, d))
+    Psi = rng.gamma(1.0, 0.1, (57, d))
+    ref = O.predict_noisy(Xs, Psi, model)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= 1e-9, name
+    tiny = gpz_amd.predict(Xs, model, Psi=np.full((57, d), 1e-14))
+    full = gpz_amd.predict(Xs, model)
+    assert rel(tiny[0], full[0]) < 1e-9 and rel(tiny[1], full[1]) < 1e-9 and np.abs(tiny[4]).max() < 1e-9
+
+
+@pytest.mark.parametrize("method,psi,nanfrac", [("VD", False, 0.0), ("VC", False, 0.0), ("VD", True, 0.3), ("GC", True, 0.0),
+                                                ("VC", False, 0.3)])
+def test_get_prior(method, psi, nanfrac):
+    model, theta, X, Y, Psi, rng = make_problem(400, 3, 7, 1, method, True, seed=77, psi=psi, nanfrac=nanfrac)
+    sel = rng.random(400) < 0.8
+    ref = O.getPrior(X, Psi, theta, model, sel)
+    got, it = gpz_amd.getPrior(X, Psi, theta, model, sel, return_iterations=True)
+    assert abs(got.sum() - 1.0) < 1e-12 and rel(got, ref) < 1e-8 and 1 <= it <= 100
