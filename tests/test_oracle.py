@@ -174,3 +174,26 @@ def test_golden_regression(name):
     assert rel(r.grad, g["grad"]) < 1e-9
     r4 = O.GPz(g["theta"], model, g["X"], g["Y"], Psi, omega, training, validation, nargout=4)
     assert rel(r4.w, g["w"]) < 1e-9
+
+
+@pytest.mark.parametrize("method", ["VD", "GL", "VC", "GC"])
+def test_predict_noisy_reduces_to_predict_full(method):
+    """predictNoisy (predictDiag.m:75-125 / predictCov.m:70-132) with Psi -> 0 must equal predictFull: the pairwise
+    product-of-Gaussians sums collapse to PHI*iSigma_w*PHI' and gamma, VlnS vanish."""
+    model, theta, X, Y, _, rng = make_problem(60, 3, 5, 2, method, True, seed=3)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w}
+    Xs = rng.standard_normal((11, 3))
+    full = O.predict(Xs, model)
+    noisy = O.predict_noisy(Xs, np.full((11, 3), 1e-12), model)
+    for i in range(4):
+        assert rel(noisy[i], full[i]) < 1e-10
+    assert np.abs(noisy[4]).max() < 1e-10
+    wide = O.predict_noisy(Xs, np.full((11, 3), 0.3), model)
+    assert (wide[4] > -1e-12).all() and (wide[1] > 0).all()          # gamma is a variance
+
+
+def test_get_prior_is_a_distribution():
+    model, theta, X, Y, _, rng = make_problem(80, 2, 6, 1, "VD", True, seed=8)
+    pr = O.getPrior(X, None, theta, model)
+    assert abs(pr.sum() - 1.0) < 1e-12 and (pr >= 0).all()
