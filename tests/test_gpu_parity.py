@@ -422,3 +422,16 @@ def test_get_prior(method, psi, nanfrac):
     ref = O.getPrior(X, Psi, theta, model, sel)
     got, it = gpz_amd.getPrior(X, Psi, theta, model, sel, return_iterations=True)
     assert abs(got.sum() - 1.0) < 1e-12 and rel(got, ref) < 1e-8 and 1 <= it <= 100
+
+
+def test_c5_math_path_fp64_small():
+    """BASELINE config 5's path (VC + input-noise cube, d = 20) at a size the oracle can do, in fp64.  The fp32
+    precision of that configuration is not built (DESIGN.md scope table)."""
+    model, theta, X, Y, Psi, rng = make_problem(500, 20, 24, 1, "VC", True, seed=58, psi=True)
+    ref = O.GPz(theta, model, X, Y, Psi)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    f, g = ctx.eval(theta)
+    ctx.close()
+    tol = max(grad_tol(ref.cond), phi_tol(model, theta))
+    assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol
