@@ -1,0 +1,25 @@
+"""Timing of the general GC/VC path (Psi cube / missing values) on a mid-size problem (developer tool)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import gpz_amd
+import bench
+
+n, d, m = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, 10, 200
+cfg = dict(n=n, d=d, m=m, method="VC", omega=None)
+model, theta, X, y, _ = bench.synth(cfg)
+rng = np.random.default_rng(5)
+Psi = np.zeros((d, d, n))
+diag = rng.gamma(1.0, 0.05, (n, d))
+Psi[np.arange(d), np.arange(d), :] = diag.T
+for name, kw in (("plain", {}), ("psi", {"Psi": Psi})):
+    ctx = gpz_amd.GPzContext(model, X, y, **kw)
+    ctx.eval(theta)
+    ctx.enable_timing(True); ctx.reset_timings()
+    t0 = time.perf_counter(); K = 3
+    for _ in range(K):
+        f, g = ctx.eval(theta)
+    dt = (time.perf_counter() - t0) / K
+    tim = ctx.timings()
+    print(name, "ms/eval %.2f" % (dt * 1e3), "f=%.6f" % f, " ".join("%s=%.2f" % (k, v[0] / K) for k, v in sorted(tim.items(), key=lambda x: -x[1][0])[:5]))
+    ctx.close()
