@@ -198,6 +198,12 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
     const double wj = w ? w[j] : 0.0, vj = v ? v[j] : 0.0;
     const double *Sj = Sig + (size_t)j * d * d;
     const int r0 = chunk * rows_per_chunk, rend = min(nrows, r0 + rows_per_chunk);
+    if (!Psi3) {   // without input noise M = Sigma_j,oo is the same for every row of the pattern: invert once
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b <= a; ++b) M[a * GDM + b] = Sj[o[a] * d + o[b]];
+        chol_small(M, no);
+        inv_from_chol(M, no, W, Mi);
+    }
     for (int rr = r0; rr < rend; ++rr) {
         const int i = rows[rr];
         const double ph = Phi[(size_t)i * ld + j];
@@ -210,16 +216,14 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
         } else {
             dp = T[(size_t)i * ld + j];                                     // dPHI already formed (k > 1)
         }
-        for (int a = 0; a < no; ++a) {
-            dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
-            for (int b = 0; b <= a; ++b) {
-                double s = Sj[o[a] * d + o[b]];
-                if (Psi3) s += Psi3[(size_t)i * d * d + o[a] + d * o[b]];
-                M[a * GDM + b] = s;
-            }
+        for (int a = 0; a < no; ++a) dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
+        if (Psi3) {
+            for (int a = 0; a < no; ++a)
+                for (int b = 0; b <= a; ++b)
+                    M[a * GDM + b] = Sj[o[a] * d + o[b]] + Psi3[(size_t)i * d * d + o[a] + d * o[b]];
+            chol_small(M, no);
+            inv_from_chol(M, no, W, Mi);                                    // iPSoo   GPz.m:170
         }
-        chol_small(M, no);
-        inv_from_chol(M, no, W, Mi);                                        // iPSoo   GPz.m:170
         for (int a = 0; a < no; ++a) {
             double s = 0.0;
             for (int b = 0; b < no; ++b) s = fma(Mi[a * GDM + b], dl[b], s);
