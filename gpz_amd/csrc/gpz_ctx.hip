@@ -177,6 +177,7 @@ struct gpz_ctx {
     bool has_psi = false, has_missing = false;
     // general covariance-kind path
     bool gen = false;
+    bool psi_fast = false;   // gen && Psi && no missing dims && d <= 10: register-resident kernels (k_psi.hip)
     int ngroups = 0, nrec = 0;
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
     unsigned char *pat_d = nullptr;
@@ -417,6 +418,7 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     }
     if (c->gen) {
         c->ngroups = (int)c->pats.size();
+        c->psi_fast = c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
@@ -447,7 +449,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     };
     if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation))) return bail(rc);
     if (c->gen) {
-        c->gen_nchunk = 64;
+        c->gen_nchunk = 256;
         if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * c->nrec))) return bail(rc);
         if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
     }
@@ -583,8 +585,13 @@ static int build_phi(gpz_ctx *c) {
     if (c->gen) {
         Stage s(c, "phi_build");
         launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
-        launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d, c->Phi,
-                       c->tr.Y);
+        if (c->psi_fast) {
+            launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp);
+            launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
+        } else {
+            launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
+                           c->Phi, c->tr.Y);
+        }
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           c->tr.om, nullptr, c->lnbeta, c->wbeta, nullptr);
     } else {
@@ -695,6 +702,16 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
                 HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");
+            if (c->gen && c->psi_fast) {
+                int nch = c->gen_nchunk;
+                if (nch > c->tr.n) nch = c->tr.n;
+                const int rpc = (c->tr.n + nch - 1) / nch;
+                nch = (c->tr.n + rpc - 1) / rpc;
+                launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
+                                   gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
+                continue;
+            }
             if (c->gen) {
                 const GenRows gr = gen_rows(c->tr);
                 for (int g = 0; g < c->ngroups; ++g) {
@@ -740,7 +757,15 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
             launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
         }
         Stage s(c, "moments");
-        if (c->gen) {
+        if (c->gen && c->psi_fast) {
+            int nch = c->gen_nchunk;
+            if (nch > c->tr.n) nch = c->tr.n;
+            const int rpc = (c->tr.n + nch - 1) / nch;
+            nch = (c->tr.n + rpc - 1) / rpc;
+            launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
+                               c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+            launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
+        } else if (c->gen) {
             const GenRows gr = gen_rows(c->tr);
             for (int g = 0; g < c->ngroups; ++g) {
                 const int rb = c->tr.group_begin[g], nr = c->tr.group_begin[g + 1] - rb;
@@ -767,8 +792,13 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
     const bool have_valid = c->va.n_pad > 0;
     if (have_valid && c->gen) {
         Stage s(c, "validation");
-        launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d, c->Phi_v,
-                       nullptr);
+        if (c->psi_fast) {
+            launch_psi_phi(c->st, gen_rows(c->va), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi_v, c->mp);
+            launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
+        } else {
+            launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
+                           c->Phi_v, nullptr);
+        }
         launch_gen_rowdot(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, c->w, c->lnbeta_v, nullptr, c->phiw_v);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);

@@ -175,6 +175,14 @@ void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, doub
                      const unsigned char *pat, int ngroups, double *lnS);
 void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
                     const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y);
+void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y);
+// register-resident variants for Psi without missing dimensions, 2 <= d <= 10 (k_psi.hip); return -1 outside that range
+bool psi_fast_path_available(int d);
+int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                   const double *lnS, double *Phi, int ld);
+int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                       const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                       int nchunk, int rows_per_chunk, double *slab, int nrec);
 void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
                        const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
                        double *phiw);

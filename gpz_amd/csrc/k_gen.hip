@@ -616,6 +616,10 @@ void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int 
     hipLaunchKernelGGL(k_gen_fill, dim3(1024), dim3(256), 0, st, Phi, mp, r.n, r.n_pad, m, mp, k, Y, (long)r.n_pad);
 }
 
+void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y) {
+    hipLaunchKernelGGL(k_gen_fill, dim3(1024), dim3(256), 0, st, Phi, ld, n, n_pad, m, mp, k, Y, (long)n_pad);
+}
+
 void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
                        const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
                        double *phiw) {

@@ -1,0 +1,242 @@
+// GC/VC with input noise, no missing dimensions, d <= 10: register-resident per-pair factorisations.
+//
+//   getPHI.m:78-89   ln PHI_ij = -1/2 Delta' M^-1 Delta + 1/2 ln|Sigma_j| - 1/2 ln|M|,   M = Psi_i + Sigma_j
+//   GPz.m:164-185    moments of M^-1 Delta and (M^-1 Delta)(M^-1 Delta)' - M^-1 (chained to dP/dGamma by k_gen_finish)
+//
+// Same mathematics as the general kernels of k_gen.hip, but the dimension is a template parameter, every small
+// matrix is a packed lower triangle with compile-time indices (registers, no scratch) and the loops are fully
+// unrolled.  The d x d Cholesky / inverse per (sample, basis) pair is the reference's own algorithm
+// (n*m interpreted iterations there); it is VALU work, not MFMA-shaped.
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+// packed lower triangle, row-major: element (r, c), c <= r, at r(r+1)/2 + c
+#define LT(r, c) ((r) * ((r) + 1) / 2 + (c))
+
+// In-place Cholesky of a packed lower triangle; returns sum(log(diag(L))) = 1/2 ln|M| through *half_logdet.
+template <int D>
+__device__ __forceinline__ void chol_packed(double (&M)[D * (D + 1) / 2], double *half_logdet) {
+    double prod = 1.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double p = M[LT(c, c)];
+#pragma unroll
+        for (int q = 0; q < c; ++q) p = fma(-M[LT(c, q)], M[LT(c, q)], p);
+        const double dd = sqrt(p);
+        const double inv = 1.0 / dd;
+        M[LT(c, c)] = dd;
+        prod *= dd;
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double s = M[LT(r, c)];
+#pragma unroll
+            for (int q = 0; q < c; ++q) s = fma(-M[LT(r, q)], M[LT(c, q)], s);
+            M[LT(r, c)] = s * inv;
+        }
+    }
+    *half_logdet = log(prod);
+}
+
+// W = inv(L) (packed lower), Mi = W' W (packed lower, symmetric)
+template <int D>
+__device__ __forceinline__ void inv_packed(const double (&L)[D * (D + 1) / 2], double (&W)[D * (D + 1) / 2],
+                                           double (&Mi)[D * (D + 1) / 2]) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        W[LT(c, c)] = 1.0 / L[LT(c, c)];
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = c; q < r; ++q) s = fma(L[LT(r, q)], W[LT(q, c)], s);
+            W[LT(r, c)] = -s / L[LT(r, r)];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = a; q < D; ++q) s = fma(W[LT(q, a)], W[LT(q, b)], s);
+            Mi[LT(a, b)] = s;
+        }
+}
+
+// PHI, one thread per row; Sigma_j / p_j / ln|Sigma_j| staged through LDS for JB basis functions at a time.
+// Xr: n_pad x de, Psi3: n_pad x d*d (column-major d x d per row), Sig: m x d*d, lnS: m (pattern 0).
+template <int D>
+__global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, int de, const double *__restrict__ Psi3,
+                                                  int n, int m, const double *__restrict__ P,
+                                                  const double *__restrict__ Sig, const double *__restrict__ lnS,
+                                                  double *__restrict__ Phi, int ld) {
+    constexpr int NP = D * (D + 1) / 2;
+    constexpr int JB = 8;
+    constexpr int REC = NP + D + 1;          // [Sigma_j packed | p_j | ln|Sigma_j|]
+    __shared__ double prm[JB * REC];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < n;
+    const int ic = act ? i : 0;
+    double x[D], psi[NP];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = Xr[(size_t)ic * de + c];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) psi[LT(r, c)] = Psi3[(size_t)ic * D * D + r + D * c];
+    for (int j0 = 0; j0 < m; j0 += JB) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < JB * REC; e += 256) {
+            const int jj = e / REC, q = e % REC, j = min(j0 + jj, m - 1);
+            double v;
+            if (q < NP) {
+                // q -> (r, c) of the packed triangle
+                int r = 0;
+                while ((r + 1) * (r + 2) / 2 <= q) ++r;
+                const int c = q - r * (r + 1) / 2;
+                v = Sig[(size_t)j * D * D + r * D + c];
+            } else if (q < NP + D) {
+                v = P[(size_t)j * de + (q - NP)];
+            } else {
+                v = lnS[j];
+            }
+            prm[e] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= m) break;
+            const double *t = prm + jj * REC;
+            double M[NP], y[D];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) M[e] = psi[e] + t[e];                 // Psi(o,o,i) + Sigma(o,o)      getPHI.m:84
+            double hl;
+            chol_packed<D>(M, &hl);
+            double quad = 0.0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {                                      // y = L^-1 Delta
+                double s = x[r] - t[NP + r];
+#pragma unroll
+                for (int c = 0; c < r; ++c) s = fma(-M[LT(r, c)], y[c], s);
+                y[r] = s / M[LT(r, r)];
+                quad = fma(y[r], y[r], quad);
+            }
+            const double lp = -0.5 * quad + 0.5 * t[NP + D] - hl;              // getPHI.m:86
+            if (act) Phi[(size_t)i * ld + j] = exp(lp);
+        }
+    }
+}
+
+// Moment records for k_gen_finish (pattern 0 = all dimensions observed): thread per basis j, rows walked with x_i and
+// Psi_i wave-uniform.  rec = [A0 | Acc1 (d) | Cacc (d*d) | r1 | r2]  (see k_gen_moments).
+template <int D>
+__global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ Phi, const double *__restrict__ T, int ld,
+                                                     const double *__restrict__ rowscal, const double *__restrict__ w,
+                                                     const double *__restrict__ v, const double *__restrict__ Xr, int de,
+                                                     const double *__restrict__ Psi3, int n, int m,
+                                                     const double *__restrict__ P, const double *__restrict__ Sig,
+                                                     int rows_per_chunk, double *__restrict__ slab, int nrec) {
+    constexpr int NP = D * (D + 1) / 2;
+    const int j = blockIdx.y * 64 + threadIdx.x;
+    const bool act = j < m;
+    const int jc = act ? j : 0;
+    const int chunk = blockIdx.x;
+    double sg[NP], p[D], acc1[D], cacc[NP];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        p[r] = P[(size_t)jc * de + r];
+        acc1[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) { sg[LT(r, c)] = Sig[(size_t)jc * D * D + r * D + c]; cacc[LT(r, c)] = 0.0; }
+    }
+    const double wj = w ? w[jc] : 0.0, vj = v ? v[jc] : 0.0;
+    double a0 = 0.0, r1 = 0.0, r2 = 0.0;
+    const int r0 = chunk * rows_per_chunk, rend = min(n, r0 + rows_per_chunk);
+    for (int i = r0; i < rend; ++i) {
+        const double ph = Phi[(size_t)i * ld + jc];
+        double dp;
+        if (rowscal) {
+            const double *rs = rowscal + (size_t)i * 4;
+            dp = (-rs[0] * T[(size_t)i * ld + jc] - rs[1] * wj + rs[2] * vj) * ph;      // GPz.m:72,90,106,113
+            r1 = fma(ph, rs[1], r1);
+            r2 = fma(ph, rs[2], r2);
+        } else {
+            dp = T[(size_t)i * ld + jc];
+        }
+        double L[NP], W[NP], Mi[NP], dl[D], u[D];
+        const double *ps = Psi3 + (size_t)i * D * D;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            dl[r] = Xr[(size_t)i * de + r] - p[r];
+#pragma unroll
+            for (int c = 0; c <= r; ++c) L[LT(r, c)] = sg[LT(r, c)] + ps[r + D * c];     // Sigma + Psi_i    GPz.m:170
+        }
+        double hl;
+        chol_packed<D>(L, &hl);
+        inv_packed<D>(L, W, Mi);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < D; ++b) s = fma(b <= a ? Mi[LT(a, b)] : Mi[LT(b, a)], dl[b], s);
+            u[a] = s;
+        }
+        a0 += dp;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            acc1[a] = fma(dp, u[a], acc1[a]);                                            // GPz.m:172
+#pragma unroll
+            for (int b = 0; b <= a; ++b) cacc[LT(a, b)] = fma(dp, u[a] * u[b] - Mi[LT(a, b)], cacc[LT(a, b)]);   // :174
+        }
+    }
+    if (act) {
+        double *rec = slab + ((size_t)chunk * m + j) * nrec;
+        rec[0] = a0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            rec[1 + a] = acc1[a];
+#pragma unroll
+            for (int b = 0; b < D; ++b) rec[1 + D + a * D + b] = b <= a ? cacc[LT(a, b)] : cacc[LT(b, a)];
+        }
+        rec[1 + D + D * D] = r1;
+        rec[2 + D + D * D] = r2;
+    }
+}
+
+#define PSI_CASES(MACRO) \
+    switch (d) {         \
+        case 2: MACRO(2); break;   \
+        case 3: MACRO(3); break;   \
+        case 4: MACRO(4); break;   \
+        case 5: MACRO(5); break;   \
+        case 6: MACRO(6); break;   \
+        case 7: MACRO(7); break;   \
+        case 8: MACRO(8); break;   \
+        case 9: MACRO(9); break;   \
+        case 10: MACRO(10); break; \
+        default: return -1;        \
+    }
+
+// returns -1 when d is outside the instantiated range (caller falls back to the general kernels)
+int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                   const double *lnS, double *Phi, int ld) {
+#define PHI_CASE(DD) \
+    hipLaunchKernelGGL(k_psi_phi<DD>, dim3((r.n + 255) / 256), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, P, Sig, lnS, Phi, ld)
+    PSI_CASES(PHI_CASE)
+#undef PHI_CASE
+    return 0;
+}
+
+int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                       const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                       int nchunk, int rows_per_chunk, double *slab, int nrec) {
+#define MOM_CASE(DD)                                                                                                  \
+    hipLaunchKernelGGL(k_psi_moments<DD>, dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, w, v, r.Xr, de, \
+                       r.Psi3, r.n, m, P, Sig, rows_per_chunk, slab, nrec)
+    PSI_CASES(MOM_CASE)
+#undef MOM_CASE
+    return 0;
+}
+
+bool psi_fast_path_available(int d) { return d >= 2 && d <= 10; }
