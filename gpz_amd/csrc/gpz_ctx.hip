@@ -393,10 +393,12 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     if (c->kind == GPZ_KIND_COV && (Psi || xnan)) {
         // general path: per-pair d x d factorisations (k_gen.hip)
         if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
-        if (desc->world > 1)
-            return fail(GPZ_ERR_UNSUPPORTED, "row-sharded runs of the general GC/VC path (Psi / missing values) are not built yet");
+        // the NaN-pattern table is built per rank in first-occurrence order: shards would disagree on the ids
+        if (desc->world > 1 && xnan)
+            return fail(GPZ_ERR_UNSUPPORTED, "row-sharded runs of GC/VC with missing values are not built yet");
         if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
+        if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
     }
     if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1)
         return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)");
@@ -870,6 +872,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
                           nullptr, c->w, c->lnbeta, nullptr, c->phiw);
         launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
+        if (int e = allreduce(c, c->rstats, GPZ_NS)) return e;
         launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
                              c->k, c->spart);
         HIPCHK(hipMemcpyAsync(nlogML_partial, c->spart, c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));

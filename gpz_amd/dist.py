@@ -22,31 +22,47 @@ def shard_bounds(n, rank, world):
     return lo, min(n, lo + per)
 
 
+def shard_index(rank, world, n, training=None, validation=None):
+    """Row indices (into the unsharded arrays) owned by ``rank``: its contiguous block of the training-selected
+    rows followed by its block of the validation rows; also returns how many of them are training rows."""
+    tr = np.ones(n, dtype=bool) if training is None else np.asarray(training, dtype=bool).ravel()
+    idx_t = np.flatnonzero(tr)
+    lo, hi = shard_bounds(idx_t.size, rank, world)
+    keep = [idx_t[lo:hi]]
+    if validation is not None:
+        idx_v = np.flatnonzero(np.asarray(validation, dtype=bool).ravel())
+        lv, hv = shard_bounds(idx_v.size, rank, world)
+        keep.append(idx_v[lv:hv])
+    return np.concatenate(keep), hi - lo
+
+
 def shard_rows(rank, world, X, Y, omega=None, training=None, validation=None):
     """Split the TRAINING-selected rows (and, independently, the validation rows) into contiguous blocks and
     return this rank's (X, Y, omega, training, validation) slices.  Rows selected by neither mask are dropped:
     the path never reads them (getPHI.m:14)."""
     X = np.asarray(X)
     Y = np.asarray(Y)
-    n = X.shape[0]
-    tr = np.ones(n, dtype=bool) if training is None else np.asarray(training, dtype=bool)
-    idx_t = np.flatnonzero(tr)
-    lo, hi = shard_bounds(idx_t.size, rank, world)
-    keep = [idx_t[lo:hi]]
-    if validation is not None:
-        idx_v = np.flatnonzero(np.asarray(validation, dtype=bool))
-        lv, hv = shard_bounds(idx_v.size, rank, world)
-        keep.append(idx_v[lv:hv])
-    rows = np.concatenate(keep)
+    rows, nt = shard_index(rank, world, X.shape[0], training, validation)
     Xs, Ys = X[rows], Y[rows]
     oms = None if omega is None else np.asarray(omega)[rows]
     trs = np.zeros(rows.size, dtype=bool)
-    trs[:hi - lo] = True
+    trs[:nt] = True
     vas = None
     if validation is not None:
         vas = np.zeros(rows.size, dtype=bool)
-        vas[hi - lo:] = True
+        vas[nt:] = True
     return Xs, Ys, oms, trs, vas
+
+
+def shard_psi(rank, world, Psi, training=None, validation=None):
+    """This rank's slice of the input-noise array, matching shard_rows: n x d rows for the diagonal kinds,
+    d x d x n slices for GC/VC (fixPsi.m:22-53)."""
+    if Psi is None:
+        return None
+    Psi = np.asarray(Psi)
+    cube = Psi.ndim == 3
+    rows, _ = shard_index(rank, world, Psi.shape[2] if cube else Psi.shape[0], training, validation)
+    return np.ascontiguousarray(Psi[:, :, rows]) if cube else Psi[rows]
 
 
 class _CudaBuf:

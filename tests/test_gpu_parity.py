@@ -93,8 +93,9 @@ def test_golden_through_c_abi(name):
 def test_unbuilt_combinations_refuse_loudly():
     """What is not built must say so (GPZ_ERR_UNSUPPORTED / GPZ_ERR_ARG), never silently compute something else."""
     model, theta, X, Y, Psi, rng = make_problem(64, 3, 4, 1, "VC", True, seed=5, psi=True)
-    with pytest.raises(_lib.GpzError) as ei:          # row-sharded general GC/VC path
-        gpz_amd.GPzContext(model, X, Y, Psi, rank=0, world=2)
+    Xn = X.copy(); Xn[3, 1] = np.nan
+    with pytest.raises(_lib.GpzError) as ei:          # row-sharded GC/VC with missing values (per-rank pattern ids)
+        gpz_amd.GPzContext(model, Xn, Y, Psi, rank=0, world=2)
     assert ei.value.code == -5
     with pytest.raises(_lib.GpzError) as ei:          # wrong Psi layout for the method (fixPsi.m)
         gpz_amd.GPzContext(model, X, Y, np.abs(X))
@@ -319,7 +320,7 @@ def test_c4_shape_against_oracle_subsample():
 
 
 # ---- sharded evaluation: two ranks on one GPU (gloo moves the CUDA buffers; RCCL needs distinct devices) ----
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, psi=False):
     import os
     import torch
     import torch.distributed as dist
@@ -328,14 +329,14 @@ def _shard_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    model, theta, X, Y, _, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33)
+    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi)
     r2 = np.random.default_rng(1)
     om = r2.random((3001, 1)) + 0.5
     tr = r2.random(3001) < 0.8
     va = ~tr
     Xs, Ys, oms, trs, vas = gdist.shard_rows(rank, world, X, Y, om, tr, va)
-    ctx = gpz_amd.GPzContext(model, Xs, Ys, None, oms, trs, vas, rank=rank, world=world,
-                             allreduce=gdist.make_allreduce())
+    ctx = gpz_amd.GPzContext(model, Xs, Ys, gdist.shard_psi(rank, world, Psi, tr, va), oms, trs, vas, rank=rank,
+                             world=world, allreduce=gdist.make_allreduce())
     f, g = ctx.eval(theta)
     w, iS, part = ctx.solve(theta)
     q.put((rank, f, g, dict(ctx.stats), w, part, ctx.n_global))
@@ -343,24 +344,26 @@ def _shard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_eval_world2_matches_unsharded():
+@pytest.mark.parametrize("psi", [False, True])
+def test_sharded_eval_world2_matches_unsharded(psi):
+    """psi=True: GC/VC with an input-noise cube (the per-pair path) row-sharded over two ranks."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q, psi)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-    model, theta, X, Y, _, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33)
+    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi)
     r2 = np.random.default_rng(1)
     om = r2.random((3001, 1)) + 0.5
     tr = r2.random(3001) < 0.8
-    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
-    r4 = O.GPz(theta, model, X, Y, None, om, tr, ~tr, nargout=4)
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    r4 = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr, nargout=4)
     tol = grad_tol(ref.cond)
     for rank, f, g, stats, w, part, n_global in res:
         assert n_global == int(tr.sum())
