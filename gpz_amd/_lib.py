@@ -45,6 +45,8 @@ SYMBOLS = {
     "gpz_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_get_phi": (C.c_int, [C.c_void_p, c_double_p]),
+    "gpz_ctx_set_pinv_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpz_ctx_last_pinv": (C.c_int, [C.c_void_p, c_double_p]),
     "gpz_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "gpz_ctx_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_double_p, C.POINTER(C.c_int64), C.c_int]),
     "gpz_ctx_reset_timings": (C.c_int, [C.c_void_p]),

@@ -167,6 +167,17 @@ class GPzContext:
         _lib.check(self._lib.gpz_solve(self._h, _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(part)))
         return w, iS, part
 
+    def set_pinv_mode(self, mode):
+        """Branch of inv_logdet.m:7-12: 0 = Cholesky, SVD pseudo-inverse when SIGMA is nearly singular (default);
+        1 = always the truncating SVD route; -1 = never."""
+        _lib.check(self._lib.gpz_ctx_set_pinv_mode(self._h, int(mode)))
+
+    def last_pinv(self):
+        """(route taken, rank kept, largest singular value, Jacobi sweeps) of the last eval/solve."""
+        out = (C.c_double * 4)()
+        _lib.check(self._lib.gpz_ctx_last_pinv(self._h, out))
+        return bool(out[0]), int(out[1]), float(out[2]), int(out[3])
+
     def phi(self):
         """PHI (n_train x m) of the last eval/solve — the 5th output of GPz.m:1."""
         out = np.empty((self.n_train, self.model.m), order="F")
@@ -281,7 +292,8 @@ def _expand_gamma(theta, model):
 
 
 def inv_logdet(X, device=0, return_info=False):
-    """[Xi,logdet] = inv_logdet(X)   (inv_logdet.m:1) for symmetric positive-definite X."""
+    """[Xi,logdet] = inv_logdet(X)   (inv_logdet.m:1-15) for symmetric X; info = singular values dropped by the
+    truncation of inv_logdet.m:7-12 (0 = none), -1 = X not finite."""
     lib = _lib.load()
     A = _f64(X)
     m = A.shape[0]

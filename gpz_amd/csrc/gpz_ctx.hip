@@ -175,6 +175,9 @@ struct gpz_ctx {
     StageTimer tm;
     bool phi_valid = false;
     bool has_psi = false, has_missing = false;
+    // truncating pseudo-inverse route (inv_logdet.m:7-12): 0 = when k_cond_flag asks for it, 1 = always, -1 = never
+    int pinv_mode = 0;
+    double pinv_last[4] = {0, 0, 0, 0};   // [route taken, rank kept, max singular value, Jacobi sweeps] of the last call
     // general covariance-kind path
     bool gen = false;
     bool psi_fast = false;   // gen && Psi && no missing dims && d <= 10: register-resident kernels (k_psi.hip)
@@ -517,8 +520,8 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     if ((rc = c->ar.alloc(&c->rstats, (size_t)GPZ_NS))) return bail(rc);
     if ((rc = c->ar.alloc(&c->spart, (size_t)8))) return bail(rc);
     if ((rc = c->ar.alloc(&c->dGfull, c->kind == GPZ_KIND_COV ? m * c->d * c->d : m * c->d))) return bail(rc);
-    if ((rc = c->ar.alloc(&c->out_d, (size_t)c->p + 8))) return bail(rc);
-    if (hipHostMalloc((void **)&c->out_h, ((size_t)c->p + 8) * sizeof(double)) != hipSuccess ||
+    if ((rc = c->ar.alloc(&c->out_d, (size_t)c->p + 10))) return bail(rc);
+    if (hipHostMalloc((void **)&c->out_h, ((size_t)c->p + 10) * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&c->theta_h, (size_t)c->p * sizeof(double)) != hipSuccess)
         return bail(fail(GPZ_ERR_ALLOC, "hipHostMalloc failed"));
     *out = c;
@@ -545,6 +548,17 @@ extern "C" int gpz_ctx_set_allreduce(gpz_ctx *c, gpz_allreduce_fn fn, void *user
 extern "C" int64_t gpz_theta_len(const gpz_ctx *c) { return c ? c->p : -1; }
 extern "C" int64_t gpz_n_train(const gpz_ctx *c) { return c ? c->tr.n : -1; }
 extern "C" int64_t gpz_n_valid(const gpz_ctx *c) { return c ? c->va.n : -1; }
+
+extern "C" int gpz_ctx_set_pinv_mode(gpz_ctx *c, int mode) {
+    if (!c || mode < -1 || mode > 1) return fail(GPZ_ERR_ARG, "gpz_ctx_set_pinv_mode: mode must be -1, 0 or 1");
+    c->pinv_mode = mode;
+    return GPZ_OK;
+}
+extern "C" int gpz_ctx_last_pinv(const gpz_ctx *c, double out[4]) {
+    if (!c || !out) return fail(GPZ_ERR_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) out[i] = c->pinv_last[i];
+    return GPZ_OK;
+}
 
 extern "C" int gpz_ctx_enable_timing(gpz_ctx *c, int enable) {
     if (!c) return fail(GPZ_ERR_ARG, "null context");
@@ -674,14 +688,35 @@ static void stage_b(gpz_ctx *c, int o) {
         Stage s(c, "solve_vectors");
         launch_post_inverse(c->st, c->Sinv, mq, S, c->mp, c->pr.alpha + (size_t)o * m, m, c->mp, o, c->Bext,
                             c->w + (size_t)o * m, c->dwda + (size_t)o * m, c->dgi + (size_t)o * m, c->info, c->logdet);
+        if (c->pinv_mode == 0) launch_cond_flag(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, c->Sinv, mq, m, c->Tmp, c->info);
     }
 }
 
-extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, double stats[4], double diag[2]) {
-    if (!c || !theta || !f || !g) return fail(GPZ_ERR_ARG, "gpz_eval: null argument");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-    if (int e = stage_a(c, theta)) return e;
+// Stage B through the rank-truncating SVD pseudo-inverse (inv_logdet.m:3-15) instead of the Cholesky inverse.
+static int stage_b_pinv(gpz_ctx *c, int o) {
+    const int mq = c->mq, m = c->m;
+    const double *S = c->comm1 + (size_t)o * c->mp * c->mp;
+    Stage s(c, "pinv_svd");
+    double *sbuf = c->Tmp, *out3 = c->Tmp + mq + 8;
+    unsigned long long *word = (unsigned long long *)(c->Tmp + mq);
+    const int sweeps = run_jacobi_pinv(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, c->A, c->Wm, mq, sbuf, word, c->Sinv,
+                                       mq, c->logdet + o, out3);
+    if (sweeps < 0) return fail(GPZ_ERR_HIP, "pseudo-inverse (Jacobi SVD) failed: %s", hipGetErrorString(hipGetLastError()));
+    double h3[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h3, out3, sizeof h3, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->pinv_last[0] = 1.0;
+    c->pinv_last[1] = (o == 0) ? h3[1] : fmin(c->pinv_last[1], h3[1]);
+    c->pinv_last[2] = h3[2];
+    c->pinv_last[3] = (double)sweeps;
+    launch_post_inverse(c->st, c->Sinv, mq, S, c->mp, c->pr.alpha + (size_t)o * m, m, c->mp, o, c->Bext,
+                        c->w + (size_t)o * m, c->dwda + (size_t)o * m, c->dgi + (size_t)o * m, c->info, c->logdet);
+    return 0;
+}
+
+// Everything of an evaluation after stage A (SIGMA partials reduced): solve, T-GEMM, row epilogue, moments, validation,
+// all-reduce #2, finish, result copy.  pinv selects the inverse: Cholesky (false) or truncating SVD (true).
+static int eval_tail(gpz_ctx *c, bool pinv) {
     const size_t mp = c->mp, m = c->m, k = c->k;
     double *mom = c->comm2;
     double *cols = mom + m * c->nm;
@@ -689,7 +724,8 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
     double *vsums = scal + k * 4;
     const bool fused = (c->k == 1);
     for (int o = 0; o < c->k; ++o) {
-        stage_b(c, o);
+        if (pinv) { if (int e = stage_b_pinv(c, o)) return e; }
+        else stage_b(c, o);
         {
             Stage s(c, "tgemm");
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
@@ -838,9 +874,27 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
                               c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         launch_finish(c->st, a);
     }
-    HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 8) * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 10) * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, double stats[4], double diag[2]) {
+    if (!c || !theta || !f || !g) return fail(GPZ_ERR_ARG, "gpz_eval: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+    if (int e = stage_a(c, theta)) return e;
+    c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
+    if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
+    // k_cond_flag (info[1], returned in slot 7 of the statistics block): SIGMA is close enough to singular that
+    // inv_logdet.m may truncate -> redo the solve and everything after it through the SVD route.  PHI and the
+    // reduced partials of stage A are still in place; every rank sees the same SIGMA and takes the same branch.
+    if (c->pinv_mode == 0 && c->out_h[1 + c->p + 7] != 0.0) {
+        HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+        if (int e = eval_tail(c, true)) return e;
+    }
+    const bool have_valid = c->va.n_pad > 0;
     if (c->timing) collect_timings(c);
     *f = c->out_h[0];
     memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
@@ -860,9 +914,23 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
     HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
     if (int e = stage_a(c, theta)) return e;
     const size_t m = c->m, mq = c->mq;
+    c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
     for (int o = 0; o < c->k; ++o) {
-        stage_b(c, o);
-        // inv(SIGMA) is symmetric: row-major == column-major
+        bool pinv = c->pinv_mode == 1;
+        if (!pinv) {
+            stage_b(c, o);
+            if (c->pinv_mode == 0) {   // see gpz_eval: take the truncating route when k_cond_flag asks for it
+                int ih[2] = {0, 0};
+                HIPCHK(hipMemcpyAsync(ih, c->info, sizeof ih, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(hipStreamSynchronize(c->st));
+                if (ih[1] != 0) {
+                    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+                    pinv = true;
+                }
+            }
+        }
+        if (pinv) { if (int e = stage_b_pinv(c, o)) return e; }
+        // inv(SIGMA) is symmetric (to rounding on the SVD route): row-major == column-major
         HIPCHK(hipMemcpy2DAsync(iSigma_w + (size_t)o * m * m, m * sizeof(double), c->Sinv, mq * sizeof(double),
                                 m * sizeof(double), m, hipMemcpyDeviceToHost, c->st));
     }
@@ -1195,19 +1263,35 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
     launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
+    launch_cond_flag(c->st, S, m, alpha0, c->Sinv, mq, m, c->Tmp, c->info);
     int info_h[2] = {0, 0};
     double ld = 0.0;
-    hipError_t e = hipMemcpy2D(Xi, (size_t)m * sizeof(double), c->Sinv, (size_t)mq * sizeof(double),
-                               (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&ld, c->logdet, sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(info_h, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(info_h, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bail(fail(GPZ_ERR_HIP, "gpz_inv_logdet: %s", hipGetErrorString(e)));
-    if (info_h[0] != 0) {
+    int dropped = 0;
+    if (info_h[1] != 0) {
+        // numerically singular or not positive definite: the truncating SVD route of inv_logdet.m:3-15
+        double *out3 = c->Tmp + mq + 8;
+        if (run_jacobi_pinv(c->st, S, m, nullptr, m, c->A, c->Wm, mq, c->Tmp, (unsigned long long *)(c->Tmp + mq), c->Sinv, mq,
+                            c->logdet, out3) < 0)
+            return bail(fail(GPZ_ERR_HIP, "gpz_inv_logdet: Jacobi SVD failed"));
+        double h3[3] = {0, 0, 0};
+        e = hipMemcpy(h3, out3, sizeof h3, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail(fail(GPZ_ERR_HIP, "gpz_inv_logdet: %s", hipGetErrorString(e)));
+        dropped = m - (int)h3[1];
+        info_h[0] = 0;
+    }
+    e = hipMemcpy2D(Xi, (size_t)m * sizeof(double), c->Sinv, (size_t)mq * sizeof(double), (size_t)m * sizeof(double), m,
+                    hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&ld, c->logdet, sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(fail(GPZ_ERR_HIP, "gpz_inv_logdet: %s", hipGetErrorString(e)));
+    if (info_h[0] != 0) {   // non-finite input
         for (size_t q = 0; q < (size_t)m * m; ++q) Xi[q] = NAN;
         ld = NAN;
+        dropped = -1;
     }
     *logdet = ld;
-    if (info) *info = info_h[0];
+    if (info) *info = dropped;
     c->ar.release();
     delete c;
     return GPZ_OK;

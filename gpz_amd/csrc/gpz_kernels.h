@@ -75,6 +75,16 @@ void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const dou
                          int m, int mp, int out, double *Bext, double *w, double *dwda, double *dgi, int *info,
                          double *logdet);
 
+// ---- rank-truncating pseudo-inverse, the other branch of inv_logdet.m:7-15 (k_pinv.hip) -----------
+// info[1] |= 1 when SIGMA = S + diag(alpha) is so ill-conditioned that the reference's SVD might drop singular values
+// (part: 128 doubles of scratch)
+void launch_cond_flag(hipStream_t st, const double *S, int lds, const double *alpha, const double *Sinv, int ldsi, int m,
+                      double *part, int *info);
+// one-sided Jacobi SVD -> Xi = V diag(1/s) U' over s > m*eps(max s), *logdet = sum ln s (kept); out3 = [logdet, rank, max s]
+// Gt, Vt: m x ld work matrices, sbuf: m doubles, word: 8-byte device word.  Returns the sweeps used, -1 on error.
+int run_jacobi_pinv(hipStream_t st, const double *S, int lds, const double *alpha, int m, double *Gt, double *Vt, int ld,
+                    double *sbuf, unsigned long long *word, double *Xi, int ldx, double *logdet, double *out3);
+
 void launch_fill_bext(hipStream_t st, const double *Sinv, int ldsi, const double *w, int m, int mp, int out,
                       double *Bext, double *dgi);
 
@@ -138,7 +148,7 @@ struct FinishArgs {
     const double *sums1;                  // [sum omega, sum_i omega_i lnbeta_io (8), n_train]       (GPZ_NS doubles)
     const double *vsums;                  // [sum omega delta^2, sum LL, per-output (8), n_valid, 0]  or nullptr
     const int *info;
-    double *out;                          // [f, grad(p), stats(4), info, n, logdet0, 0]   (p + 8 doubles)
+    double *out;                          // [f, grad(p), stats(4), info, n, logdet0, svd-route flag, 0]   (p + 10 doubles)
     double *dGfull;                       // scratch m*d or m*d*d
     int p;
     int nmp;                              // leading dimension of cols (= mp)

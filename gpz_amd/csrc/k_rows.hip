@@ -688,6 +688,7 @@ __global__ __launch_bounds__(256) void k_finish_b(FinishArgs a, int de) {
         st[4] = (double)(*a.info);
         st[5] = n;
         st[6] = a.logdet[0];
+        st[7] = (double)a.info[1];                                         // k_cond_flag: the SVD route is wanted
     }
     if (*a.info != 0) {
         const double nanv = __longlong_as_double(0x7ff8000000000000LL);

@@ -104,6 +104,15 @@ int gpz_solve(gpz_ctx *ctx, const double *theta, double *w, double *iSigma_w, do
  * (5th output of GPz.m:1). */
 int gpz_get_phi(gpz_ctx *ctx, double *PHI);
 
+/* Which branch of inv_logdet.m:7-12 an evaluation takes.  mode 0 (default): the Cholesky inverse, and the
+ * rank-truncating SVD pseudo-inverse whenever SIGMA is close enough to singular that the reference might drop
+ * singular values (decided on the device from ||SIGMA||_F and ||inv||_F, or a failed pivot); 1: always the
+ * SVD route; -1: never (a failed pivot then gives NaN f/g).
+ * gpz_ctx_last_pinv: out[0] = 1 if the last gpz_eval/gpz_solve took the SVD route, out[1] = rank kept
+ * (minimum over outputs), out[2] = largest singular value, out[3] = Jacobi sweeps. */
+int gpz_ctx_set_pinv_mode(gpz_ctx *ctx, int mode);
+int gpz_ctx_last_pinv(const gpz_ctx *ctx, double out[4]);
+
 /* Per-stage GPU time (HIP events on the context's stream).  enable!=0 turns recording on;
  * gpz_ctx_timings copies up to `cap` accumulated stage times in ms and the call counts, returns
  * the number of stages; names are static strings. */
@@ -131,8 +140,11 @@ int gpz_predict_noisy(const gpz_desc *desc, const double *theta, const double *w
 int gpz_prior(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns,
               const double *Psi, int32_t psi_kind, double *prior, int32_t *iterations);
 
-/* Inverse and log-determinant of a symmetric positive-definite m x m matrix.  info (optional):
- * 0 ok, j>0 not positive definite at pivot j (Xi, logdet are NaN then). */
+/* [Xi,logdet] = inv_logdet(X) for a symmetric m x m matrix (GPz/inv_logdet.m:1-15).  A comfortably
+ * positive-definite X goes through the Cholesky inverse; a numerically singular or indefinite one
+ * through a Jacobi SVD with the reference's truncation (singular values <= m*eps(max s) dropped from
+ * both Xi and logdet).  info (optional): number of singular values dropped (0 = none), -1 = X is not
+ * finite (Xi, logdet are NaN then; MATLAB's svd raises). */
 int gpz_inv_logdet(const double *A, int32_t m, int32_t device, double *Xi, double *logdet, int32_t *info);
 
 /* D = | |x|^2 + |y|^2 - 2 x y' |, X nx x d, Y ny x d, D nx x ny. */

@@ -226,10 +226,106 @@ def test_inv_logdet(m):
     assert info == 0 and rel(Xi, Ri) <= 50 * cond * 2.2e-16 and abs(ld - rl) <= 1e-12 * max(1.0, abs(rl))
 
 
-def test_inv_logdet_not_positive_definite():
+def test_inv_logdet_indefinite_and_nonfinite():
+    """Not positive definite: the reference's SVD route still answers (singular values = |eigenvalues|); a NaN
+    entry makes MATLAB's svd raise -> NaN outputs here."""
     S = np.array([[1.0, 2.0], [2.0, 1.0]])
     Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
-    assert info > 0 and np.isnan(Xi).all() and math.isnan(ld)
+    Xr, lr = O.inv_logdet(S)
+    assert info == 0 and rel(Xi, Xr) < 1e-13 and abs(ld - lr) < 1e-13
+    S[0, 1] = S[1, 0] = np.nan
+    Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
+    assert info == -1 and np.isnan(Xi).all() and math.isnan(ld)
+
+
+@pytest.mark.parametrize("m,rank", [(2, 1), (7, 3), (50, 30), (257, 200), (600, 599)])
+def test_inv_logdet_rank_deficient_truncates_like_the_reference(m, rank):
+    """inv_logdet.m:7-15 on a singular PSD matrix: singular values below m*eps(max s) are dropped from the inverse
+    and from the log-determinant."""
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, rank))
+    S = B @ B.T
+    S = 0.5 * (S + S.T)
+    Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
+    Xr, lr = O.inv_logdet(S)
+    s = np.linalg.svd(S, compute_uv=False)
+    condk = s[0] / s[rank - 1]
+    assert info == m - rank
+    assert abs(ld - lr) <= 1e-10 * max(1.0, abs(lr))
+    assert rel(Xi, Xr) <= 1e3 * condk * 2.2e-16
+
+
+def test_inv_logdet_near_singular_full_rank():
+    """cond ~ 1e13 but every singular value above the threshold: nothing may be dropped."""
+    rng = np.random.default_rng(9)
+    m = 40
+    Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    s = np.logspace(0, -12.5, m)
+    S = (Q * s) @ Q.T
+    S = 0.5 * (S + S.T)
+    Xi, ld, info = gpz_amd.inv_logdet(S, return_info=True)
+    Xr, lr = O.inv_logdet(S)
+    # both SVDs carry an absolute error ~eps*max(s) in every singular value: ln s_min is good to cond*eps
+    assert info == 0 and abs(ld - lr) <= 10 * (s[0] / s[-1]) * 2.2e-16
+    assert rel(Xi @ S, np.eye(m)) < 1e-2      # the inverse itself is only good to cond*eps
+
+
+def _singular_problem(method="VD"):
+    """Duplicate basis functions with vanishing alpha: SIGMA is singular to working precision, the reference truncates."""
+    model, theta, X, Y, _, rng = make_problem(400, 3, 12, 1, method, True, seed=91)
+    m, d = model.m, model.d
+    th = theta.copy()
+    P = th[:m * d].reshape((m, d), order="F")
+    P[6:] = P[:6]                                   # basis 6..11 = copies of 0..5
+    th[:m * d] = P.ravel(order="F")
+    g0 = m * d
+    if method == "VD":
+        G = th[g0:g0 + m * d].reshape((m, d), order="F"); G[6:] = G[:6]; th[g0:g0 + m * d] = G.ravel(order="F")
+    else:
+        G = th[g0:g0 + d * d * m].reshape((d, d, m), order="F"); G[:, :, 6:] = G[:, :, :6]
+        th[g0:g0 + d * d * m] = G.ravel(order="F")
+    a0 = g0 + model.g_dim
+    th[a0:a0 + m] = -60.0                           # alpha = e^-60: far below m*eps(max s)
+    return model, th, X, Y
+
+
+@pytest.mark.parametrize("method", ["VD", "VC"])
+def test_eval_singular_sigma_takes_the_truncating_route(method):
+    model, th, X, Y = _singular_problem(method)
+    ref = O.GPz(th, model, X, Y)
+    r4 = O.GPz(th, model, X, Y, nargout=4)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f, g = ctx.eval(th)
+    used, rank, smax, sweeps = ctx.last_pinv()
+    assert used and rank == 6 and sweeps >= 1
+    assert np.isfinite(f) and np.isfinite(g).all()
+    assert abs(f - ref.nlogML) <= 1e-7 * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= 1e-6
+    w, iS, part = ctx.solve(th)
+    assert ctx.last_pinv()[0] and rel(w, r4.w) <= 1e-6 and rel(iS, r4.iSigma_w) <= 1e-6
+    ctx.set_pinv_mode(-1)                           # the Cholesky-only route cannot follow the reference here
+    f2, g2 = ctx.eval(th)
+    assert not ctx.last_pinv()[0]
+    assert (not np.isfinite(f2)) or abs(f2 - ref.nlogML) > 1e-7 * abs(ref.nlogML) or rel(g2, ref.grad) > 1e-6
+    ctx.close()
+
+
+@pytest.mark.parametrize("method,k", [("VD", 1), ("VC", 2), ("GL", 1)])
+def test_forced_svd_route_equals_cholesky_route(method, k):
+    """On a well-conditioned SIGMA nothing is truncated and both branches of inv_logdet give the same evaluation."""
+    model, theta, X, Y, _, rng = make_problem(900, 4, 37, k, method, True, seed=92)
+    ref = O.GPz(theta, model, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    assert not ctx.last_pinv()[0]
+    ctx.set_pinv_mode(1)
+    f1, g1 = ctx.eval(theta)
+    used, rank, smax, sweeps = ctx.last_pinv()
+    ctx.close()
+    assert used and rank == model.m
+    tol = grad_tol(ref.cond)
+    assert abs(f1 - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g1, ref.grad) <= tol
+    assert abs(f1 - f0) <= 1e-10 * abs(f0) and rel(g1, g0) <= tol
 
 
 def test_dxy():
