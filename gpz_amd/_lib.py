@@ -56,6 +56,9 @@ SYMBOLS = {
                                    c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_predict_noisy": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64,
                                     c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_predict_missing": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                      C.c_int64, c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p,
+                                      c_double_p]),
     "gpz_prior": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, C.c_int64, c_double_p, C.c_int32, c_double_p,
                             c_int32_p]),
     "gpz_inv_logdet": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_int32_p]),

@@ -328,8 +328,9 @@ def nan_groups(X, device=0):
 
 
 def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
-    """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1).  Built branches: no input
-    noise (predictFull) and input noise without missing values (predictNoisy); inputs with NaN refuse."""
+    """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1).  Rows are grouped by NaN
+    pattern as predict.m:45-57 does; a group without missing values runs predictFull / predictNoisy, a group with
+    missing values predictMissing / predictNoisyMissing (diagonal kinds; GC/VC with missing values refuse)."""
     lib = _lib.load()
     X = np.asarray(X, dtype=np.float64)
     psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)
@@ -343,21 +344,42 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
     theta = np.ascontiguousarray(np.asarray(st["theta"], dtype=np.float64).ravel())
     w = _f64(st["w"], 2)
     iS = np.asfortranarray(np.asarray(st["iSigma_w"], dtype=np.float64).reshape(model.m, model.m, model.k))
-    ns, k = Xn.shape[0], model.k
-    mu = np.empty((ns, k), order="F"); nu = np.empty((ns, k), order="F"); beta_i = np.empty((ns, k), order="F")
-    PHI = np.empty((ns, model.m), order="F")
-    ds = _desc(model, device)
-    if psi is None:
-        _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
-                                        _lib.dptr(mu), _lib.dptr(nu), _lib.dptr(beta_i), _lib.dptr(PHI)))
-        gamma = np.zeros((ns, k))                                    # predictDiag.m:74
-    else:
+    ns, k, m = Xn.shape[0], model.k, model.m
+    psin = None
+    if psi is not None:
         from .host import fixPsi
         psin = np.asfortranarray(fixPsi(psi, ns, model.sdX, model.method))   # predict.m:43
-        gamma = np.empty((ns, k), order="F")
-        _lib.check(lib.gpz_predict_noisy(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xn), ns,
-                                         _lib.dptr(psin), 2 if psin.ndim == 3 else 1, _lib.dptr(mu), _lib.dptr(nu),
-                                         _lib.dptr(beta_i), _lib.dptr(gamma), _lib.dptr(PHI)))
+    cube = psin is not None and psin.ndim == 3
+    ds = _desc(model, device)
+    mu = np.zeros((ns, k)); nu = np.zeros((ns, k)); beta_i = np.zeros((ns, k)); gamma = np.zeros((ns, k))
+    PHI = np.zeros((ns, m))
+    # predict.m:45-57: groups of identical NaN patterns (any order gives the same outputs)
+    missing = np.isnan(Xn)
+    _, gid = np.unique(missing, axis=0, return_inverse=True)
+    gid = np.asarray(gid).ravel()
+    for g in range(int(gid.max()) + 1 if ns else 0):
+        idx = np.flatnonzero(gid == g)
+        ng = idx.size
+        Xg = _f64(Xn[idx], 2)
+        Pg = None if psin is None else np.asfortranarray(psin[:, :, idx] if cube else psin[idx])
+        o_mu = np.empty((ng, k), order="F"); o_nu = np.empty((ng, k), order="F"); o_be = np.empty((ng, k), order="F")
+        o_ga = np.zeros((ng, k), order="F"); o_ph = np.empty((ng, m), order="F")
+        if not missing[idx[0]].any():
+            if Pg is None:                                           # predictFull, gamma = 0 (predictDiag.m:74)
+                _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xg), ng,
+                                                _lib.dptr(o_mu), _lib.dptr(o_nu), _lib.dptr(o_be), _lib.dptr(o_ph)))
+            else:
+                _lib.check(lib.gpz_predict_noisy(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xg), ng,
+                                                 _lib.dptr(Pg), 2 if cube else 1, _lib.dptr(o_mu), _lib.dptr(o_nu),
+                                                 _lib.dptr(o_be), _lib.dptr(o_ga), _lib.dptr(o_ph)))
+        else:
+            pri = st.get("priors")
+            pri = np.full(m, 1.0 / m) if pri is None else np.ascontiguousarray(np.asarray(pri, dtype=np.float64).ravel())
+            _lib.check(lib.gpz_predict_missing(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(pri),
+                                               _lib.dptr(Xg), ng, _lib.dptr(Pg), 0 if Pg is None else (2 if cube else 1),
+                                               _lib.dptr(o_mu), _lib.dptr(o_nu), _lib.dptr(o_be), _lib.dptr(o_ga),
+                                               _lib.dptr(o_ph)))
+        mu[idx] = o_mu; nu[idx] = o_nu; beta_i[idx] = o_be; gamma[idx] = o_ga; PHI[idx] = o_ph
     sigma = nu + beta_i + gamma                                      # predict.m:72
     mu = mu + model.muY                                              # predict.m:73
     return mu, sigma, nu, beta_i, gamma, PHI, w, iS

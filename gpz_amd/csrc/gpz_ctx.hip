@@ -1186,6 +1186,99 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
     return rc;
 }
 
+// predictMissing / predictNoisyMissing (predictDiag.m:127-297) for ONE group of rows sharing a NaN pattern (the caller
+// groups the rows as predict.m:45-69 does; the pattern is taken from the first row, predictDiag.m:3).
+extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                                   const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
+                                   double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
+    if (!desc || !theta || !w || !iSigma_w || !priors || !Xs || ns < 1 || !mu || !nu || !beta_i || !gamma)
+        return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
+    const int d = desc->d;
+    if (d > 20) return fail(GPZ_ERR_UNSUPPORTED, "d = %d > 20 not supported", d);
+    unsigned obs = 0;
+    for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1u << c; }
+    for (int c = 0; c < d; ++c)
+        for (int64_t i = 0; i < ns; ++i) {
+            const double xv = Xs[(size_t)c * ns + i];
+            if ((xv == xv) != (((obs >> c) & 1u) != 0))
+                return fail(GPZ_ERR_ARG, "gpz_predict_missing: the rows of a group must share one NaN pattern (predict.m:45-57)");
+        }
+    if (obs == (d >= 32 ? ~0u : ((1u << d) - 1u)))
+        return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
+    if (method_id_of(desc->method) >= 4)
+        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values for GC/VC (predictCov.m:134-337) is not built");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
+    const int n = c->tr.n, de = c->de;
+    int rc = 0;
+    HIPCHK(hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+    launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+    double *No = nullptr, *Pio = nullptr, *B = nullptr, *T = nullptr, *wd = nullptr, *iSd = nullptr, *prd = nullptr,
+           *rec = nullptr, *sums = nullptr, *phiw = nullptr, *outb = nullptr, *tmp = nullptr;
+    const int nrec = 2 * d + 1 + 3 * (int)k;
+    if (!rc) rc = c->ar.alloc(&No, np * mp);
+    if (!rc) rc = c->ar.alloc(&Pio, np * mp);
+    if (!rc) rc = c->ar.alloc(&B, mp * mp);
+    if (!rc) rc = c->ar.alloc(&T, np * mp);
+    if (!rc) rc = c->ar.alloc(&wd, m * k);
+    if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
+    if (!rc) rc = c->ar.alloc(&prd, m);
+    if (!rc) rc = c->ar.alloc(&rec, mp * nrec);
+    if (!rc) rc = c->ar.alloc(&sums, 3 * k * np);
+    if (!rc) rc = c->ar.alloc(&phiw, np * k);
+    if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(iSd, iSigma_w, m * m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(prd, priors, m * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+    }
+    if (!rc) {
+        const double *Psir = c->has_psi ? c->tr.Psir : nullptr;
+        launch_pm_no(c->st, c->tr.Xr, Psir, de, n, (long)np, c->m, (int)mp, d, obs, c->pr.P, c->pr.G, prd, No, Pio);
+        // PHI = No .* (Pio * Nij') .* exp(lnz)                                              predictDiag.m:158-161
+        launch_pm_nij(c->st, c->m, (int)mp, d, de, obs, c->pr.P, c->pr.G, B);
+        launch_tgemm(c->st, Pio, (int)mp, B, (int)mp, T, (int)np, (int)mp, nullptr, nullptr, c->m, -1);
+        launch_pm_phi(c->st, No, T, (int)mp, n, (long)np, c->m, d, de, c->pr.G, c->Phi);
+        // mu = PHI*w, ElnS = PHI*v (+ b)                                                    predictDiag.m:163-164,203
+        launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
+                          c->lnbeta, nullptr, phiw);
+        launch_zero(c->st, sums, 3 * k * np);
+        const long npairs = (long)m * (m + 1) / 2;
+        for (long q0 = 0; q0 < npairs; q0 += (long)mp) {                                     // predictDiag.m:170-200
+            const int npq = (int)((npairs - q0 < (long)mp) ? npairs - q0 : (long)mp);
+            launch_pm_pairtab(c->st, q0, npairs, c->m, (int)mp, d, de, c->k, obs, c->has_psi ? 1 : 0, c->pr.P, c->pr.G, wd,
+                              c->hetero ? c->pr.v : nullptr, iSd, B, rec, nrec);
+            launch_tgemm(c->st, Pio, (int)mp, B, (int)mp, T, (int)np, (int)mp, nullptr, nullptr, c->m, -1);
+            launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)mp, d, c->k, obs, npq, T, rec, nrec, sums);
+        }
+        launch_predict_noisy_final(c->st, sums, (long)np, n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
+                                   outb + 2 * k * np);
+        auto down = [&](double *dst, const double *src) {
+            return hipMemcpy2DAsync(dst, (size_t)ns * sizeof(double), src, np * sizeof(double), (size_t)ns * sizeof(double), k,
+                                    hipMemcpyDeviceToHost, c->st);
+        };
+        hipError_t e = down(gamma, outb);
+        if (e == hipSuccess) e = down(nu, outb + k * np);
+        if (e == hipSuccess) e = down(beta_i, outb + 2 * k * np);
+        if (e == hipSuccess) e = down(mu, phiw);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+    }
+    if (!rc && PHI) {
+        rc = c->ar.alloc(&tmp, (size_t)ns * m);
+        if (!rc) {
+            launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+            if (hipMemcpyAsync(PHI, tmp, (size_t)ns * m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+                rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+        }
+    }
+    if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: sync failed");
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: kernel failed");
+    free_eval_ctx(c);
+    return rc;
+}
+
 // prior = getPrior(X,Psi,theta,model,[])   (getPrior.m): N once, then the fixed point on the device; the convergence
 // test on the m-vector (getPrior.m:18) runs on the host between iterations.
 extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double *Xs, int64_t ns, const double *Psi,

@@ -215,6 +215,18 @@ void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, in
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
                        int nwg);
 
+// prediction with missing dimensions, diagonal kinds (predictDiag.m:127-297; k_pmiss.hip).  obs: bit c set = dimension c observed.
+void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                  unsigned obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B);
+void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
+                   const double *G, double *Phi);
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs, int has_psi,
+                       const double *P, const double *G, const double *w, const double *v, const double *iS, double *B,
+                       double *rec, int nrec);
+void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
+                     unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums);
+
 // N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
 struct NormArgs {
     const double *Phi; int ld; int n, m, d, de, kind, gen;

@@ -1,0 +1,221 @@
+// Prediction for inputs with missing dimensions, diagonal kinds (GL/VL/GD/VD):
+//   predictMissing       predictDiag.m:127-209   (no input noise)
+//   predictNoisyMissing  predictDiag.m:211-297   (input noise Psi, n x d)
+// for one group of rows that share a NaN pattern (predict.m:45-69 groups the rows; predictDiag.m:3 takes the
+// pattern from the group's first row).  o = observed dimensions, u = missing ones.
+//
+// The reference's pair loop costs O(n m^3): for every basis pair (i,j) it forms N = No*Nu' (n x m) and
+// EcCij = sum(N.*Pio,2).  That is No .* (Pio*Nu), and over all pairs a GEMM  Pio (n x m) * Nu (m x pairs) — it runs
+// on the f64 MFMA T-GEMM kernel here, a chunk of mp pairs per launch; PHI = No .* (Pio*Nij') likewise.
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+// No(i,j) = exp(-1/2 sum_o (x-p_j)^2/(sigma_j [+psi_i]) - 1/2 sum_o ln(sigma_j [+psi_i]))   predictDiag.m:142-148 / :226-233
+// written to No[i*ld + j]; columns j >= m and rows i >= n are zero.
+__global__ void k_pm_no(const double *__restrict__ Xr, const double *__restrict__ Psir, int de, int n, long n_pad, int m,
+                        int ld, int d, unsigned obs, const double *__restrict__ P, const double *__restrict__ G,
+                        double *__restrict__ No) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = blockIdx.y;
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < m && i < n) {
+        double q = 0.0, ls = 0.0;
+        for (int c = 0; c < d; ++c) {
+            if (!((obs >> c) & 1u)) continue;
+            const double g = G[(size_t)j * de + c];
+            double s = 1.0 / (g * g);                                  // Sigma = Gamma.^-2
+            if (Psir) s += Psir[(size_t)i * de + c];
+            const double dl = Xr[(size_t)i * de + c] - P[(size_t)j * de + c];
+            q += dl * dl / s;
+            ls += log(s);
+        }
+        v = exp(-0.5 * q - 0.5 * ls);
+    }
+    No[(size_t)i * ld + j] = v;
+}
+
+// Pio = (No .* priors) ./ rowsum   (predictDiag.m:147-152); one wave per row.
+__global__ __launch_bounds__(256) void k_pm_pio(const double *__restrict__ No, int ld, int n, int m,
+                                                 const double *__restrict__ priors, double *__restrict__ Pio) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < m; j += 64) s += No[(size_t)i * ld + j] * priors[j];
+    s = wave_sum(s);
+    for (int j = lane; j < ld; j += 64) Pio[(size_t)i * ld + j] = (j < m) ? No[(size_t)i * ld + j] * priors[j] / s : 0.0;
+}
+
+// B[j*ld + i] = Nij(i,j) = exp(-1/2 sum_u (p_i-p_j)^2/(sigma_i+sigma_j) - 1/2 sum_u ln(sigma_i+sigma_j))   predictDiag.m:158
+__global__ void k_pm_nij(int m, int ld, int d, int de, unsigned obs, const double *__restrict__ P,
+                         const double *__restrict__ G, double *__restrict__ B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= ld) return;
+    double v = 0.0;
+    if (i < m && j < m) {
+        double q = 0.0, ls = 0.0;
+        for (int c = 0; c < d; ++c) {
+            if ((obs >> c) & 1u) continue;
+            const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
+            const double s = 1.0 / (gi * gi) + 1.0 / (gj * gj);
+            const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
+            q += dl * dl / s;
+            ls += log(s);
+        }
+        v = exp(-0.5 * q - 0.5 * ls);
+    }
+    B[(size_t)j * ld + i] = v;
+}
+
+// PHI(i,j) = exp(lnz_j) * No(i,j) * T1(i,j),  lnz_j = -1/2 sum_c ln(gamma_jc^2)   predictDiag.m:138,160-161
+__global__ void k_pm_phi(const double *__restrict__ No, const double *__restrict__ T1, int ld, int n, long n_pad, int m,
+                         int d, int de, const double *__restrict__ G, double *__restrict__ Phi) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = blockIdx.y;
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < m && i < n) {
+        double lz = 0.0;
+        for (int c = 0; c < d; ++c) { const double g = G[(size_t)j * de + c]; lz += log(g * g); }
+        v = exp(-0.5 * lz) * No[(size_t)i * ld + j] * T1[(size_t)i * ld + j];
+    }
+    Phi[(size_t)i * ld + j] = v;
+}
+
+// pair index q = i(i+1)/2 + j, j <= i
+__device__ __forceinline__ void pair_of(long q, int *pi, int *pj) {
+    int i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((long)(i + 1) * (i + 2) / 2 <= q) ++i;
+    while ((long)i * (i + 1) / 2 > q) --i;
+    *pi = i;
+    *pj = (int)(q - (long)i * (i + 1) / 2);
+}
+
+// Tables of one chunk of pairs [q0, q0+ld):
+//   B[l*ld + qq]  = Nu^{q}_l = exp(-1/2 sum_u (p_l - cij)^2/(sigma_l + Cij) - 1/2 sum_u ln(sigma_l + Cij))     :181-183 / :266-268
+//   rec[qq]       = [cij (d) | Cij (d) | lnZ | c2*w_i*w_j (k) | c2*v_i*v_j (k) | c2*iSigma_w(i,j,:) (k)]
+//     lnZ = lnz_i + lnz_j - 1/2 sum_c (p_i-p_j)^2/(sigma_i+sigma_j) - 1/2 sum_c ln(sigma_i+sigma_j)            :189 / :274
+//           [- 1/2 sum_o ln Cij when there is no input noise: the x-independent part of No,                    :178]
+//     c2  = 2 for j < i, 1 for j == i (2x inside the loop, minus 1x for the diagonal term after it,            :191-199)
+// Columns past the last pair are zero (B) / c2 = 0 (rec).
+__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs,
+                                                    int has_psi, const double *__restrict__ P,
+                                                    const double *__restrict__ G, const double *__restrict__ w,
+                                                    const double *__restrict__ v, const double *__restrict__ iS,
+                                                    double *__restrict__ B, double *__restrict__ rec, int nrec) {
+    const int qq = blockIdx.x;
+    const long q = q0 + qq;
+    double *r = rec + (size_t)qq * nrec;
+    if (q >= npairs) {
+        for (int l = threadIdx.x; l < ld; l += 256) B[(size_t)l * ld + qq] = 0.0;
+        for (int e = threadIdx.x; e < nrec; e += 256) r[e] = (e >= d && e < 2 * d) ? 1.0 : 0.0;
+        return;
+    }
+    int i, j;
+    pair_of(q, &i, &j);
+    __shared__ double cij[32], Cij[32];
+    if (threadIdx.x < d) {
+        const int c = threadIdx.x;
+        const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
+        const double isi = gi * gi, isj = gj * gj;
+        const double C = 1.0 / (isi + isj);                                      // :173 / :257
+        Cij[c] = C;
+        cij[c] = (P[(size_t)i * de + c] * isi + P[(size_t)j * de + c] * isj) * C;  // :174 / :258
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < ld; l += 256) {
+        double val = 0.0;
+        if (l < m) {
+            double qd = 0.0, ls = 0.0;
+            for (int c = 0; c < d; ++c) {
+                if ((obs >> c) & 1u) continue;
+                const double gl = G[(size_t)l * de + c];
+                const double s = 1.0 / (gl * gl) + Cij[c];
+                const double dl = P[(size_t)l * de + c] - cij[c];
+                qd += dl * dl / s;
+                ls += log(s);
+            }
+            val = exp(-0.5 * qd - 0.5 * ls);
+        }
+        B[(size_t)l * ld + qq] = val;
+    }
+    if (threadIdx.x == 0) {
+        double lz = 0.0, qd = 0.0, ls = 0.0, lo = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
+            lz += log(gi * gi) + log(gj * gj);
+            const double s = 1.0 / (gi * gi) + 1.0 / (gj * gj);
+            const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
+            qd += dl * dl / s;
+            ls += log(s);
+            if (((obs >> c) & 1u) && !has_psi) lo += log(Cij[c]);
+            r[c] = cij[c];
+            r[d + c] = Cij[c];
+        }
+        r[2 * d] = -0.5 * lz - 0.5 * qd - 0.5 * ls - 0.5 * lo;
+        const double c2 = (j < i) ? 2.0 : 1.0;
+        for (int o = 0; o < k; ++o) {
+            r[2 * d + 1 + o] = c2 * w[i + (size_t)m * o] * w[j + (size_t)m * o];
+            r[2 * d + 1 + k + o] = v ? c2 * v[i + (size_t)m * o] * v[j + (size_t)m * o] : 0.0;
+            r[2 * d + 1 + 2 * k + o] = c2 * iS[i + (size_t)m * j + (size_t)m * m * o];
+        }
+    }
+}
+
+// sums[3][k][n_pad] += over the pairs of the chunk:  Z = exp(lnZ + lnNo_q(x)) * T2(row, qq)
+//   lnNo_q = -1/2 sum_o (x - cij)^2/(Cij [+ psi]) [- 1/2 sum_o ln(Cij + psi)]                                  :176-178 / :260-263
+__global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr, const double *__restrict__ Psir, int de,
+                                                   int n, long n_pad, int ld, int d, int k, unsigned obs, int npq,
+                                                   const double *__restrict__ T2, const double *__restrict__ rec, int nrec,
+                                                   double *__restrict__ sums) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double x[20], ps[20];
+    for (int c = 0; c < d; ++c) {
+        x[c] = Xr[(size_t)i * de + c];
+        ps[c] = Psir ? Psir[(size_t)i * de + c] : 0.0;
+    }
+    double acc[24];
+    for (int e = 0; e < 3 * k; ++e) acc[e] = 0.0;
+    for (int qq = 0; qq < npq; ++qq) {
+        const double *r = rec + (size_t)qq * nrec;
+        double qd = 0.0, ls = 0.0;
+        for (int c = 0; c < d; ++c) {
+            if (!((obs >> c) & 1u)) continue;
+            const double s = r[d + c] + ps[c];
+            const double dl = x[c] - r[c];
+            qd += dl * dl / s;
+            if (Psir) ls += log(s);
+        }
+        const double Z = exp(r[2 * d] - 0.5 * qd - 0.5 * ls) * T2[(size_t)i * ld + qq];
+        for (int e = 0; e < 3 * k; ++e) acc[e] = fma(Z, r[2 * d + 1 + e], acc[e]);
+    }
+    for (int e = 0; e < 3 * k; ++e) sums[(size_t)e * n_pad + i] += acc[e];
+}
+
+void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                  unsigned obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
+    hipLaunchKernelGGL(k_pm_no, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, Xr, Psir, de, n, n_pad, m, ld, d, obs,
+                       P, G, No);
+    hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double *)No, ld, n, m, priors, Pio);
+}
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B) {
+    hipLaunchKernelGGL(k_pm_nij, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
+}
+void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
+                   const double *G, double *Phi) {
+    hipLaunchKernelGGL(k_pm_phi, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, No, T1, ld, n, n_pad, m, d, de, G,
+                       Phi);
+}
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs, int has_psi,
+                       const double *P, const double *G, const double *w, const double *v, const double *iS, double *B,
+                       double *rec, int nrec) {
+    hipLaunchKernelGGL(k_pm_pairtab, dim3(ld), dim3(256), 0, st, q0, npairs, m, ld, d, de, k, obs, has_psi, P, G, w, v, iS, B,
+                       rec, nrec);
+}
+void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
+                     unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums) {
+    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
+                       npq, T2, rec, nrec, sums);
+}

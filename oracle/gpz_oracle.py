@@ -547,6 +547,192 @@ def predict_noisy(X, Psi, model: Model, whichSet="best"):
     return mu + model.muY, sigma, nu, beta_i, gamma, PHI
 
 
+def _pm_finish(PHI, w, v, b, gamma, VlnS, nu):
+    """Tail shared by predictMissing / predictNoisyMissing (predictDiag.m:198-209, predictCov.m:216-229)."""
+    mu = PHI @ w
+    ElnS = PHI @ v
+    VlnS = VlnS - ElnS ** 2
+    ElnS = ElnS + b
+    beta_i = np.exp(ElnS) * (1.0 + 0.5 * VlnS)
+    gamma = gamma - mu ** 2
+    return mu, nu, beta_i, gamma, PHI
+
+
+def _predict_missing_diag(X, Psi, Gamma, w, v, b, P, iSigma_w, priors):
+    """predictMissing (Psi is None, predictDiag.m:127-209) and predictNoisyMissing (predictDiag.m:211-297) for one
+    group of rows sharing the NaN pattern of X[0].  Psi: n x d or None."""
+    o = ~np.isnan(X[0]); u = ~o
+    n = X.shape[0]; m, k = w.shape
+    iSigma = Gamma ** 2.0; Sigma = Gamma ** -2.0
+    lnz = -0.5 * np.sum(np.log(iSigma), axis=1)                 # :138 / :222 (0.5*sum(log(Sigma)) is the same number)
+    No = np.zeros((n, m)); Ex = np.zeros((n, m))
+    for i in range(m):                                           # :142-148 / :226-233
+        Delta = X[:, o] - P[i, o]
+        if Psi is None:
+            No[:, i] = np.exp(-0.5 * np.sum(Delta ** 2 / Sigma[i, o], axis=1) - 0.5 * np.sum(np.log(Sigma[i, o])))
+        else:
+            SpP = Psi[:, o] + Sigma[i, o]
+            No[:, i] = np.exp(-0.5 * np.sum(Delta ** 2 / SpP, axis=1) - 0.5 * np.sum(np.log(SpP), axis=1))
+        Ex[:, i] = No[:, i] * priors[i]
+    Pio = Ex / Ex.sum(axis=1, keepdims=True)                     # :150-152
+    # Nij(i,j) over the missing dimensions (:158); PHI(:,i) = No(:,i) * sum_j Pio(:,j) Nij(i,j), times exp(lnz) (:160-161)
+    dP = P[:, None, u] - P[None, :, u]
+    SS = Sigma[:, None, u] + Sigma[None, :, u]
+    Nij = np.exp(-0.5 * np.sum(dP ** 2 / SS, axis=2) - 0.5 * np.sum(np.log(SS), axis=2))
+    PHI = No * (Pio @ Nij.T) * np.exp(lnz)[None, :]
+    gamma = np.zeros((n, k)); nu = np.zeros((n, k)); VlnS = np.zeros((n, k))
+    for i in range(m):                                           # :170-195 / :254-283
+        for j in range(i + 1):
+            Cij = 1.0 / (iSigma[i] + iSigma[j])
+            cij = (P[i] * iSigma[i] + P[j] * iSigma[j]) * Cij
+            Delta = X[:, o] - cij[o]
+            if Psi is None:
+                Nobs = np.exp(-0.5 * np.sum(Delta ** 2 / Cij[o], axis=1) - 0.5 * np.sum(np.log(Cij[o])))
+            else:
+                CpP = Psi[:, o] + Cij[o]
+                Nobs = np.exp(-0.5 * np.sum(Delta ** 2 / CpP, axis=1) - 0.5 * np.sum(np.log(CpP), axis=1))
+            Dl = P[:, u] - cij[u]
+            CpS = Sigma[:, u] + Cij[u]
+            Nu = np.exp(-0.5 * np.sum(Dl ** 2 / CpS, axis=1) - 0.5 * np.sum(np.log(CpS), axis=1))
+            EcCij = Nobs * (Pio @ Nu)                            # sum(N.*Pio,2), N = No*Nu'
+            Dl = P[i] - P[j]
+            Z = (math.exp(lnz[i] + lnz[j] - 0.5 * np.sum(Dl ** 2 / (Sigma[i] + Sigma[j]))
+                          - 0.5 * np.sum(np.log(Sigma[i] + Sigma[j]))) * EcCij)[:, None]
+            c2 = 2.0 if j < i else 1.0                           # 2x in the loop, minus 1x for the (i,i) term after it
+            gamma = gamma + c2 * Z * (w[i] * w[j])
+            VlnS = VlnS + c2 * Z * (v[i] * v[j])
+            nu = nu + c2 * Z * iSigma_w[i, j, :]
+    return _pm_finish(PHI, w, v, b, gamma, VlnS, nu)
+
+
+def _predict_missing_cov(X, Psi, Gamma, w, v, b, P, iSigma_w, priors):
+    """predictMissing (Psi is None, predictCov.m:134-229) and predictNoisyMissing (predictCov.m:231-337) for one
+    group of rows sharing the NaN pattern of X[0].  Psi: d x d x n or None.  Kept quirk: in predictNoisyMissing the
+    post-loop correction reads `PHI(id,j) = PHI(id,i)-NPio` with j == i (:316), the same as predictMissing's :205."""
+    o = ~np.isnan(X[0]); u = ~o
+    oi = np.flatnonzero(o); ui = np.flatnonzero(u)
+    n, d = X.shape; m, k = w.shape
+    iSigma = np.zeros((d, d, m)); Sigma = np.zeros((d, d, m)); lnz = np.zeros(m)
+    R = []
+    for i in range(m):
+        iSigma[:, :, i] = Gamma[:, :, i].T @ Gamma[:, :, i]
+        Sigma[:, :, i] = np.linalg.inv(iSigma[:, :, i])
+        lnz[i] = -0.5 * _sum_log_svd(iSigma[:, :, i])
+        Soo = Sigma[np.ix_(oi, oi, [i])][:, :, 0]
+        R.append(np.linalg.solve(Soo, Sigma[np.ix_(oi, ui, [i])][:, :, 0]))       # Sigma(o,o)\Sigma(o,~o)
+    PHI = np.zeros((n, m)); gamma = np.zeros((n, k)); nu = np.zeros((n, k)); VlnS = np.zeros((n, k))
+    Ex = np.zeros((n, m))
+    X_hat = np.zeros((n, d, m))
+    Psi_hat = np.zeros((d, d, m, n if Psi is not None else 1))
+    for i in range(m):
+        Soo = Sigma[np.ix_(oi, oi, [i])][:, :, 0]
+        Delta = X[:, oi] - P[i, oi]
+        cond_u = Sigma[np.ix_(ui, ui, [i])][:, :, 0] - Sigma[np.ix_(ui, oi, [i])][:, :, 0] @ R[i]
+        if Psi is None:
+            Ex[:, i] = np.exp(-0.5 * np.sum(_mrdivide(Delta, Soo) * Delta, axis=1) - 0.5 * _sum_log_svd(Soo)) * priors[i]
+            Psi_hat[np.ix_(ui, ui, [i], [0])] = cond_u[:, :, None, None]
+        else:
+            T = np.vstack([np.eye(oi.size), R[i].T])             # [eye(do); R']
+            # [~,unshuffle] = sort([find(o) find(~o)]); Psi_hat(unshuffle,unshuffle,i,id) = T*Psi(o,o,id)*T'   (:266-268)
+            # As an ASSIGNMENT target this scatters block row a (dimension perm[a]) to row unshuffle[a], which is the
+            # intended row perm[a] only when the permutation is its own inverse; kept as written.
+            unshuffle = np.argsort(np.concatenate([oi, ui]), kind="stable")
+            for r in range(n):
+                Moo = Soo + Psi[np.ix_(oi, oi, [r])][:, :, 0]
+                Dr = Delta[r][None, :]
+                Ex[r, i] = math.exp(-0.5 * float((_mrdivide(Dr, Moo) @ Dr.T)[0, 0]) - 0.5 * _sum_log_svd(Moo)) * priors[i]
+                blk = T @ Psi[np.ix_(oi, oi, [r])][:, :, 0] @ T.T
+                full = np.zeros((d, d))
+                full[np.ix_(unshuffle, unshuffle)] = blk
+                full[np.ix_(ui, ui)] += cond_u
+                Psi_hat[:, :, i, r] = full
+        X_hat[:, ui, i] = Delta @ R[i] + P[i, ui]
+        X_hat[:, oi, i] = X[:, oi]
+    Pio = Ex / Ex.sum(axis=1, keepdims=True)
+
+    def dens(Dl, S):                                             # exp(-1/2 sum((D/S).*D,2) - 1/2 sum(log(svd(S))))
+        return np.exp(-0.5 * np.sum(_mrdivide(Dl, S) * Dl, axis=1) - 0.5 * _sum_log_svd(S))
+
+    for r in range(n if Psi is not None else 1):
+        rows = slice(r, r + 1) if Psi is not None else slice(0, n)
+        pr = r if Psi is not None else 0
+        for i in range(m):
+            NPio = None; Z = None
+            for j in range(i + 1):
+                iCij = iSigma[:, :, i] + iSigma[:, :, j]
+                Cij = np.linalg.inv(iCij)
+                cij = _mrdivide((P[i] @ iSigma[:, :, i] + P[j] @ iSigma[:, :, j])[None, :], iCij)[0]
+                N = dens(X_hat[rows, :, j] - P[i], Sigma[:, :, i] + Psi_hat[:, :, j, pr])
+                NPio = N * Pio[rows, j]
+                PHI[rows, i] += NPio
+                N = dens(X_hat[rows, :, i] - P[j], Sigma[:, :, j] + Psi_hat[:, :, i, pr])
+                NPio = N * Pio[rows, i]
+                PHI[rows, j] += NPio
+                EcCij = 0.0
+                for l in range(m):
+                    N = dens(X_hat[rows, :, l] - cij, Cij + Psi_hat[:, :, l, pr])
+                    EcCij = EcCij + N * Pio[rows, l]
+                Dl = (P[i] - P[j])[None, :]
+                Sij = Sigma[:, :, i] + Sigma[:, :, j]
+                Z = (math.exp(lnz[i] + lnz[j] - 0.5 * float((_mrdivide(Dl, Sij) @ Dl.T)[0, 0]) - 0.5 * _sum_log_svd(Sij))
+                     * EcCij)[:, None]
+                c2 = 2.0 if j < i else 1.0
+                gamma[rows] += c2 * Z * (w[i] * w[j])
+                VlnS[rows] += c2 * Z * (v[i] * v[j])
+                nu[rows] += c2 * Z * iSigma_w[i, j, :]
+            PHI[rows, i] -= NPio                                 # the (i,i) term was added twice (:205 / :316)
+    PHI = PHI * np.exp(lnz)[None, :]
+    return _pm_finish(PHI, w, v, b, gamma, VlnS, nu)
+
+
+def predict_any(X, model: Model, Psi=None, whichSet="best", selection=None):
+    """[mu,sigma,nu,beta_i,gamma,PHI] = predict(X,model,'Psi',Psi,...) with every branch of predict.m:45-69:
+    rows are grouped by NaN pattern; a group without missing values goes to predictFull / predictNoisy, a group
+    with missing values to predictMissing / predictNoisyMissing (predictDiag.m:39-55, predictCov.m:34-50)."""
+    X = np.asarray(X, dtype=np.float64)
+    if selection is not None:
+        sel = np.asarray(selection, dtype=bool)
+        X = X[sel]
+        if Psi is not None:
+            Psi = np.asarray(Psi)
+            Psi = Psi[:, :, sel] if (model.method[1] == "C" and Psi.ndim == 3) else Psi[sel]
+    n, d = X.shape
+    st = model.sets[whichSet]
+    Xn = (X - model.muX) / model.sdX
+    PsiN = fixPsi(Psi, n, model.sdX, model.method)
+    theta, w, iSigma_w = st["theta"], st["w"], st["iSigma_w"]
+    m, k = model.m, model.k
+    P, G, lnAlpha, b, v, lnTau = unpack_theta(theta, model)
+    if v is None:
+        v = np.zeros((m, k))
+    Gamma = expand_gamma(G, model)
+    priors = np.asarray(st.get("priors", np.ones(m) / m), dtype=np.float64).ravel()
+    cov = model.method[1] == "C"
+    mu = np.zeros((n, k)); nu = np.zeros((n, k)); beta_i = np.zeros((n, k)); gamma = np.zeros((n, k)); PHI = np.zeros((n, m))
+    gid, pats = nan_groups(Xn)
+    G_ = len(pats)
+    sub = Model(m=m, d=d, k=k, method=model.method, heteroscedastic=model.heteroscedastic)
+    sub.sets = model.sets
+    for g in range(G_):
+        idx = np.flatnonzero(gid == g)
+        Xg = Xn[idx]
+        Pg = None if PsiN is None else (PsiN[:, :, idx] if cov else PsiN[idx])
+        if not np.isnan(Xg[0]).any():
+            if Pg is None:
+                out = predict(Xg, sub, whichSet)
+                res = (out[0], out[2], out[3], out[4], out[5])
+            else:
+                out = predict_noisy(Xg, Pg, sub, whichSet)
+                res = (out[0], out[2], out[3], out[4], out[5])
+        else:
+            fn = _predict_missing_cov if cov else _predict_missing_diag
+            res = fn(Xg, Pg, Gamma, w, v, b, P, iSigma_w, priors)
+        for dst, src in zip((mu, nu, beta_i, gamma, PHI), res):
+            dst[idx] = src
+    sigma = nu + beta_i + gamma
+    return mu + model.muY, sigma, nu, beta_i, gamma, PHI
+
+
 def getPrior(X, Psi, theta, model: Model, selection=None):
     """prior = getPrior(X,Sx,theta,model,set)   (getPrior.m:1-22): EM-style fixed point on the mixture weights of
     the normalised basis densities N (N is loop-invariant; the reference recomputes it every iteration)."""

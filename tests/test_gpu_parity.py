@@ -513,6 +513,56 @@ def test_predict_with_input_noise(method, d, k):
     assert rel(tiny[0], full[0]) < 1e-9 and rel(tiny[1], full[1]) < 1e-9 and np.abs(tiny[4]).max() < 1e-9
 
 
+def _trained_like_model(method, d, m, k, seed):
+    model, theta, X, Y, _, rng = make_problem(300, d, m, k, method, True, seed=seed)
+    model.muX = rng.standard_normal(d) * 0.1; model.sdX = 1.0 + rng.random(d); model.muY = rng.standard_normal(k)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = rng.random(m) + 0.2
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri / pri.sum()}
+    return model, rng
+
+
+@pytest.mark.parametrize("method,d,m,k", [("VD", 4, 9, 2), ("GL", 3, 20, 1), ("VL", 5, 33, 1), ("GD", 2, 6, 1)])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_predict_with_missing_values_diag_kinds(method, d, m, k, noisy):
+    """predict.m with NaN inputs: predictMissing / predictNoisyMissing (predictDiag.m:127-297) per NaN-pattern group,
+    mixed with complete rows (predictFull / predictNoisy), against the oracle."""
+    model, rng = _trained_like_model(method, d, m, k, seed=61 + d)
+    ns = 83
+    Xs = rng.standard_normal((ns, d))
+    miss = rng.random((ns, d)) < 0.3
+    miss[miss.all(axis=1), 0] = False                   # keep one observed dimension per row
+    Xs[miss] = np.nan
+    Psi = rng.gamma(1.0, 0.1, (ns, d)) if noisy else None
+    ref = O.predict_any(Xs, model, Psi=Psi)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= 1e-9, name
+    if noisy:                                           # Psi -> 0 is predictMissing
+        tiny = gpz_amd.predict(Xs, model, Psi=np.full((ns, d), 1e-14))
+        plain = gpz_amd.predict(Xs, model)
+        assert rel(tiny[0], plain[0]) < 1e-9 and rel(tiny[1], plain[1]) < 1e-9
+
+
+def test_predict_missing_many_bases():
+    """m = 150 (11 325 pairs, 71 pair chunks through the T-GEMM) against the oracle."""
+    model, rng = _trained_like_model("VD", 3, 150, 1, seed=70)
+    Xs = rng.standard_normal((40, 3))
+    Xs[:25, 2] = np.nan; Xs[25:, 0] = np.nan
+    ref = O.predict_any(Xs, model)
+    out = gpz_amd.predict(Xs, model)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= 1e-9, name
+
+
+def test_predict_missing_cov_kinds_refuse():
+    model, rng = _trained_like_model("VC", 3, 5, 1, seed=71)
+    Xs = rng.standard_normal((6, 3)); Xs[2, 1] = np.nan
+    with pytest.raises(_lib.GpzError) as ei:
+        gpz_amd.predict(Xs, model)
+    assert ei.value.code == -5
+
+
 @pytest.mark.parametrize("method,psi,nanfrac", [("VD", False, 0.0), ("VC", False, 0.0), ("VD", True, 0.3), ("GC", True, 0.0),
                                                 ("VC", False, 0.3)])
 def test_get_prior(method, psi, nanfrac):

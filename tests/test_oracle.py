@@ -197,3 +197,75 @@ def test_get_prior_is_a_distribution():
     model, theta, X, Y, _, rng = make_problem(80, 2, 6, 1, "VD", True, seed=8)
     pr = O.getPrior(X, None, theta, model)
     assert abs(pr.sum() - 1.0) < 1e-12 and (pr >= 0).all()
+
+
+# ---- predict.m with missing values: predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337) ----
+def _pm_models(d, m, k, seed):
+    """A VD model and the VC model with Gamma_j = diag(gamma_j): the same predictor through two different code paths."""
+    model, theta, X, Y, _, rng = make_problem(60, d, m, k, "VD", True, seed=seed)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = rng.random(m); pri /= pri.sum()
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
+    mc = O.Model(m=m, d=d, k=k, method="VC", heteroscedastic=True)
+    P, G, lnA, b, v, lnT = O.unpack_theta(theta, model)
+    Gd = O.expand_gamma(G, model)
+    Gc = np.zeros((d, d, m))
+    for j in range(m):
+        Gc[:, :, j] = np.diag(Gd[j])
+    thc = np.concatenate([P.ravel(order="F"), Gc.ravel(order="F"), theta[m * d + m * d:]])
+    mc.sets["best"] = dict(model.sets["best"], theta=thc)
+    return model, mc, rng
+
+
+def test_predict_missing_diag_and_cov_restatements_agree():
+    """predictDiag.m and predictCov.m are separate code (GEMM-style sums vs per-pair d x d solves, X_hat / Psi_hat
+    conditioning); on a diagonal covariance they must give the same predictor.  Patterns whose [o u] ordering is
+    an involution only: for the others predictCov.m:268's scatter through `unshuffle` differs (next test)."""
+    d, m, k, n = 3, 4, 2, 9
+    model, mc, rng = _pm_models(d, m, k, 5)
+    Xs = rng.standard_normal((n, d))
+    pats = [[2], [1], [], [1, 2]]
+    for r in range(n):
+        Xs[r, pats[r % len(pats)]] = np.nan
+    a = O.predict_any(Xs, model); c = O.predict_any(Xs, mc)
+    for x, y in zip(a, c):
+        assert rel(x, y) < 1e-12
+    Psi = rng.gamma(1.0, 0.1, (n, d))
+    a = O.predict_any(Xs, model, Psi=Psi); c = O.predict_any(Xs, mc, Psi=Psi)
+    for x, y in zip(a, c):
+        assert rel(x, y) < 1e-12
+    z = O.predict_any(Xs, model, Psi=np.full((n, d), 1e-13))       # Psi -> 0: predictNoisyMissing -> predictMissing
+    p0 = O.predict_any(Xs, model)
+    for x, y in zip(z, p0):
+        assert rel(x, y) < 1e-10
+
+
+def test_predict_noisy_missing_cov_unshuffle_quirk_is_kept():
+    """predictCov.m:266-268 assigns T*Psi_oo*T' through `unshuffle` (the inverse of [find(o) find(~o)]); as an
+    assignment target that is the intended placement only when the permutation is its own inverse.  With the first
+    dimension missing (perm = [2 3 1]) the cov path therefore differs from the diag path; without Psi it does not."""
+    d, m, k, n = 3, 4, 1, 4
+    model, mc, rng = _pm_models(d, m, k, 6)
+    Xs = rng.standard_normal((n, d)); Xs[:, 0] = np.nan
+    a = O.predict_any(Xs, model); c = O.predict_any(Xs, mc)
+    assert rel(a[1], c[1]) < 1e-12
+    Psi = rng.gamma(1.0, 0.1, (n, d))
+    a = O.predict_any(Xs, model, Psi=Psi); c = O.predict_any(Xs, mc, Psi=Psi)
+    assert rel(a[1], c[1]) > 1e-5
+
+
+def test_predict_missing_marginalises_a_single_basis_exactly():
+    """m = 1: the conditional mixture is the basis function itself, so PHI for a row with missing dimensions is the
+    basis function of the observed dimensions times sqrt|Sigma_uu|-style constants — hand-computed."""
+    d, m = 2, 1
+    model = O.Model(m=m, d=d, k=1, method="VD", heteroscedastic=False)
+    P = np.array([[0.3, -0.2]]); G = np.array([[1.5, 0.7]])
+    theta = np.concatenate([P.ravel(), G.ravel(), [0.1], [-0.4]])
+    model.sets["best"] = {"theta": theta, "w": np.array([[0.8]]), "iSigma_w": np.array([[[0.05]]]), "priors": np.ones(1)}
+    x0 = 0.9
+    out = O.predict_any(np.array([[x0, np.nan]]), model)
+    sig = G[0] ** -2.0
+    No = math.exp(-0.5 * (x0 - P[0, 0]) ** 2 / sig[0] - 0.5 * math.log(sig[0]))
+    Nij = math.exp(-0.5 * math.log(2 * sig[1]))
+    phi = No * 1.0 * Nij * math.exp(-0.5 * np.sum(np.log(G[0] ** 2)))
+    assert abs(out[5][0, 0] - phi) < 1e-15 and abs(out[0][0, 0] - 0.8 * phi) < 1e-15

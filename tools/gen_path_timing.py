@@ -5,7 +5,9 @@ import numpy as np
 import gpz_amd
 import bench
 
-n, d, m = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, 10, 200
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 cfg = dict(n=n, d=d, m=m, method="VC", omega=None)
 model, theta, X, y, _ = bench.synth(cfg)
 rng = np.random.default_rng(5)
@@ -16,7 +18,7 @@ for name, kw in (("plain", {}), ("psi", {"Psi": Psi})):
     ctx = gpz_amd.GPzContext(model, X, y, **kw)
     ctx.eval(theta)
     ctx.enable_timing(True); ctx.reset_timings()
-    t0 = time.perf_counter(); K = 3
+    t0 = time.perf_counter(); K = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     for _ in range(K):
         f, g = ctx.eval(theta)
     dt = (time.perf_counter() - t0) / K
