@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpz_hip.so")
+LIB_PATH = os.environ.get("GPZ_HIP_LIB") or os.path.join(_HERE, "lib", "libgpz_hip.so")   # override: kernel experiments
 
 c_double_p = C.POINTER(C.c_double)
 c_uint8_p = C.POINTER(C.c_uint8)
@@ -27,7 +27,8 @@ class gpz_desc(C.Structure):
         ("stream", C.c_void_p),
         ("rank", C.c_int32),
         ("world", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("dtype", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -53,8 +53,11 @@ class Model:
             self.muY = np.zeros(self.k)
 
 
-def _desc(model, device=0, stream=None, rank=0, world=1):
+def _desc(model, device=0, stream=None, rank=0, world=1, dtype="f64"):
     ds = _lib.gpz_desc()
+    if dtype not in ("f64", "f32"):
+        raise ValueError("dtype must be 'f64' or 'f32'")
+    ds.dtype = 1 if dtype == "f32" else 0
     ds.d, ds.m, ds.k = int(model.d), int(model.m), int(model.k)
     ds.method = str(model.method).encode()
     ds.heteroscedastic = 1 if model.heteroscedastic else 0
@@ -91,7 +94,7 @@ class GPzContext:
     building the closure."""
 
     def __init__(self, model, X, Y, Psi=None, omega=None, training=None, validation=None, device=0, stream=None,
-                 rank=0, world=1, allreduce=None):
+                 rank=0, world=1, allreduce=None, dtype="f64"):
         lib = _lib.load()
         X = _f64(X, 2)
         Y = _f64(Y, 2)
@@ -110,7 +113,7 @@ class GPzContext:
         self._tr = _mask(training, n_tot)
         self._va = _mask(validation, n_tot)
         self.model = model
-        self._desc = _desc(model, device, stream, rank, world)
+        self._desc = _desc(model, device, stream, rank, world, dtype)
         h = C.c_void_p()
         _lib.check(lib.gpz_ctx_create(
             C.byref(self._desc), n_tot, _lib.dptr(X), _lib.dptr(Y), _lib.dptr(psi), psi_kind, _lib.dptr(om),

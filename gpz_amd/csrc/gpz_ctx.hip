@@ -100,6 +100,8 @@ struct RowSet {          // a device-resident row selection of the data
     // covariance kinds, general path (Psi cube and/or missing dimensions)
     int *gid = nullptr, *rows_by_group = nullptr;
     double *Psi3 = nullptr;                    // n_pad x d*d
+    float *PsiT = nullptr;                     // dtype f32: packed lower triangles, element-major [e][n_pad] (k_psi32.hip)
+    int psi_diag = 0;                          // every Psi_i of this row set is diagonal: PsiT holds only the diagonals
     std::vector<int> group_begin;              // offsets into rows_by_group (size G+1)
 };
 
@@ -181,10 +183,11 @@ struct gpz_ctx {
     // general covariance-kind path
     bool gen = false;
     bool psi_fast = false;   // gen && Psi && no missing dims && d <= 10: register-resident kernels (k_psi.hip)
+    bool psi32 = false;      // dtype f32 && gen && Psi && no missing dims: fp32 register-resident kernels (k_psi32.hip)
     int ngroups = 0, nrec = 0;
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
     unsigned char *pat_d = nullptr;
-    double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr;
+    double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
     int gen_nchunk = 1;
 };
 
@@ -293,6 +296,28 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
                 memcpy(&hp[r * d * d], Psi + (size_t)idx[r] * d * d, (size_t)d * d * sizeof(double));
             if (int e = c->ar.alloc(&rs.Psi3, np * d * d)) return e;
             HIPCHK(hipMemcpy(rs.Psi3, hp.data(), np * d * d * sizeof(double), hipMemcpyHostToDevice));
+            if (c->psi32) {
+                const int D = psi32_pad_dim(d);
+                bool diag = true;
+                for (size_t r = 0; r < idx.size() && diag; ++r)
+                    for (int a = 0; a < d && diag; ++a)
+                        for (int b = 0; b < d; ++b)
+                            if (a != b && hp[r * d * d + a + (size_t)d * b] != 0.0) { diag = false; break; }
+                rs.psi_diag = diag ? 1 : 0;
+                const size_t ne = diag ? (size_t)D : (size_t)D * (D + 1) / 2;
+                std::vector<float> ht(ne * np, 0.0f);
+                for (size_t r = 0; r < idx.size(); ++r) {
+                    if (diag) {
+                        for (int a = 0; a < d; ++a) ht[(size_t)a * np + r] = (float)hp[r * d * d + a + (size_t)d * a];
+                    } else {
+                        for (int a = 0; a < d; ++a)
+                            for (int b = 0; b <= a; ++b)   // lower triangle of the symmetric Psi(:,:,i): element (a, b)
+                                ht[((size_t)a * (a + 1) / 2 + b) * np + r] = (float)hp[r * d * d + a + (size_t)d * b];
+                    }
+                }
+                if (int e = c->ar.alloc(&rs.PsiT, ne * np)) return e;
+                HIPCHK(hipMemcpy(rs.PsiT, ht.data(), ne * np * sizeof(float), hipMemcpyHostToDevice));
+            }
         }
     }
     if (Psi && !c->gen) {   // n_tot x d (fixPsi.m:42-53); entries of missing dimensions are never read by the reference
@@ -402,7 +427,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
         if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
+        c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan;
     }
+    if (desc->dtype != GPZ_F64 && desc->dtype != GPZ_F32) return fail(GPZ_ERR_ARG, "dtype must be GPZ_F64 or GPZ_F32");
     if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1)
         return fail(GPZ_ERR_ARG, "diagonal kinds take Psi as n x d (fixPsi.m:42-53)");
     c->has_psi = Psi != nullptr;
@@ -423,7 +450,7 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     }
     if (c->gen) {
         c->ngroups = (int)c->pats.size();
-        c->psi_fast = c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
+        c->psi_fast = !c->psi32 && c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
@@ -455,7 +482,9 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
     if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation))) return bail(rc);
     if (c->gen) {
         c->gen_nchunk = 256;
-        if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * c->nrec))) return bail(rc);
+        const size_t per = (c->psi32 && psi32_raw_len(c->d) > c->nrec) ? (size_t)psi32_raw_len(c->d) : (size_t)c->nrec;
+        if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * per))) return bail(rc);
+        if (c->psi32 && (rc = c->ar.alloc(&c->psi32_raw, (size_t)c->m * psi32_raw_len(c->d)))) return bail(rc);
         if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
     }
     if ((rc = alloc_mm(c))) return bail(rc);
@@ -589,6 +618,14 @@ static GenRows gen_rows(const RowSet &rs) {
     return r;
 }
 
+// row chunks of the fp32 moment kernel: whole 64-row wave blocks, at most gen_nchunk chunks
+static void psi32_chunks(const gpz_ctx *c, int *nch, int *rpc) {
+    int r = (c->tr.n + c->gen_nchunk - 1) / c->gen_nchunk;
+    r = rup(r > 0 ? r : 1, 64);
+    *rpc = r;
+    *nch = c->tr.n > 0 ? (c->tr.n + r - 1) / r : 1;
+}
+
 static int allreduce(gpz_ctx *c, double *buf, size_t count) {
     if (c->desc.world <= 1) return 0;
     if (!c->ar_fn) return fail(GPZ_ERR_COMM, "world=%d but no all-reduce hook set (gpz_ctx_set_allreduce)", c->desc.world);
@@ -601,7 +638,11 @@ static int build_phi(gpz_ctx *c) {
     if (c->gen) {
         Stage s(c, "phi_build");
         launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
-        if (c->psi_fast) {
+        if (c->psi32) {
+            launch_psi32_phi(c->st, c->tr.Xr, c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m,
+                             c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi, c->mp);
+            launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
+        } else if (c->psi_fast) {
             launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else {
@@ -740,6 +781,16 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");
+            if (c->gen && c->psi32) {
+                int nch, rpc;
+                psi32_chunks(c, &nch, &rpc);
+                launch_psi32_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, c->tr.Xr,
+                                     c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig,
+                                     c->pr.Rc, nch, rpc, c->gen_slab, c->nrec);
+                launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
+                launch_psi32_records(c->st, c->psi32_raw, c->d, c->de, c->tr.psi_diag, c->pr.Rc, c->m, mom, c->nrec);
+                continue;
+            }
             if (c->gen && c->psi_fast) {
                 int nch = c->gen_nchunk;
                 if (nch > c->tr.n) nch = c->tr.n;
@@ -795,7 +846,15 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
         }
         Stage s(c, "moments");
-        if (c->gen && c->psi_fast) {
+        if (c->gen && c->psi32) {
+            int nch, rpc;
+            psi32_chunks(c, &nch, &rpc);
+            launch_psi32_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, c->tr.Xr, c->de, c->d, c->tr.PsiT,
+                                 (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig, c->pr.Rc, nch, rpc,
+                                 c->gen_slab, c->nrec);
+            launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
+            launch_psi32_records(c->st, c->psi32_raw, c->d, c->de, c->tr.psi_diag, c->pr.Rc, c->m, mom, c->nrec);
+        } else if (c->gen && c->psi_fast) {
             int nch = c->gen_nchunk;
             if (nch > c->tr.n) nch = c->tr.n;
             const int rpc = (c->tr.n + nch - 1) / nch;
@@ -830,7 +889,11 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
     const bool have_valid = c->va.n_pad > 0;
     if (have_valid && c->gen) {
         Stage s(c, "validation");
-        if (c->psi_fast) {
+        if (c->psi32) {
+            launch_psi32_phi(c->st, c->va.Xr, c->de, c->d, c->va.PsiT, (long)c->va.n_pad, c->va.psi_diag, c->va.n, c->m,
+                             c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi_v, c->mp);
+            launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
+        } else if (c->psi_fast) {
             launch_psi_phi(c->st, gen_rows(c->va), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi_v, c->mp);
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else {

@@ -193,6 +193,19 @@ int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                        int nchunk, int rows_per_chunk, double *slab, int nrec);
+// fp32 per-pair kernels for Psi without missing dimensions, d <= 20 (k_psi32.hip).  PsiT: packed lower triangles of
+// Psi_i, element-major [e][ldp] (diag != 0: only the D diagonals), D = psi32_pad_dim(d).
+int psi32_pad_dim(int d);
+int psi32_raw_len(int d);   // doubles per (chunk, basis) the moment kernel writes: 3 + D + D(D+1)/2
+// chunk-summed raw sums [m][psi32_raw_len] -> records [m][nrec] in the layout of k_gen_moments (un-whitened when diag)
+void launch_psi32_records(hipStream_t st, const double *raw, int d, int de, int diag, const double *Rc, int m, double *recs,
+                          int nrec);
+int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
+                     const double *P, const double *Sig, const double *Rc, const double *lnS, double *Phi, int ld);
+int launch_psi32_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                         const double *v, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
+                         const double *P, const double *Sig, const double *Rc, int nchunk, int rows_per_chunk, double *slab,
+                         int nrec);
 void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
                        const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
                        double *phiw);

@@ -385,69 +385,93 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
     for (int e = 0; e < NS; ++e) S[e] = 0.0;
     const int r0 = chunk * rows_per_chunk;
     const int rend = min(n, r0 + rows_per_chunk);
-    // register double buffering: the loads of the next UR rows are in flight while this batch is consumed
-    double ph[UR], tt[UR], phn[UR], ttn[UR];
-    auto rload = [&](int ib, double *a, double *b) {
+    // One row of work.  sc = the wave-uniform row data [omega*beta, c, dbeta | x_i (D)] (scalar registers).
+    auto consume = [&](int i, const double phu, const double ttu, const double (&sc)[3 + D]) {
+        const double ob = sc[0], cc = sc[1], db = sc[2];
+        const double dp = (-ob * ttu - cc * wj + db * vj) * phu;
+        if (A0 == 0) {
+            r1 = fma(phu, cc, r1);
+            r2 = fma(phu, db, r2);
+        }
+        if (KIND == GPZ_KIND_COV) {
+            double dl[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dl[c] = sc[3 + c] - p[c];
+            if (A0 == 0) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) M1[c] = fma(dp, dl[c], M1[c]);
+            }
+            int e = 0;
+#pragma unroll
+            for (int aa = A0; aa < A1; ++aa) {
+                const double t = dp * dl[aa];
+#pragma unroll
+                for (int bb = aa; bb < D; ++bb) { S[e] = fma(t, dl[bb], S[e]); ++e; }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double mk = Mr ? Mr[(size_t)i * D + c] : 1.0;
+                const double dl = (sc[3 + c] - p[c]) * mk;
+                if (PSI) {
+                    const double psi = Psir[(size_t)i * D + c];
+                    const double iu = 1.0 / fma(psi, g2[c], 1.0);
+                    const double dr = dl * iu;
+                    M1[c] = fma(dp * dl, g2[c] * iu, M1[c]);
+                    S[c] = fma(dp * dr, dr, S[c]);
+                    S3[c] = fma(dp, -psi * iu, S3[c]);
+                } else {
+                    const double t = dp * dl;
+                    M1[c] += t;
+                    S[c] = fma(t, dl, S[c]);
+                }
+            }
+        }
+    };
+    auto sload = [&](int i, double (&sc)[3 + D]) {     // scalar loads (uniform address)
+        const double *rs = rowscal + (size_t)i * 4;
+        sc[0] = rs[0]; sc[1] = rs[1]; sc[2] = rs[2];
+        const double *xi = Xr + (size_t)i * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sc[3 + c] = xi[c];
+    };
+    // Two register sets of UR rows each, the loop unrolled over both so that no set is ever copied: while set A is
+    // consumed the loads of set B are in flight and vice versa (a copy would make the compiler wait for the loads
+    // it copies).  The uniform data of row i+1 is fetched while row i is worked on.  No branches in the main loop.
+    double phA[UR], ttA[UR], phB[UR], ttB[UR];
+    const int last = max(rend - 1, 0);
+    auto vload = [&](int i0, double (&a)[UR], double (&b)[UR]) {
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-            const int i = min(ib + u, rend - 1);
+            const int i = min(i0 + u, last);
             a[u] = Phi[(size_t)i * ld + jc];
             b[u] = T[(size_t)i * ld + jc];
         }
     };
-    if (r0 < rend) rload(r0, ph, tt);
-    for (int ib = r0; ib < rend; ib += UR) {
-        if (ib + UR < rend) rload(ib + UR, phn, ttn);
+    double sc[3 + D], scn[3 + D];
+    auto batch = [&](int i0, const double (&a)[UR], const double (&b)[UR]) {
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-            const int i = ib + u;
-            if (i < rend) {
-                const double *rs = rowscal + (size_t)i * 4;
-                const double ob = rs[0], cc = rs[1], db = rs[2];
-                const double dp = (-ob * tt[u] - cc * wj + db * vj) * ph[u];
-                if (A0 == 0) {
-                    r1 = fma(ph[u], cc, r1);
-                    r2 = fma(ph[u], db, r2);
-                }
-                const double *xi = Xr + (size_t)i * D;
-                if (KIND == GPZ_KIND_COV) {
-                    double dl[D];
+            sload(min(i0 + u + 1, last), scn);
+            consume(i0 + u, a[u], b[u], sc);
 #pragma unroll
-                    for (int c = 0; c < D; ++c) dl[c] = xi[c] - p[c];
-                    if (A0 == 0) {
-#pragma unroll
-                        for (int c = 0; c < D; ++c) M1[c] = fma(dp, dl[c], M1[c]);
-                    }
-                    int e = 0;
-#pragma unroll
-                    for (int aa = A0; aa < A1; ++aa) {
-                        const double t = dp * dl[aa];
-#pragma unroll
-                        for (int bb = aa; bb < D; ++bb) { S[e] = fma(t, dl[bb], S[e]); ++e; }
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        const double mk = Mr ? Mr[(size_t)i * D + c] : 1.0;
-                        const double dl = (xi[c] - p[c]) * mk;
-                        if (PSI) {
-                            const double psi = Psir[(size_t)i * D + c];
-                            const double iu = 1.0 / fma(psi, g2[c], 1.0);
-                            const double dr = dl * iu;
-                            M1[c] = fma(dp * dl, g2[c] * iu, M1[c]);
-                            S[c] = fma(dp * dr, dr, S[c]);
-                            S3[c] = fma(dp, -psi * iu, S3[c]);
-                        } else {
-                            const double t = dp * dl;
-                            M1[c] += t;
-                            S[c] = fma(t, dl, S[c]);
-                        }
-                    }
-                }
-            }
+            for (int c = 0; c < 3 + D; ++c) sc[c] = scn[c];
         }
-#pragma unroll
-        for (int u = 0; u < UR; ++u) { ph[u] = phn[u]; tt[u] = ttn[u]; }
+    };
+    vload(r0, phA, ttA);
+    sload(min(r0, last), sc);
+    int ib = r0;
+    for (; ib + 2 * UR <= rend; ib += 2 * UR) {
+        vload(ib + UR, phB, ttB);
+        batch(ib, phA, ttA);
+        vload(ib + 2 * UR, phA, ttA);
+        batch(ib + UR, phB, ttB);
+    }
+    // remainder (< 2 UR rows): set A holds rows ib .. ib+UR-1
+#pragma unroll 1
+    for (int i = ib; i < rend; ++i) {
+        sload(i, sc);
+        consume(i, Phi[(size_t)i * ld + jc], T[(size_t)i * ld + jc], sc);
     }
     if (act) {
         double *o = slab + ((size_t)chunk * m + j) * (nm + 2);
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
 }
 
 #ifndef GPZ_MOM_UR
-#define GPZ_MOM_UR 4    // rows in flight per thread (16 rows at one wave per SIMD measured 2.2x slower)
+#define GPZ_MOM_UR 4    // rows per register set (two sets; 6 or 8 drop the kernel to one wave per SIMD: 8.1 ms vs 4.8 ms at c4)
 #endif
 #define MOMF_(KIND, D, A0, A1, PS) \
     hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, GPZ_MOM_UR, PS>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, \

@@ -65,8 +65,13 @@ typedef struct gpz_desc {
     void   *stream;           /* hipStream_t to run on; NULL = null stream */
     int32_t rank;             /* this shard's rank (0 when unsharded) */
     int32_t world;            /* number of row shards (1 when unsharded) */
-    int32_t reserved[4];
+    int32_t dtype;            /* GPZ_F64 (0, default) or GPZ_F32: precision flag of the path.  f32 selects
+                               * fp32 per-(sample, basis) factorisations for GC/VC with input noise (BASELINE config 5);
+                               * every other stage, theta, f and g stay fp64 */
+    int32_t reserved[3];
 } gpz_desc;
+#define GPZ_F64 0
+#define GPZ_F32 1
 
 /* In-place SUM all-reduce over ranks of `count` doubles at device pointer `buf`, ordered on
  * `stream`.  Return 0 on success.  The Python host wires this to torch.distributed (RCCL);

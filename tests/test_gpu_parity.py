@@ -584,3 +584,55 @@ def test_c5_math_path_fp64_small():
     tol = max(grad_tol(ref.cond), phi_tol(model, theta))
     assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
     assert rel(g, ref.grad) <= tol
+
+
+# ---- precision flag dtype = f32 (BASELINE config 5 "VC + input-noise (Psi), fp32 path") ----
+# fp32 is used for the per-(sample, basis) d x d factorisations only; tolerances are the fp32 ones of SURVEY 8(d):
+# 1e-4 on f, 1e-3 on g (relative to max|g|).
+F32_FTOL, F32_GTOL = 1e-4, 1e-3
+
+
+def _well_conditioned_gamma(model, theta, rng):
+    """make_problem perturbs Gamma_j = gamma_j*I by 0.05*N(0,1) per entry, which for d >= 10 is as large as gamma_j
+    itself: Sigma_j = inv(Gamma_j'Gamma_j) then has cond 1e4..1e6 and an fp32 factorisation of Sigma_j + Psi_i cannot
+    hold 1e-3 (cond * 6e-8).  The fp32 tests use a RELATIVE perturbation instead (cond(Sigma_j) ~ 2)."""
+    m, d = model.m, model.d
+    th = theta.copy()
+    g0 = m * d
+    nmat = m if model.method == "VC" else 1
+    G = th[g0:g0 + d * d * nmat].reshape((d, d, nmat), order="F")
+    for j in range(nmat):
+        gam = float(np.mean(np.diag(G[:, :, j])))
+        G[:, :, j] = gam * (np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d))
+    th[g0:g0 + d * d * nmat] = G.ravel(order="F")
+    return th
+
+
+@pytest.mark.parametrize("method", ["VC", "GC"])
+@pytest.mark.parametrize("shape,diag", [((300, 3, 8, 1), False), ((500, 7, 12, 2), False), ((400, 10, 10, 1), True),
+                                        ((350, 16, 9, 1), False), ((260, 20, 24, 1), False), ((500, 20, 17, 1), True)])
+def test_f32_pair_path_against_oracle(method, shape, diag):
+    n, d, m, k = shape
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=101 + d, psi=True)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    if diag:                                            # what fixPsi.m builds from per-dimension variances
+        Psi = np.zeros((d, d, n))
+        Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.2, (d, n))
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, None, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, None, tr, ~tr, dtype="f32")
+    f, g = ctx.eval(theta)
+    stats = dict(ctx.stats)
+    ctx.close()
+    assert abs(f - ref.nlogML) <= F32_FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= F32_GTOL
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-4 * max(1.0, abs(val)), key
+
+
+def test_f32_flag_leaves_the_other_paths_in_fp64():
+    """dtype = f32 only changes the per-pair kernels: without input noise the evaluation is the fp64 one, bit for bit."""
+    model, theta, X, Y, _, rng = make_problem(700, 5, 20, 1, "VC", True, seed=111)
+    a = gpz_amd.GPzContext(model, X, Y); fa, ga = a.eval(theta); a.close()
+    b = gpz_amd.GPzContext(model, X, Y, dtype="f32"); fb, gb = b.eval(theta); b.close()
+    assert fa == fb and np.array_equal(ga, gb)

@@ -14,7 +14,13 @@ rng = np.random.default_rng(5)
 Psi = np.zeros((d, d, n))
 diag = rng.gamma(1.0, 0.05, (n, d))
 Psi[np.arange(d), np.arange(d), :] = diag.T
-for name, kw in (("plain", {}), ("psi", {"Psi": Psi})):
+full = len(sys.argv) > 5 and sys.argv[5] == "full"
+if full:   # full (non-diagonal) cubes
+    B = 0.05 * rng.standard_normal((n, d, d))
+    Psi = Psi + np.einsum("nab,ncb->acn", B, B)
+runs = [("plain", {}), ("psi f64", {"Psi": Psi}), ("psi f32", {"Psi": Psi, "dtype": "f32"})]
+if d > 10 and n * m > 5e6: runs = [runs[0], runs[2]]     # the fp64 general kernels take seconds at this size
+for name, kw in runs:
     ctx = gpz_amd.GPzContext(model, X, y, **kw)
     ctx.eval(theta)
     ctx.enable_timing(True); ctx.reset_timings()
