@@ -12,6 +12,7 @@ Workloads (synthetic data per SURVEY.md §8d):
     c4  n=1e6 d=10 m=1000 VC heteroscedastic fp64   <- the configuration the metric's target is quoted on (default)
     c3  n=1e5 d=10 m=500  VC heteroscedastic + cost-sensitive omega
     c2  n=1e5 d=10 m=200  VD heteroscedastic
+    c5  n=2e6 d=20 m=2000 VC heteroscedastic + input noise Psi (diagonal cubes), dtype f32 (fp32 per-pair factorisations)
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -30,6 +31,7 @@ CONFIGS = {
     "c4": dict(n=1_000_000, d=10, m=1000, method="VC", omega=None),
     "c3": dict(n=100_000, d=10, m=500, method="VC", omega="normalized"),
     "c2": dict(n=100_000, d=10, m=200, method="VD", omega=None),
+    "c5": dict(n=2_000_000, d=20, m=2000, method="VC", omega=None, psi=True, dtype="f32"),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (datasheet f64 matrix = f64 vector rate)
 F64_MFMA_UBENCH_TFLOPS = 77.7  # tools/mfma_f64_bench.hip on this pool's MI355X: back-to-back v_mfma_f64_16x16x4_f64, >=3 waves/SIMD
@@ -78,6 +80,16 @@ def synth(cfg, n=None):
     return model, theta, X, y, omega
 
 
+def synth_psi(cfg, rows):
+    """Input noise of config 5: Gamma(1, 0.5) variances per dimension as diagonal d x d cubes, built
+    for the given row indices only (the full cube of n = 2e6 rows is 6.4 GB)."""
+    d = cfg["d"]
+    var = np.random.default_rng(4).gamma(1.0, 0.5, (cfg["n"], d))[rows]
+    Psi = np.zeros((d, d, var.shape[0]))
+    Psi[np.arange(d), np.arange(d), :] = var.T
+    return Psi
+
+
 def cpu_baseline(cfg, model, theta, X, y, omega, rows):
     """The oracle (as-written NumPy restatement of the reference path) timed on a bounded row sample."""
     from oracle import gpz_oracle as O
@@ -85,8 +97,9 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
     Omodel = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
     Xs, ys = X[:rows], y[:rows]
     oms = None if omega is None else omega[:rows]
+    psis = synth_psi(cfg, np.arange(rows)) if cfg.get("psi") else None
     t0 = time.perf_counter()
-    ref = O.GPz(theta, Omodel, Xs, ys, None, oms)
+    ref = O.GPz(theta, Omodel, Xs, ys, psis, oms)
     t_all = time.perf_counter() - t0
     # the m^3 part does not scale with n: time it alone
     S = np.eye(model.m) + np.ones((model.m, model.m)) * 1e-3
@@ -143,12 +156,17 @@ def main():
     model, theta0, X, y, omega = synth(cfg)
     n = cfg["n"]
     stream = torch.cuda.current_stream().cuda_stream
+    dtype = cfg.get("dtype", "f64")
     if use_dist:
         Xs, ys, oms, trs, _ = gdist.shard_rows(rank, world, X, y, omega)
-        ctx = gpz_amd.GPzContext(model, Xs, ys, None, oms, trs, None, device=local_rank, stream=stream or None,
-                                 rank=rank, world=world, allreduce=gdist.make_allreduce())
+        rows, _ = gdist.shard_index(rank, world, n)
+        psi = synth_psi(cfg, rows) if cfg.get("psi") else None
+        ctx = gpz_amd.GPzContext(model, Xs, ys, psi, oms, trs, None, device=local_rank, stream=stream or None,
+                                 rank=rank, world=world, allreduce=gdist.make_allreduce(), dtype=dtype)
     else:
-        ctx = gpz_amd.GPzContext(model, X, y, None, omega, None, None, device=local_rank, stream=stream or None)
+        psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
+        ctx = gpz_amd.GPzContext(model, X, y, psi, omega, None, None, device=local_rank, stream=stream or None, dtype=dtype)
+    del psi
     n_local = ctx.n_train
 
     prng = np.random.default_rng(3)
@@ -195,9 +213,11 @@ def main():
         out = {
             "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations", "data": "synthetic",
             "config": {"workload": f"{args.config}: n={n} d={cfg['d']} m={m} method={cfg['method']} heteroscedastic k=1"
-                                   + (" omega=(1+y-min y)^-2" if cfg["omega"] else ""),
+                                   + (" omega=(1+y-min y)^-2" if cfg["omega"] else "")
+                                   + (" Psi=diag cubes dtype=f32" if cfg.get("psi") else ""),
                        "rows_per_gpu": n_local, "sharding": f"rows/{world} + RCCL all-reduce of m x m and m x d partials"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)",
@@ -214,11 +234,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rows = max(2000, min(n, n // 32 if n >= 200000 else n // 4))   # ~20 s of CPU work at c4
+            if cfg.get("psi"):
+                rows = 60                                                  # per-pair d x d loops in NumPy: ~1e5 pairs
             ref, cb = cpu_baseline(cfg, model, theta0, X, y, omega, rows)
             out["cpu_baseline"] = cb
             # parity gate on the same sample through the HIP path
-            c2 = gpz_amd.GPzContext(model, X[:rows], y[:rows], None, None if omega is None else omega[:rows],
-                                    device=local_rank)
+            c2 = gpz_amd.GPzContext(model, X[:rows], y[:rows], synth_psi(cfg, np.arange(rows)) if cfg.get("psi") else None,
+                                    None if omega is None else omega[:rows], device=local_rank, dtype=dtype)
             f2, g2 = c2.eval(theta0)
             c2.close()
             out["parity"] = {"rows": rows, "rel_f": abs(f2 - ref.nlogML) / abs(ref.nlogML),

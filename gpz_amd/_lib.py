@@ -38,6 +38,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 SYMBOLS = {
     "gpz_ctx_create": (C.c_int, [C.POINTER(gpz_desc), C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int32,
                                  c_double_p, c_uint8_p, c_uint8_p, C.POINTER(C.c_void_p)]),
+    "gpz_ctx_create_sharded": (C.c_int, [C.POINTER(gpz_desc), C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int32,
+                                         c_double_p, c_uint8_p, c_uint8_p, c_uint8_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gpz_ctx_destroy": (None, [C.c_void_p]),
     "gpz_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "gpz_theta_len": (C.c_int64, [C.c_void_p]),

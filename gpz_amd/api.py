@@ -94,7 +94,9 @@ class GPzContext:
     building the closure."""
 
     def __init__(self, model, X, Y, Psi=None, omega=None, training=None, validation=None, device=0, stream=None,
-                 rank=0, world=1, allreduce=None, dtype="f64"):
+                 rank=0, world=1, allreduce=None, dtype="f64", patterns=None):
+        """patterns: NaN-pattern table of the whole data set (G x d bool, True = missing, first-occurrence order; see
+        gpz_amd.dist.nan_patterns) — needed by row-sharded GC/VC runs with missing values."""
         lib = _lib.load()
         X = _f64(X, 2)
         Y = _f64(Y, 2)
@@ -115,10 +117,14 @@ class GPzContext:
         self.model = model
         self._desc = _desc(model, device, stream, rank, world, dtype)
         h = C.c_void_p()
-        _lib.check(lib.gpz_ctx_create(
+        pat = None
+        if patterns is not None:
+            pat = np.ascontiguousarray(np.asarray(patterns, dtype=bool).reshape(-1, model.d).astype(np.uint8))
+        _lib.check(lib.gpz_ctx_create_sharded(
             C.byref(self._desc), n_tot, _lib.dptr(X), _lib.dptr(Y), _lib.dptr(psi), psi_kind, _lib.dptr(om),
             None if self._tr is None else self._tr.ctypes.data_as(_lib.c_uint8_p),
-            None if self._va is None else self._va.ctypes.data_as(_lib.c_uint8_p), C.byref(h)))
+            None if self._va is None else self._va.ctypes.data_as(_lib.c_uint8_p),
+            None if pat is None else pat.ctypes.data_as(_lib.c_uint8_p), 0 if pat is None else pat.shape[0], C.byref(h)))
         self._h = h
         self._lib = lib
         self.p = int(lib.gpz_theta_len(h))

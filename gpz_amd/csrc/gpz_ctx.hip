@@ -186,6 +186,7 @@ struct gpz_ctx {
     bool psi32 = false;      // dtype f32 && gen && Psi && no missing dims: fp32 register-resident kernels (k_psi32.hip)
     int ngroups = 0, nrec = 0;
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
+    bool pats_fixed = false;                        // table given by the caller (sharded runs): rows must match an entry
     unsigned char *pat_d = nullptr;
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
     int gen_nchunk = 1;
@@ -276,7 +277,11 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
             int g = -1;
             for (size_t q = 0; q < c->pats.size(); ++q)
                 if (c->pats[q] == pt) { g = (int)q; break; }
-            if (g < 0) { c->pats.push_back(pt); g = (int)c->pats.size() - 1; }
+            if (g < 0) {
+                if (c->pats_fixed) return fail(GPZ_ERR_ARG, "row %lld has a NaN pattern that is not in the given pattern table", (long long)idx[r]);
+                c->pats.push_back(pt);
+                g = (int)c->pats.size() - 1;
+            }
             hg[r] = g;
         }
         if (int e = c->ar.alloc(&rs.gid, np)) return e;
@@ -413,7 +418,8 @@ static int alloc_mm(gpz_ctx *c) {   // m x m stage buffers
 
 // Data-dependent part of a context: path selection (tuned / general), row sets, pattern table, parameter block.
 static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *Y, const double *Psi, int32_t psi_kind,
-                      const double *omega, const uint8_t *training, const uint8_t *validation) {
+                      const double *omega, const uint8_t *training, const uint8_t *validation,
+                      const uint8_t *patterns = nullptr, int32_t n_patterns = 0) {
     const gpz_desc *desc = &c->desc;
     int rc = 0;
     if ((Psi != nullptr) != (psi_kind != 0)) return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree");
@@ -421,12 +427,21 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     if (c->kind == GPZ_KIND_COV && (Psi || xnan)) {
         // general path: per-pair d x d factorisations (k_gen.hip)
         if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
-        // the NaN-pattern table is built per rank in first-occurrence order: shards would disagree on the ids
-        if (desc->world > 1 && xnan)
-            return fail(GPZ_ERR_UNSUPPORTED, "row-sharded runs of GC/VC with missing values are not built yet");
+        // the NaN-pattern table is built per rank in first-occurrence order: shards would disagree on the ids and on the
+        // size of the second all-reduce, so a sharded run must be given the table of the whole data set
+        if (desc->world > 1 && xnan && !(patterns && n_patterns > 0))
+            return fail(GPZ_ERR_UNSUPPORTED, "row-sharded GC/VC with missing values needs the global NaN-pattern table "
+                                             "(gpz_ctx_create_sharded)");
         if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
-        if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
+        if (patterns && n_patterns > 0) {   // 1 = missing, as isnan(X) (getPHI.m:43); stored here as observed flags
+            for (int g = 0; g < n_patterns; ++g) {
+                std::vector<unsigned char> pt((size_t)c->d);
+                for (int q = 0; q < c->d; ++q) pt[q] = patterns[(size_t)g * c->d + q] ? 0 : 1;
+                c->pats.push_back(pt);
+            }
+            c->pats_fixed = true;
+        } else if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
         c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan;
     }
     if (desc->dtype != GPZ_F64 && desc->dtype != GPZ_F32) return fail(GPZ_ERR_ARG, "dtype must be GPZ_F64 or GPZ_F32");
@@ -467,6 +482,13 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
 extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y, const double *Psi,
                               int32_t psi_kind, const double *omega, const uint8_t *training,
                               const uint8_t *validation, gpz_ctx **out) {
+    return gpz_ctx_create_sharded(desc, n_tot, X, Y, Psi, psi_kind, omega, training, validation, nullptr, 0, out);
+}
+
+extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y,
+                                      const double *Psi, int32_t psi_kind, const double *omega, const uint8_t *training,
+                                      const uint8_t *validation, const uint8_t *patterns, int32_t n_patterns,
+                                      gpz_ctx **out) {
     if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
     *out = nullptr;
     gpz_ctx *c = new gpz_ctx();
@@ -479,7 +501,7 @@ extern "C" int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot, const double 
         delete c;
         return code;
     };
-    if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation))) return bail(rc);
+    if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation, patterns, n_patterns))) return bail(rc);
     if (c->gen) {
         c->gen_nchunk = 256;
         const size_t per = (c->psi32 && psi32_raw_len(c->d) > c->nrec) ? (size_t)psi32_raw_len(c->d) : (size_t)c->nrec;

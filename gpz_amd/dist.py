@@ -65,6 +65,19 @@ def shard_psi(rank, world, Psi, training=None, validation=None):
     return np.ascontiguousarray(Psi[:, :, rows]) if cube else Psi[rows]
 
 
+def nan_patterns(X, training=None, validation=None):
+    """NaN-pattern table (G x d bool, True = missing) of the rows the evaluation reads, in first-occurrence order —
+    the groups of getPHI.m:43-54 on the unsharded data.  Every rank passes the same table to GPzContext(patterns=...)."""
+    X = np.asarray(X)
+    n = X.shape[0]
+    keep = np.ones(n, dtype=bool) if training is None else np.asarray(training, dtype=bool).ravel().copy()
+    if training is not None and validation is not None:
+        keep |= np.asarray(validation, dtype=bool).ravel()
+    miss = np.isnan(X[keep])
+    _, first = np.unique(miss, axis=0, return_index=True)
+    return miss[np.sort(first)]
+
+
 class _CudaBuf:
     """Minimal __cuda_array_interface__ view of a raw device pointer (float64, 1-D)."""
 

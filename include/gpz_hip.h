@@ -88,6 +88,15 @@ int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot,
                    const double *omega,
                    const uint8_t *training, const uint8_t *validation,
                    gpz_ctx **out);
+
+/* gpz_ctx_create for a row shard of GC/VC data with missing values.  The NaN-pattern groups of getPHI.m:43-54 must be
+ * the same on every rank (the second all-reduce carries one record block per pattern): `patterns` is the table of the
+ * WHOLE data set, n_patterns x d bytes row-major, 1 = missing (isnan), in first-occurrence order; a rank may hold no
+ * row of some pattern.  NULL / 0 behaves like gpz_ctx_create. */
+int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const double *X, const double *Y,
+                           const double *Psi, int32_t psi_kind, const double *omega,
+                           const uint8_t *training, const uint8_t *validation,
+                           const uint8_t *patterns, int32_t n_patterns, gpz_ctx **out);
 void gpz_ctx_destroy(gpz_ctx *ctx);
 int  gpz_ctx_set_allreduce(gpz_ctx *ctx, gpz_allreduce_fn fn, void *user);
 

@@ -94,7 +94,7 @@ def test_unbuilt_combinations_refuse_loudly():
     """What is not built must say so (GPZ_ERR_UNSUPPORTED / GPZ_ERR_ARG), never silently compute something else."""
     model, theta, X, Y, Psi, rng = make_problem(64, 3, 4, 1, "VC", True, seed=5, psi=True)
     Xn = X.copy(); Xn[3, 1] = np.nan
-    with pytest.raises(_lib.GpzError) as ei:          # row-sharded GC/VC with missing values (per-rank pattern ids)
+    with pytest.raises(_lib.GpzError) as ei:          # row-sharded GC/VC with missing values and no global pattern table
         gpz_amd.GPzContext(model, Xn, Y, Psi, rank=0, world=2)
     assert ei.value.code == -5
     with pytest.raises(_lib.GpzError) as ei:          # wrong Psi layout for the method (fixPsi.m)
@@ -416,7 +416,7 @@ def test_c4_shape_against_oracle_subsample():
 
 
 # ---- sharded evaluation: two ranks on one GPU (gloo moves the CUDA buffers; RCCL needs distinct devices) ----
-def _shard_worker(rank, world, port, q, psi=False):
+def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0):
     import os
     import torch
     import torch.distributed as dist
@@ -425,14 +425,15 @@ def _shard_worker(rank, world, port, q, psi=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi)
+    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi, nanfrac=nanfrac)
     r2 = np.random.default_rng(1)
     om = r2.random((3001, 1)) + 0.5
     tr = r2.random(3001) < 0.8
     va = ~tr
     Xs, Ys, oms, trs, vas = gdist.shard_rows(rank, world, X, Y, om, tr, va)
+    pats = gdist.nan_patterns(X, tr, va) if nanfrac > 0 else None     # the whole data set's table, same on every rank
     ctx = gpz_amd.GPzContext(model, Xs, Ys, gdist.shard_psi(rank, world, Psi, tr, va), oms, trs, vas, rank=rank,
-                             world=world, allreduce=gdist.make_allreduce())
+                             world=world, allreduce=gdist.make_allreduce(), patterns=pats)
     f, g = ctx.eval(theta)
     w, iS, part = ctx.solve(theta)
     q.put((rank, f, g, dict(ctx.stats), w, part, ctx.n_global))
@@ -440,21 +441,22 @@ def _shard_worker(rank, world, port, q, psi=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("psi", [False, True])
-def test_sharded_eval_world2_matches_unsharded(psi):
-    """psi=True: GC/VC with an input-noise cube (the per-pair path) row-sharded over two ranks."""
+@pytest.mark.parametrize("psi,nanfrac", [(False, 0.0), (True, 0.0), (False, 0.3), (True, 0.3)])
+def test_sharded_eval_world2_matches_unsharded(psi, nanfrac):
+    """psi: GC/VC with an input-noise cube (the per-pair path) row-sharded over two ranks; nanfrac > 0: missing values,
+    the ranks share the NaN-pattern table of the whole data set (gpz_ctx_create_sharded)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q, psi)) for r in range(2)]
+    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q, psi, nanfrac)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi)
+    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi, nanfrac=nanfrac)
     r2 = np.random.default_rng(1)
     om = r2.random((3001, 1)) + 0.5
     tr = r2.random(3001) < 0.8
