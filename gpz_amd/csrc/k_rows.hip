@@ -448,18 +448,21 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
             b[u] = T[(size_t)i * ld + jc];
         }
     };
-    double sc[3 + D], scn[3 + D];
+    // the uniform row data alternates between two scalar register sets (no copies): row i+1 is fetched into the other
+    // set while row i is worked on
+    double scA[3 + D], scB[3 + D];
+    static_assert(UR % 2 == 0, "UR must be even");
     auto batch = [&](int i0, const double (&a)[UR], const double (&b)[UR]) {
 #pragma unroll
-        for (int u = 0; u < UR; ++u) {
-            sload(min(i0 + u + 1, last), scn);
-            consume(i0 + u, a[u], b[u], sc);
-#pragma unroll
-            for (int c = 0; c < 3 + D; ++c) sc[c] = scn[c];
+        for (int u = 0; u < UR; u += 2) {
+            sload(min(i0 + u + 1, last), scB);
+            consume(i0 + u, a[u], b[u], scA);
+            sload(min(i0 + u + 2, last), scA);
+            consume(i0 + u + 1, a[u + 1], b[u + 1], scB);
         }
     };
     vload(r0, phA, ttA);
-    sload(min(r0, last), sc);
+    sload(min(r0, last), scA);
     int ib = r0;
     for (; ib + 2 * UR <= rend; ib += 2 * UR) {
         vload(ib + UR, phB, ttB);
@@ -470,8 +473,8 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
     // remainder (< 2 UR rows): set A holds rows ib .. ib+UR-1
 #pragma unroll 1
     for (int i = ib; i < rend; ++i) {
-        sload(i, sc);
-        consume(i, Phi[(size_t)i * ld + jc], T[(size_t)i * ld + jc], sc);
+        sload(i, scA);
+        consume(i, Phi[(size_t)i * ld + jc], T[(size_t)i * ld + jc], scA);
     }
     if (act) {
         double *o = slab + ((size_t)chunk * m + j) * (nm + 2);
