@@ -339,7 +339,7 @@ def nan_groups(X, device=0):
 def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
     """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1).  Rows are grouped by NaN
     pattern as predict.m:45-57 does; a group without missing values runs predictFull / predictNoisy, a group with
-    missing values predictMissing / predictNoisyMissing (diagonal kinds; GC/VC with missing values refuse)."""
+    missing values predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337)."""
     lib = _lib.load()
     X = np.asarray(X, dtype=np.float64)
     psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)

@@ -1271,7 +1271,86 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
     return rc;
 }
 
-// predictMissing / predictNoisyMissing (predictDiag.m:127-297) for ONE group of rows sharing a NaN pattern (the caller
+// GC/VC branch of gpz_predict_missing (predictCov.m:134-337); see k_pmiss_cov.hip.
+static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double *theta, const double *w, const double *iSigma_w,
+                               const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
+                               double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
+    if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
+    gpz_ctx *c = nullptr;
+    if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
+    const int n = c->tr.n, d = c->d, de = c->de;
+    int rc = 0;
+    if (hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st) != hipSuccess)
+        rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+    launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+    launch_gen_prep(c->st, c->pr.G, c->m, d, de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+    const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * (int)k;
+    const long npairs = (long)m * (m + 1) / 2;
+    // rows per block: X_hat / Psi_hat of a block stay below ~512 MB
+    long rb = (1L << 26) / ((long)m * d * d);
+    if (rb > n) rb = n;
+    if (rb < 1) rb = 1;
+    const int rows_blk = (int)rb;
+    int nchunk = (int)(npairs < 64 ? npairs : 64);
+    const long ppc = (npairs + nchunk - 1) / nchunk;
+    nchunk = (int)((npairs + ppc - 1) / ppc);
+    double *wd = nullptr, *iSd = nullptr, *prd = nullptr, *rec = nullptr, *tab = nullptr, *Ex = nullptr, *Pio = nullptr,
+           *Xhat = nullptr, *Phat = nullptr, *part = nullptr, *sums = nullptr, *phiw = nullptr, *outb = nullptr, *tmp = nullptr;
+    if (!rc) rc = c->ar.alloc(&wd, m * k);
+    if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
+    if (!rc) rc = c->ar.alloc(&prd, m);
+    if (!rc) rc = c->ar.alloc(&rec, m * nrec);
+    if (!rc) rc = c->ar.alloc(&tab, (size_t)npairs * ntab);
+    if (!rc) rc = c->ar.alloc(&Ex, (size_t)rows_blk * mp);
+    if (!rc) rc = c->ar.alloc(&Pio, (size_t)rows_blk * mp);
+    if (!rc) rc = c->ar.alloc(&Xhat, (size_t)rows_blk * m * d);
+    if (!rc && Psi) rc = c->ar.alloc(&Phat, (size_t)rows_blk * m * d * d);
+    if (!rc) rc = c->ar.alloc(&part, (size_t)nchunk * 3 * k * np);
+    if (!rc) rc = c->ar.alloc(&sums, 3 * k * np);
+    if (!rc) rc = c->ar.alloc(&phiw, np * k);
+    if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(iSd, iSigma_w, m * m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(prd, priors, m * sizeof(double), hipMemcpyHostToDevice, c->st);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+    }
+    if (!rc) {
+        launch_zero(c->st, c->Phi, np * mp);
+        launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
+        launch_pmc(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, c->Sig, c->iSig, prd, wd,
+                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi);
+        launch_slab_sum(c->st, part, nchunk, 3 * k * np, sums);
+        launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
+                          c->lnbeta, nullptr, phiw);
+        launch_predict_noisy_final(c->st, sums, (long)np, n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
+                                   outb + 2 * k * np);
+        auto down = [&](double *dst, const double *src) {
+            return hipMemcpy2DAsync(dst, (size_t)ns * sizeof(double), src, np * sizeof(double), (size_t)ns * sizeof(double), k,
+                                    hipMemcpyDeviceToHost, c->st);
+        };
+        hipError_t e = down(gamma, outb);
+        if (e == hipSuccess) e = down(nu, outb + k * np);
+        if (e == hipSuccess) e = down(beta_i, outb + 2 * k * np);
+        if (e == hipSuccess) e = down(mu, phiw);
+        if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+    }
+    if (!rc && PHI) {
+        rc = c->ar.alloc(&tmp, (size_t)ns * m);
+        if (!rc) {
+            launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+            if (hipMemcpyAsync(PHI, tmp, (size_t)ns * m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
+                rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+        }
+    }
+    if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: sync failed");
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: kernel failed");
+    free_eval_ctx(c);
+    return rc;
+}
+
+// predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337) for ONE group of rows sharing a NaN pattern (the caller
 // groups the rows as predict.m:45-69 does; the pattern is taken from the first row, predictDiag.m:3).
 extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
                                    const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
@@ -1291,7 +1370,7 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     if (obs == (d >= 32 ? ~0u : ((1u << d) - 1u)))
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
     if (method_id_of(desc->method) >= 4)
-        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values for GC/VC (predictCov.m:134-337) is not built");
+        return predict_missing_cov(desc, obs, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;

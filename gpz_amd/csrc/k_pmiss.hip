@@ -200,6 +200,9 @@ void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, 
                        P, G, No);
     hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double *)No, ld, n, m, priors, Pio);
 }
+void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio) {
+    hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, No, ld, n, m, priors, Pio);
+}
 void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B) {
     hipLaunchKernelGGL(k_pm_nij, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
 }

@@ -14,7 +14,7 @@
  *   gpz_phi             [PHI,Gamma,lnBeta_i,N] = getPHI(X,Psi,theta,model,[]) GPz/getPHI.m:1
  *   gpz_predict_full    predictFull(X,theta,w,iSigma_w,model) GPz/predictDiag.m:58-74, predictCov.m:53-69
  *   gpz_predict_noisy   predictNoisy(X,Psi,...)               GPz/predictDiag.m:75-125, predictCov.m:70-132
- *   gpz_predict_missing predictMissing / predictNoisyMissing  GPz/predictDiag.m:127-297
+ *   gpz_predict_missing predictMissing / predictNoisyMissing  GPz/predictDiag.m:127-297, predictCov.m:134-337
  *   gpz_prior           prior = getPrior(X,Psi,theta,model,set) GPz/getPrior.m:1
  *   gpz_inv_logdet      [Xi,logdet] = inv_logdet(X)         GPz/inv_logdet.m:1
  *   gpz_dxy             D = Dxy(X,Y)                        GPz/Dxy.m:1
@@ -150,10 +150,10 @@ int gpz_predict_noisy(const gpz_desc *desc, const double *theta, const double *w
                       const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                       double *mu, double *nu, double *beta_i, double *gamma, double *PHI);
 
-/* predictMissing / predictNoisyMissing (GPz/predictDiag.m:127-297) for ONE group of rows that share a NaN
- * pattern (predict.m:45-69 forms the groups; the pattern is read from the first row, predictDiag.m:3).
- * priors: 1 x m mixture weights (model.best.priors, train.m:59,74).  Psi: n x d or NULL.  GC/VC
- * (predictCov.m:134-337) are not built: GPZ_ERR_UNSUPPORTED. */
+/* predictMissing / predictNoisyMissing (GPz/predictDiag.m:127-297, GPz/predictCov.m:134-337) for ONE group of
+ * rows that share a NaN pattern (predict.m:45-69 forms the groups; the pattern is read from the first row,
+ * predictDiag.m:3).  priors: 1 x m mixture weights (model.best.priors, train.m:59,74).  Psi: n x d (diagonal
+ * kinds) / d x d x n (GC, VC) or NULL. */
 int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
                         const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                         double *mu, double *nu, double *beta_i, double *gamma, double *PHI);

@@ -557,12 +557,29 @@ def test_predict_missing_many_bases():
         assert rel(out[i], ref[i]) <= 1e-9, name
 
 
-def test_predict_missing_cov_kinds_refuse():
-    model, rng = _trained_like_model("VC", 3, 5, 1, seed=71)
-    Xs = rng.standard_normal((6, 3)); Xs[2, 1] = np.nan
-    with pytest.raises(_lib.GpzError) as ei:
-        gpz_amd.predict(Xs, model)
-    assert ei.value.code == -5
+@pytest.mark.parametrize("method,d,m,k", [("VC", 3, 5, 2), ("GC", 4, 6, 1), ("VC", 5, 4, 1)])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_predict_with_missing_values_cov_kinds(method, d, m, k, noisy):
+    """predictCov.m:134-337 (X_hat / Psi_hat conditioning, per-(row, pair, component) d x d factorisations) against the
+    oracle, all NaN patterns of the rows mixed with complete rows — including patterns whose [o u] ordering is not an
+    involution, where predictCov.m:266-268's `unshuffle` scatter is kept as written."""
+    model, rng = _trained_like_model(method, d, m, k, seed=81 + d)
+    ns = 14
+    Xs = rng.standard_normal((ns, d))
+    miss = rng.random((ns, d)) < 0.35
+    miss[miss.all(axis=1), d - 1] = False
+    miss[0] = False; miss[1] = False; miss[1, 0] = True           # a complete row, and "first dimension missing"
+    Xs[miss] = np.nan
+    Psi = None
+    if noisy:
+        Psi = np.zeros((d, d, ns))
+        for i in range(ns):
+            B = 0.3 * rng.standard_normal((d, d))
+            Psi[:, :, i] = B @ B.T
+    ref = O.predict_any(Xs, model, Psi=Psi)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= 1e-8, name
 
 
 @pytest.mark.parametrize("method,psi,nanfrac", [("VD", False, 0.0), ("VC", False, 0.0), ("VD", True, 0.3), ("GC", True, 0.0),
