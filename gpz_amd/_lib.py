@@ -48,6 +48,14 @@ SYMBOLS = {
     "gpz_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_get_phi": (C.c_int, [C.c_void_p, c_double_p]),
+    "gpz_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_void_p, c_double_p, c_double_p]),
+    "gpz_lbfgs_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gpz_lbfgs_destroy": (None, [C.c_void_p]),
+    "gpz_lbfgs_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, c_int32_p]),
+    "gpz_lbfgs_direction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpz_lbfgs_last_error": (C.c_char_p, []),
+    "gpz_vec_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, c_double_p]),
+    "gpz_vec_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "gpz_ctx_set_pinv_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "gpz_ctx_last_pinv": (C.c_int, [C.c_void_p, c_double_p]),
     "gpz_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -85,6 +93,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library pulls in /opt/rocm's runtime first, a later
+    # `import torch` finds "No HIP GPUs"; loaded in the other order both share one runtime.  torch is only plumbing
+    # here (device buffers for the sharded / device-resident callers), so it is optional.
+    if os.environ.get("GPZ_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with ./build.sh or __graft_entry__.build(); "
@@ -101,6 +117,13 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().gpz_last_error()
+        raise GpzError(rc, msg.decode() if msg else "")
+
+
+def check_plain(rc):
+    """Status check for the entry points that keep their own error string (gpz_lbfgs_*, gpz_vec_*)."""
+    if rc != 0:
+        msg = load().gpz_lbfgs_last_error()
         raise GpzError(rc, msg.decode() if msg else "")
 
 

@@ -166,6 +166,26 @@ class GPzContext:
         self.n_global = int(dg[1])
         return f.value, g
 
+    def eval_dev(self, theta_t):
+        """gpz_eval_dev: theta_t is a float64 CUDA tensor on the context's device; returns (f, g) with g a new CUDA
+        tensor — theta and the gradient never visit the host."""
+        import torch
+        if theta_t.numel() != self.p or theta_t.dtype != torch.float64 or not theta_t.is_cuda:
+            raise ValueError(f"theta must be a float64 CUDA tensor of {self.p} elements")
+        theta_t = theta_t.contiguous()
+        g = torch.empty_like(theta_t)
+        torch.cuda.current_stream(theta_t.device).synchronize()     # the context runs on its own stream
+        f = C.c_double()
+        st = (C.c_double * 4)(float("nan"), float("nan"), float("nan"), float("nan"))
+        dg = (C.c_double * 2)()
+        _lib.check(self._lib.gpz_eval_dev(self._h, theta_t.data_ptr(), C.byref(f), g.data_ptr(), st, dg))
+        self.stats = {"trainRMSE": st[0], "trainLL": st[1]}
+        if self.n_valid > 0 or (self._va is not None and self._desc.world > 1):
+            self.stats.update(validRMSE=st[2], validLL=st[3])
+        self.info = int(dg[0])
+        self.n_global = int(dg[1])
+        return f.value, g
+
     def solve(self, theta):
         """[~, ~, w, iSigma_w] = GPz(theta, ...)  (GPz.m:84-87); also returns the 1 x k partial nlogML."""
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())

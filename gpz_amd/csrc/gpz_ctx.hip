@@ -179,6 +179,7 @@ struct gpz_ctx {
     bool has_psi = false, has_missing = false;
     // truncating pseudo-inverse route (inv_logdet.m:7-12): 0 = when k_cond_flag asks for it, 1 = always, -1 = never
     int pinv_mode = 0;
+    double *g_dev_out = nullptr;          // set for the duration of gpz_eval_dev: device destination of the gradient
     double pinv_last[4] = {0, 0, 0, 0};   // [route taken, rank kept, max singular value, Jacobi sweeps] of the last call
     // general covariance-kind path
     bool gen = false;
@@ -689,9 +690,13 @@ static int build_phi(gpz_ctx *c) {
 }
 
 // Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
-static int stage_a(gpz_ctx *c, const double *theta) {
-    memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
-    HIPCHK(hipMemcpyAsync(c->theta_d, c->theta_h, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nullptr) {
+    if (theta_dev) {   // device-resident caller (gpz_eval_dev): theta never visits the host
+        HIPCHK(hipMemcpyAsync(c->theta_d, theta_dev, (size_t)c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    } else {
+        memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
+        HIPCHK(hipMemcpyAsync(c->theta_d, c->theta_h, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
+    }
     {
         Stage s(c, "unpack");
         launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
@@ -959,17 +964,40 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                               c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         launch_finish(c->st, a);
     }
-    HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 10) * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    if (c->g_dev_out) {   // gpz_eval_dev: the gradient stays on the device, only f and the statistics block come up
+        HIPCHK(hipMemcpyAsync(c->g_dev_out, c->out_d + 1, (size_t)c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, sizeof(double), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(hipMemcpyAsync(c->out_h + 1 + c->p, c->out_d + 1 + c->p, 9 * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 10) * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    }
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
     return 0;
 }
 
+static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
+                       double stats[4], double diag[2]);
+
 extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, double stats[4], double diag[2]) {
     if (!c || !theta || !f || !g) return fail(GPZ_ERR_ARG, "gpz_eval: null argument");
+    return eval_common(c, theta, nullptr, f, g, nullptr, stats, diag);
+}
+
+extern "C" int gpz_eval_dev(gpz_ctx *c, const double *theta_dev, double *f, double *g_dev, double stats[4], double diag[2]) {
+    if (!c || !theta_dev || !f || !g_dev) return fail(GPZ_ERR_ARG, "gpz_eval_dev: null argument");
+    c->g_dev_out = g_dev;
+    const int rc = eval_common(c, nullptr, theta_dev, f, nullptr, g_dev, stats, diag);
+    c->g_dev_out = nullptr;
+    return rc;
+}
+
+static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
+                       double stats[4], double diag[2]) {
+    (void)g_dev;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-    if (int e = stage_a(c, theta)) return e;
+    if (int e = stage_a(c, theta, theta_dev)) return e;
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
     if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
     // k_cond_flag (info[1], returned in slot 7 of the statistics block): SIGMA is close enough to singular that
@@ -982,7 +1010,7 @@ extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, d
     const bool have_valid = c->va.n_pad > 0;
     if (c->timing) collect_timings(c);
     *f = c->out_h[0];
-    memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
+    if (g) memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
     const double *st = c->out_h + 1 + c->p;
     if (stats) {
         stats[0] = st[0];

@@ -28,8 +28,75 @@ from .api import GPzContext, Model
 # --------------------------------------------------------------------------------------------------
 def _legal(v):
     """isLegal.m: real, no NaN, no Inf."""
+    if isinstance(v, DevVec):
+        return v.legal()
     a = np.asarray(v)
     return bool(np.all(np.isfinite(a)))
+
+
+def _amax(v):
+    """max(abs(v)) for a host array or a device vector."""
+    return v.amax() if isinstance(v, DevVec) else float(np.max(np.abs(v)))
+
+
+def _asum(v):
+    return v.asum() if isinstance(v, DevVec) else float(np.sum(np.abs(v)))
+
+
+class DevVec:
+    """A p-vector that lives on the GPU (a float64 torch tensor used as plain device memory).  It supports exactly the
+    operations minFunc's L-BFGS driver and line searches perform on x, g and d — x + t*d, g'd, max|.|, sum|.|, copies —
+    so the same driver code runs with host arrays or with device-resident vectors; the reductions are the library's
+    kernels (gpz_vec_stats), only scalars come back to the host."""
+
+    __array_priority__ = 1000
+
+    def __init__(self, t):
+        self.t = t
+
+    @staticmethod
+    def from_host(a, device=0):
+        import torch
+        return DevVec(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(f"cuda:{device}"))
+
+    def host(self):
+        return self.t.cpu().numpy()
+
+    @property
+    def size(self):
+        return self.t.numel()
+
+    def _stats(self, other=None):
+        from . import _lib
+        import ctypes as C
+        out = (C.c_double * 4)()
+        _lib.check_plain(_lib.load().gpz_vec_stats(self.t.data_ptr(), None if other is None else other.t.data_ptr(),
+                                                   self.t.numel(), self.t.device.index or 0, None, out))
+        return out
+
+    def __matmul__(self, other):
+        return float(self._stats(other)[0])
+
+    def amax(self):
+        return float(self._stats()[1])
+
+    def asum(self):
+        return float(self._stats()[2])
+
+    def legal(self):
+        return bool(np.isfinite(self._stats()[1]))
+
+    def __rmul__(self, a):
+        return DevVec(self.t * float(a))
+
+    def __add__(self, other):
+        return DevVec(self.t + other.t)
+
+    def __neg__(self):
+        return DevVec(-self.t)
+
+    def copy(self):
+        return DevVec(self.t.clone())
 
 
 def _polyinterp(points, xmin_bound=None, xmax_bound=None):
@@ -95,7 +162,7 @@ def _armijo(fun, x, t, d, f, fr, g, gtd, c1, prog_tol):
             t = temp * 0.6
         f_new, g_new = fun(x + t * d)
         evals += 1
-        if np.max(np.abs(t * d)) <= prog_tol:
+        if _amax(t * d) <= prog_tol:
             return 0.0, f, g, evals
     return t, f_new, g_new, evals
 
@@ -108,7 +175,7 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
     gtd_new = float(g_new @ d) if _legal(g_new) else float("nan")
     ls_iter = 0
     t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
-    nrm_d = float(np.max(np.abs(d)))
+    nrm_d = _amax(d)
     done = False
     bracket = None
     while ls_iter < max_ls:
@@ -176,13 +243,51 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
     return best[0], best[1], best[2], evals
 
 
+class _LBFGSDevice:
+    """The same memory on the GPU: S and Y never leave the device (gpz_lbfgs_* of the C ABI, k_lbfgs.hip)."""
+
+    def __init__(self, p, corrections, device=0):
+        from . import _lib
+        import ctypes as C
+        self._lib = _lib
+        self._h = C.c_void_p()
+        _lib.check_plain(_lib.load().gpz_lbfgs_create(int(p), int(corrections), int(device), None, C.byref(self._h)))
+
+    def add_step(self, g, g_old, t, d):
+        import ctypes as C
+        added = C.c_int32()
+        self._lib.check_plain(self._lib.load().gpz_lbfgs_add(self._h, g.t.data_ptr(), g_old.t.data_ptr(), float(t),
+                                                            d.t.data_ptr(), C.byref(added)))
+        return bool(added.value)
+
+    def direction(self, g):
+        import torch
+        d = torch.empty_like(g.t)
+        self._lib.check_plain(self._lib.load().gpz_lbfgs_direction(self._h, g.t.data_ptr(), d.data_ptr()))
+        return DevVec(d)
+
+    def close(self):
+        if self._h:
+            self._lib.load().gpz_lbfgs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _LBFGS:
     """Circular-buffer L-BFGS memory: lbfgsAdd.m (skip when y's <= 1e-10) and the two-loop product lbfgsProd.m."""
 
     def __init__(self, p, corrections):
-        self.S = np.zeros((p, corrections)); self.Y = np.zeros((p, corrections)); self.YS = np.zeros(corrections)
+        self.S = np.zeros((corrections, p)); self.Y = np.zeros((corrections, p)); self.YS = np.zeros(corrections)   # one pair per row
         self.start, self.end, self.hdiag, self.cap = 0, -1, 1.0, corrections
         self.count = 0
+
+    def add_step(self, g, g_old, t, d):
+        return self.add(g - g_old, t * d)
 
     def add(self, y, s):
         ys = float(y @ s)
@@ -194,7 +299,7 @@ class _LBFGS:
         else:
             self.start = (self.start + 1) % self.cap
             self.end = (self.end + 1) % self.cap
-        self.S[:, self.end] = s; self.Y[:, self.end] = y; self.YS[self.end] = ys
+        self.S[self.end] = s; self.Y[self.end] = y; self.YS[self.end] = ys
         self.hdiag = ys / float(y @ y)
         return True
 
@@ -203,12 +308,12 @@ class _LBFGS:
         d = -g.copy()
         al = {}
         for i in reversed(idx):
-            al[i] = float(self.S[:, i] @ d) / self.YS[i]
-            d -= al[i] * self.Y[:, i]
+            al[i] = float(self.S[i] @ d) / self.YS[i]
+            d -= al[i] * self.Y[i]
         d *= self.hdiag
         for i in idx:
-            be = float(self.Y[:, i] @ d) / self.YS[i]
-            d += self.S[:, i] * (al[i] - be)
+            be = float(self.Y[i] @ d) / self.YS[i]
+            d += self.S[i] * (al[i] - be)
         return d
 
 
@@ -218,14 +323,15 @@ def minfunc_lbfgs(fun, x0, max_iter=200, output_fcn=None, corrections=100, opt_t
 
     ``fun(x) -> (f, g)``; ``output_fcn(x, kind, i, fun_evals, f, t, gtd, g, d, opt_cond) -> stop`` is called with
     kind 'init', 'iter' and 'done' like minFunc's outputFcn.  Returns (x, f, exitflag, fun_evals, message)."""
-    x = np.asarray(x0, dtype=np.float64).copy()
+    on_device = isinstance(x0, DevVec)
+    x = x0.copy() if on_device else np.asarray(x0, dtype=np.float64).copy()
     f, g = fun(x)
     evals = 1
-    if np.max(np.abs(g)) <= opt_tol:
+    if _amax(g) <= opt_tol:
         return x, f, 1, evals, "Optimality Condition below optTol"
-    if output_fcn and output_fcn(x, "init", 0, evals, f, None, None, g, None, float(np.max(np.abs(g)))):
+    if output_fcn and output_fcn(x, "init", 0, evals, f, None, None, g, None, _amax(g)):
         return x, f, -1, evals, "Stopped by output function"
-    mem = _LBFGS(x.size, corrections)
+    mem = _LBFGSDevice(x.size, corrections, x.t.device.index or 0) if on_device else _LBFGS(x.size, corrections)
     exitflag, msg = 0, "Reached Maximum Number of Iterations"
     t = 1.0
     d = None
@@ -235,7 +341,7 @@ def minfunc_lbfgs(fun, x0, max_iter=200, output_fcn=None, corrections=100, opt_t
         if i == 1:
             d = -g
         else:
-            mem.add(g - g_old, t * d)
+            mem.add_step(g, g_old, t, d)
             d = mem.direction(g)
         g_old = g.copy()
         if not _legal(d):
@@ -245,26 +351,26 @@ def minfunc_lbfgs(fun, x0, max_iter=200, output_fcn=None, corrections=100, opt_t
         if gtd > -prog_tol:
             exitflag, msg = 2, "Directional Derivative below progTol"
             break
-        t = min(1.0, 1.0 / float(np.sum(np.abs(g)))) if i == 1 else 1.0     # minFunc.m:983,988-990
+        t = min(1.0, 1.0 / _asum(g)) if i == 1 else 1.0                      # minFunc.m:983,988-990
         f_old = f
         t, f, g, ev = _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol)
         evals += ev
         x = x + t * d
-        opt_cond = float(np.max(np.abs(g)))
+        opt_cond = _amax(g)
         if output_fcn and output_fcn(x, "iter", i, evals, f, t, gtd, g, d, opt_cond):
             exitflag, msg = -1, "Stopped by output function"
             break
         if opt_cond <= opt_tol:
             exitflag, msg = 1, "Optimality Condition below optTol"
             break
-        if np.max(np.abs(t * d)) <= prog_tol:
+        if _amax(t * d) <= prog_tol:
             exitflag, msg = 2, "Step Size below progTol"
             break
         if abs(f - f_old) < prog_tol:
             exitflag, msg = 2, "Function Value changing by less than progTol"
             break
     if output_fcn:
-        output_fcn(x, "done", i, evals, f, None, None, g, None, float(np.max(np.abs(g))))
+        output_fcn(x, "done", i, evals, f, None, None, g, None, _amax(g))
     return x, f, exitflag, evals, msg
 
 
@@ -430,10 +536,11 @@ def init(X, Y, method, m, heteroscedastic=True, normalize=True, omega=None, trai
 
 
 def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=None, validation=None, Psi=None,
-          verbose=True, device=0):
+          verbose=True, device=0, device_resident=False, dtype="f64"):
     """model = train(model,X,Y,...)   (train.m + callBack.m): L-BFGS on the negative log marginal likelihood with
     per-iteration statistics, best-on-validation tracking and early stopping after maxAttempts non-improving
-    iterations."""
+    iterations.  device_resident=True keeps theta, the gradient, the search direction and the L-BFGS memory on the GPU
+    (gpz_eval_dev + gpz_lbfgs_*): per evaluation only f and the statistics cross PCIe."""
     X = np.asarray(X, dtype=np.float64); Y = np.asarray(Y, dtype=np.float64)
     if Y.ndim == 1:
         Y = Y[:, None]
@@ -444,9 +551,13 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
     training_only = validation is None or not np.asarray(validation).any()
     state = {"best_theta": model.sets["best"]["theta"].copy(), "best_valid": model.sets["best"].get("LL", -np.inf),
              "attempts": 0, "tic": time.time()}
-    ctx = GPzContext(model, Xn, Yc, PsiN, omega, training, None if training_only else validation, device=device)
+    ctx = GPzContext(model, Xn, Yc, PsiN, omega, training, None if training_only else validation, device=device,
+                     dtype=dtype)
 
     def fun(theta):
+        if isinstance(theta, DevVec):
+            f, g = ctx.eval_dev(theta.t)
+            return f, DevVec(g)
         return ctx.eval(theta)                                                     # refreshes ctx.stats (the globals)
 
     def callback(theta, kind, i, evals, f, t, gtd, g, d, opt_cond):               # callBack.m
@@ -472,9 +583,16 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
         return state["attempts"] == maxAttempts
 
     try:
-        theta, f, flag, evals, msg = minfunc_lbfgs(fun, model.sets["last"]["theta"], maxIter, callback)   # train.m:42-48
+        theta0 = model.sets["last"]["theta"]
+        if device_resident:
+            theta0 = DevVec.from_host(theta0, device)
+        theta, f, flag, evals, msg = minfunc_lbfgs(fun, theta0, maxIter, callback)   # train.m:42-48
         if verbose:
             print(msg)
+        if device_resident:
+            theta = theta.host()
+            if isinstance(state["best_theta"], DevVec):
+                state["best_theta"] = state["best_theta"].host()
         m, d, k, g_dim = model.m, model.d, model.k, model.g_dim
         for name, th in (("last", theta), ("best", state["best_theta"])):          # train.m:53-80
             w, iS, _ = ctx.solve(th)

@@ -115,6 +115,10 @@ int gpz_eval(gpz_ctx *ctx, const double *theta, double *f, double *g, double sta
  * is the un-normalised 1 x k vector of GPz.m:81-82. */
 int gpz_solve(gpz_ctx *ctx, const double *theta, double *w, double *iSigma_w, double *nlogML_partial);
 
+/* gpz_eval for a device-resident caller: theta_dev and g_dev are device pointers on the context's device; only f and
+ * the statistics cross PCIe.  Used with the L-BFGS memory below to keep the optimiser's vectors on the GPU. */
+int gpz_eval_dev(gpz_ctx *ctx, const double *theta_dev, double *f, double *g_dev, double stats[4], double diag[2]);
+
 /* Copy PHI (n_train x m, column-major) of the last gpz_eval/gpz_solve back to the host
  * (5th output of GPz.m:1). */
 int gpz_get_phi(gpz_ctx *ctx, double *PHI);
@@ -157,6 +161,21 @@ int gpz_predict_noisy(const gpz_desc *desc, const double *theta, const double *w
 int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
                         const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                         double *mu, double *nu, double *beta_i, double *gamma, double *PHI);
+
+/* ---- device-resident L-BFGS memory: minFunc's lbfgsAdd.m / lbfgsProd.m (mex/lbfgsAddC.c, mex/lbfgsProdC.c) ----
+ * S and Y (p x corrections) live on the device; all vector arguments are device pointers.
+ * gpz_lbfgs_add:        y = g - g_old, s = t*d; skipped (added = 0) when y's <= 1e-10        (lbfgsAdd.m:2-4)
+ * gpz_lbfgs_direction:  d = -H*g with Hdiag = y's/y'y of the newest pair                      (lbfgsProd.m, minFunc.m:553-578)
+ * gpz_vec_stats:        out = [g.d, max|g|, sum|g|, max|d|] (NaN-propagating), the scalars of minFunc's tests
+ * gpz_vec_axpy:         out = x + t*d */
+typedef struct gpz_lbfgs gpz_lbfgs;
+int gpz_lbfgs_create(int64_t p, int32_t corrections, int32_t device, void *stream, gpz_lbfgs **out);
+void gpz_lbfgs_destroy(gpz_lbfgs *h);
+int gpz_lbfgs_add(gpz_lbfgs *h, const double *g_dev, const double *g_old_dev, double t, const double *d_dev, int32_t *added);
+int gpz_lbfgs_direction(gpz_lbfgs *h, const double *g_dev, double *d_dev);
+const char *gpz_lbfgs_last_error(void);
+int gpz_vec_stats(const double *g_dev, const double *d_dev, int64_t p, int32_t device, void *stream, double out[4]);
+int gpz_vec_axpy(double *out_dev, const double *x_dev, double t, const double *d_dev, int64_t p, int32_t device, void *stream);
 
 /* prior = getPrior(X,Psi,theta,model,[]): mixture weights (1 x m) of the normalised basis densities;
  * iterations (optional) receives the number of fixed-point iterations used (<= 100). */

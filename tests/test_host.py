@@ -122,3 +122,67 @@ def test_training_trajectory_matches_oracle_objective():
     host.minfunc_lbfgs(lambda t: (lambda r: (r.nlogML, r.grad))(O.GPz(t, model, X, Y)), theta, max_iter=6,
                        output_fcn=rec(fs_cpu))
     assert len(fs_gpu) == len(fs_cpu) and rel(np.array(fs_gpu), np.array(fs_cpu)) < 1e-7
+
+
+# ---- device-resident optimiser vectors and L-BFGS memory (gpz_eval_dev, gpz_lbfgs_*, k_lbfgs.hip) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,corr,steps", [(1000, 5, 12), (113001, 7, 10), (4097, 100, 30)])
+def test_device_lbfgs_direction_matches_two_loop(p, corr, steps):
+    """lbfgsAdd.m / lbfgsProd.m on the device (Gram-matrix form of the two-loop recursion) against the host two-loop,
+    through a wrapping ring and with rejected (y's <= 1e-10) pairs in between."""
+    rng = np.random.default_rng(p)
+    hostmem = host._LBFGS(p, corr)
+    devmem = host._LBFGSDevice(p, corr)
+    g_old = rng.standard_normal(p)
+    for it in range(steps):
+        d = rng.standard_normal(p)
+        t = float(rng.random() + 0.1)
+        g = g_old + (0.3 * t) * d + 0.05 * rng.standard_normal(p)        # y's > 0 mostly
+        if it % 5 == 3:
+            g = g_old - 0.2 * t * d                                       # y's < 0: the pair must be skipped
+        a_h = hostmem.add_step(g, g_old, t, d)
+        a_d = devmem.add_step(host.DevVec.from_host(g), host.DevVec.from_host(g_old), t, host.DevVec.from_host(d))
+        assert a_h == a_d
+        dh = hostmem.direction(g)
+        dd = devmem.direction(host.DevVec.from_host(g)).host()
+        assert rel(dd, dh) < 1e-10, it
+        g_old = g
+    devmem.close()
+
+
+@pytest.mark.gpu
+def test_devvec_reductions():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(50001); b = rng.standard_normal(50001)
+    A, B = host.DevVec.from_host(a), host.DevVec.from_host(b)
+    assert abs((A @ B) - a @ b) < 1e-9 and abs(A.amax() - np.abs(a).max()) == 0 and abs(A.asum() - np.abs(a).sum()) < 1e-8
+    assert rel((A + 0.25 * B).host(), a + 0.25 * b) < 1e-15 and A.legal()
+    a[77] = np.nan
+    assert not host.DevVec.from_host(a).legal()
+
+
+@pytest.mark.gpu
+def test_device_resident_training_matches_host_training():
+    """train(..., device_resident=True): theta, g, d and the L-BFGS memory stay on the GPU; same optimiser, same
+    objective, so the iterates agree with the host-vector run to rounding."""
+    import gpz_amd
+    X, Y = _sinc_data()
+    rng = np.random.default_rng(0)
+    tr, va, te = gpz_amd.sample(X.shape[0], 0.7, 0.15, 0.15, rng)
+    m0 = gpz_amd.init(X, Y, "VL", 20, training=tr, rng=np.random.default_rng(5))
+    import copy
+    # the two memories sum in different orders (two-loop vs Gram-matrix form), so the iterates drift apart at the
+    # rounding level and the drift grows with the iteration count: compare a short run tightly, a long one by outcome
+    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=12, maxAttempts=50, training=tr, validation=va, verbose=False)
+    mb = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=12, maxAttempts=50, training=tr, validation=va, verbose=False,
+                       device_resident=True)
+    assert ma.train_info["funEvals"] == mb.train_info["funEvals"]
+    assert abs(ma.train_info["f"] - mb.train_info["f"]) <= 1e-7 * abs(ma.train_info["f"])
+    assert rel(mb.sets["last"]["theta"], ma.sets["last"]["theta"]) < 1e-5
+    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False)
+    mb = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False,
+                       device_resident=True)
+    assert abs(ma.train_info["f"] - mb.train_info["f"]) <= 2e-2 * abs(ma.train_info["f"])
+    mu_a = gpz_amd.predict(X, ma, selection=te)[0]; mu_b = gpz_amd.predict(X, mb, selection=te)[0]
+    ra = math.sqrt(np.mean((mu_a[:, 0] - Y[te, 0]) ** 2)); rb = math.sqrt(np.mean((mu_b[:, 0] - Y[te, 0]) ** 2))
+    assert rb < 0.2 and abs(ra - rb) < 0.02
