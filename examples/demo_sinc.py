@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--method", default="VL")              # demo_sinc.m:9
     ap.add_argument("--maxIter", type=int, default=500)
     ap.add_argument("--maxAttempts", type=int, default=50)
+    ap.add_argument("--device-resident", action="store_true", help="keep theta, g and the L-BFGS memory on the GPU")
     args = ap.parse_args()
 
     rng = np.random.default_rng(1)                         # demo_sinc.m:1  rng(1)
@@ -38,13 +39,19 @@ def main():
     tr, va, te = gpz_amd.sample(n, 0.70, 0.15, 0.15, rng)  # demo_sinc.m:30-32
     model = gpz_amd.init(Xn, Y, args.method, args.m, heteroscedastic=True, training=tr, Psi=Psi, rng=rng)
     model = gpz_amd.train(model, Xn, Y, maxIter=args.maxIter, maxAttempts=args.maxAttempts, training=tr, validation=va,
-                          Psi=Psi)
-    # prediction on the test split, noise-free inputs (the Psi / missing-value prediction branches are not built)
-    mu, sigma, nu, beta_i, gamma, PHI, w, iS = gpz_amd.predict(X, model, selection=te)
-    err = mu[:, 0] - Y[te, 0]
-    rmse = math.sqrt(np.mean(err ** 2))
-    mll = np.mean(-0.5 * err ** 2 / sigma[:, 0] - 0.5 * np.log(sigma[:, 0])) - 0.5 * math.log(2 * math.pi)
-    print(f"test RMSE = {rmse:.5f}   test MLL = {mll:.5f}   ({te.sum()} test points, m = {args.m}, method = {model.method})")
+                          Psi=Psi, device_resident=args.device_resident)
+
+    def report(name, mu, sigma):
+        err = mu[:, 0] - Y[te, 0]
+        rmse = math.sqrt(np.mean(err ** 2))
+        mll = np.mean(-0.5 * err ** 2 / sigma[:, 0] - 0.5 * np.log(sigma[:, 0])) - 0.5 * math.log(2 * math.pi)
+        print(f"{name}: test RMSE = {rmse:.5f}   test MLL = {mll:.5f}")
+
+    print(f"{te.sum()} test points, m = {args.m}, method = {model.method}")
+    mu, sigma = gpz_amd.predict(X, model, selection=te)[:2]                  # noise-free inputs      (predictFull)
+    report("clean inputs      ", mu, sigma)
+    mu, sigma = gpz_amd.predict(Xn, model, Psi=Psi, selection=te)[:2]        # noisy inputs, known Psi (predictNoisy, demo_sinc.m:101)
+    report("noisy inputs + Psi", mu, sigma)
 
 
 if __name__ == "__main__":

@@ -505,8 +505,11 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
 #ifndef GPZ_MOM_UR
 #define GPZ_MOM_UR 4    // rows per register set (two sets; 6 or 8 drop the kernel to one wave per SIMD: 8.1 ms vs 4.8 ms at c4)
 #endif
+#ifndef GPZ_MOM_UR_DIAG
+#define GPZ_MOM_UR_DIAG 2   // diagonal kinds do ~4d flops per row: short row chunks, so a short pipeline (c2: 0.27 -> 0.20 ms)
+#endif
 #define MOMF_(KIND, D, A0, A1, PS) \
-    hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, GPZ_MOM_UR, PS>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, \
+    hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, (KIND == GPZ_KIND_COV ? GPZ_MOM_UR : GPZ_MOM_UR_DIAG), PS>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, \
                        a.m, a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2)
 #define MOMF(KIND, D, A0, A1) \
     do { \

@@ -93,14 +93,18 @@ def make_allreduce(group=None, device="cuda"):
     device "cpu": ``buf`` is a host pointer (used by the gloo tests)."""
     import torch
     import torch.distributed as dist
+    views = {}   # the library all-reduces the same two buffers every evaluation: build each tensor view once
 
     def hook(user, buf, count, stream):
         try:
-            if device == "cpu":
-                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
-                t = torch.from_numpy(arr)
-            else:
-                t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+            t = views.get((buf, count))
+            if t is None:
+                if device == "cpu":
+                    arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                    t = torch.from_numpy(arr)
+                else:
+                    t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+                views[(buf, count)] = t
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return 0
         except Exception as e:  # never unwind through the C frame
