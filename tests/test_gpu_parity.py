@@ -6,6 +6,7 @@ NaN-pattern group ids bit-exact.  Full-size cases use size-independent propertie
 differences with the reference's derivative-check step, method-nesting identities).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -655,3 +656,16 @@ def test_f32_flag_leaves_the_other_paths_in_fp64():
     a = gpz_amd.GPzContext(model, X, Y); fa, ga = a.eval(theta); a.close()
     b = gpz_amd.GPzContext(model, X, Y, dtype="f32"); fb, gb = b.eval(theta); b.close()
     assert fa == fb and np.array_equal(ga, gb)
+
+
+def test_rccl_hook_on_device_buffers():
+    """The library's two all-reduces through torch.distributed's 'nccl' backend (= RCCL) on the device buffers, in a
+    one-rank group (all-reduce = identity): bit-identical to the plain evaluation of the same rows.  Runs in its own
+    process because a process group is process-global."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_hook_check.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "equal=True grad equal=True repeat equal=True" in r.stdout, r.stdout[-2000:]
