@@ -160,7 +160,7 @@ class GPzContext:
         dg = (C.c_double * 2)()
         _lib.check(self._lib.gpz_eval(self._h, _lib.dptr(theta), C.byref(f), _lib.dptr(g), st, dg))
         self.stats = {"trainRMSE": st[0], "trainLL": st[1]}
-        if self.n_valid > 0 or (self._va is not None and self._desc.world > 1):
+        if self._va is not None:     # a mask that selects no row gives NaN, as GPz.m:258-259 does (0/0)
             self.stats.update(validRMSE=st[2], validLL=st[3])
         self.info = int(dg[0])
         self.n_global = int(dg[1])
@@ -180,7 +180,7 @@ class GPzContext:
         dg = (C.c_double * 2)()
         _lib.check(self._lib.gpz_eval_dev(self._h, theta_t.data_ptr(), C.byref(f), g.data_ptr(), st, dg))
         self.stats = {"trainRMSE": st[0], "trainLL": st[1]}
-        if self.n_valid > 0 or (self._va is not None and self._desc.world > 1):
+        if self._va is not None:
             self.stats.update(validRMSE=st[2], validLL=st[3])
         self.info = int(dg[0])
         self.n_global = int(dg[1])

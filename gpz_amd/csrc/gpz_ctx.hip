@@ -466,6 +466,11 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     }
     if (c->gen) {
         c->ngroups = (int)c->pats.size();
+        // the training rows were grouped before the validation rows could add their own patterns: give every row set an
+        // (empty) range for the patterns it has never seen
+        for (RowSet *rs : {&c->tr, &c->va})
+            while ((int)rs->group_begin.size() < c->ngroups + 1)
+                rs->group_begin.push_back(rs->group_begin.empty() ? 0 : rs->group_begin.back());
         c->psi_fast = !c->psi32 && c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records

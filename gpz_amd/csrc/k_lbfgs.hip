@@ -287,13 +287,20 @@ extern "C" int gpz_vec_stats(const double *g_dev, const double *d_dev, int64_t p
     LBCHK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)((p + LB_ROWS - 1) / LB_ROWS);
-    double *part = nullptr;
-    LBCHK(hipMalloc((void **)&part, (size_t)nb * 4 * sizeof(double)));
+    // per-thread scratch for the block partials, grown on demand and kept (a hipMalloc per call would cost more than the
+    // reduction); one device per calling thread is the supported use
+    static thread_local double *part = nullptr;
+    static thread_local int part_cap = 0, part_dev = -1;
+    if (nb > part_cap || part_dev != device) {
+        if (part) (void)hipFree(part);
+        part = nullptr; part_cap = 0;
+        LBCHK(hipMalloc((void **)&part, (size_t)nb * 4 * sizeof(double)));
+        part_cap = nb; part_dev = device;
+    }
     hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(256), 0, st, g_dev, d_dev, (long)p, part);
     std::vector<double> hb((size_t)nb * 4);
     hipError_t e = hipMemcpyAsync(hb.data(), part, hb.size() * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(part);
     if (e != hipSuccess) { snprintf(lb_err, sizeof lb_err, "gpz_vec_stats: %s", hipGetErrorString(e)); return GPZ_ERR_HIP; }
     double gd = 0.0, mg = 0.0, sg = 0.0, md = 0.0;
     for (int b = 0; b < nb; ++b) {

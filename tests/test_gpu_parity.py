@@ -669,3 +669,20 @@ def test_rccl_hook_on_device_buffers():
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "equal=True grad equal=True repeat equal=True" in r.stdout, r.stdout[-2000:]
+
+
+def test_nan_pattern_seen_only_in_validation_rows():
+    """GC/VC with missing values: a NaN pattern that occurs in the validation rows but in no training row gets an empty
+    training group (found by tools/fuzz_parity.py: the gradient read past the training group table)."""
+    model, theta, X, Y, _, rng = make_problem(60, 4, 6, 1, "GC", True, seed=12)
+    tr = np.ones(60, dtype=bool); tr[50:] = False
+    X[3, 1] = np.nan; X[7, 2] = np.nan                  # training patterns
+    X[55, 0] = np.nan; X[57, [0, 3]] = np.nan           # patterns of validation rows only
+    ref = O.GPz(theta, model, X, Y, None, None, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, None, tr, ~tr)
+    f, g = ctx.eval(theta)
+    st = dict(ctx.stats)
+    ctx.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= max(grad_tol(ref.cond), phi_tol(model, theta))
+    for key, val in ref.stats.items():
+        assert abs(st[key] - val) <= 1e-10 * max(1.0, abs(val)), key

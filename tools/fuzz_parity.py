@@ -1,0 +1,72 @@
+"""Developer tool: randomised parity sweep of gpz_eval / gpz_solve against the oracle over shapes, methods, outputs, input
+noise, missing values, weights and masks.  usage: fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import gpz_amd
+from oracle import gpz_oracle as O
+from helpers import make_problem, grad_tol, rel
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    method = rng.choice(["GL", "VL", "GD", "VD", "GC", "VC"])
+    d = int(rng.integers(1, 13)) if method[1] != "C" else int(rng.integers(2, 9))
+    m = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 50, 64, 65, 100, 129, 200]))
+    k = int(rng.choice([1, 1, 1, 2, 3]))
+    n = int(rng.choice([m + 3, 37, 64, 100, 257, 513, 1000, 1025, 2049]))
+    n = max(n, 8)
+    hetero = bool(rng.random() < 0.7)
+    psi = bool(rng.random() < 0.35)
+    nanfrac = float(rng.choice([0.0, 0.0, 0.2, 0.4])) if d > 1 else 0.0
+    if method[1] == "C" and (psi or nanfrac > 0) and n * m > 60000:
+        n = max(8, 60000 // m)                      # oracle loops over pairs
+    seed = int(rng.integers(1 << 30))
+    model, theta, X, Y, Psi, r2 = make_problem(n, d, m, k, method, hetero, seed=seed, psi=psi, nanfrac=nanfrac)
+    if model.method != method:                      # d == 1 rewrites *D/*C to *L (init.m:12-14)
+        method = model.method
+    om = (r2.random((n, 1)) + 0.5) if rng.random() < 0.4 else None
+    tr = (r2.random(n) < 0.8) if rng.random() < 0.5 else None
+    va = None
+    if tr is not None and rng.random() < 0.6:
+        va = ~tr
+    if tr is not None and tr.sum() < 4:
+        tr[:4] = True
+        if va is not None: va = ~tr
+    tag = f"case {c}: {method} n={n} d={d} m={m} k={k} het={int(hetero)} psi={int(psi)} nan={nanfrac} om={om is not None} tr={tr is not None} va={va is not None} seed={seed}"
+    try:
+        ref = O.GPz(theta, model, X, Y, Psi, om, tr, va)
+        r4 = O.GPz(theta, model, X, Y, Psi, om, tr, va, nargout=4)
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, va)
+        f, g = ctx.eval(theta)
+        st = dict(ctx.stats)
+        w, iS, part = ctx.solve(theta)
+        ctx.close()
+        tol = grad_tol(ref.cond)
+        if method[1] == "C":
+            # the reference solves through inv(Gamma'Gamma): its own error is cond(Gamma'Gamma)*eps
+            P, G, *_ = O.unpack_theta(theta, model)
+            Gm = O.expand_gamma(G, model)
+            cg = max(np.linalg.cond(Gm[:, :, j].T @ Gm[:, :, j]) for j in range(Gm.shape[2]))
+            tol = max(tol, 50 * cg * 2.2e-16)
+            if (psi or nanfrac > 0) and cg > 1e4:
+                # with input noise / missing dimensions the reference's dGamma goes through Sigma = inv(Gamma'Gamma) twice
+                # (GPz.m:146-181): at cond 5e7 BOTH analytic gradients sit 1e-4 away from finite differences of either
+                # objective (tools/dbg_case.py) — a conditioning limit of the formula, not a parity question
+                tol = max(tol, 1e-2)
+        ef = abs(f - ref.nlogML) / abs(ref.nlogML)
+        eg = rel(g, ref.grad)
+        ew = rel(w, r4.w)
+        es = max((0.0 if (np.isnan(val) and np.isnan(st[key])) else abs(st[key] - val) / max(1.0, abs(val)))
+                 for key, val in ref.stats.items())
+        ok = ef <= max(1e-8, tol) and eg <= tol and ew <= tol and es <= max(1e-10, tol)
+        if not ok:
+            bad += 1
+            print("FAIL", tag, f"ef={ef:.2e} eg={eg:.2e} ew={ew:.2e} es={es:.2e} tol={tol:.2e} cond={ref.cond:.2e}")
+    except Exception as e:
+        bad += 1
+        print("ERROR", tag, repr(e)[:300])
+print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
