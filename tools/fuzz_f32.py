@@ -1,0 +1,39 @@
+"""Developer tool: randomised sweep of the dtype=f32 path (GC/VC + Psi cubes, diagonal and full, d <= 20) against the fp64
+oracle at the fp32 tolerances (1e-4 on f, 1e-3 on g relative to max|g|).  usage: fuzz_f32.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import gpz_amd
+from oracle import gpz_oracle as O
+from helpers import make_problem, rel
+from test_gpu_parity import _well_conditioned_gamma
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0; t0 = time.time()
+for c in range(cases):
+    method = str(rng.choice(["GC", "VC"]))
+    d = int(rng.integers(2, 21)); m = int(rng.choice([1, 3, 8, 9, 17, 40])); k = int(rng.choice([1, 1, 2]))
+    n = int(rng.choice([20, 64, 65, 200, 500]))
+    if n * m > 4000: n = max(8, 4000 // m)
+    seed = int(rng.integers(1 << 30))
+    model, theta, X, Y, Psi, r2 = make_problem(n, d, m, k, method, True, seed=seed, psi=True)
+    diag = bool(rng.random() < 0.5)
+    if diag:
+        Psi = np.zeros((d, d, n)); Psi[np.arange(d), np.arange(d), :] = r2.gamma(1.0, 0.2, (d, n))
+    else:
+        theta = _well_conditioned_gamma(model, theta, r2)      # the direct M = Sigma + Psi form needs a benign Sigma_j
+    tr = (r2.random(n) < 0.8) if rng.random() < 0.5 else None
+    va = (~tr) if (tr is not None and rng.random() < 0.5) else None
+    tag = f"case {c}: {method} n={n} d={d} m={m} k={k} diag={int(diag)} tr={tr is not None} va={va is not None} seed={seed}"
+    try:
+        ref = O.GPz(theta, model, X, Y, Psi, None, tr, va)
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, None, tr, va, dtype="f32")
+        f, g = ctx.eval(theta); ctx.close()
+        ef = abs(f - ref.nlogML) / abs(ref.nlogML); eg = rel(g, ref.grad)
+        if not (ef <= 1e-4 and eg <= 1e-3):
+            bad += 1; print("FAIL", tag, f"ef={ef:.2e} eg={eg:.2e} cond={ref.cond:.1e}")
+    except Exception as e:
+        bad += 1; print("ERROR", tag, repr(e)[:300])
+print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
