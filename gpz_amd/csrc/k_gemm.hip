@@ -18,14 +18,19 @@
 // TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
 // WC = wave columns of the 2 x WC wave grid: WC = 2 -> 4 waves of 64x64 each, WC = 4 -> 8 waves of 64x32 each
 // (64 accumulator registers per wave, 4 waves per SIMD with two workgroups per CU).
-template <bool WEIGHTED, bool EDGE, int WC>
+template <bool WEIGHTED, bool EDGE, int WC, bool DIAGT>
 __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld, const double *__restrict__ wgt,
-                                          int mp, int i0, int j0, bool diag_tile, int r_begin, int r_end,
+                                          int mp, int i0, int j0, int r_begin, int r_end,
                                           double *__restrict__ out, double (*sA)[16][LDS_LD128],
                                           double (*sB)[16][LDS_LD128], double (*sW)[16]) {
     constexpr int NT = 128 * WC;          // threads
     constexpr int NI = 8 / WC;            // 16-column MFMA tiles per wave
     constexpr int Q = 1024 / NT;          // double2 per thread per operand slice (16 x 128 doubles)
+    constexpr bool diag_tile = DIAGT;
+    // Off-diagonal tiles scale the A operand by the row weight once, while it is staged (Q multiplies per thread and
+    // slice); diagonal tiles stage one operand for both sides, so there the A fragment is scaled in the MFMA loop.
+    // f64 VALU multiplies run on the MFMA pipe: the fragment form costs 4 per K step and wave.
+    constexpr bool PRESCALE = WEIGHTED && !DIAGT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
 
@@ -37,7 +42,7 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 
     // staging map: a wave reads one full 1 KiB tile row per q
     d2_t ra[Q], rb[Q];
-    double rw = 0.0;
+    double rw = 0.0, rwq[PRESCALE ? Q : 1];
     auto gload = [&](int r0) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -47,18 +52,20 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
             ra[q] = (!EDGE || i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
             if (!diag_tile)
                 rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + j0 + c) : (d2_t){0.0, 0.0};
+            if (PRESCALE) rwq[q] = wgt[r0 + row];
         }
-        if (WEIGHTED && tid < 16) rw = wgt[r0 + tid];
+        if (WEIGHTED && !PRESCALE && tid < 16) rw = wgt[r0 + tid];
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
+            if (PRESCALE) { ra[q].x *= rwq[q]; ra[q].y *= rwq[q]; }
             *reinterpret_cast<d2_t *>(&sA[buf][row][c]) = ra[q];
             if (!diag_tile) *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
         }
-        if (WEIGHTED && tid < 16) sW[buf][tid] = rw;
+        if (WEIGHTED && !PRESCALE && tid < 16) sW[buf][tid] = rw;
     };
 
     // Software pipeline: the global loads of slice s+2 are issued in the middle of slice s, right after slice s+1
@@ -82,11 +89,11 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int krow = kk * 4 + (lane >> 4);
             double a[4], b[NI];
-            const double wv = WEIGHTED ? sW[cur][krow] : 1.0;
+            const double wv = (WEIGHTED && !PRESCALE) ? sW[cur][krow] : 1.0;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 double t = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
-                a[mi] = WEIGHTED ? t * wv : t;
+                a[mi] = (WEIGHTED && !PRESCALE) ? t * wv : t;
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
@@ -148,10 +155,17 @@ __global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict_
     if (TRI) r_begin = max(r_begin, j0 & ~15);
     double *out = slab + (size_t)split * mp * mp;
     // interior tiles take the guard-free body (no exec-mask branches in the K loop)
-    if (j0 + 128 <= mp)
-        syrk_body<WEIGHTED, false, WC>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
-    else
-        syrk_body<WEIGHTED, true, WC>(Phi, ld, wgt, mp, i0, j0, diag_tile, r_begin, r_end, out, sA, sB, sW);
+    if (diag_tile) {
+        if (j0 + 128 <= mp)
+            syrk_body<WEIGHTED, false, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+        else
+            syrk_body<WEIGHTED, true, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+    } else {
+        if (j0 + 128 <= mp)
+            syrk_body<WEIGHTED, false, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+        else
+            syrk_body<WEIGHTED, true, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+    }
 }
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
