@@ -9,8 +9,19 @@ from oracle import gpz_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+def golden_names(prefix="g_"):
+    """g_: GPz / getPHI / predictFull cases (make_golden.py); p_: predict with every branch; s_: truncating inv_logdet
+    (make_golden_predict.py)."""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def load_predict_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    model = O.Model(m=int(g["m"]), d=int(g["d"]), k=int(g["k"]), method=str(g["method"]), heteroscedastic=True)
+    model.muX, model.sdX, model.muY = g["muX"], g["sdX"], g["muY"]
+    model.sets["best"] = {"theta": g["theta"], "w": g["w"], "iSigma_w": g["iSigma_w"], "priors": g["priors"]}
+    return g, model, (g["Psi"] if int(g["has_psi"]) else None)
 
 
 def load_golden(name):

@@ -14,7 +14,7 @@ import pytest
 import gpz_amd
 from gpz_amd import _lib
 from oracle import gpz_oracle as O
-from helpers import golden_names, grad_tol, load_golden, make_problem, rel
+from helpers import golden_names, grad_tol, load_golden, load_predict_golden, make_problem, rel
 
 pytestmark = pytest.mark.gpu
 METHODS = ["GL", "VL", "GD", "VD", "GC", "VC"]
@@ -686,3 +686,26 @@ def test_nan_pattern_seen_only_in_validation_rows():
     assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= max(grad_tol(ref.cond), phi_tol(model, theta))
     for key, val in ref.stats.items():
         assert abs(st[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
+@pytest.mark.parametrize("name", golden_names("p_"))
+def test_predict_golden_through_c_abi(name):
+    """Frozen predict() cases with every branch (full / noisy / missing / noisy + missing, mixed NaN patterns) and getPrior."""
+    g, model, Psi = load_predict_golden(name)
+    out = gpz_amd.predict(g["Xs"], model, Psi=Psi)
+    for i, key in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], g[key]) <= 1e-8, key
+    Xn = (g["Xs"] - model.muX) / model.sdX
+    from gpz_amd.host import fixPsi
+    got = gpz_amd.getPrior(Xn, fixPsi(Psi, Xn.shape[0], model.sdX, model.method), g["theta"], model)
+    assert rel(got, g["prior"]) <= 1e-8
+
+
+@pytest.mark.parametrize("name", golden_names("s_"))
+def test_pinv_golden_through_c_abi(name):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    Xi, ld, info = gpz_amd.inv_logdet(z["S"], return_info=True)
+    s = np.linalg.svd(z["S"], compute_uv=False)
+    r = int(z["rank"])
+    assert info == z["S"].shape[0] - r and abs(ld - float(z["logdet"])) <= 1e-10 * max(1.0, abs(float(z["logdet"])))
+    assert rel(Xi, z["Xi"]) <= 1e3 * (s[0] / s[r - 1]) * 2.2e-16

@@ -11,12 +11,13 @@ pinned by properties derived from the reference's own code:
   6. the committed golden fixtures (regression).
 """
 import math
+import os
 
 import numpy as np
 import pytest
 
 from oracle import gpz_oracle as O
-from helpers import golden_names, load_golden, make_problem, rel
+from helpers import golden_names, load_golden, load_predict_golden, make_problem, rel
 
 METHODS = ["GL", "VL", "GD", "VD", "GC", "VC"]
 
@@ -269,3 +270,20 @@ def test_predict_missing_marginalises_a_single_basis_exactly():
     Nij = math.exp(-0.5 * math.log(2 * sig[1]))
     phi = No * 1.0 * Nij * math.exp(-0.5 * np.sum(np.log(G[0] ** 2)))
     assert abs(out[5][0, 0] - phi) < 1e-15 and abs(out[0][0, 0] - 0.8 * phi) < 1e-15
+
+
+@pytest.mark.parametrize("name", golden_names("p_"))
+def test_predict_golden_regression(name):
+    g, model, Psi = load_predict_golden(name)
+    out = O.predict_any(g["Xs"], model, Psi=Psi)
+    for i, key in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], g[key]) < 1e-12, key
+    Xn = (g["Xs"] - model.muX) / model.sdX
+    assert rel(O.getPrior(Xn, O.fixPsi(Psi, Xn.shape[0], model.sdX, model.method), g["theta"], model), g["prior"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", golden_names("s_"))
+def test_pinv_golden_regression(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    Xi, ld = O.inv_logdet(z["S"])
+    assert np.linalg.matrix_rank(Xi) == int(z["rank"]) and rel(Xi, z["Xi"]) < 1e-9 and abs(ld - float(z["logdet"])) < 1e-9
