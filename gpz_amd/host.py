@@ -36,11 +36,21 @@ def _legal(v):
 
 def _amax(v):
     """max(abs(v)) for a host array or a device vector."""
-    return v.amax() if isinstance(v, DevVec) else float(np.max(np.abs(v)))
+    return v.amax() if isinstance(v, (DevVec, _Scaled)) else float(np.max(np.abs(v)))
 
 
 def _asum(v):
     return v.asum() if isinstance(v, DevVec) else float(np.sum(np.abs(v)))
+
+
+class _Scaled:
+    """The product t*d of a scalar and a device vector, kept symbolic."""
+
+    def __init__(self, a, v):
+        self.a, self.v = a, v
+
+    def amax(self):
+        return abs(self.a) * self.v.amax()
 
 
 class DevVec:
@@ -53,6 +63,7 @@ class DevVec:
 
     def __init__(self, t):
         self.t = t
+        self._own = None        # [., max|v|, sum|v|, .] of this vector, computed once (vectors are never modified in place)
 
     @staticmethod
     def from_host(a, device=0):
@@ -75,25 +86,45 @@ class DevVec:
         return out
 
     def __matmul__(self, other):
-        return float(self._stats(other)[0])
+        st = self._stats(other)                 # one kernel gives g'd and the maxima of both vectors
+        if self._own is None:
+            self._own = tuple(st)
+        return float(st[0])
+
+    def _self_stats(self):
+        if self._own is None:
+            self._own = tuple(self._stats())
+        return self._own
 
     def amax(self):
-        return float(self._stats()[1])
+        return float(self._self_stats()[1])
 
     def asum(self):
-        return float(self._stats()[2])
+        return float(self._self_stats()[2])
 
     def legal(self):
-        return bool(np.isfinite(self._stats()[1]))
+        return bool(np.isfinite(self._self_stats()[1]))
 
     def __rmul__(self, a):
-        return DevVec(self.t * float(a))
+        return _Scaled(float(a), self)          # t*d is only ever added to x or measured: no kernel, no temporary
 
     def __add__(self, other):
-        return DevVec(self.t + other.t)
+        """x + t*d in one kernel of the library (gpz_vec_axpy)."""
+        import torch
+        from . import _lib
+        a, v = (other.a, other.v) if isinstance(other, _Scaled) else (1.0, other)
+        out = torch.empty_like(self.t)
+        _lib.check_plain(_lib.load().gpz_vec_axpy(out.data_ptr(), self.t.data_ptr(), a, v.t.data_ptr(), self.t.numel(),
+                                                  self.t.device.index or 0, None))
+        return DevVec(out)
 
     def __neg__(self):
-        return DevVec(-self.t)
+        import torch
+        from . import _lib
+        out = torch.empty_like(self.t)          # 0*x - 1*x written as x + (-2)*x
+        _lib.check_plain(_lib.load().gpz_vec_axpy(out.data_ptr(), self.t.data_ptr(), -2.0, self.t.data_ptr(),
+                                                  self.t.numel(), self.t.device.index or 0, None))
+        return DevVec(out)
 
     def copy(self):
         return DevVec(self.t.clone())
