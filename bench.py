@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
-    ap.add_argument("--n", type=int, default=None, help="override the row count (debug)")
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="override the row count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
