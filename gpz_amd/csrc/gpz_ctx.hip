@@ -185,6 +185,7 @@ struct gpz_ctx {
     bool gen = false;
     bool psi_fast = false;   // gen && Psi && no missing dims && d <= 10: register-resident kernels (k_psi.hip)
     bool psi32 = false;      // dtype f32 && gen && Psi && no missing dims: fp32 register-resident kernels (k_psi32.hip)
+    bool psi32_agreed = false;   // sharded runs: the ranks have agreed on diagonal vs full Psi (first evaluation)
     int ngroups = 0, nrec = 0;
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
     bool pats_fixed = false;                        // table given by the caller (sharded runs): rows must match an entry
@@ -661,6 +662,37 @@ static int allreduce(gpz_ctx *c, double *buf, size_t count) {
     return 0;
 }
 
+// Sharded fp32 runs: the diagonal-Psi kernels leave WHITENED moment records, the full-Psi kernels plain ones, and the
+// records are summed over ranks — so every rank must run the same form.  A rank whose own rows are all diagonal
+// switches to the full form (its diagonals expanded to packed triangles on the device) when any other rank needs it.
+static int psi32_agree(gpz_ctx *c) {
+    if (!c->psi32 || c->psi32_agreed || c->desc.world <= 1) return 0;
+    const double mine = (c->tr.psi_diag && (c->va.n_pad == 0 || c->va.psi_diag)) ? 0.0 : 1.0;
+    HIPCHK(hipMemcpyAsync(c->rstats, &mine, sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (int e = allreduce(c, c->rstats, 1)) return e;
+    double total = 0.0;
+    HIPCHK(hipMemcpyAsync(&total, c->rstats, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (total > 0.0) {
+        const int D = psi32_pad_dim(c->d);
+        for (RowSet *rs : {&c->tr, &c->va}) {
+            if (!rs->PsiT || !rs->psi_diag) continue;
+            float *full = nullptr;
+            const size_t np = (size_t)rs->n_pad;
+            if (int e = c->ar.alloc(&full, (size_t)D * (D + 1) / 2 * np)) return e;
+            HIPCHK(hipMemsetAsync(full, 0, (size_t)D * (D + 1) / 2 * np * sizeof(float), c->st));
+            for (int a = 0; a < D; ++a)   // diagonal a -> packed element (a, a)
+                HIPCHK(hipMemcpyAsync(full + ((size_t)a * (a + 1) / 2 + a) * np, rs->PsiT + (size_t)a * np, np * sizeof(float),
+                                      hipMemcpyDeviceToDevice, c->st));
+            rs->PsiT = full;
+            rs->psi_diag = 0;
+        }
+    }
+    c->psi32_agreed = true;
+    return 0;
+}
+
 // PHI, ln beta and omega*beta of the training row set from the unpacked parameters (getPHI.m:60-125, GPz.m:43-48).
 static int build_phi(gpz_ctx *c) {
     if (c->gen) {
@@ -707,6 +739,7 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
         if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
     }
+    if (int e = psi32_agree(c)) return e;
     if (int e = build_phi(c)) return e;
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
     {
@@ -820,7 +853,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                                      c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig,
                                      c->pr.Rc, nch, rpc, c->gen_slab, c->nrec);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
-                launch_psi32_records(c->st, c->psi32_raw, c->d, c->de, c->tr.psi_diag, c->pr.Rc, c->m, mom, c->nrec);
+                launch_psi32_records(c->st, c->psi32_raw, c->d, c->tr.psi_diag, c->m, mom, c->nrec);
                 continue;
             }
             if (c->gen && c->psi_fast) {
@@ -885,7 +918,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                                  (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig, c->pr.Rc, nch, rpc,
                                  c->gen_slab, c->nrec);
             launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
-            launch_psi32_records(c->st, c->psi32_raw, c->d, c->de, c->tr.psi_diag, c->pr.Rc, c->m, mom, c->nrec);
+            launch_psi32_records(c->st, c->psi32_raw, c->d, c->tr.psi_diag, c->m, mom, c->nrec);
         } else if (c->gen && c->psi_fast) {
             int nch = c->gen_nchunk;
             if (nch > c->tr.n) nch = c->tr.n;
@@ -964,7 +997,10 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         a.sums1 = c->comm1 + k * mp * mp; a.vsums = have_valid ? vsums : nullptr; a.info = c->info;
         a.out = c->out_d; a.dGfull = c->dGfull; a.p = (int)c->p; a.nmp = c->mp; a.de = c->de;
         a.psi = (c->has_psi && !c->gen) ? 1 : 0; a.gen = c->gen ? 1 : 0;
-        if (c->gen)
+        if (c->gen && c->psi32 && c->tr.psi_diag)   // whitened records: the stable chain through R (k_psi32.hip)
+            launch_psi32_finish(c->st, mom, c->m, c->d, c->de, c->pr.G, c->pr.Rc, c->mid, a.sums1, c->k, c->out_d + 1, c->dGfull,
+                                c->k == 1 ? cols : nullptr, c->mp, c->nrec);
+        else if (c->gen)
             launch_gen_finish(c->st, mom, c->ngroups, c->pat_d, c->m, c->d, c->de, c->pr.G, c->Sig, c->iSig, c->mid, a.sums1,
                               c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         launch_finish(c->st, a);

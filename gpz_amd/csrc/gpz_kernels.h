@@ -197,9 +197,12 @@ int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int l
 // Psi_i, element-major [e][ldp] (diag != 0: only the D diagonals), D = psi32_pad_dim(d).
 int psi32_pad_dim(int d);
 int psi32_raw_len(int d);   // doubles per (chunk, basis) the moment kernel writes: 3 + D + D(D+1)/2
-// chunk-summed raw sums [m][psi32_raw_len] -> records [m][nrec] in the layout of k_gen_moments (un-whitened when diag)
-void launch_psi32_records(hipStream_t st, const double *raw, int d, int de, int diag, const double *Rc, int m, double *recs,
-                          int nrec);
+// chunk-summed raw sums [m][psi32_raw_len] -> records [m][nrec]: the layout of k_gen_moments (diag = 0, consumed by
+// k_gen_finish) or whitened records (diag = 1, consumed by launch_psi32_finish: dP = R'a, dGamma = -Q C~' R^-T)
+void launch_psi32_records(hipStream_t st, const double *raw, int d, int diag, int m, double *recs, int nrec);
+void launch_psi32_finish(hipStream_t st, const double *recs, int m, int d, int de, const double *Gam, const double *Rc,
+                         int method_id, const double *sums1, int k, double *grad, double *dGfull, double *cols, int mp,
+                         int nrec);
 int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
                      const double *P, const double *Sig, const double *Rc, const double *lnS, double *Phi, int ld);
 int launch_psi32_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,

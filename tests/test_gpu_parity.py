@@ -709,3 +709,37 @@ def test_pinv_golden_through_c_abi(name):
     r = int(z["rank"])
     assert info == z["S"].shape[0] - r and abs(ld - float(z["logdet"])) <= 1e-10 * max(1.0, abs(float(z["logdet"])))
     assert rel(Xi, z["Xi"]) <= 1e3 * (s[0] / s[r - 1]) * 2.2e-16
+
+
+def test_f32_whitened_gradient_is_stable_for_ill_conditioned_gamma():
+    """dtype = f32 with diagonal Psi: dGamma_j is chained through the QR factor of Gamma_j (dGamma = -Q C~' R^-T), not through
+    Sigma_j = inv(Gamma_j'Gamma_j) twice as GPz.m:174-180 does.  For a basis function with cond(Gamma_j'Gamma_j) = 1e10 the
+    reference chain (oracle and fp64 general kernels alike) has no correct digit left; central differences of the objective
+    are the judge."""
+    n, d, m = 300, 8, 6
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VC", True, seed=131)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    g0 = m * d
+    G = theta[g0:g0 + d * d * m].reshape((d, d, m), order="F")
+    U, _ = np.linalg.qr(rng.standard_normal((d, d))); V, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    G[:, :, 2] = U @ np.diag(np.logspace(0, -5, d) * 0.5) @ V.T          # cond(Gamma'Gamma) = 1e10
+    theta[g0:g0 + d * d * m] = G.ravel(order="F")
+    Psi = np.zeros((d, d, n)); Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.2, (d, n))
+    ref = O.GPz(theta, model, X, Y, Psi)
+    c32 = gpz_amd.GPzContext(model, X, Y, Psi, dtype="f32"); f32, g32 = c32.eval(theta); c32.close()
+    c64 = gpz_amd.GPzContext(model, X, Y, Psi)
+    assert abs(f32 - ref.nlogML) <= 1e-5 * abs(ref.nlogML)
+    blk = slice(g0 + d * d * 2, g0 + d * d * 3)                           # the entries of Gamma_2
+    gmax = np.abs(ref.grad).max()
+    worst32 = worst_ref = 0.0
+    for trial in range(6):
+        v = np.zeros(theta.size); v[blk] = rng.standard_normal(d * d); v /= np.linalg.norm(v)
+        h = 1e-5
+        fd = (c64.eval(theta + h * v)[0] - c64.eval(theta - h * v)[0]) / (2 * h)
+        worst32 = max(worst32, abs(g32 @ v - fd) / gmax)
+        worst_ref = max(worst_ref, abs(ref.grad @ v - fd) / gmax)
+    c64.close()
+    assert worst32 <= 2e-3, (worst32, worst_ref)
+    # everything outside the ill-conditioned block agrees with the oracle at the fp32 tolerance
+    keep = np.ones(theta.size, dtype=bool); keep[blk] = False
+    assert np.abs(g32[keep] - ref.grad[keep]).max() / gmax <= F32_GTOL
