@@ -417,7 +417,15 @@ def test_c4_shape_against_oracle_subsample():
 
 
 # ---- sharded evaluation: two ranks on one GPU (gloo moves the CUDA buffers; RCCL needs distinct devices) ----
-def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0):
+def _mixed_psi(Psi, n):
+    """First half of the rows: diagonal Psi_i; second half: full cubes — so one shard is all-diagonal, the other is not."""
+    P = Psi.copy()
+    for i in range(n // 2):
+        P[:, :, i] = np.diag(np.diag(P[:, :, i]))
+    return P
+
+
+def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0, dtype="f64"):
     import os
     import torch
     import torch.distributed as dist
@@ -427,6 +435,9 @@ def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=psi, nanfrac=nanfrac)
+    if dtype == "f32":
+        theta = _well_conditioned_gamma(model, theta, rng)
+        Psi = _mixed_psi(Psi, 3001)
     r2 = np.random.default_rng(1)
     om = r2.random((3001, 1)) + 0.5
     tr = r2.random(3001) < 0.8
@@ -434,7 +445,7 @@ def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0):
     Xs, Ys, oms, trs, vas = gdist.shard_rows(rank, world, X, Y, om, tr, va)
     pats = gdist.nan_patterns(X, tr, va) if nanfrac > 0 else None     # the whole data set's table, same on every rank
     ctx = gpz_amd.GPzContext(model, Xs, Ys, gdist.shard_psi(rank, world, Psi, tr, va), oms, trs, vas, rank=rank,
-                             world=world, allreduce=gdist.make_allreduce(), patterns=pats)
+                             world=world, allreduce=gdist.make_allreduce(), patterns=pats, dtype=dtype)
     f, g = ctx.eval(theta)
     w, iS, part = ctx.solve(theta)
     q.put((rank, f, g, dict(ctx.stats), w, part, ctx.n_global))
@@ -743,3 +754,30 @@ def test_f32_whitened_gradient_is_stable_for_ill_conditioned_gamma():
     # everything outside the ill-conditioned block agrees with the oracle at the fp32 tolerance
     keep = np.ones(theta.size, dtype=bool); keep[blk] = False
     assert np.abs(g32[keep] - ref.grad[keep]).max() / gmax <= F32_GTOL
+
+
+def test_sharded_f32_ranks_agree_on_the_psi_form():
+    """dtype = f32 over two ranks where one rank's rows have diagonal Psi_i only and the other's do not: the diagonal
+    kernels leave whitened records, the full ones plain records, and they are summed over ranks — the all-diagonal rank
+    must switch to the full form (psi32_agree)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q, True, 0.0, "f32")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    model, theta, X, Y, Psi, rng = make_problem(3001, 6, 40, 2, "VC", True, seed=33, psi=True)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    Psi = _mixed_psi(Psi, 3001)
+    r2 = np.random.default_rng(1)
+    om = r2.random((3001, 1)) + 0.5
+    tr = r2.random(3001) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    for rank, f, g, stats, w, part, n_global in res:
+        assert abs(f - ref.nlogML) <= F32_FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= F32_GTOL
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
