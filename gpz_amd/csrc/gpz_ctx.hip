@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,8 @@ struct RowSet {          // a device-resident row selection of the data
     double *ucnt = nullptr;                    // number of missing dimensions per row
     // covariance kinds, general path (Psi cube and/or missing dimensions)
     int *gid = nullptr, *rows_by_group = nullptr;
+    int *orig = nullptr;                       // GC/VC general path: rows are stored sorted by NaN pattern; orig[r] = position of
+    std::vector<int> orig_h;                   // stored row r in the caller's row order (device / host copy)
     double *Psi3 = nullptr;                    // n_pad x d*d
     float *PsiT = nullptr;                     // dtype f32: packed lower triangles, element-major [e][n_pad] (k_psi32.hip)
     int psi_diag = 0;                          // every Psi_i of this row set is diagonal: PsiT holds only the diagonals
@@ -232,8 +235,34 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
     idx.reserve((size_t)n_tot);
     for (int64_t i = 0; i < n_tot; ++i)
         if (!mask || mask[i]) idx.push_back(i);                            // X(selection,:)  getPHI.m:14
+    if (c->gen) {
+        // Group the rows by NaN pattern up front (ids in first-occurrence order over the rows seen so far, getPHI.m:43-54)
+        // and store them sorted by pattern: every pattern is then a contiguous row range that the tuned kernels can
+        // work on.  Sums over rows do not care about the order; per-row outputs are un-permuted on the way out.
+        std::vector<int> hg0(idx.size());
+        for (size_t r = 0; r < idx.size(); ++r) {
+            std::vector<unsigned char> pt(d);
+            for (int c_ = 0; c_ < d; ++c_) { const double xv = X[(size_t)c_ * n_tot + idx[r]]; pt[c_] = (xv != xv) ? 0 : 1; }
+            int g = -1;
+            for (size_t q = 0; q < c->pats.size(); ++q)
+                if (c->pats[q] == pt) { g = (int)q; break; }
+            if (g < 0) {
+                if (c->pats_fixed) return fail(GPZ_ERR_ARG, "row %lld has a NaN pattern that is not in the given pattern table", (long long)idx[r]);
+                c->pats.push_back(pt);
+                g = (int)c->pats.size() - 1;
+            }
+            hg0[r] = g;
+        }
+        std::vector<int> ord(idx.size());
+        for (size_t r = 0; r < idx.size(); ++r) ord[r] = (int)r;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hg0[a] < hg0[b]; });
+        std::vector<int64_t> idx2(idx.size());
+        rs.orig_h.resize(idx.size());
+        for (size_t r = 0; r < idx.size(); ++r) { idx2[r] = idx[ord[r]]; rs.orig_h[r] = ord[r]; }
+        idx.swap(idx2);
+    }
     rs.n = (int)idx.size();
-    rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 1024);   // multiple of the PHI kernel's rows per workgroup (4 waves x 64 lanes x 4 rows)
+    rs.n_pad = rup(rs.n > 0 ? rs.n : 1, 1024) + (c->gen ? 1024 : 0);   // general path: slack for per-pattern launches of the tuned kernels   // multiple of the PHI kernel's rows per workgroup (4 waves x 64 lanes x 4 rows)
     const size_t np = (size_t)rs.n_pad;
     // column-layout (de x n_pad) and row-layout (n_pad x de) uploads of a per-(row, dim) quantity
     auto up2 = [&](const std::vector<double> &cm, double **dc, double **dr, bool want_r) -> int {
@@ -279,13 +308,11 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
             int g = -1;
             for (size_t q = 0; q < c->pats.size(); ++q)
                 if (c->pats[q] == pt) { g = (int)q; break; }
-            if (g < 0) {
-                if (c->pats_fixed) return fail(GPZ_ERR_ARG, "row %lld has a NaN pattern that is not in the given pattern table", (long long)idx[r]);
-                c->pats.push_back(pt);
-                g = (int)c->pats.size() - 1;
-            }
+            if (g < 0) return fail(GPZ_ERR_ARG, "internal: pattern table changed during the upload");
             hg[r] = g;
         }
+        if (int e = c->ar.alloc(&rs.orig, idx.size() ? idx.size() : 1)) return e;
+        if (!idx.empty()) HIPCHK(hipMemcpy(rs.orig, rs.orig_h.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
         if (int e = c->ar.alloc(&rs.gid, np)) return e;
         HIPCHK(hipMemcpy(rs.gid, hg.data(), np * sizeof(int), hipMemcpyHostToDevice));
         const int G = (int)c->pats.size();
@@ -1134,7 +1161,7 @@ extern "C" int gpz_get_phi(gpz_ctx *c, double *PHI) {
     HIPCHK(hipSetDevice(c->device));
     double *tmp = nullptr;
     HIPCHK(hipMalloc((void **)&tmp, (size_t)c->tr.n * c->m * sizeof(double)));
-    launch_transpose_out(c->st, c->Phi, c->mp, c->tr.n, c->m, tmp);
+    launch_transpose_out(c->st, c->Phi, c->mp, c->tr.n, c->m, tmp, c->tr.orig);
     hipError_t e = hipMemcpyAsync(PHI, tmp, (size_t)c->tr.n * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st);
     if (e == hipSuccess) e = hipStreamSynchronize(c->st);
     (void)hipFree(tmp);
@@ -1178,7 +1205,7 @@ extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *
     double *tmp = nullptr, *nd = nullptr;
     if (!rc && (PHI || N)) rc = c->ar.alloc(&tmp, (size_t)ns * c->m);
     if (!rc && PHI) {
-        launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp);
+        launch_transpose_out(c->st, c->Phi, c->mp, ns, c->m, tmp, c->tr.orig);
         if (hipMemcpyAsync(PHI, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
             rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
     }
@@ -1190,7 +1217,7 @@ extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *
             a.gen = c->gen ? 1 : 0; a.G = c->pr.G; a.Rc = c->pr.Rc; a.Mr = c->tr.Mr; a.ucnt = c->tr.ucnt;
             a.gid = c->tr.gid; a.pat = c->pat_d; a.lnS = c->lnS; a.N = nd;
             launch_phi_norm(c->st, a);
-            launch_transpose_out(c->st, nd, c->mp, ns, c->m, tmp);
+            launch_transpose_out(c->st, nd, c->mp, ns, c->m, tmp, c->tr.orig);
             if (hipMemcpyAsync(N, tmp, (size_t)ns * c->m * sizeof(double), hipMemcpyDeviceToHost, c->st) != hipSuccess)
                 rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
         }
@@ -1201,6 +1228,14 @@ extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *
             rc = fail(GPZ_ERR_HIP, "gpz_phi: copy failed");
     }
     if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_phi: sync failed");
+    if (!rc && lnBeta_i && !c->tr.orig_h.empty()) {   // rows are stored sorted by NaN pattern: back to the caller's order
+        std::vector<double> t((size_t)ns);
+        for (int o = 0; o < c->k; ++o) {
+            double *col = lnBeta_i + (size_t)o * ns;
+            for (int64_t r = 0; r < ns; ++r) t[(size_t)c->tr.orig_h[(size_t)r]] = col[r];
+            memcpy(col, t.data(), (size_t)ns * sizeof(double));
+        }
+    }
     free_eval_ctx(c);
     return rc;
 }

@@ -263,5 +263,6 @@ void launch_phi_norm(hipStream_t st, const NormArgs &a);
 
 // misc
 void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long ny, int d, double *D);
-void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst /* n x m col-major */);
+void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst /* n x m col-major */,
+                          const int *perm = nullptr /* source row i -> destination row perm[i] */);
 void launch_nu(hipStream_t st, const double *Phi, const double *T, int ld, int n, int m, double *nu);

@@ -858,8 +858,9 @@ void launch_dxy(hipStream_t st, const double *X, long nx, const double *Y, long 
 }
 
 // dst (n x m column-major) = src (row-major, leading dimension ld), tiled through LDS.
+// perm (optional): source row i goes to destination row perm[i].
 __global__ __launch_bounds__(256) void k_transpose_out(const double *__restrict__ src, int ld, long n, int m,
-                                                        double *__restrict__ dst) {
+                                                        double *__restrict__ dst, const int *__restrict__ perm) {
     __shared__ double t[32][33];
     const long i0 = (long)blockIdx.x * 32;
     const int j0 = blockIdx.y * 32;
@@ -873,13 +874,13 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double *__restrict_
     for (int r = ty; r < 32; r += 8) {
         const int j = j0 + r;
         const long i = i0 + tx;
-        if (i < n && j < m) dst[(size_t)j * n + i] = t[tx][r];
+        if (i < n && j < m) dst[(size_t)j * n + (perm ? perm[i] : i)] = t[tx][r];
     }
 }
 
-void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst) {
+void launch_transpose_out(hipStream_t st, const double *src, int ld, long n, int m, double *dst, const int *perm) {
     hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, st, src,
-                       ld, n, m, dst);
+                       ld, n, m, dst, perm);
 }
 
 // nu_i = sum_j PHI_ij T_ij, one wave per row (predictDiag.m:69-71).
