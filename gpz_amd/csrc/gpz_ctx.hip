@@ -194,6 +194,9 @@ struct gpz_ctx {
     bool pats_fixed = false;                        // table given by the caller (sharded runs): rows must match an entry
     unsigned char *pat_d = nullptr;
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
+    // missing dimensions without input noise: per-pattern parameter blocks and moment slabs of the tuned kernels
+    double *RcP = nullptr, *gen_tslab = nullptr, *gen_frec = nullptr, *fin_part = nullptr;
+    int gen_tnch = 1;
     int gen_nchunk = 1;
 };
 
@@ -509,6 +512,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         if ((rc = c->ar.alloc(&c->Sig, (size_t)c->m * c->d * c->d))) return rc;
         if ((rc = c->ar.alloc(&c->iSig, (size_t)c->m * c->d * c->d))) return rc;
         if ((rc = c->ar.alloc(&c->lnS, (size_t)c->ngroups * c->m))) return rc;
+        if (!c->has_psi &&
+            (rc = c->ar.alloc(&c->RcP, (size_t)c->ngroups * c->m * (c->de * (c->de + 1) / 2 + c->de))))
+            return rc;
     }
     return alloc_params(c);
 }
@@ -541,6 +547,14 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         const size_t per = (c->psi32 && psi32_raw_len(c->d) > c->nrec) ? (size_t)psi32_raw_len(c->d) : (size_t)c->nrec;
         if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * per))) return bail(rc);
         if (c->psi32 && (rc = c->ar.alloc(&c->psi32_raw, (size_t)c->m * psi32_raw_len(c->d)))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->fin_part, (size_t)c->ngroups * c->m * (c->d + c->d * c->d + 2)))) return bail(rc);
+        if (!c->has_psi) {
+            const int nmt = c->de + c->de * (c->de + 1) / 2;
+            c->gen_tnch = 2048 / ((c->m + 255) / 256);
+            if (c->gen_tnch < 1) c->gen_tnch = 1;
+            if ((rc = c->ar.alloc(&c->gen_tslab, (size_t)c->gen_tnch * c->m * (nmt + 2)))) return bail(rc);
+            if ((rc = c->ar.alloc(&c->gen_frec, (size_t)c->ngroups * c->m * (nmt + 2)))) return bail(rc);
+        }
         if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
     }
     if ((rc = alloc_mm(c))) return bail(rc);
@@ -720,11 +734,83 @@ static int psi32_agree(gpz_ctx *c) {
     return 0;
 }
 
+// GC/VC with missing dimensions and no input noise: the rows of every NaN pattern (stored contiguously) go through the
+// tuned PHI kernel with that pattern's parameter block (k_gen_pattern_params).  Launches run in row order on one
+// stream: a launch zero-fills up to the end of its last 1024-row block, the next pattern's launch rewrites those rows.
+static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, double *wbeta, const double *w, double *phiw,
+                          bool with_y) {
+    const size_t np = (size_t)rs.n_pad, mp = (size_t)c->mp;
+    const int de = c->de, npar = de * (de + 1) / 2 + de;
+    const size_t tail = np - (size_t)rs.n;   // rows past the data: zero (the slack block is never written otherwise)
+    if (Phi) HIPCHK(hipMemsetAsync(Phi + (size_t)rs.n * mp, 0, tail * mp * sizeof(double), c->st));
+    for (int o = 0; o < c->k; ++o) {
+        HIPCHK(hipMemsetAsync(lnbeta + (size_t)o * np + rs.n, 0, tail * sizeof(double), c->st));
+        if (wbeta) HIPCHK(hipMemsetAsync(wbeta + (size_t)o * np + rs.n, 0, tail * sizeof(double), c->st));
+        if (phiw) HIPCHK(hipMemsetAsync(phiw + (size_t)o * np + rs.n, 0, tail * sizeof(double), c->st));
+    }
+    for (int g = 0; g < c->ngroups; ++g) {
+        const int rb = rs.group_begin[g], nr = rs.group_begin[g + 1] - rb;
+        if (nr <= 0) continue;
+        PhiArgs a{};
+        a.Xc = rs.Xc + rb; a.ldx = (long)np; a.n = nr; a.n_pad = rup(nr, 1024);
+        a.m = c->m; a.mp = c->mp; a.d = de; a.k = c->k; a.kind = GPZ_KIND_COV;
+        a.P = c->pr.P; a.G = c->RcP + (size_t)g * c->m * npar;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b;
+        a.omega = rs.om ? rs.om + rb : nullptr;
+        a.Y = (with_y && rs.Y) ? rs.Y + rb : nullptr;
+        a.Phi = Phi ? Phi + (size_t)rb * mp : nullptr;
+        a.lnbeta = lnbeta + rb; a.wbeta = wbeta ? wbeta + rb : nullptr;
+        a.w = w; a.phiw = phiw ? phiw + rb : nullptr;
+        a.part = nullptr; a.part_groups = 0;
+        if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", de);
+    }
+    return 0;
+}
+
+// dP/dGamma moment records of every pattern through the tuned moment kernels (fused: single output, dPHI formed on
+// the fly; plain: dPHI already in T), converted to the records k_gen_finish chains (k_gen_convert_moments).
+static int moments_by_pattern(gpz_ctx *c, bool fused, double *mom) {
+    const int de = c->de, nmt = de + de * (de + 1) / 2, stride = fused ? nmt + 2 : nmt;
+    const size_t mp = (size_t)c->mp, m = (size_t)c->m;
+    for (int g = 0; g < c->ngroups; ++g) {
+        const int rb = c->tr.group_begin[g], nr = c->tr.group_begin[g + 1] - rb;
+        double *frec_g = c->gen_frec + (size_t)g * m * stride;
+        if (nr <= 0) { launch_zero(c->st, frec_g, m * stride); continue; }
+        int nch = c->gen_tnch;
+        const int cap = nr / 32 > 0 ? nr / 32 : 1;
+        if (nch > cap) nch = cap;
+        const int rpc = (nr + nch - 1) / nch;
+        nch = (nr + rpc - 1) / rpc;
+        if (fused) {
+            FusedMomentArgs a{};
+            a.Phi = c->Phi + (size_t)rb * mp; a.T = c->T + (size_t)rb * mp; a.ld = c->mp;
+            a.Xr = c->tr.Xr + (size_t)rb * de; a.rowscal = c->rowscal + (size_t)rb * 4;
+            a.n = nr; a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.w = c->w;
+            a.v = c->hetero ? c->pr.v : nullptr; a.nchunk = nch; a.rows_per_chunk = rpc; a.slab = c->gen_tslab; a.nm = nmt;
+            if (launch_moments_fused(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", de);
+        } else {
+            MomentArgs a{};
+            a.dPhi = c->T + (size_t)rb * mp; a.ld = c->mp; a.Xr = c->tr.Xr + (size_t)rb * de; a.n = nr; a.n_pad = rup(nr, 1024);
+            a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.nchunk = nch; a.rows_per_chunk = rpc;
+            a.slab = c->gen_tslab; a.nm = nmt;
+            if (launch_moments(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", de);
+        }
+        launch_slab_sum(c->st, c->gen_tslab, nch, m * stride, frec_g);
+    }
+    launch_gen_convert_moments(c->st, c->gen_frec, stride, fused ? 1 : 0, c->Sig, c->pat_d, c->ngroups, c->m, c->d, de, mom,
+                               c->nrec);
+    return 0;
+}
+
 // PHI, ln beta and omega*beta of the training row set from the unpacked parameters (getPHI.m:60-125, GPz.m:43-48).
 static int build_phi(gpz_ctx *c) {
     if (c->gen) {
         Stage s(c, "phi_build");
         launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+        if (!c->has_psi) {   // missing dimensions only: tuned kernels, one launch per NaN pattern
+            launch_gen_pattern_params(c->st, c->Sig, c->pr.P, c->pat_d, c->ngroups, c->m, c->d, c->de, c->RcP);
+            return phi_by_pattern(c, c->tr, c->Phi, c->lnbeta, c->wbeta, nullptr, nullptr, true);
+        }
         if (c->psi32) {
             launch_psi32_phi(c->st, c->tr.Xr, c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m,
                              c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi, c->mp);
@@ -873,6 +959,10 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");
+            if (c->gen && !c->has_psi) {
+                if (int e = moments_by_pattern(c, true, mom)) return e;
+                continue;
+            }
             if (c->gen && c->psi32) {
                 int nch, rpc;
                 psi32_chunks(c, &nch, &rpc);
@@ -938,7 +1028,9 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);
         }
         Stage s(c, "moments");
-        if (c->gen && c->psi32) {
+        if (c->gen && !c->has_psi) {
+            if (int e = moments_by_pattern(c, false, mom)) return e;
+        } else if (c->gen && c->psi32) {
             int nch, rpc;
             psi32_chunks(c, &nch, &rpc);
             launch_psi32_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, c->tr.Xr, c->de, c->d, c->tr.PsiT,
@@ -979,7 +1071,12 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         }
     }
     const bool have_valid = c->va.n_pad > 0;
-    if (have_valid && c->gen) {
+    if (have_valid && c->gen && !c->has_psi) {
+        Stage s(c, "validation");
+        if (int e = phi_by_pattern(c, c->va, nullptr, c->lnbeta_v, nullptr, c->w, c->phiw_v, false)) return e;
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+    } else if (have_valid && c->gen) {
         Stage s(c, "validation");
         if (c->psi32) {
             launch_psi32_phi(c->st, c->va.Xr, c->de, c->d, c->va.PsiT, (long)c->va.n_pad, c->va.psi_diag, c->va.n, c->m,
@@ -1029,7 +1126,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                                 c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         else if (c->gen)
             launch_gen_finish(c->st, mom, c->ngroups, c->pat_d, c->m, c->d, c->de, c->pr.G, c->Sig, c->iSig, c->mid, a.sums1,
-                              c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec);
+                              c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec, c->fin_part);
         launch_finish(c->st, a);
     }
     if (c->g_dev_out) {   // gpz_eval_dev: the gradient stays on the device, only f and the statistics block come up

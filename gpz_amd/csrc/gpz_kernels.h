@@ -183,6 +183,13 @@ struct GenRows {
 };
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
                      const unsigned char *pat, int ngroups, double *lnS);
+// missing dimensions without input noise: per-pattern parameter block for the tuned PHI kernel ([R~ | c~], layout of
+// k_prep_cov) and conversion of the tuned moment sums of a pattern into the records k_gen_finish consumes
+void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *P, const unsigned char *pat, int G, int m,
+                               int d, int de, double *RcAll /* G blocks of m*(nt+de) */);
+void launch_gen_convert_moments(hipStream_t st, const double *frecAll /* [G][m][stride] */, int stride, int has_r,
+                                const double *Sig, const unsigned char *pat, int G, int m, int d, int de,
+                                double *recsAll /* [G][m][nrec] */, int nrec);
 void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
                     const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y);
 void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y);
@@ -218,7 +225,8 @@ void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int 
                         int nrec);
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
-                       double *grad, double *dGfull, double *cols, int mp, int nrec);
+                       double *grad, double *dGfull, double *cols, int mp, int nrec,
+                       double *part /* G*m*(d + d*d + 2) doubles of scratch */);
 
 // prediction with input noise (predictDiag.m:75-125 / predictCov.m:70-132) and the getPrior iteration (getPrior.m:7-20)
 void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,

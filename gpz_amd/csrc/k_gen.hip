@@ -248,16 +248,14 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
 
 // Chain the per-(pattern, basis) records to dP, dGamma (GPz.m:151-159,174-181) and the column sums.
 // recs: [G][m][nrec] reduced over chunks.  Writes grad dP (scaled), dGamma into grad (VC) or dGfull (GC), cols[2][mp].
+// One thread per (basis, pattern): the pattern's contribution [dP (d) | dGamma (d x d) | r1 | r2] goes to
+// part[(g*m + j)*(d + d*d + 2)]; k_gen_finish_sum adds the patterns up in fixed order and writes the gradient blocks.
 __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ recs, int G,
                                                     const unsigned char *__restrict__ pat, int m, int d, int de,
                                                     const double *__restrict__ Gam, const double *__restrict__ Sig,
-                                                    const double *__restrict__ iSig, int method_id,
-                                                    const double *__restrict__ sums1, int k, double *__restrict__ grad,
-                                                    double *__restrict__ dGfull, double *__restrict__ cols, int mp,
-                                                    int nrec) {
+                                                    const double *__restrict__ iSig, double *__restrict__ part, int nrec) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const double nk = sums1[10] * (double)k;
     double dP[GDM], dG[GDM * GDM];
     for (int c = 0; c < d; ++c) dP[c] = 0.0;
     for (int e = 0; e < d * GDM; ++e) dG[e] = 0.0;
@@ -265,7 +263,8 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
     const double *Sj = Sig + (size_t)j * d * d, *iSj = iSig + (size_t)j * d * d;
     const double *Gj = Gam + (size_t)j * de * de;
     double Soo[GDM * GDM], W[GDM * GDM], Sinv[GDM * GDM], dS[GDM * GDM], tmp[GDM * GDM], Kuo[GDM * GDM], Aeff[GDM * GDM];
-    for (int g = 0; g < G; ++g) {
+    {
+        const int g = blockIdx.y;
         const double *rec = recs + ((size_t)g * m + j) * nrec;
         int o[GDM], uix[GDM], no = 0, nu = 0;
         for (int c = 0; c < d; ++c) {
@@ -332,17 +331,32 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
             }
         }
     }
-    const int md = m * d;
-    for (int c = 0; c < d; ++c) grad[j + m * c] = -dP[c] / nk;
+    double *o = part + ((size_t)blockIdx.y * m + j) * (d + d * d + 2);
+    for (int c = 0; c < d; ++c) o[c] = dP[c];
     for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) {
-            const double val = dG[a * GDM + b];
-            if (method_id == 5) grad[md + a + d * b + d * d * j] = -val / nk;
-            else dGfull[(size_t)j * d * d + a * d + b] = val;
+        for (int b = 0; b < d; ++b) o[d + a * d + b] = dG[a * GDM + b];
+    o[d + d * d] = r1;
+    o[d + d * d + 1] = r2;
+}
+
+__global__ void k_gen_finish_sum(const double *__restrict__ part, int G, int m, int d, int method_id,
+                                 const double *__restrict__ sums1, int k, double *__restrict__ grad,
+                                 double *__restrict__ dGfull, double *__restrict__ cols, int mp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double nk = sums1[10] * (double)k;
+    const int md = m * d, np = d + d * d + 2;
+    for (int e = 0; e < np; ++e) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += part[((size_t)g * m + j) * np + e];
+        if (e < d) grad[j + m * e] = -s / nk;
+        else if (e < d + d * d) {
+            const int a = (e - d) / d, b = (e - d) % d;
+            if (method_id == 5) grad[md + a + d * b + d * d * j] = -s / nk;
+            else dGfull[(size_t)j * d * d + a * d + b] = s;
+        } else if (cols) {
+            cols[(e == d + d * d ? 0 : mp) + j] = s;
         }
-    if (cols) {
-        cols[j] = r1;
-        cols[mp + j] = r2;
     }
 }
 
@@ -602,6 +616,105 @@ void launch_phi_norm(hipStream_t st, const NormArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Missing dimensions WITHOUT input noise: M = Sigma_j,oo does not depend on the row, so each (pattern, basis) pair has
+// one triangular factor and the rows of a pattern (stored contiguously) run through the tuned kernels of k_phi.hip /
+// k_rows.hip with a pattern-specific parameter block:
+//     ln PHI_ij = -1/2 Delta_o' Sigma_oo^-1 Delta_o - 1/2 |u| ln 2 = -1/2 |R~ x - c~|^2          (getPHI.m:73-76)
+// R~ = upper Cholesky factor of Sigma_oo^-1 scattered into d x d (zero rows / columns at the missing dimensions),
+// c~ = R~ p_j, and the constant |u| ln 2 rides on the first missing dimension's (otherwise empty) row: c~[u0] = sqrt(|u| ln 2).
+// Output in the layout of k_prep_cov: [R~ packed upper, row a at a*de - a(a-1)/2 | c~ (de)] per basis function.
+__global__ void k_gen_pattern_params(const double *__restrict__ Sig, const double *__restrict__ P,
+                                     const unsigned char *__restrict__ pat, int m, int d, int de,
+                                     double *__restrict__ RcAll) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;                          // one parameter block of m*(nt+de) doubles per pattern
+    if (j >= m) return;
+    double *Rc = RcAll + (size_t)g * m * (de * (de + 1) / 2 + de);
+    int o[GDM], no = 0, u0 = -1;
+    for (int c = 0; c < d; ++c) {
+        if (pat[g * d + c]) o[no++] = c;
+        else if (u0 < 0) u0 = c;
+    }
+    double A[GDM * GDM], W[GDM * GDM], Ki[GDM * GDM];
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b < no; ++b) A[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
+    chol_small(A, no);
+    inv_from_chol(A, no, W, Ki);                       // Ki = Sigma_oo^-1
+    chol_small(Ki, no);                                // Ki = L L'  ->  R~ = L' (upper)
+    const int nt = de * (de + 1) / 2;
+    double *out = Rc + (size_t)j * (nt + de);
+    for (int e = 0; e < nt + de; ++e) out[e] = 0.0;
+    for (int a = 0; a < no; ++a) {
+        double cs = 0.0;
+        for (int b = a; b < no; ++b) {
+            const double r = Ki[b * GDM + a];          // R~[o_a][o_b] = L[b][a]
+            out[o[a] * de - o[a] * (o[a] - 1) / 2 + (o[b] - o[a])] = r;
+            cs = fma(r, P[(size_t)j * de + o[b]], cs);
+        }
+        out[nt + o[a]] = cs;
+    }
+    if (u0 >= 0) out[nt + u0] = sqrt((double)(d - no) * GPZ_LOG2);
+}
+
+// Tuned moment sums of one pattern, [m][nmt (+2)] = [M1 (de) | S packed upper (de(de+1)/2) | r1, r2], -> the records of
+// k_gen_moments for k_gen_finish:  acc1 = Sigma_oo^-1 M1_o,  cacc = Sigma_oo^-1 S_oo Sigma_oo^-1,  a0 = 0 (its two
+// occurrences in GPz.m:174 cancel without input noise).  Entries of missing dimensions are never read.
+__global__ void k_gen_convert_moments(const double *__restrict__ frecAll, int stride, int has_r,
+                                      const double *__restrict__ Sig, const unsigned char *__restrict__ pat, int m, int d,
+                                      int de, double *__restrict__ recsAll, int nrec) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;                          // [G][m][stride] in, [G][m][nrec] out
+    if (j >= m) return;
+    const double *frec = frecAll + (size_t)g * m * stride;
+    double *recs = recsAll + (size_t)g * m * nrec;
+    int o[GDM], no = 0;
+    for (int c = 0; c < d; ++c)
+        if (pat[g * d + c]) o[no++] = c;
+    double A[GDM * GDM], W[GDM * GDM], Ki[GDM * GDM], T1[GDM * GDM];
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b < no; ++b) A[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
+    chol_small(A, no);
+    inv_from_chol(A, no, W, Ki);
+    const double *f = frec + (size_t)j * stride;
+    auto S = [&](int a, int b) -> double {             // packed upper of the tuned kernels, symmetric
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        return f[de + lo * de - lo * (lo - 1) / 2 + (hi - lo)];
+    };
+    double *rec = recs + (size_t)j * nrec;
+    for (int e = 0; e < nrec; ++e) rec[e] = 0.0;
+    for (int a = 0; a < no; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < no; ++b) s = fma(Ki[a * GDM + b], f[o[b]], s);
+        rec[1 + o[a]] = s;
+    }
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b < no; ++b) {
+            double s = 0.0;
+            for (int q = 0; q < no; ++q) s = fma(Ki[a * GDM + q], S(o[q], o[b]), s);
+            T1[a * GDM + b] = s;
+        }
+    for (int a = 0; a < no; ++a)
+        for (int b = 0; b < no; ++b) {
+            double s = 0.0;
+            for (int q = 0; q < no; ++q) s = fma(T1[a * GDM + q], Ki[q * GDM + b], s);
+            rec[1 + d + o[a] * d + o[b]] = s;
+        }
+    if (has_r) {
+        rec[1 + d + d * d] = f[stride - 2];
+        rec[2 + d + d * d] = f[stride - 1];
+    }
+}
+
+void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *P, const unsigned char *pat, int G, int m,
+                               int d, int de, double *RcAll) {
+    hipLaunchKernelGGL(k_gen_pattern_params, dim3((m + 63) / 64, G), dim3(64), 0, st, Sig, P, pat, m, d, de, RcAll);
+}
+void launch_gen_convert_moments(hipStream_t st, const double *frecAll, int stride, int has_r, const double *Sig,
+                                const unsigned char *pat, int G, int m, int d, int de, double *recsAll, int nrec) {
+    hipLaunchKernelGGL(k_gen_convert_moments, dim3((m + 63) / 64, G), dim3(64), 0, st, frecAll, stride, has_r, Sig, pat, m, d,
+                       de, recsAll, nrec);
+}
+
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
                      const unsigned char *pat, int ngroups, double *lnS) {
     hipLaunchKernelGGL(k_gen_prep, dim3((m + 63) / 64), dim3(64), 0, st, G, m, d, de, Sig, iSig);
@@ -638,7 +751,8 @@ void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int 
 
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
-                       double *grad, double *dGfull, double *cols, int mp, int nrec) {
-    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, method_id,
-                       sums1, k, grad, dGfull, cols, mp, nrec);
+                       double *grad, double *dGfull, double *cols, int mp, int nrec, double *part) {
+    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64, G), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, part, nrec);
+    hipLaunchKernelGGL(k_gen_finish_sum, dim3((m + 63) / 64), dim3(64), 0, st, (const double *)part, G, m, d, method_id, sums1, k,
+                       grad, dGfull, cols, mp);
 }
