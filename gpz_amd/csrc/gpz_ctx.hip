@@ -456,17 +456,20 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     int rc = 0;
     if ((Psi != nullptr) != (psi_kind != 0)) return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree");
     const bool xnan = has_nan(X, n_tot * (int64_t)c->d) != 0;
-    if (c->kind == GPZ_KIND_COV && (Psi || xnan)) {
+    // a given pattern table means "the data set has missing values": every rank takes the general path then, also one
+    // whose own rows happen to be complete (the second all-reduce carries one record block per pattern)
+    const bool table = patterns && n_patterns > 0;
+    if (c->kind == GPZ_KIND_COV && (Psi || xnan || table)) {
         // general path: per-pair d x d factorisations (k_gen.hip)
         if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
         // the NaN-pattern table is built per rank in first-occurrence order: shards would disagree on the ids and on the
         // size of the second all-reduce, so a sharded run must be given the table of the whole data set
-        if (desc->world > 1 && xnan && !(patterns && n_patterns > 0))
+        if (desc->world > 1 && xnan && !table)
             return fail(GPZ_ERR_UNSUPPORTED, "row-sharded GC/VC with missing values needs the global NaN-pattern table "
                                              "(gpz_ctx_create_sharded)");
         if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
-        if (patterns && n_patterns > 0) {   // 1 = missing, as isnan(X) (getPHI.m:43); stored here as observed flags
+        if (table) {   // 1 = missing, as isnan(X) (getPHI.m:43); stored here as observed flags
             for (int g = 0; g < n_patterns; ++g) {
                 std::vector<unsigned char> pt((size_t)c->d);
                 for (int q = 0; q < c->d; ++q) pt[q] = patterns[(size_t)g * c->d + q] ? 0 : 1;
@@ -976,8 +979,11 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             if (c->gen && c->psi_fast) {
                 int nch = c->gen_nchunk;
                 if (nch > c->tr.n) nch = c->tr.n;
-                const int rpc = (c->tr.n + nch - 1) / nch;
+                if (nch < 1) nch = 1;   // a rank without training rows still writes its (zero) records
+                const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
                 nch = (c->tr.n + rpc - 1) / rpc;
+            if (nch < 1) nch = 1;
+                if (nch < 1) nch = 1;
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
                                    gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
@@ -1041,8 +1047,10 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         } else if (c->gen && c->psi_fast) {
             int nch = c->gen_nchunk;
             if (nch > c->tr.n) nch = c->tr.n;
-            const int rpc = (c->tr.n + nch - 1) / nch;
+            if (nch < 1) nch = 1;
+            const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
             nch = (c->tr.n + rpc - 1) / rpc;
+            if (nch < 1) nch = 1;
             launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
                                c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
             launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);

@@ -724,8 +724,9 @@ void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, doub
 
 void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
                     const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y) {
-    hipLaunchKernelGGL(k_gen_phi, dim3((r.n + 63) / 64), dim3(64), 0, st, r.Xr, de, r.gid, pat, r.Psi3, r.n, m, d, P, Sig, lnS,
-                       Phi, mp);
+    if (r.n > 0)   // a rank of a sharded run may hold no row of this set
+        hipLaunchKernelGGL(k_gen_phi, dim3((r.n + 63) / 64), dim3(64), 0, st, r.Xr, de, r.gid, pat, r.Psi3, r.n, m, d, P, Sig,
+                           lnS, Phi, mp);
     hipLaunchKernelGGL(k_gen_fill, dim3(1024), dim3(256), 0, st, Phi, mp, r.n, r.n_pad, m, mp, k, Y, (long)r.n_pad);
 }
 

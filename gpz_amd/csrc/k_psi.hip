@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
 // returns -1 when d is outside the instantiated range (caller falls back to the general kernels)
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                    const double *lnS, double *Phi, int ld) {
+    if (r.n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;   // a rank of a sharded run may hold no row of this set
 #define PHI_CASE(DD) \
     hipLaunchKernelGGL(k_psi_phi<DD>, dim3((r.n + 255) / 256), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, P, Sig, lnS, Phi, ld)
     PSI_CASES(PHI_CASE)

@@ -450,6 +450,7 @@ int psi32_pad_dim(int d) {
 int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
                      const double *P, const double *Sig, const double *Rc, const double *lnS, double *Phi, int ld) {
     const int Dp = psi32_pad_dim(d);
+    if (n <= 0) return Dp > 0 ? 0 : -1;   // a rank of a sharded run may hold no row of this set
     // split the basis functions over blockIdx.y until ~1024 workgroups exist (groups are multiples of the staging block)
     const int nrb = (n + 255) / 256;
     int ng = (1024 + nrb - 1) / nrb;

@@ -15,11 +15,9 @@ import numpy as np
 
 
 def shard_bounds(n, rank, world):
-    """Contiguous block [lo, hi) of rank ``rank`` out of ``world`` over n rows: ceil(n/world) rows per rank,
-    the last ranks may be short or empty."""
-    per = -(-n // world)
-    lo = min(n, rank * per)
-    return lo, min(n, lo + per)
+    """Contiguous block [lo, hi) of rank ``rank`` out of ``world`` over n rows: balanced blocks (sizes differ by at
+    most one row), so no rank is left empty as long as n >= world."""
+    return (rank * n) // world, ((rank + 1) * n) // world
 
 
 def shard_index(rank, world, n, training=None, validation=None):
@@ -27,6 +25,8 @@ def shard_index(rank, world, n, training=None, validation=None):
     rows followed by its block of the validation rows; also returns how many of them are training rows."""
     tr = np.ones(n, dtype=bool) if training is None else np.asarray(training, dtype=bool).ravel()
     idx_t = np.flatnonzero(tr)
+    if idx_t.size < world:
+        raise ValueError(f"{idx_t.size} training rows cannot be sharded over {world} ranks: every rank needs at least one")
     lo, hi = shard_bounds(idx_t.size, rank, world)
     keep = [idx_t[lo:hi]]
     if validation is not None:
