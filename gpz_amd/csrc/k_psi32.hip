@@ -376,41 +376,43 @@ __global__ __launch_bounds__(64) void k_psi32_finish(const double *__restrict__ 
                                                       double *__restrict__ grad, double *__restrict__ dGfull,
                                                       double *__restrict__ cols, int mp, int nrec) {
     constexpr int GD = 20;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
+    __shared__ double Y[GD * GD], Q[GD * GD];
+    const int j = blockIdx.x, t = threadIdx.x;                             // one workgroup per basis function
     const double nk = sums1[10] * (double)k;
     const double *rec = recs + (size_t)j * nrec;
     const double *Rj = Rc + (size_t)j * (de * (de + 1) / 2 + de);
     const double *Gj = Gam + (size_t)j * de * de;
     auto R = [&](int a, int b) -> double { return Rj[a * de - a * (a - 1) / 2 + (b - a)]; };   // b >= a
     const int md = m * d;
-    for (int c = 0; c < d; ++c) {                                          // dP = R' a~1      (GPz.m:172)
+    if (t < d) {                                                           // dP = R' a~1      (GPz.m:172)
         double s = 0.0;
-        for (int q = 0; q <= c; ++q) s = fma(R(q, c), rec[1 + q], s);
-        grad[j + m * c] = -s / nk;
+        for (int q = 0; q <= t; ++q) s = fma(R(q, t), rec[1 + q], s);
+        grad[j + m * t] = -s / nk;
     }
-    double Y[GD * GD], Q[GD * GD];
-    for (int r = 0; r < d; ++r)                                            // Y = C~' R^-T:  sum_b Y[r][b] R[c][b] = C[r][c]
+    if (t < d) {                                                           // row t of Y = C~' R^-T:  sum_b Y[t][b] R[c][b] = C[t][c]
         for (int c = d - 1; c >= 0; --c) {
-            double s = rec[1 + d + r * d + c];
-            for (int b = c + 1; b < d; ++b) s = fma(-Y[r * GD + b], R(c, b), s);
-            Y[r * GD + c] = s / R(c, c);
+            double s = rec[1 + d + t * d + c];
+            for (int b = c + 1; b < d; ++b) s = fma(-Y[t * GD + b], R(c, b), s);
+            Y[t * GD + c] = s / R(c, c);
         }
-    for (int a = 0; a < d; ++a)                                            // Q = Gamma R^-1:  sum_b Q[a][b] R[b][c] = Gamma[a][c]
+    } else if (t >= 32 && t < 32 + d) {                                    // row a of Q = Gamma R^-1:  sum_b Q[a][b] R[b][c] = Gamma[a][c]
+        const int a = t - 32;
         for (int c = 0; c < d; ++c) {
             double s = Gj[a * de + c];
             for (int b = 0; b < c; ++b) s = fma(-Q[a * GD + b], R(b, c), s);
             Q[a * GD + c] = s / R(c, c);
         }
-    for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) {
-            double s = 0.0;
-            for (int q = 0; q < d; ++q) s = fma(Q[a * GD + q], Y[q * GD + b], s);
-            const double val = -s;                                         // dGamma_j(a, b)
-            if (method_id == 5) grad[md + a + d * b + d * d * j] = -val / nk;
-            else dGfull[(size_t)j * d * d + a * d + b] = val;
-        }
-    if (cols) {
+    }
+    __syncthreads();
+    for (int e = t; e < d * d; e += 64) {
+        const int a = e / d, b = e % d;
+        double s = 0.0;
+        for (int q = 0; q < d; ++q) s = fma(Q[a * GD + q], Y[q * GD + b], s);
+        const double val = -s;                                             // dGamma_j(a, b)
+        if (method_id == 5) grad[md + a + d * b + d * d * j] = -val / nk;
+        else dGfull[(size_t)j * d * d + a * d + b] = val;
+    }
+    if (cols && t == 0) {
         cols[j] = rec[1 + d + d * d];
         cols[mp + j] = rec[2 + d + d * d];
     }
@@ -436,8 +438,8 @@ void launch_psi32_records(hipStream_t st, const double *raw, int d, int diag, in
 void launch_psi32_finish(hipStream_t st, const double *recs, int m, int d, int de, const double *Gam, const double *Rc,
                          int method_id, const double *sums1, int k, double *grad, double *dGfull, double *cols, int mp,
                          int nrec) {
-    hipLaunchKernelGGL(k_psi32_finish, dim3((m + 63) / 64), dim3(64), 0, st, recs, m, d, de, Gam, Rc, method_id, sums1, k, grad,
-                       dGfull, cols, mp, nrec);
+    hipLaunchKernelGGL(k_psi32_finish, dim3(m), dim3(64), 0, st, recs, m, d, de, Gam, Rc, method_id, sums1, k, grad, dGfull, cols,
+                       mp, nrec);
 }
 
 int psi32_pad_dim(int d) {
