@@ -809,7 +809,10 @@ static int moments_by_pattern(gpz_ctx *c, bool fused, double *mom) {
 static int build_phi(gpz_ctx *c) {
     if (c->gen) {
         Stage s(c, "phi_build");
-        launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+        // Sigma_j / inv(Sigma_j) / ln|Sigma_j|: everything except the whitened fp32 route (which works from the QR factor)
+        const bool whitened = c->psi32 && c->tr.psi_diag && (c->va.n_pad == 0 || c->va.psi_diag);
+        if (!whitened)
+            launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
         if (!c->has_psi) {   // missing dimensions only: tuned kernels, one launch per NaN pattern
             launch_gen_pattern_params(c->st, c->Sig, c->pr.P, c->pat_d, c->ngroups, c->m, c->d, c->de, c->RcP);
             return phi_by_pattern(c, c->tr, c->Phi, c->lnbeta, c->wbeta, nullptr, nullptr, true);
