@@ -15,6 +15,8 @@ A NumPy fp64 restatement of the reference's MATLAB code, written from reading
     GPz/Dxy.m:1-9          -> :func:`Dxy`
     GPz/predict.m:1-76 + predictDiag.m:58-74 / predictCov.m:53-69 -> :func:`predict`
     predictDiag.m:75-125 / predictCov.m:70-132 (predictNoisy) -> :func:`predict_noisy`
+    predict.m:45-69 + predictDiag.m:127-297 / predictCov.m:134-337 (predictMissing, predictNoisyMissing, all
+                           branches dispatched by NaN-pattern group) -> :func:`predict_any`
     GPz/getPrior.m:1-22    -> :func:`getPrior`
     GPz/fixPsi.m:1-55      -> :func:`fixPsi`
     GPz/getOmega.m:1-23    -> :func:`getOmega`
@@ -31,8 +33,14 @@ from the reference's own code (tests/test_oracle.py): the minFunc
 derivative-check protocol (autoDif/autoGrad.m:34-45, derivativeCheck.m:29-40),
 the method-nesting identities of getPHI.m:26-40 / GPz.m:215-225, Psi=0 == no
 Psi, omega=1 == no omega, mask=all == no mask, an independent dense n x n
-Gaussian log-density (Woodbury) check of GPz.m:65-82,110, and a hand-computed
-m=1,d=1 case.
+Gaussian log-density (Woodbury) check of GPz.m:65-82,110, a hand-computed
+m=1,d=1 case, and the agreement of the separately written predictDiag.m /
+predictCov.m missing-value branches on a diagonal covariance.
+
+Known numerical limit of the reference, reproduced here: with input noise the
+dGamma chain of GPz.m:174-180 goes through Sigma = inv(Gamma'Gamma) twice and
+loses cond(Gamma'Gamma)^1.5 * eps; for cond >~ 1e6 central differences of the
+objective disagree with this gradient (tools/c5_parity_by_cond.py).
 
 Conventions: arrays are NumPy float64; ``theta`` is a 1-D vector in the
 reference's packing order (column-major reshapes, SURVEY.md §8 "theta layout");
