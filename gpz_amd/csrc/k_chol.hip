@@ -35,8 +35,9 @@ __device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane) {
     for (int c = 0; c < CH_NB; ++c) {
         const double piv = __shfl(a[c], c, 64);                 // a_cc lives in lane c
         if (!(piv > 0.0) && bad == 0) bad = c + 1;
-        const double d = sqrt(piv);
-        const double l = a[c] / d;                              // l_rc for this lane's row r (meaningful for r >= c)
+        const double invd = rsqrt(piv);                         // one reciprocal square root instead of sqrt + divide:
+        const double d = piv * invd;                            // both sit on the 32-step serial chain of the panel
+        const double l = a[c] * invd;                           // l_rc for this lane's row r (meaningful for r >= c)
         a[c] = (lane == c) ? d : l;
 #pragma unroll
         for (int cc = c + 1; cc < CH_NB; ++cc) {
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A
                                                      int mq, int k0, double *__restrict__ logdet,
                                                      int *__restrict__ info) {
     __shared__ double D[CH_NB][CH_NB + 1];
+    __shared__ double Dinv[CH_NB];
     const int tid = threadIdx.x;
     if (tid < 64) {
         const int lane = tid;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A
         if (lane < CH_NB) {
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) D[lane][c] = (c <= lane) ? a[c] : 0.0;
+            Dinv[lane] = 1.0 / D[lane][lane];                   // the row solves multiply instead of dividing
             if (blockIdx.x == 0) {
                 double *lr = Lm + (size_t)(k0 + lane) * lda + k0;
 #pragma unroll
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A
             double s = x[c];
 #pragma unroll
             for (int q = 0; q < c; ++q) s = fma(-x[q], D[c][q], s);
-            x[c] = s / D[c][c];
+            x[c] = s * Dinv[c];
         }
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) lr[c] = x[c];
