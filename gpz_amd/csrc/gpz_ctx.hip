@@ -894,8 +894,7 @@ static void stage_b(gpz_ctx *c, int o) {
         launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq);
         launch_zero(c->st, c->logdet + o, 1);
         for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-            launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
-            launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, GPZ_CH_NB);
+            launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
         }
     }
     {
@@ -1724,8 +1723,7 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq);
     launch_zero(c->st, c->logdet, 1);
     for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-        launch_chol_panel(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
-        launch_chol_trailing(c->st, c->A, c->Lm, mq, mq, k0, GPZ_CH_NB);
+        launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
     }
     launch_zero(c->st, c->Wm, (size_t)mq * mq);
     launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);

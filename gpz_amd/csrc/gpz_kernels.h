@@ -68,6 +68,8 @@ void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp,
 // A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda);
 void launch_chol_panel(hipStream_t st, const double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
+// panel + trailing update of one step in a single launch (GPZ_CH_NB == 32)
+void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
 void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq);
 void launch_zero(hipStream_t st, double *p, size_t count);
 // Bext (mp x mp) <- [inv | w column at m | 0]; iS (m x m col-major == row-major, symmetric) copy; w, dwda, diag.

