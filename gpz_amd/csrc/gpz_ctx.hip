@@ -573,10 +573,15 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         if ((rc = c->ar.alloc(&c->lnbeta_v, (size_t)c->va.n_pad * k))) return bail(rc);
         if ((rc = c->ar.alloc(&c->phiw_v, (size_t)c->va.n_pad * k))) return bail(rc);
     }
-    // SYRK split over rows: aim at ~1024 workgroups (two resident rounds of 2 per CU; the slab sum costs nsplit*mp^2 reads)
+    // SYRK split over rows: one resident round of 512 workgroups (2 per CU); two rounds once a split still keeps
+    // >= 16k rows, where the second round's better tail outweighs the doubled slab traffic (every split writes and
+    // the slab sum re-reads mp^2 doubles: measured c2 1.44 -> 1.39 ms, c3 3.49 -> 3.35 ms, 125k-row c4 shard
+    // 9.88 -> 9.71 ms with 512; full c4 unchanged with 1024).  GPZ_SYRK_WGS overrides (tuning only).
     {
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
-        int ns = 1024 / npairs;   // floor: npairs*ns workgroups fill at most two full rounds of 512 resident slots
+        int target = (c->tr.n_pad / (1024 / npairs > 0 ? 1024 / npairs : 1) >= 16384) ? 1024 : 512;
+        if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e);
+        int ns = target / npairs;   // floor: npairs*ns workgroups fill at most two full rounds of 512 resident slots
         const int max_ns = c->tr.n_pad / 64;
         if (ns > max_ns) ns = max_ns;
         if (ns < 1) ns = 1;

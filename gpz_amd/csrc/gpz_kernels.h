@@ -58,7 +58,6 @@ int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart p
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
                   double *nupart, double *phiw, int m, int mcol);
-void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
 #ifndef GPZ_CH_NB
@@ -67,7 +66,6 @@ void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp,
 // ---- m x m factorisation pieces (k_chol.hip) -----------------------------------------------------
 // A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda);
-void launch_chol_panel(hipStream_t st, const double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
 // panel + trailing update of one step in a single launch (GPZ_CH_NB == 32)
 void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
 void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq);

@@ -48,71 +48,9 @@ __device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane) {
     return bad;
 }
 
-// Factor the 32x32 diagonal block at k0 (wave 0 of every workgroup does it redundantly in registers and publishes
-// it through LDS; workgroup 0 writes it back) and solve the panel rows below it:  L21 = A21 * inv(L11)'.
-// Reads A, writes the factor to Lm (a separate buffer: the redundant per-workgroup factorisation must
-// never observe another workgroup's write-back).
-__global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ A, double *__restrict__ Lm, int lda,
-                                                     int mq, int k0, double *__restrict__ logdet,
-                                                     int *__restrict__ info) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    __shared__ double Dinv[CH_NB];
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int lane = tid;
-        const int r = lane & (CH_NB - 1);   // CH_NB = 32: lanes 32..63 duplicate rows 0..31; CH_NB = 64: one row per lane
-        double a[CH_NB];
-        const double *ar = A + (size_t)(k0 + r) * lda + k0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) a[c] = ar[c];
-        const int bad = chol32_rows(a, lane);
-        if (lane < CH_NB) {
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) D[lane][c] = (c <= lane) ? a[c] : 0.0;
-            Dinv[lane] = 1.0 / D[lane][lane];                   // the row solves multiply instead of dividing
-            if (blockIdx.x == 0) {
-                double *lr = Lm + (size_t)(k0 + lane) * lda + k0;
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c) lr[c] = (c <= lane) ? a[c] : 0.0;
-            }
-        }
-        if (blockIdx.x == 0) {
-            // log-determinant contribution: 2*sum(log(diag))   (inv_logdet.m:15, sum of logs)
-            double ld = 0.0;
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
-                const double dcc = __shfl(a[c], c, 64);
-                ld += log(dcc);
-            }
-            if (lane == 0) {
-                *logdet += 2.0 * ld;
-                if (bad && *info == 0) *info = k0 + bad;
-            }
-        }
-    }
-    __syncthreads();
-    const int row = k0 + CH_NB + blockIdx.x * 256 + tid;
-    if (row < mq) {
-        double x[CH_NB];
-        const double *ar = A + (size_t)row * lda + k0;
-        double *lr = Lm + (size_t)row * lda + k0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) x[c] = ar[c];
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) {
-            double s = x[c];
-#pragma unroll
-            for (int q = 0; q < c; ++q) s = fma(-x[q], D[c][q], s);
-            x[c] = s * Dinv[c];
-        }
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) lr[c] = x[c];
-    }
-}
-
 // One whole step of the right-looking factorisation in a single launch (CH_NB == 32): every workgroup owns one
 // 64x64 tile (tm >= tn) of the trailing matrix.  Wave 0 factors the diagonal block at k0 in registers (redundantly
-// per workgroup, as in k_chol_panel) while waves 1 and 2 already hold the panel rows of row blocks tm and tn in
+// per workgroup: it must never observe another workgroup's write-back, hence the separate factor buffer Lm) while waves 1 and 2 already hold the panel rows of row blocks tm and tn in
 // registers; after the barrier they solve their rows against L11, park the result in LDS, and all four waves apply
 // the rank-32 update to the tile on the f64 MFMA.  The row solves are repeated by every tile of a block row/column
 // (about half the tile's own flops) in exchange for half the launches of the panel + trailing pair: the step is
@@ -288,12 +226,6 @@ __global__ void k_fill_bext(const double *__restrict__ Sinv, int ldsi, const dou
 
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda) {
     hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda);
-}
-
-void launch_chol_panel(hipStream_t st, const double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info) {
-    const int rows = mq - k0 - CH_NB;
-    const int nwg = rows > 0 ? (rows + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_chol_panel, dim3(nwg), dim3(256), 0, st, A, Lm, lda, mq, k0, logdet, info);
 }
 
 void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info) {

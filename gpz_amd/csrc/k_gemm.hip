@@ -176,9 +176,19 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit, int m
     const int ti = i >> 7, tj = j >> 7;
     const bool upper = (ti < tj) || (ti == tj && i <= j);
     const size_t src = upper ? ((size_t)i * mp + j) : ((size_t)j * mp + i);
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * mp * mp + src];
-    S[(size_t)i * lds + j] = s;
+    const size_t stride = (size_t)mp * mp;
+    const double *p = slab + src;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;           // four chains, eight loads in flight: the sum is latency bound
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(k + q) * stride];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; k < nsplit; ++k) s0 += p[(size_t)k * stride];
+    S[(size_t)i * lds + j] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,18 +401,6 @@ __device__ void gemm_tile_64(const double *__restrict__ A, long sa_r, long sa_c,
         }
 }
 
-// Trailing update of the right-looking Cholesky:  A22 -= L21 * L21'  (lower 64-tiles only).
-// A, Lm: mq x lda row-major; panel columns [k0, k0+nb) of the factor Lm; trailing rows/cols start at t0 = k0+nb.
-__global__ __launch_bounds__(256) void k_chol_trailing(double *__restrict__ A, const double *__restrict__ Lm, int lda,
-                                                        int mq, int k0, int nb) {
-    const int t0 = k0 + nb;
-    const int tm = blockIdx.y, tn = blockIdx.x;
-    if (tn > tm) return;
-    const int M = mq - t0;
-    const double *L21 = Lm + (size_t)t0 * lda + k0;
-    gemm_tile_64(L21, lda, 1, L21, 1, lda, A + (size_t)t0 * lda + t0, lda, M, M, nb, -1.0, 1.0, tm, tn);
-}
-
 // One level of the recursive triangular inverse W = inv(L) (both lower triangular, mq x ld):
 // for pair p with left block [a, a+gs) and right block [a+gs, a+2gs):
 //   phase 0:  Tmp(right,left) = L(right,left) * W(left,left)
@@ -459,13 +457,6 @@ void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, in
     dim3 grid((n_pad / 128) * nct), block(128 * WC);
     hipLaunchKernelGGL(k_tgemm<WC>, grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
                        (long)n_pad);
-}
-
-void launch_chol_trailing(hipStream_t st, double *A, const double *Lm, int lda, int mq, int k0, int nb) {
-    const int M = mq - k0 - nb;
-    if (M <= 0) return;
-    const int nt = (M + 63) / 64;
-    hipLaunchKernelGGL(k_chol_trailing, dim3(nt, nt), dim3(256), 0, st, A, Lm, lda, mq, k0, nb);
 }
 
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs) {
