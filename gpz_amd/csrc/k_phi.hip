@@ -295,6 +295,52 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
     }
 }
 
+// |R_j x - c_j|^2 for R rows per lane, wide inputs (D > 10): the packed factor is streamed from LDS in chunks of 8
+// operands, one chunk ahead of the multiply-adds.  Holding two whole rows of R_j (as the D <= 10 path does) needs
+// 4(D+1) VGPRs on top of the 2*R*D of x and spilled 0.5-1.5 KB per lane at D = 12..20.
+template <int D, int R>
+__device__ __forceinline__ void cov_quad_chunked(const double *__restrict__ rj, const double (&x)[R][D], double (&q)[R]) {
+    constexpr int NT = D * (D + 1) / 2;
+    constexpr int CH = 8;
+    double cur[CH + 1], nxt[CH + 1];                 // [CH]: c_a, fetched with the first chunk of row a
+    auto load = [&](int a, int b0, double (&dst)[CH + 1]) {
+        const int off = a * D - a * (a - 1) / 2 + (b0 - a);
+#pragma unroll
+        for (int e = 0; e < CH; ++e)
+            if (b0 + e < D) dst[e] = rj[off + e];
+        if (b0 == a) dst[CH] = rj[NT + a];
+    };
+    double s[R];
+    load(0, 0, cur);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+        for (int b0 = a; b0 < D; b0 += CH) {
+            const bool last = b0 + CH >= D;
+            const int na = last ? a + 1 : a, nb0 = last ? a + 1 : b0 + CH;
+            if (na < D) load(na, nb0, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b0 == a) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) s[r] = -cur[CH];
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                if (b0 + e < D) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) s[r] = fma(cur[e], x[r][b0 + e], s[r]);
+                }
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) q[r] = fma(s[r], s[r], q[r]);           // getPHI.m:73,76
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e <= CH; ++e) cur[e] = nxt[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PHI build, covariance kinds.  Same thread mapping (lanes along rows, R rows per thread) but the per-basis
 // parameters [R_j | c_j] are staged once per workgroup into LDS for JB basis functions at a time and read back
@@ -362,11 +408,23 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 
     for (int j0 = jlo; j0 < jhi; j0 += JB) {
         if (j0 + JB < m && j0 + JB < jhi) pload(j0 + JB);   // in flight during the compute phase
+        // Two loops instead of one with an `if (j < m)` inside: the optimiser hoists LDS reads out of a conditional
+        // (they are speculatable), i.e. above the sched_barriers that bound their live ranges - at D = 20 that held
+        // the whole factor in registers and spilled 1.5 KB per lane.
+        const int jcnt = min(JB, m - j0);
 #pragma unroll 1
-        for (int jj = 0; jj < JB; ++jj) {
+        for (int jj = 0; jj < jcnt; ++jj) {
             const int j = j0 + jj;
             double ph[R];
-            if (j < m) {
+            {
+                // v_j, w_j first: a conditional load between the quadratic form and its use would let the optimiser
+                // sink all multiply-adds below it, away from the LDS reads that the sched_barriers pair them with
+                double vj[KM], wj[KM];
+#pragma unroll
+                for (int o = 0; o < KM; ++o) {
+                    vj[o] = (v && o < k) ? v[j + (size_t)m * o] : 0.0;
+                    wj[o] = (wv && o < k) ? wv[j + (size_t)m * o] : 0.0;
+                }
                 const double *rj = prm + jj * NP;
                 double q[R];
 #pragma unroll
@@ -374,6 +432,9 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                 // software-pipelined over the rows of R_j: the LDS (broadcast) reads of row a+1 are issued before
                 // the multiply-adds of row a, and sched_barrier keeps the compiler from hoisting every read of
                 // the factor to the top (which needs d(d+1) VGPRs and spills)
+                if constexpr (D > 10) {
+                    cov_quad_chunked<D, R>(rj, x, q);
+                } else {
                 double gc[D + 1], gn[D + 1];
 #pragma unroll
                 for (int b = 0; b < D; ++b) gc[b] = rj[b];
@@ -400,11 +461,6 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 #pragma unroll
                     for (int b = a + 1; b <= D; ++b) gc[b] = gn[b];
                 }
-                double vj[KM], wj[KM];
-#pragma unroll
-                for (int o = 0; o < KM; ++o) {
-                    vj[o] = (v && o < k) ? v[j + (size_t)m * o] : 0.0;
-                    wj[o] = (wv && o < k) ? wv[j + (size_t)m * o] : 0.0;
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -416,16 +472,21 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                         sw[r][o] = fma(ph[r], wj[o], sw[r][o]);
                     }
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const long i = row0 + r * 64 + lane;
-                    ph[r] = (Y != nullptr && (j - m) < k) ? Y[(size_t)(j - m) * ldx + i] : 0.0;   // zero-padded rows
-                }
             }
             if (Phi) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) tile[wave][r][lane][jj] = ph[r];
+            }
+        }
+        if (Phi) {
+#pragma unroll 1
+            for (int jj = max(jcnt, 0); jj < JB; ++jj) {                                  // padding columns: [Y | 0]
+                const int j = j0 + jj;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const long i = row0 + r * 64 + lane;
+                    tile[wave][r][lane][jj] = (Y != nullptr && (j - m) < k) ? Y[(size_t)(j - m) * ldx + i] : 0.0;   // zero-padded rows
+                }
             }
         }
         __syncthreads();                             // tile complete; every wave is done with prm

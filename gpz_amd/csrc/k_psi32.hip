@@ -197,10 +197,23 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
 
 // Transposing butterfly over the 64 lanes of a wave for NV = 32 values per lane: afterwards lane l holds, in v[0], the
 // sum over all lanes of value (l >> 1).  31 exchanges + 1 instead of 6 per value.
+// The two widest stages (partner 32 and 16 lanes away, 24 of the 31 exchanges) are gfx950's v_permlane32_swap /
+// v_permlane16_swap: one instruction trades the halves (odd rows of the first register with even rows of the second),
+// after which a single add leaves "own half + partner's same half" in every lane - no selects, no LDS crossbar.
 __device__ __forceinline__ void reduce32(float (&v)[32], int lane) {
 #pragma unroll
-    for (int s = 16, bit = 32; s >= 1; s >>= 1, bit >>= 1) {
-        // bitwise select (v_bfi_b32) instead of ?: — a select between two array elements is turned into a dynamically
+    for (int k = 0; k < 16; ++k) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 16]), false, false);
+        v[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 8]), false, false);
+        v[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int s = 4, bit = 8; s >= 1; s >>= 1, bit >>= 1) {
+        // bitwise select (v_bfi_b32) instead of ?: - a select between two array elements is turned into a dynamically
         // indexed load by the optimiser, which would push the whole array into scratch
         const unsigned msk = (lane & bit) ? 0xffffffffu : 0u;
 #pragma unroll
