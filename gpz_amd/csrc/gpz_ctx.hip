@@ -769,7 +769,8 @@ static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, d
         a.Phi = Phi ? Phi + (size_t)rb * mp : nullptr;
         a.lnbeta = lnbeta + rb; a.wbeta = wbeta ? wbeta + rb : nullptr;
         a.w = w; a.phiw = phiw ? phiw + rb : nullptr;
-        a.part = nullptr; a.part_groups = 0;
+        // a pattern with few rows is a handful of workgroups walking all m basis functions: split the columns
+        a.part = c->phipart ? c->phipart + rb : nullptr; a.part_groups = c->phipart_groups;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", de);
     }
     return 0;

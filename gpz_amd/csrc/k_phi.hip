@@ -537,11 +537,11 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 }
 
 // lnbeta = b + sum_g part_v[g], omega*beta, PHI*w from the column-group partial sums (fixed order: repeatable)
-__global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long ldx, int n, int k,
+__global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long ldx, long rows, int n, int k,
                                const double *__restrict__ bvec, const double *__restrict__ omega,
                                double *__restrict__ lnbeta, double *__restrict__ wbeta, double *__restrict__ phiw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ldx) return;
+    if (i >= rows) return;
     for (int o = 0; o < k; ++o) {
         double sv = 0.0, sw = 0.0;
         for (int g = 0; g < ngroup; ++g) {
@@ -588,8 +588,8 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
         hipLaunchKernelGGL((k_phi_cov<D, true, R, JB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
                            a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part);
     if (part)
-        hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.ldx + 255) / 256)), dim3(256), 0, st, (const double *)part,
-                           ngroup, a.ldx, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
+        hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
+                           ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
 template <int KIND, int D>
