@@ -106,6 +106,8 @@ struct RowSet {          // a device-resident row selection of the data
     float *PsiT = nullptr;                     // dtype f32: packed lower triangles, element-major [e][n_pad] (k_psi32.hip)
     int psi_diag = 0;                          // every Psi_i of this row set is diagonal: PsiT holds only the diagonals
     std::vector<int> group_begin;              // offsets into rows_by_group (size G+1)
+    int *wgtab = nullptr;                      // missing dimensions without input noise: workgroup table of the one-launch
+    int nwg_tab = 0;                           // PHI build over all patterns (PhiArgs::wgtab)
 };
 
 struct StageTimer {
@@ -505,6 +507,22 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         for (RowSet *rs : {&c->tr, &c->va})
             while ((int)rs->group_begin.size() < c->ngroups + 1)
                 rs->group_begin.push_back(rs->group_begin.empty() ? 0 : rs->group_begin.back());
+        if (!c->has_psi) {
+            const int rpw = phi_cov_rows_per_wg(c->de);
+            for (RowSet *rs : {&c->tr, &c->va}) {
+                std::vector<int> tab;
+                for (int g = 0; g < c->ngroups; ++g)
+                    for (int r = rs->group_begin[g]; r < rs->group_begin[g + 1]; r += rpw) {
+                        const int e[4] = {r, rs->group_begin[g + 1], g, 0};
+                        tab.insert(tab.end(), e, e + 4);
+                    }
+                rs->nwg_tab = (int)(tab.size() / 4);
+                if (!rs->nwg_tab) continue;
+                if ((rc = c->ar.alloc(&rs->wgtab, tab.size()))) return rc;
+                if (hipMemcpy(rs->wgtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(GPZ_ERR_HIP, "copy failed");
+            }
+        }
         c->psi_fast = !c->psi32 && c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
@@ -748,7 +766,7 @@ static int psi32_agree(gpz_ctx *c) {
 static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, double *wbeta, const double *w, double *phiw,
                           bool with_y) {
     const size_t np = (size_t)rs.n_pad, mp = (size_t)c->mp;
-    const int de = c->de, npar = de * (de + 1) / 2 + de;
+    const int de = c->de;
     const size_t tail = np - (size_t)rs.n;   // rows past the data: zero (the slack block is never written otherwise)
     if (Phi) HIPCHK(hipMemsetAsync(Phi + (size_t)rs.n * mp, 0, tail * mp * sizeof(double), c->st));
     for (int o = 0; o < c->k; ++o) {
@@ -756,23 +774,21 @@ static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, d
         if (wbeta) HIPCHK(hipMemsetAsync(wbeta + (size_t)o * np + rs.n, 0, tail * sizeof(double), c->st));
         if (phiw) HIPCHK(hipMemsetAsync(phiw + (size_t)o * np + rs.n, 0, tail * sizeof(double), c->st));
     }
-    for (int g = 0; g < c->ngroups; ++g) {
-        const int rb = rs.group_begin[g], nr = rs.group_begin[g + 1] - rb;
-        if (nr <= 0) continue;
-        PhiArgs a{};
-        a.Xc = rs.Xc + rb; a.ldx = (long)np; a.n = nr; a.n_pad = rup(nr, 1024);
-        a.m = c->m; a.mp = c->mp; a.d = de; a.k = c->k; a.kind = GPZ_KIND_COV;
-        a.P = c->pr.P; a.G = c->RcP + (size_t)g * c->m * npar;
-        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b;
-        a.omega = rs.om ? rs.om + rb : nullptr;
-        a.Y = (with_y && rs.Y) ? rs.Y + rb : nullptr;
-        a.Phi = Phi ? Phi + (size_t)rb * mp : nullptr;
-        a.lnbeta = lnbeta + rb; a.wbeta = wbeta ? wbeta + rb : nullptr;
-        a.w = w; a.phiw = phiw ? phiw + rb : nullptr;
-        // a pattern with few rows is a handful of workgroups walking all m basis functions: split the columns
-        a.part = c->phipart ? c->phipart + rb : nullptr; a.part_groups = c->phipart_groups;
-        if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", de);
-    }
+    if (!rs.nwg_tab) return 0;
+    // one launch over all patterns: every workgroup looks up its row range and its pattern's parameter block
+    PhiArgs a{};
+    a.Xc = rs.Xc; a.ldx = (long)np; a.n = rs.n; a.n_pad = rs.n_pad;
+    a.m = c->m; a.mp = c->mp; a.d = de; a.k = c->k; a.kind = GPZ_KIND_COV;
+    a.P = c->pr.P; a.G = c->RcP;
+    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b;
+    a.omega = rs.om;
+    a.Y = (with_y && rs.Y) ? rs.Y : nullptr;
+    a.Phi = Phi;
+    a.lnbeta = lnbeta; a.wbeta = wbeta;
+    a.w = w; a.phiw = phiw;
+    a.part = c->phipart; a.part_groups = c->phipart_groups;      // few workgroups: split the basis functions as well
+    a.wgtab = rs.wgtab; a.nwg_tab = rs.nwg_tab;
+    if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", de);
     return 0;
 }
 

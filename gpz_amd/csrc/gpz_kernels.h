@@ -46,7 +46,13 @@ struct PhiArgs {
     // cov kinds: scratch for the column-group split used at small row counts ([part_groups][2][k][ldx]); nullptr disables it
     double *part;
     int part_groups;
+    // cov kinds, rows sorted by NaN pattern: one launch over all patterns.  wgtab holds 4 ints per workgroup:
+    // {first row, end of the pattern's rows, pattern index, 0}; G then points at [pattern][m][params] and n_pad / n
+    // describe the whole row set.  nullptr = one parameter set for all rows.
+    const int *wgtab;
+    int nwg_tab;
 };
+int phi_cov_rows_per_wg(int de);   // rows one workgroup of the cov-kind PHI kernel covers (granularity of wgtab)
 void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
 

@@ -347,14 +347,15 @@ __device__ __forceinline__ void cov_quad_chunked(const double *__restrict__ rj, 
 // as wave-uniform (broadcast) ds_reads: d(d+1)/2 + d doubles per basis do not fit the SGPR file, and each
 // LDS operand feeds R = 4 multiply-adds, so the LDS pipe stays well below the VALU time.
 // ---------------------------------------------------------------------------------------------
-template <int D, bool KGEN, int R, int JB>
+template <int D, bool KGEN, int R, int JB, bool TAB>
 __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
                                                   const double *__restrict__ Rc,
                                                   const double *__restrict__ v, const double *__restrict__ bvec,
                                                   const double *__restrict__ omega, const double *__restrict__ Y,
                                                   double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                   double *__restrict__ wbeta, const double *__restrict__ wv,
-                                                  double *__restrict__ phiw, int jgroup, double *__restrict__ part) {
+                                                  double *__restrict__ phiw, int jgroup, double *__restrict__ part,
+                                                  const int *__restrict__ wgtab) {
     constexpr int KM = KGEN ? 8 : 1;
     constexpr int NT = D * (D + 1) / 2;
     constexpr int NP = NT + D;                       // doubles per basis function
@@ -363,14 +364,24 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
     __shared__ double tile[4][R][64][JB + 1];
     __shared__ double prm[NPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
+    // TAB: rows are sorted by NaN pattern and this workgroup serves the rows [tab.x, tab.y) of pattern tab.z, whose
+    // parameter block follows the others in Rc; rows at or past tab.y belong to another workgroup and are not written.
+    long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
+    long row_end = n;
+    if (TAB) {
+        const int *t = wgtab + 4 * (size_t)blockIdx.x;
+        row0 = (long)t[0] + wave * (64 * R);
+        row_end = t[1];
+        Rc += (size_t)t[2] * m * (NT + D);
+    }
+    const long wr_end = TAB ? row_end : ldx;
 
     double x[R][D];
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
-        valid[r] = i < n;
+        valid[r] = i < row_end;
 #pragma unroll
         for (int c = 0; c < D; ++c) x[r][c] = Xc[c * ldx + i];   // rows >= n are zero-padded
     }
@@ -498,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 #pragma unroll 4
             for (int qq = 0; qq < R * JB; ++qq) {
                 const int r = qq / JB, it = qq % JB;
-                base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
+                if (!TAB || row0 + r * 64 + it * RPI + lr < row_end)
+                    base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
             }
         }
         if (j0 + JB < m && j0 + JB < jhi) pstore();
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
             const long i = row0 + r * 64 + lane;
 #pragma unroll
             for (int o = 0; o < KM; ++o)
-                if (o < k && i < ldx) {
+                if (o < k && i < wr_end) {
                     part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldx + i] = sv[r][o];
                     part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldx + i] = sw[r][o];
                 }
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
         const long i = row0 + r * 64 + lane;
 #pragma unroll
         for (int o = 0; o < KM; ++o) {
-            if (o < k && i < ldx) {
+            if (o < k && i < wr_end) {
                 const double lb = bvec[o] + sv[r][o];                      // getPHI.m:119,124
                 lnbeta[(size_t)o * ldx + i] = valid[r] ? lb : 0.0;
                 if (wbeta) {
@@ -555,19 +567,25 @@ __global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long
             const double om = omega ? omega[i] : 1.0;
             wbeta[(size_t)o * ldx + i] = valid ? om * exp(-lb) : 0.0;
         }
-        if (phiw) phiw[(size_t)o * ldx + i] = sw;
+        if (phiw) phiw[(size_t)o * ldx + i] = valid ? sw : 0.0;   // rows past the data carry no partial sums
     }
 }
 
+// 4 rows per thread and 8-wide blocks while [tile | params] fits twice in a CU's LDS; else 2 rows
+template <int D>
+struct PhiCovShape {
+    static constexpr int NP = D * (D + 1) / 2 + D;
+    static constexpr bool BIG = (4 * 4 * 64 * 9 + 8 * NP) * 8 * 2 <= 160 * 1024;
+    static constexpr int R = BIG ? 4 : 2;
+};
+
 template <int D>
 static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
-    // 4 rows per thread and 8-wide blocks while [tile | params] fits twice in a CU's LDS; else 2 rows
-    constexpr int NP = D * (D + 1) / 2 + D;
-    constexpr bool BIG = (4 * 4 * 64 * 9 + 8 * NP) * 8 * 2 <= 160 * 1024;
-    constexpr int R = BIG ? 4 : 2;
+    constexpr int R = PhiCovShape<D>::R;
     constexpr int JB = 8;
     const int rows_per_wg = 4 * 64 * R;
-    const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
+    const int nwg = a.wgtab ? a.nwg_tab : (a.n_pad + rows_per_wg - 1) / rows_per_wg;
+    if (nwg <= 0) return;
     // few rows: split the basis functions into groups (multiples of JB) until ~1024 workgroups exist
     int ngroup = 1;
     if (a.part && nwg < 1024) {
@@ -581,12 +599,12 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     ngroup = (a.mp + jgroup - 1) / jgroup;
     double *part = ngroup > 1 ? a.part : nullptr;
     dim3 grid(nwg, ngroup);
-    if (a.k == 1)
-        hipLaunchKernelGGL((k_phi_cov<D, false, R, JB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
-                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part);
-    else
-        hipLaunchKernelGGL((k_phi_cov<D, true, R, JB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k,
-                           a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part);
+#define PHI_COV(KG, TB) \
+    hipLaunchKernelGGL((k_phi_cov<D, KG, R, JB, TB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.G, a.v, \
+                       a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part, a.wgtab)
+    if (a.wgtab) { if (a.k == 1) PHI_COV(false, true); else PHI_COV(true, true); }
+    else { if (a.k == 1) PHI_COV(false, false); else PHI_COV(true, false); }
+#undef PHI_COV
     if (part)
         hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
                            ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
@@ -629,6 +647,15 @@ static int launch_phi_k(hipStream_t st, const PhiArgs &a) {
 }
 
 // a.d must be one of the padded dimensions returned by gpz_pad_dim().
+int phi_cov_rows_per_wg(int de) {
+    switch (de) {
+        case 12: return 256 * PhiCovShape<12>::R;
+        case 16: return 256 * PhiCovShape<16>::R;
+        case 20: return 256 * PhiCovShape<20>::R;
+        default: return 256 * PhiCovShape<10>::R;    // every width up to 10 takes the 4-row shape
+    }
+}
+
 int launch_phi(hipStream_t st, const PhiArgs &a) {
     if (a.k > 8) return -1;
     return (a.kind == GPZ_KIND_DIAG) ? launch_phi_k<GPZ_KIND_DIAG>(st, a) : launch_phi_k<GPZ_KIND_COV>(st, a);
