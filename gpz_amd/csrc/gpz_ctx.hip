@@ -199,6 +199,8 @@ struct gpz_ctx {
     // missing dimensions without input noise: per-pattern parameter blocks and moment slabs of the tuned kernels
     double *RcP = nullptr, *gen_tslab = nullptr, *gen_frec = nullptr, *fin_part = nullptr;
     int gen_tnch = 1;
+    int *mom_chunktab = nullptr, *mom_segtab = nullptr;   // moment chunks {first row, end row} that respect the pattern
+    int mom_nchunk = 0;                                   // boundaries, and each pattern's range of chunks
     int gen_nchunk = 1;
 };
 
@@ -573,7 +575,27 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             const int nmt = c->de + c->de * (c->de + 1) / 2;
             c->gen_tnch = 2048 / ((c->m + 255) / 256);
             if (c->gen_tnch < 1) c->gen_tnch = 1;
-            if ((rc = c->ar.alloc(&c->gen_tslab, (size_t)c->gen_tnch * c->m * (nmt + 2)))) return bail(rc);
+            // one moment launch over all patterns: row chunks of ~n/gen_tnch rows (at least 32) that end at pattern boundaries
+            int rpc = (c->tr.n + c->gen_tnch - 1) / c->gen_tnch;
+            if (rpc < 32) rpc = 32;
+            std::vector<int> ct, seg((size_t)c->ngroups + 1);
+            for (int g = 0; g < c->ngroups; ++g) {
+                seg[g] = (int)(ct.size() / 2);
+                const int re = c->tr.group_begin[g + 1];
+                for (int r = c->tr.group_begin[g]; r < re; r += rpc) {
+                    ct.push_back(r);
+                    ct.push_back(r + rpc < re ? r + rpc : re);
+                }
+            }
+            seg[c->ngroups] = c->mom_nchunk = (int)(ct.size() / 2);
+            if (ct.empty()) ct.assign(2, 0);
+            if ((rc = c->ar.alloc(&c->mom_chunktab, ct.size()))) return bail(rc);
+            if ((rc = c->ar.alloc(&c->mom_segtab, seg.size()))) return bail(rc);
+            if (hipMemcpy(c->mom_chunktab, ct.data(), ct.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(c->mom_segtab, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(GPZ_ERR_HIP, "copy failed"));
+            const size_t nslab = c->mom_nchunk > 0 ? (size_t)c->mom_nchunk : 1;
+            if ((rc = c->ar.alloc(&c->gen_tslab, nslab * c->m * (nmt + 2)))) return bail(rc);
             if ((rc = c->ar.alloc(&c->gen_frec, (size_t)c->ngroups * c->m * (nmt + 2)))) return bail(rc);
         }
         if (c->va.n_pad && (rc = c->ar.alloc(&c->Phi_v, (size_t)c->va.n_pad * c->mp))) return bail(rc);
@@ -796,32 +818,24 @@ static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, d
 // the fly; plain: dPHI already in T), converted to the records k_gen_finish chains (k_gen_convert_moments).
 static int moments_by_pattern(gpz_ctx *c, bool fused, double *mom) {
     const int de = c->de, nmt = de + de * (de + 1) / 2, stride = fused ? nmt + 2 : nmt;
-    const size_t mp = (size_t)c->mp, m = (size_t)c->m;
-    for (int g = 0; g < c->ngroups; ++g) {
-        const int rb = c->tr.group_begin[g], nr = c->tr.group_begin[g + 1] - rb;
-        double *frec_g = c->gen_frec + (size_t)g * m * stride;
-        if (nr <= 0) { launch_zero(c->st, frec_g, m * stride); continue; }
-        int nch = c->gen_tnch;
-        const int cap = nr / 32 > 0 ? nr / 32 : 1;
-        if (nch > cap) nch = cap;
-        const int rpc = (nr + nch - 1) / nch;
-        nch = (nr + rpc - 1) / rpc;
+    const size_t m = (size_t)c->m;
+    if (c->mom_nchunk > 0) {   // one launch: the chunk table keeps every chunk inside one pattern's rows
         if (fused) {
             FusedMomentArgs a{};
-            a.Phi = c->Phi + (size_t)rb * mp; a.T = c->T + (size_t)rb * mp; a.ld = c->mp;
-            a.Xr = c->tr.Xr + (size_t)rb * de; a.rowscal = c->rowscal + (size_t)rb * 4;
-            a.n = nr; a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.w = c->w;
-            a.v = c->hetero ? c->pr.v : nullptr; a.nchunk = nch; a.rows_per_chunk = rpc; a.slab = c->gen_tslab; a.nm = nmt;
+            a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.rowscal = c->rowscal;
+            a.n = c->tr.n; a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.w = c->w;
+            a.v = c->hetero ? c->pr.v : nullptr; a.nchunk = c->mom_nchunk; a.rows_per_chunk = 0; a.slab = c->gen_tslab;
+            a.nm = nmt; a.chunktab = c->mom_chunktab;
             if (launch_moments_fused(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", de);
         } else {
             MomentArgs a{};
-            a.dPhi = c->T + (size_t)rb * mp; a.ld = c->mp; a.Xr = c->tr.Xr + (size_t)rb * de; a.n = nr; a.n_pad = rup(nr, 1024);
-            a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.nchunk = nch; a.rows_per_chunk = rpc;
-            a.slab = c->gen_tslab; a.nm = nmt;
+            a.dPhi = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
+            a.m = c->m; a.d = de; a.kind = GPZ_KIND_COV; a.P = c->pr.P; a.nchunk = c->mom_nchunk; a.rows_per_chunk = 0;
+            a.slab = c->gen_tslab; a.nm = nmt; a.chunktab = c->mom_chunktab;
             if (launch_moments(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", de);
         }
-        launch_slab_sum(c->st, c->gen_tslab, nch, m * stride, frec_g);
     }
+    launch_slab_sum_seg(c->st, c->gen_tslab, c->mom_segtab, c->ngroups, m * stride, c->gen_frec);
     launch_gen_convert_moments(c->st, c->gen_frec, stride, fused ? 1 : 0, c->Sig, c->pat_d, c->ngroups, c->m, c->d, de, mom,
                                c->nrec);
     return 0;

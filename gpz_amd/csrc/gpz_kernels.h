@@ -119,6 +119,7 @@ struct MomentArgs {
     double *slab;            // [nchunk][m][nm]
     int nm;                  // moments per basis: cov d + d(d+1)/2, diag 2d (3d with Psi)
     const double *Psir, *Mr, *G2;   // diag kinds: Psi rows (n_pad x d), observed mask rows, gamma^2 (nullptr = absent)
+    const int *chunktab;            // cov kinds, optional: {first row, end row} per chunk instead of chunk*rows_per_chunk
 };
 int launch_moments(hipStream_t st, const MomentArgs &a);
 
@@ -137,11 +138,14 @@ struct FusedMomentArgs {
     double *slab;              // [nchunk][m][nm + 2]: moments, then PHI'(omega beta delta), PHI'dbeta
     int nm;
     const double *Psir, *Mr, *G2;   // as in MomentArgs
+    const int *chunktab;            // as in MomentArgs
 };
 int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a);
 // split the reduced [m][nm+2] records into mom [m][nm] and cols [2][mp]
 void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols);
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out);
+// out[g][count] = sum of slabs seg[g] .. seg[g+1]-1, g < nseg (seg: nseg+1 device ints)
+void launch_slab_sum_seg(hipStream_t st, const double *slab, const int *seg, int nseg, size_t count, double *out);
 
 struct FinishArgs {
     int method_id, kind, m, d, k, hetero, g_dim;

@@ -125,6 +125,37 @@ __global__ __launch_bounds__(256) void k_slab_sum(const double *__restrict__ sla
     }
 }
 
+// out[g] = sum of the slabs seg[g] .. seg[g+1]-1 (a segment per NaN pattern; an empty segment yields zeros)
+__global__ __launch_bounds__(256) void k_slab_sum_seg(const double *__restrict__ slab, const int *__restrict__ seg,
+                                                       size_t count, double *__restrict__ out) {
+    __shared__ double part[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k0 = seg[blockIdx.y], k1 = seg[blockIdx.y + 1];
+    double *o = out + (size_t)blockIdx.y * count;
+    for (size_t e0 = (size_t)blockIdx.x * 16; e0 < count; e0 += (size_t)gridDim.x * 16) {
+        const size_t e = e0 + el;
+        double s = 0.0;
+        if (e < count)
+            for (int k = k0 + sl; k < k1; k += 16) s += slab[(size_t)k * count + e];
+        part[sl][el] = s;
+        __syncthreads();
+        if (sl == 0 && e < count) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][el];
+            o[e] = t;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_slab_sum_seg(hipStream_t st, const double *slab, const int *seg, int nseg, size_t count, double *out) {
+    size_t nb = (count + 15) / 16;
+    if (nb > 1024) nb = 1024;
+    if (nb == 0 || nseg <= 0) return;
+    hipLaunchKernelGGL(k_slab_sum_seg, dim3((unsigned)nb, (unsigned)nseg), dim3(256), 0, st, slab, seg, count, out);
+}
+
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out) {
     size_t nb = (count + 15) / 16;
     if (nb > 8192) nb = 8192;
@@ -158,7 +189,8 @@ template <int D, int A0, int A1>
 __global__ __launch_bounds__(256) void k_moments_cov(const double *__restrict__ dPhi, int ld,
                                                       const double *__restrict__ Xr, int n, int m,
                                                       const double *__restrict__ P, int rows_per_chunk,
-                                                      double *__restrict__ slab, int nm) {
+                                                      double *__restrict__ slab, int nm,
+                                                      const int *__restrict__ chunktab) {
     const int j = blockIdx.y * 256 + threadIdx.x;
     const int chunk = blockIdx.x;
     const bool act = j < m;
@@ -171,8 +203,9 @@ __global__ __launch_bounds__(256) void k_moments_cov(const double *__restrict__ 
     for (int c = 0; c < D; ++c) M1[c] = 0.0;
 #pragma unroll
     for (int e = 0; e < NS; ++e) S[e] = 0.0;
-    const int r0 = chunk * rows_per_chunk;
-    const int r1 = min(n, r0 + rows_per_chunk);
+    int r0 = chunk * rows_per_chunk;
+    int r1 = min(n, r0 + rows_per_chunk);
+    if (chunktab) { r0 = chunktab[2 * chunk]; r1 = chunktab[2 * chunk + 1]; }   // chunks that respect NaN-pattern boundaries
     for (int i = r0; i < r1; ++i) {
         const double dp = act ? dPhi[(size_t)i * ld + j] : 0.0;
         const double *xi = Xr + (size_t)i * D;
@@ -261,7 +294,7 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
 }
 
 #define MOM_COV(D, A0, A1) \
-    hipLaunchKernelGGL((k_moments_cov<D, A0, A1>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm)
+    hipLaunchKernelGGL((k_moments_cov<D, A0, A1>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm, a.chunktab)
 #define MOM_DIAG(D) \
     do { \
         if (a.Psir) hipLaunchKernelGGL((k_moments_diag<D, true>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                                                         const double *__restrict__ v, int rows_per_chunk,
                                                         double *__restrict__ slab, int nm,
                                                         const double *__restrict__ Psir, const double *__restrict__ Mr,
-                                                        const double *__restrict__ G2) {
+                                                        const double *__restrict__ G2, const int *__restrict__ chunktab) {
     const int j = blockIdx.y * 256 + threadIdx.x;
     const int chunk = blockIdx.x;
     const bool act = j < m;
@@ -383,8 +416,9 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
     }
 #pragma unroll
     for (int e = 0; e < NS; ++e) S[e] = 0.0;
-    const int r0 = chunk * rows_per_chunk;
-    const int rend = min(n, r0 + rows_per_chunk);
+    int r0 = chunk * rows_per_chunk;
+    int rend = min(n, r0 + rows_per_chunk);
+    if (chunktab) { r0 = chunktab[2 * chunk]; rend = chunktab[2 * chunk + 1]; }   // chunks that respect NaN-pattern boundaries
     // One row of work.  sc = the wave-uniform row data [omega*beta, c, dbeta | x_i (D)] (scalar registers).
     auto consume = [&](int i, const double phu, const double ttu, const double (&sc)[3 + D]) {
         const double ob = sc[0], cc = sc[1], db = sc[2];
@@ -510,7 +544,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
 #endif
 #define MOMF_(KIND, D, A0, A1, PS) \
     hipLaunchKernelGGL((k_moments_fused<KIND, D, A0, A1, (KIND == GPZ_KIND_COV ? GPZ_MOM_UR : GPZ_MOM_UR_DIAG), PS>), g, b, 0, st, a.Phi, a.T, a.ld, a.Xr, a.rowscal, a.n, \
-                       a.m, a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2)
+                       a.m, a.P, a.w, a.v, a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2, a.chunktab)
 #define MOMF(KIND, D, A0, A1) \
     do { \
         if (KIND == GPZ_KIND_DIAG && a.Psir) MOMF_(KIND, D, A0, A1, true); \
