@@ -1172,7 +1172,8 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                                 c->k == 1 ? cols : nullptr, c->mp, c->nrec);
         else if (c->gen)
             launch_gen_finish(c->st, mom, c->ngroups, c->pat_d, c->m, c->d, c->de, c->pr.G, c->Sig, c->iSig, c->mid, a.sums1,
-                              c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec, c->fin_part);
+                              c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec, c->fin_part,
+                              c->has_psi ? 0 : 1);
         launch_finish(c->st, a);
     }
     if (c->g_dev_out) {   // gpz_eval_dev: the gradient stays on the device, only f and the statistics block come up

@@ -236,7 +236,8 @@ void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int 
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
                        double *grad, double *dGfull, double *cols, int mp, int nrec,
-                       double *part /* G*m*(d + d*d + 2) doubles of scratch */);
+                       double *part /* G*m*(d + d*d + 2) doubles of scratch */,
+                       int raw /* records hold plain moment sums (no input noise): see k_gen_convert_moments */);
 
 // prediction with input noise (predictDiag.m:75-125 / predictCov.m:70-132) and the getPrior iteration (getPrior.m:7-20)
 void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,

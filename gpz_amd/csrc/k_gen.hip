@@ -253,7 +253,8 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
 __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ recs, int G,
                                                     const unsigned char *__restrict__ pat, int m, int d, int de,
                                                     const double *__restrict__ Gam, const double *__restrict__ Sig,
-                                                    const double *__restrict__ iSig, double *__restrict__ part, int nrec) {
+                                                    const double *__restrict__ iSig, double *__restrict__ part, int nrec,
+                                                    int raw) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     double dP[GDM], dG[GDM * GDM];
@@ -272,12 +273,31 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
         }
         r1 += rec[1 + d + d * d];
         r2 += rec[2 + d + d * d];
-        for (int a = 0; a < no; ++a) dP[o[a]] += rec[1 + o[a]];
-        // Sigma_oo^-1
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b) Soo[a * GDM + b] = Sj[o[a] * d + o[b]];
         for (int e = 0; e < no * GDM; ++e) tmp[e] = Soo[e];
         chol_small(tmp, no);
+        if (raw) {
+            // No input noise: the records are the plain sums M1 = sum dPHI Delta_o and S = sum dPHI Delta_o Delta_o'.
+            // dP_o = Sigma_oo^-1 M1 (GPz.m:153) by two triangular solves, and since dSoo = 1/2 Sigma_oo^-1 S Sigma_oo^-1
+            // (GPz.m:154, the A0 terms of :174 cancel), diSoo = -Soo dSoo Soo = -1/2 S: no inverse, no products.
+            double y[GDM];
+            for (int a = 0; a < no; ++a) {
+                double t = rec[1 + o[a]];
+                for (int q = 0; q < a; ++q) t = fma(-tmp[a * GDM + q], y[q], t);
+                y[a] = t / tmp[a * GDM + a];
+            }
+            for (int a = no - 1; a >= 0; --a) {
+                double t = y[a];
+                for (int q = a + 1; q < no; ++q) t = fma(-tmp[q * GDM + a], y[q], t);
+                y[a] = t / tmp[a * GDM + a];
+                dP[o[a]] += y[a];
+            }
+            for (int a = 0; a < no; ++a)
+                for (int b = 0; b < no; ++b) dS[a * GDM + b] = -0.5 * rec[1 + d + o[a] * d + o[b]];
+        } else {
+        for (int a = 0; a < no; ++a) dP[o[a]] += rec[1 + o[a]];
+        // Sigma_oo^-1
         inv_from_chol(tmp, no, W, Sinv);
         // dSoo = 1/2 (A0 Sigma_oo^-1 + Cacc)       GPz.m:174
         for (int a = 0; a < no; ++a)
@@ -296,6 +316,7 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
                 for (int q = 0; q < no; ++q) s = fma(tmp[a * GDM + q], Soo[q * GDM + b], s);
                 dS[a * GDM + b] = -s;                                       // now diSoo
             }
+        }
         // GuuGuo = iSigma_uu^-1 iSigma_uo  (nu x no)   GPz.m:156,178
         if (nu > 0) {
             for (int a = 0; a < nu; ++a)
@@ -339,24 +360,24 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
     o[d + d * d + 1] = r2;
 }
 
+// One thread per (basis, entry): threads along the entries so the loads of a pattern's block are contiguous.
 __global__ void k_gen_finish_sum(const double *__restrict__ part, int G, int m, int d, int method_id,
                                  const double *__restrict__ sums1, int k, double *__restrict__ grad,
                                  double *__restrict__ dGfull, double *__restrict__ cols, int mp) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const double nk = sums1[10] * (double)k;
     const int md = m * d, np = d + d * d + 2;
-    for (int e = 0; e < np; ++e) {
-        double s = 0.0;
-        for (int g = 0; g < G; ++g) s += part[((size_t)g * m + j) * np + e];
-        if (e < d) grad[j + m * e] = -s / nk;
-        else if (e < d + d * d) {
-            const int a = (e - d) / d, b = (e - d) % d;
-            if (method_id == 5) grad[md + a + d * b + d * d * j] = -s / nk;
-            else dGfull[(size_t)j * d * d + a * d + b] = s;
-        } else if (cols) {
-            cols[(e == d + d * d ? 0 : mp) + j] = s;
-        }
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)m * np) return;
+    const int j = (int)(t / np), e = (int)(t % np);
+    const double nk = sums1[10] * (double)k;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += part[((size_t)g * m + j) * np + e];
+    if (e < d) grad[j + m * e] = -s / nk;
+    else if (e < d + d * d) {
+        const int a = (e - d) / d, b = (e - d) % d;
+        if (method_id == 5) grad[md + a + d * b + d * d * j] = -s / nk;
+        else dGfull[(size_t)j * d * d + a * d + b] = s;
+    } else if (cols) {
+        cols[(e == d + d * d ? 0 : mp) + j] = s;
     }
 }
 
@@ -656,53 +677,28 @@ __global__ void k_gen_pattern_params(const double *__restrict__ Sig, const doubl
     if (u0 >= 0) out[nt + u0] = sqrt((double)(d - no) * GPZ_LOG2);
 }
 
-// Tuned moment sums of one pattern, [m][nmt (+2)] = [M1 (de) | S packed upper (de(de+1)/2) | r1, r2], -> the records of
-// k_gen_moments for k_gen_finish:  acc1 = Sigma_oo^-1 M1_o,  cacc = Sigma_oo^-1 S_oo Sigma_oo^-1,  a0 = 0 (its two
-// occurrences in GPz.m:174 cancel without input noise).  Entries of missing dimensions are never read.
+// Tuned moment sums of one pattern, [m][nmt (+2)] = [M1 (de) | S packed upper (de(de+1)/2) | r1, r2], scattered into the
+// record layout of k_gen_moments ([a0 = 0 | M1 (d) | S (d x d) | r1 | r2], zeros on missing dimensions) for k_gen_finish's
+// `raw` mode.  The sums stay linear in the rows, so they can be all-reduced across ranks as they are.
 __global__ void k_gen_convert_moments(const double *__restrict__ frecAll, int stride, int has_r,
-                                      const double *__restrict__ Sig, const unsigned char *__restrict__ pat, int m, int d,
+                                      const unsigned char *__restrict__ pat, int m, int d,
                                       int de, double *__restrict__ recsAll, int nrec) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;                          // [G][m][stride] in, [G][m][nrec] out
     if (j >= m) return;
-    const double *frec = frecAll + (size_t)g * m * stride;
-    double *recs = recsAll + (size_t)g * m * nrec;
-    int o[GDM], no = 0;
-    for (int c = 0; c < d; ++c)
-        if (pat[g * d + c]) o[no++] = c;
-    double A[GDM * GDM], W[GDM * GDM], Ki[GDM * GDM], T1[GDM * GDM];
-    for (int a = 0; a < no; ++a)
-        for (int b = 0; b < no; ++b) A[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
-    chol_small(A, no);
-    inv_from_chol(A, no, W, Ki);
-    const double *f = frec + (size_t)j * stride;
-    auto S = [&](int a, int b) -> double {             // packed upper of the tuned kernels, symmetric
-        const int lo = a < b ? a : b, hi = a < b ? b : a;
-        return f[de + lo * de - lo * (lo - 1) / 2 + (hi - lo)];
-    };
-    double *rec = recs + (size_t)j * nrec;
-    for (int e = 0; e < nrec; ++e) rec[e] = 0.0;
-    for (int a = 0; a < no; ++a) {
-        double s = 0.0;
-        for (int b = 0; b < no; ++b) s = fma(Ki[a * GDM + b], f[o[b]], s);
-        rec[1 + o[a]] = s;
-    }
-    for (int a = 0; a < no; ++a)
-        for (int b = 0; b < no; ++b) {
-            double s = 0.0;
-            for (int q = 0; q < no; ++q) s = fma(Ki[a * GDM + q], S(o[q], o[b]), s);
-            T1[a * GDM + b] = s;
+    const double *f = frecAll + ((size_t)g * m + j) * stride;
+    double *rec = recsAll + ((size_t)g * m + j) * nrec;
+    const unsigned char *pg = pat + (size_t)g * d;
+    rec[0] = 0.0;
+    for (int a = 0; a < d; ++a) {
+        rec[1 + a] = pg[a] ? f[a] : 0.0;
+        for (int b = 0; b < d; ++b) {
+            const int lo = a < b ? a : b, hi = a < b ? b : a;   // packed upper of the tuned kernels, symmetric
+            rec[1 + d + a * d + b] = (pg[a] && pg[b]) ? f[de + lo * de - lo * (lo - 1) / 2 + (hi - lo)] : 0.0;
         }
-    for (int a = 0; a < no; ++a)
-        for (int b = 0; b < no; ++b) {
-            double s = 0.0;
-            for (int q = 0; q < no; ++q) s = fma(T1[a * GDM + q], Ki[q * GDM + b], s);
-            rec[1 + d + o[a] * d + o[b]] = s;
-        }
-    if (has_r) {
-        rec[1 + d + d * d] = f[stride - 2];
-        rec[2 + d + d * d] = f[stride - 1];
     }
+    rec[1 + d + d * d] = has_r ? f[stride - 2] : 0.0;
+    rec[2 + d + d * d] = has_r ? f[stride - 1] : 0.0;
 }
 
 void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *P, const unsigned char *pat, int G, int m,
@@ -711,8 +707,9 @@ void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *
 }
 void launch_gen_convert_moments(hipStream_t st, const double *frecAll, int stride, int has_r, const double *Sig,
                                 const unsigned char *pat, int G, int m, int d, int de, double *recsAll, int nrec) {
-    hipLaunchKernelGGL(k_gen_convert_moments, dim3((m + 63) / 64, G), dim3(64), 0, st, frecAll, stride, has_r, Sig, pat, m, d,
-                       de, recsAll, nrec);
+    (void)Sig;
+    hipLaunchKernelGGL(k_gen_convert_moments, dim3((m + 63) / 64, G), dim3(64), 0, st, frecAll, stride, has_r, pat, m, d, de,
+                       recsAll, nrec);
 }
 
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
@@ -752,8 +749,10 @@ void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int 
 
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
-                       double *grad, double *dGfull, double *cols, int mp, int nrec, double *part) {
-    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64, G), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, part, nrec);
-    hipLaunchKernelGGL(k_gen_finish_sum, dim3((m + 63) / 64), dim3(64), 0, st, (const double *)part, G, m, d, method_id, sums1, k,
-                       grad, dGfull, cols, mp);
+                       double *grad, double *dGfull, double *cols, int mp, int nrec, double *part, int raw) {
+    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64, G), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, part, nrec,
+                       raw);
+    const long nt = (long)m * (d + d * d + 2);
+    hipLaunchKernelGGL(k_gen_finish_sum, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const double *)part, G, m, d,
+                       method_id, sums1, k, grad, dGfull, cols, mp);
 }
