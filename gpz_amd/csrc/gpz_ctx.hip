@@ -188,7 +188,8 @@ struct gpz_ctx {
     double pinv_last[4] = {0, 0, 0, 0};   // [route taken, rank kept, max singular value, Jacobi sweeps] of the last call
     // general covariance-kind path
     bool gen = false;
-    bool psi_fast = false;   // gen && Psi && no missing dims && d <= 10: register-resident kernels (k_psi.hip)
+    bool psi_fast = false;   // gen && Psi && d <= 10 && fp64: register-resident kernels (k_psi.hip), missing dimensions included
+    bool psi_miss = false;   // psi_fast with more than one NaN pattern (or a pattern with missing dimensions)
     bool psi32 = false;      // dtype f32 && gen && Psi && no missing dims: fp32 register-resident kernels (k_psi32.hip)
     bool psi32_agreed = false;   // sharded runs: the ranks have agreed on diagonal vs full Psi (first evaluation)
     int ngroups = 0, nrec = 0;
@@ -525,7 +526,8 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
                     return fail(GPZ_ERR_HIP, "copy failed");
             }
         }
-        c->psi_fast = !c->psi32 && c->has_psi && !c->has_missing && c->ngroups == 1 && psi_fast_path_available(c->d);
+        c->psi_fast = !c->psi32 && c->has_psi && psi_fast_path_available(c->d);
+        c->psi_miss = c->psi_fast && (c->has_missing || c->ngroups > 1);
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
@@ -565,8 +567,35 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         return code;
     };
     if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation, patterns, n_patterns))) return bail(rc);
+    // moment chunks of the training rows that end at NaN-pattern boundaries: ~n/target rows each (at least min_rows),
+    // plus each pattern's range of chunks for the segmented slab sum
+    auto build_chunks = [&](int target, int min_rows) -> int {
+        int rpc = (c->tr.n + target - 1) / target;
+        if (rpc < min_rows) rpc = min_rows;
+        std::vector<int> ct, seg((size_t)c->ngroups + 1);
+        for (int g = 0; g < c->ngroups; ++g) {
+            seg[g] = (int)(ct.size() / 2);
+            const int re = c->tr.group_begin[g + 1];
+            for (int r = c->tr.group_begin[g]; r < re; r += rpc) {
+                ct.push_back(r);
+                ct.push_back(r + rpc < re ? r + rpc : re);
+            }
+        }
+        seg[c->ngroups] = c->mom_nchunk = (int)(ct.size() / 2);
+        if (ct.empty()) ct.assign(2, 0);
+        if (int e = c->ar.alloc(&c->mom_chunktab, ct.size())) return e;
+        if (int e = c->ar.alloc(&c->mom_segtab, seg.size())) return e;
+        if (hipMemcpy(c->mom_chunktab, ct.data(), ct.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->mom_segtab, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(GPZ_ERR_HIP, "copy failed");
+        return 0;
+    };
     if (c->gen) {
         c->gen_nchunk = 256;
+        if (c->psi_miss) {
+            if ((rc = build_chunks(256, 1))) return bail(rc);
+            if (c->mom_nchunk > c->gen_nchunk) c->gen_nchunk = c->mom_nchunk;     // gen_slab holds one record set per chunk
+        }
         const size_t per = (c->psi32 && psi32_raw_len(c->d) > c->nrec) ? (size_t)psi32_raw_len(c->d) : (size_t)c->nrec;
         if ((rc = c->ar.alloc(&c->gen_slab, (size_t)c->gen_nchunk * c->m * per))) return bail(rc);
         if (c->psi32 && (rc = c->ar.alloc(&c->psi32_raw, (size_t)c->m * psi32_raw_len(c->d)))) return bail(rc);
@@ -575,25 +604,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             const int nmt = c->de + c->de * (c->de + 1) / 2;
             c->gen_tnch = 2048 / ((c->m + 255) / 256);
             if (c->gen_tnch < 1) c->gen_tnch = 1;
-            // one moment launch over all patterns: row chunks of ~n/gen_tnch rows (at least 32) that end at pattern boundaries
-            int rpc = (c->tr.n + c->gen_tnch - 1) / c->gen_tnch;
-            if (rpc < 32) rpc = 32;
-            std::vector<int> ct, seg((size_t)c->ngroups + 1);
-            for (int g = 0; g < c->ngroups; ++g) {
-                seg[g] = (int)(ct.size() / 2);
-                const int re = c->tr.group_begin[g + 1];
-                for (int r = c->tr.group_begin[g]; r < re; r += rpc) {
-                    ct.push_back(r);
-                    ct.push_back(r + rpc < re ? r + rpc : re);
-                }
-            }
-            seg[c->ngroups] = c->mom_nchunk = (int)(ct.size() / 2);
-            if (ct.empty()) ct.assign(2, 0);
-            if ((rc = c->ar.alloc(&c->mom_chunktab, ct.size()))) return bail(rc);
-            if ((rc = c->ar.alloc(&c->mom_segtab, seg.size()))) return bail(rc);
-            if (hipMemcpy(c->mom_chunktab, ct.data(), ct.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(c->mom_segtab, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-                return bail(fail(GPZ_ERR_HIP, "copy failed"));
+            if ((rc = build_chunks(c->gen_tnch, 32))) return bail(rc);
             const size_t nslab = c->mom_nchunk > 0 ? (size_t)c->mom_nchunk : 1;
             if ((rc = c->ar.alloc(&c->gen_tslab, nslab * c->m * (nmt + 2)))) return bail(rc);
             if ((rc = c->ar.alloc(&c->gen_frec, (size_t)c->ngroups * c->m * (nmt + 2)))) return bail(rc);
@@ -858,7 +869,8 @@ static int build_phi(gpz_ctx *c) {
                              c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi, c->mp);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else if (c->psi_fast) {
-            launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp);
+            launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp,
+                           c->psi_miss ? c->pat_d : nullptr);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else {
             launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
@@ -1022,8 +1034,16 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 nch = (c->tr.n + rpc - 1) / rpc;
             if (nch < 1) nch = 1;
                 if (nch < 1) nch = 1;
+                if (c->psi_miss) {   // one launch over all NaN patterns, one record set per pattern
+                    launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
+                                       gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab,
+                                       c->nrec, c->pat_d, c->mom_chunktab);
+                    launch_slab_sum_seg(c->st, c->gen_slab, c->mom_segtab, c->ngroups, m * c->nrec, mom);
+                    continue;
+                }
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
-                                   gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                                   gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec,
+                                   nullptr, nullptr);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
                 continue;
             }
@@ -1089,9 +1109,15 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
             nch = (c->tr.n + rpc - 1) / rpc;
             if (nch < 1) nch = 1;
-            launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
-                               c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
-            launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
+            if (c->psi_miss) {
+                launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
+                                   c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab, c->nrec, c->pat_d, c->mom_chunktab);
+                launch_slab_sum_seg(c->st, c->gen_slab, c->mom_segtab, c->ngroups, m * c->nrec, mom);
+            } else {
+                launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
+                                   c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec, nullptr, nullptr);
+                launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
+            }
         } else if (c->gen) {
             const GenRows gr = gen_rows(c->tr);
             for (int g = 0; g < c->ngroups; ++g) {
@@ -1129,7 +1155,8 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                              c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi_v, c->mp);
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else if (c->psi_fast) {
-            launch_psi_phi(c->st, gen_rows(c->va), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi_v, c->mp);
+            launch_psi_phi(c->st, gen_rows(c->va), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi_v, c->mp,
+                           c->psi_miss ? c->pat_d : nullptr);
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else {
             launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,

@@ -205,11 +205,14 @@ void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int 
 void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y);
 // register-resident variants for Psi without missing dimensions, 2 <= d <= 10 (k_psi.hip); return -1 outside that range
 bool psi_fast_path_available(int d);
+// pat (observed flags [G][d]) non-null: rows carry missing dimensions (r.gid = pattern per row, lnS = [G][m]);
+// chunktab (optional): {first row, end row} per moment chunk
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                   const double *lnS, double *Phi, int ld);
+                   const double *lnS, double *Phi, int ld, const unsigned char *pat);
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                       int nchunk, int rows_per_chunk, double *slab, int nrec);
+                       int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
+                       const int *chunktab);
 // fp32 per-pair kernels for Psi without missing dimensions, d <= 20 (k_psi32.hip).  PsiT: packed lower triangles of
 // Psi_i, element-major [e][ldp] (diag != 0: only the D diagonals), D = psi32_pad_dim(d).
 int psi32_pad_dim(int d);

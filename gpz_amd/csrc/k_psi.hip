@@ -65,11 +65,16 @@ __device__ __forceinline__ void inv_packed(const double (&L)[D * (D + 1) / 2], d
 
 // PHI, one thread per row; Sigma_j / p_j / ln|Sigma_j| staged through LDS for JB basis functions at a time.
 // Xr: n_pad x de, Psi3: n_pad x d*d (column-major d x d per row), Sig: m x d*d, lnS: m (pattern 0).
-template <int D>
+// MISS: rows may have missing dimensions (gid = pattern per row, pat = observed flags [G][D], lnS = ln|Sigma_j,oo| as
+// [G][m]).  A missing dimension is marginalised by making M block diagonal with an identity block on it and zeroing
+// its Delta: ln|M| = ln|M_oo| and Delta' M^-1 Delta = Delta_o' M_oo^-1 Delta_o exactly, so the full-width register
+// kernel serves every pattern (getPHI.m:80-87 with o = observed dimensions).
+template <int D, bool MISS>
 __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, int de, const double *__restrict__ Psi3,
                                                   int n, int m, const double *__restrict__ P,
                                                   const double *__restrict__ Sig, const double *__restrict__ lnS,
-                                                  double *__restrict__ Phi, int ld) {
+                                                  double *__restrict__ Phi, int ld, const int *__restrict__ gid,
+                                                  const unsigned char *__restrict__ pat) {
     constexpr int NP = D * (D + 1) / 2;
     constexpr int JB = 8;
     constexpr int REC = NP + D + 1;          // [Sigma_j packed | p_j | ln|Sigma_j|]
@@ -77,13 +82,26 @@ __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, 
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n;
     const int ic = act ? i : 0;
-    double x[D], psi[NP];
+    double x[D], psi[NP], sel[MISS ? D : 1];
+    const int g = MISS ? gid[ic] : 0;
+    double cmiss = 0.0;
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] = Xr[(size_t)ic * de + c];
+    if (MISS) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            sel[c] = pat[g * D + c] ? 1.0 : 0.0;
+            cmiss -= 0.5 * GPZ_LOG2 * (1.0 - sel[c]);                           // -1/2 |u| ln 2   (getPHI.m:87)
+        }
+    }
 #pragma unroll
     for (int r = 0; r < D; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) psi[LT(r, c)] = Psi3[(size_t)ic * D * D + r + D * c];
+        for (int c = 0; c <= r; ++c) {
+            const double v = Psi3[(size_t)ic * D * D + r + D * c];
+            if (MISS) psi[LT(r, c)] = (sel[r] * sel[c] != 0.0) ? v : (r == c ? 1.0 : 0.0);   // Psi of a missing dimension is never read
+            else psi[LT(r, c)] = v;
+        }
     for (int j0 = 0; j0 < m; j0 += JB) {
         __syncthreads();
         for (int e = threadIdx.x; e < JB * REC; e += 256) {
@@ -109,20 +127,29 @@ __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, 
             if (j >= m) break;
             const double *t = prm + jj * REC;
             double M[NP], y[D];
+            if (MISS) {
 #pragma unroll
-            for (int e = 0; e < NP; ++e) M[e] = psi[e] + t[e];                 // Psi(o,o,i) + Sigma(o,o)      getPHI.m:84
+                for (int r = 0; r < D; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) M[LT(r, c)] = fma(sel[r] * sel[c], t[LT(r, c)], psi[LT(r, c)]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NP; ++e) M[e] = psi[e] + t[e];             // Psi(o,o,i) + Sigma(o,o)      getPHI.m:84
+            }
             double hl;
             chol_packed<D>(M, &hl);
             double quad = 0.0;
 #pragma unroll
             for (int r = 0; r < D; ++r) {                                      // y = L^-1 Delta
                 double s = x[r] - t[NP + r];
+                if (MISS) s *= sel[r];
 #pragma unroll
                 for (int c = 0; c < r; ++c) s = fma(-M[LT(r, c)], y[c], s);
                 y[r] = s / M[LT(r, r)];
                 quad = fma(y[r], y[r], quad);
             }
-            const double lp = -0.5 * quad + 0.5 * t[NP + D] - hl;              // getPHI.m:86
+            const double lns = MISS ? lnS[(size_t)g * m + j] : t[NP + D];
+            const double lp = -0.5 * quad + 0.5 * lns - hl + cmiss;            // getPHI.m:86
             if (act) Phi[(size_t)i * ld + j] = exp(lp);
         }
     }
@@ -130,13 +157,15 @@ __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, 
 
 // Moment records for k_gen_finish (pattern 0 = all dimensions observed): thread per basis j, rows walked with x_i and
 // Psi_i wave-uniform.  rec = [A0 | Acc1 (d) | Cacc (d*d) | r1 | r2]  (see k_gen_moments).
-template <int D>
+template <int D, bool MISS>
 __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ Phi, const double *__restrict__ T, int ld,
                                                      const double *__restrict__ rowscal, const double *__restrict__ w,
                                                      const double *__restrict__ v, const double *__restrict__ Xr, int de,
                                                      const double *__restrict__ Psi3, int n, int m,
                                                      const double *__restrict__ P, const double *__restrict__ Sig,
-                                                     int rows_per_chunk, double *__restrict__ slab, int nrec) {
+                                                     int rows_per_chunk, double *__restrict__ slab, int nrec,
+                                                     const int *__restrict__ gid, const unsigned char *__restrict__ pat,
+                                                     const int *__restrict__ chunktab) {
     constexpr int NP = D * (D + 1) / 2;
     const int j = blockIdx.y * 64 + threadIdx.x;
     const bool act = j < m;
@@ -152,7 +181,8 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
     }
     const double wj = w ? w[jc] : 0.0, vj = v ? v[jc] : 0.0;
     double a0 = 0.0, r1 = 0.0, r2 = 0.0;
-    const int r0 = chunk * rows_per_chunk, rend = min(n, r0 + rows_per_chunk);
+    int r0 = chunk * rows_per_chunk, rend = min(n, r0 + rows_per_chunk);
+    if (chunktab) { r0 = chunktab[2 * chunk]; rend = chunktab[2 * chunk + 1]; }   // chunks that end at pattern boundaries
     for (int i = r0; i < rend; ++i) {
         const double ph = Phi[(size_t)i * ld + jc];
         double dp;
@@ -166,11 +196,22 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
         }
         double L[NP], W[NP], Mi[NP], dl[D], u[D];
         const double *ps = Psi3 + (size_t)i * D * D;
+        if (MISS) {   // a missing dimension: identity block in M, zero Delta (see k_psi_phi); wave-uniform flags
+            const unsigned char *ob = pat + (size_t)gid[i] * D;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                dl[r] = ob[r] ? Xr[(size_t)i * de + r] - p[r] : 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c)
+                    L[LT(r, c)] = (ob[r] && ob[c]) ? sg[LT(r, c)] + ps[r + D * c] : (r == c ? 1.0 : 0.0);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < D; ++r) {
             dl[r] = Xr[(size_t)i * de + r] - p[r];
 #pragma unroll
             for (int c = 0; c <= r; ++c) L[LT(r, c)] = sg[LT(r, c)] + ps[r + D * c];     // Sigma + Psi_i    GPz.m:170
+        }
         }
         double hl;
         chol_packed<D>(L, &hl);
@@ -218,23 +259,41 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
         default: return -1;        \
     }
 
-// returns -1 when d is outside the instantiated range (caller falls back to the general kernels)
+// returns -1 when d is outside the instantiated range (caller falls back to the general kernels).
+// pat != nullptr: rows carry missing dimensions (r.gid, lnS = [G][m]); nullptr: one pattern, lnS = [m].
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                   const double *lnS, double *Phi, int ld) {
+                   const double *lnS, double *Phi, int ld, const unsigned char *pat) {
     if (r.n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;   // a rank of a sharded run may hold no row of this set
-#define PHI_CASE(DD) \
-    hipLaunchKernelGGL(k_psi_phi<DD>, dim3((r.n + 255) / 256), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, P, Sig, lnS, Phi, ld)
+#define PHI_CASE(DD)                                                                                                       \
+    do {                                                                                                                   \
+        if (pat)                                                                                                           \
+            hipLaunchKernelGGL((k_psi_phi<DD, true>), dim3((r.n + 255) / 256), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, P, \
+                               Sig, lnS, Phi, ld, r.gid, pat);                                                            \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_psi_phi<DD, false>), dim3((r.n + 255) / 256), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, P, \
+                               Sig, lnS, Phi, ld, nullptr, nullptr);                                                      \
+    } while (0)
     PSI_CASES(PHI_CASE)
 #undef PHI_CASE
     return 0;
 }
 
+// chunktab (optional): {first row, end row} per chunk instead of chunk * rows_per_chunk
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                       int nchunk, int rows_per_chunk, double *slab, int nrec) {
-#define MOM_CASE(DD)                                                                                                  \
-    hipLaunchKernelGGL(k_psi_moments<DD>, dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, w, v, r.Xr, de, \
-                       r.Psi3, r.n, m, P, Sig, rows_per_chunk, slab, nrec)
+                       int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
+                       const int *chunktab) {
+    if (nchunk <= 0) return (d >= 2 && d <= 10) ? 0 : -1;
+#define MOM_CASE(DD)                                                                                                       \
+    do {                                                                                                                   \
+        if (pat)                                                                                                           \
+            hipLaunchKernelGGL((k_psi_moments<DD, true>), dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, \
+                               w, v, r.Xr, de, r.Psi3, r.n, m, P, Sig, rows_per_chunk, slab, nrec, r.gid, pat, chunktab);   \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_psi_moments<DD, false>), dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, \
+                               w, v, r.Xr, de, r.Psi3, r.n, m, P, Sig, rows_per_chunk, slab, nrec, nullptr, nullptr,       \
+                               chunktab);                                                                                  \
+    } while (0)
     PSI_CASES(MOM_CASE)
 #undef MOM_CASE
     return 0;
