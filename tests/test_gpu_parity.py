@@ -782,3 +782,34 @@ def test_sharded_f32_ranks_agree_on_the_psi_form():
     for rank, f, g, stats, w, part, n_global in res:
         assert abs(f - ref.nlogML) <= F32_FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= F32_GTOL
     assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,k,psi", [("VC", 10, 1, False), ("GC", 10, 2, False), ("VC", 8, 1, True), ("GC", 7, 2, True),
+                                            ("VC", 12, 1, False), ("VC", 16, 1, False)])
+def test_many_nan_patterns_single_launch(method, d, k, psi):
+    """GC/VC with dozens of distinct NaN patterns (most of them a handful of rows): the PHI build and the moment sums run
+    as ONE launch over all patterns (workgroup / chunk tables), with input noise on the register-resident kernels where a
+    missing dimension is an identity block of M.  Validation rows bring patterns the training rows never show."""
+    n, m = 700, 24
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=400 + d + k, psi=psi)
+    miss = rng.random((n, d)) < 0.12            # several missing dimensions per row (make_problem's nanfrac drops one)
+    miss[:, int(rng.integers(d))] = False       # keep every row at least one observed dimension
+    miss[:3] = False
+    X = X.copy(); X[miss] = np.nan
+    pats = {tuple(r) for r in miss}
+    assert len(pats) >= 20
+    tr = rng.random(n) < 0.7
+    om = rng.random((n, 1)) + 0.5
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        stats = ctx.stats
+    finally:
+        ctx.close()
+    tol = max(grad_tol(ref.cond), phi_tol(model, theta))
+    assert abs(f - ref.nlogML) <= max(FTOL, phi_tol(model, theta)) * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol
+    for key in ("trainRMSE", "trainLL", "validRMSE", "validLL"):
+        assert abs(stats[key] - ref.stats[key]) <= 1e-9 * max(1.0, abs(ref.stats[key]))

@@ -28,6 +28,11 @@ for c in range(cases):
     model, theta, X, Y, Psi, r2 = make_problem(n, d, m, k, method, hetero, seed=seed, psi=psi, nanfrac=nanfrac)
     if model.method != method:                      # d == 1 rewrites *D/*C to *L (init.m:12-14)
         method = model.method
+    multi = bool(nanfrac > 0 and d > 2 and rng.random() < 0.5)
+    if multi:                                       # several missing dimensions per row, many distinct patterns
+        miss = r2.random((n, d)) < nanfrac / 2
+        miss[:, int(r2.integers(d))] = False
+        X = X.copy(); X[miss] = np.nan
     om = (r2.random((n, 1)) + 0.5) if rng.random() < 0.4 else None
     tr = (r2.random(n) < 0.8) if rng.random() < 0.5 else None
     va = None
@@ -36,7 +41,7 @@ for c in range(cases):
     if tr is not None and tr.sum() < 4:
         tr[:4] = True
         if va is not None: va = ~tr
-    tag = f"case {c}: {method} n={n} d={d} m={m} k={k} het={int(hetero)} psi={int(psi)} nan={nanfrac} om={om is not None} tr={tr is not None} va={va is not None} seed={seed}"
+    tag = f"case {c}: {method} n={n} d={d} m={m} k={k} het={int(hetero)} psi={int(psi)} nan={nanfrac} multi={int(multi)} om={om is not None} tr={tr is not None} va={va is not None} seed={seed}"
     try:
         ref = O.GPz(theta, model, X, Y, Psi, om, tr, va)
         r4 = O.GPz(theta, model, X, Y, Psi, om, tr, va, nargout=4)
