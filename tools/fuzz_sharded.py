@@ -27,6 +27,10 @@ def build(cfg):
     if cfg["f32"]:
         theta = _well_conditioned_gamma(model, theta, r2)
     n = cfg["n"]
+    if cfg["nanfrac"] > 0 and cfg["d"] > 2 and cfg["seed"] % 2:   # several missing dimensions per row, many patterns
+        miss = r2.random((n, cfg["d"])) < 0.15
+        miss[:, int(r2.integers(cfg["d"]))] = False
+        X = X.copy(); X[miss] = np.nan
     om = (r2.random((n, 1)) + 0.5) if cfg["om"] else None
     tr = va = None
     if cfg["masks"] >= 1:
