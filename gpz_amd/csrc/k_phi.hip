@@ -610,6 +610,9 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
                            ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
+#ifndef GPZ_PHI_DIAG_RP
+#define GPZ_PHI_DIAG_RP(D) ((D) == 16 ? 1 : 2)   // measured: d=16 0.69 -> 0.52 ms, d=20 0.93 -> 1.05 ms (n=1e5, m=256)
+#endif
 template <int KIND, int D>
 static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     if (KIND == GPZ_KIND_COV) {
@@ -617,10 +620,11 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
         return;
     }
     constexpr int R = 2, JB = 16;                    // diagonal kinds are store-bound
-    const int rows_per_wg = 4 * 64 * R;
-    const int nwg = (a.n_pad + rows_per_wg - 1) / rows_per_wg;
+    // with input noise a thread holds x, the mask and Psi of its rows (3 R D doubles): one row per thread where that measured faster
+    constexpr int RP = GPZ_PHI_DIAG_RP(D);
 #define PHI_DIAG(KG, PS) \
-    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, R, JB>), dim3(nwg), dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P, \
+    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, (PS ? RP : R), JB>), dim3((a.n_pad + 256 * (PS ? RP : R) - 1) / (256 * (PS ? RP : R))), \
+                       dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,                                           \
                        a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt)
     if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
     else { if (a.Psic) PHI_DIAG(true, true); else PHI_DIAG(true, false); }
