@@ -340,15 +340,15 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// generic strided tile GEMM for the m x m factorisation (sizes <= a few thousand; L2 resident)
+// tile GEMM for the m x m factorisation (sizes <= a few thousand; L2 resident)
 // ---------------------------------------------------------------------------------------------
-// C[M x N] (row stride sc, unit column stride) = beta*C + alpha * A[M x K] * B[K x N]
-// A element (i,k) at A[i*sa_r + k*sa_c];  B element (k,j) at B[k*sb_r + j*sb_c].
-// One workgroup computes the 64x64 tile (tm, tn).
-__device__ void gemm_tile_64(const double *__restrict__ A, long sa_r, long sa_c,
-                             const double *__restrict__ B, long sb_r, long sb_c,
-                             double *__restrict__ C, long sc, int M, int N, int K,
-                             double alpha, double beta, int tm, int tn) {
+// C[M x N] (row-major, stride ldc) = alpha * A[M x K] * B[K x N] over k in [kbeg, kend) only (both multiples of 16):
+// the callers' operands are triangular, so half of every product is structurally zero.  A and B row-major (lda, ldb,
+// both multiples of 4 with 32-byte aligned rows).  One workgroup computes the 64x64 tile (tm, tn); the next 16-deep
+// slice is fetched into registers (row-wise, 32 bytes per lane) while the current one is multiplied.
+__device__ void gemm_tile_64(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
+                             double *__restrict__ C, long ldc, int M, int N, int kbeg, int kend, double alpha, int tm,
+                             int tn) {
     __shared__ double sA[16][LDS_LD64];
     __shared__ double sB[16][LDS_LD64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -360,15 +360,26 @@ __device__ void gemm_tile_64(const double *__restrict__ A, long sa_r, long sa_c,
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kk = (tid >> 6) + 4 * q, ii = tid & 63;
-            const int gi = i0 + ii, gj = j0 + ii, gk = k0 + kk;
-            sA[kk][ii] = (gi < M && gk < K) ? A[gi * sa_r + gk * sa_c] : 0.0;
-            sB[kk][ii] = (gj < N && gk < K) ? B[gk * sb_r + gj * sb_c] : 0.0;
-        }
+    const int ar = tid >> 2, ak = (tid & 3) * 4;       // A slice: 64 rows x 16 k, four consecutive k per lane
+    const int bk = tid >> 4, bc = (tid & 15) * 4;      // B slice: 16 k x 64 columns, four consecutive columns per lane
+    const bool aok = i0 + ar < M, bok = j0 + bc < N;   // N is a multiple of 4
+    const double *ap = A + (size_t)(i0 + ar) * lda + ak;
+    const double *bp = B + (size_t)bk * ldb + j0 + bc;
+    d2_t ra[2], rb[2];
+    auto gload = [&](int k0) {
+        const d2_t z = {0.0, 0.0};
+        ra[0] = aok ? *reinterpret_cast<const d2_t *>(ap + k0) : z;
+        ra[1] = aok ? *reinterpret_cast<const d2_t *>(ap + k0 + 2) : z;
+        rb[0] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb) : z;
+        rb[1] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb + 2) : z;
+    };
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        sA[ak + 0][ar] = ra[0][0]; sA[ak + 1][ar] = ra[0][1]; sA[ak + 2][ar] = ra[1][0]; sA[ak + 3][ar] = ra[1][1];
+        *reinterpret_cast<d2_t *>(&sB[bk][bc]) = rb[0];
+        *reinterpret_cast<d2_t *>(&sB[bk][bc + 2]) = rb[1];
         __syncthreads();
+        if (k0 + 16 < kend) gload(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int kr = kk * 4 + (lane >> 4);
@@ -392,11 +403,7 @@ __device__ void gemm_tile_64(const double *__restrict__ A, long sa_r, long sa_c,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wr * 32 + mi * 16 + (lane >> 4) + 4 * r;
-                if (row < M && col < N) {
-                    double *p = C + row * sc + col;
-                    const double v = alpha * acc[mi][ni][r];
-                    *p = (beta == 0.0) ? v : (beta * (*p) + v);
-                }
+                if (row < M && col < N) C[row * ldc + col] = alpha * acc[mi][ni][r];
             }
         }
 }
@@ -414,12 +421,12 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
     const int Mr = min(gs, mq - rb);
     const int tm = blockIdx.y, tn = blockIdx.x;
     if (tm * 64 >= Mr) return;
-    if (phase == 0) {
-        gemm_tile_64(L + (size_t)rb * ld + a, ld, 1, W + (size_t)a * ld + a, ld, 1,
-                     Tmp + (size_t)rb * ld + a, ld, Mr, gs, gs, 1.0, 0.0, tm, tn);
-    } else {
-        gemm_tile_64(W + (size_t)rb * ld + rb, ld, 1, Tmp + (size_t)rb * ld + a, ld, 1,
-                     W + (size_t)rb * ld + a, ld, Mr, gs, Mr, -1.0, 0.0, tm, tn);
+    if (phase == 0) {   // W(left,left) is lower triangular: rows k < 64 tn of it are zero in this tile's columns
+        gemm_tile_64(L + (size_t)rb * ld + a, ld, W + (size_t)a * ld + a, ld, Tmp + (size_t)rb * ld + a, ld, Mr, gs,
+                     tn * 64, gs, 1.0, tm, tn);
+    } else {            // W(right,right) is lower triangular: columns k >= 64 (tm + 1) of this tile's rows are zero
+        gemm_tile_64(W + (size_t)rb * ld + rb, ld, Tmp + (size_t)rb * ld + a, ld, W + (size_t)rb * ld + a, ld, Mr, gs,
+                     0, min(Mr, tm * 64 + 64), -1.0, tm, tn);
     }
 }
 
