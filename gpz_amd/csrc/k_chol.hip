@@ -68,6 +68,19 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
     while (tm * (tm + 1) / 2 > (int)blockIdx.x) --tm;
     const int tn = (int)blockIdx.x - tm * (tm + 1) / 2;
+    // this wave's part of the trailing tile is fetched first, so its latency hides behind the factorisation
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+    double cold[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = t0 + tm * 64 + wr * 32 + a * 16 + lk + 4 * r;
+                const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
+                cold[a][b][r] = (gr < mq && gc < mq) ? A[(size_t)gr * lda + gc] : 0.0;
+            }
     double x[CH_NB];
     int row = -1;
     if (wave == 0) {
@@ -87,9 +100,14 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
             }
         }
         if (blockIdx.x == 0) {
-            double ld = 0.0;
+            // one logarithm per lane (lane c holds l_cc) and a wave sum, instead of 32 logarithms in sequence on the
+            // critical path of the workgroup that also owns tile (0, 0)
+            double dg = 1.0;
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) ld += log(__shfl(x[c], c, 64));
+            for (int c = 0; c < CH_NB; ++c) dg = (lane == c) ? x[c] : dg;
+            double ld = log(dg);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) ld += __shfl_xor(ld, off, 64);
             if (lane == 0) {
                 *logdet += 2.0 * ld;                                       // inv_logdet.m:15
                 if (bad && *info == 0) *info = k0 + bad;
@@ -111,12 +129,13 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     __syncthreads();
     if (wave == 1 || wave == 2) {
         if (row >= 0) {
+            // column-oriented substitution: the updates of one column are independent of each other (a row-oriented
+            // dot product is one dependent chain of up to 31 multiply-adds per entry)
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) {
-                double s = x[c];
+                x[c] *= Dinv[c];
 #pragma unroll
-                for (int q = 0; q < c; ++q) s = fma(-x[q], D[c][q], s);
-                x[c] = s * Dinv[c];
+                for (int q = c + 1; q < CH_NB; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
             }
             if (tn == 0 && wave == 1) {
                 double *lr = Lm + (size_t)row * lda + k0;
@@ -131,7 +150,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     if (t0 + tm * 64 >= mq) return;                                        // last step: nothing below the diagonal block
     const double (*Xm)[CH_NB + 1] = Xs[0];
     const double (*Xn)[CH_NB + 1] = Xs[tm == tn ? 0 : 1];
-    const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
     d4_t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
             for (int r = 0; r < 4; ++r) {
                 const int gr = t0 + tm * 64 + wr * 32 + a * 16 + lk + 4 * r;
                 const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
-                if (gr < mq && gc < mq) A[(size_t)gr * lda + gc] -= acc[a][b][r];
+                if (gr < mq && gc < mq) A[(size_t)gr * lda + gc] = cold[a][b][r] - acc[a][b][r];
             }
 }
 
