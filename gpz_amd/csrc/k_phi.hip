@@ -622,13 +622,18 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     constexpr int R = 2, JB = 16;                    // diagonal kinds are store-bound
     // with input noise a thread holds x, the mask and Psi of its rows (3 R D doubles): one row per thread where that measured faster
     constexpr int RP = GPZ_PHI_DIAG_RP(D);
-#define PHI_DIAG(KG, PS) \
-    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, (PS ? RP : R), JB>), dim3((a.n_pad + 256 * (PS ? RP : R) - 1) / (256 * (PS ? RP : R))), \
+    // few rows (fewer than two workgroups per CU at two rows per thread): one row per thread doubles the workgroups
+    const bool small = (a.n_pad + 511) / 512 < 512;
+#define PHI_DIAG_R(KG, PS, RR) \
+    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, RR, JB>), dim3((a.n_pad + 256 * RR - 1) / (256 * RR)),                      \
                        dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,                                           \
                        a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt)
+#define PHI_DIAG(KG, PS) \
+    do { if (PS) PHI_DIAG_R(KG, PS, RP); else if (small) PHI_DIAG_R(KG, PS, 1); else PHI_DIAG_R(KG, PS, R); } while (0)
     if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
     else { if (a.Psic) PHI_DIAG(true, true); else PHI_DIAG(true, false); }
 #undef PHI_DIAG
+#undef PHI_DIAG_R
 }
 
 template <int KIND>
