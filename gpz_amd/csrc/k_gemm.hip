@@ -81,37 +81,55 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     // diagonal tiles: the wave blocks strictly below the diagonal (rows 64..127 x columns 0..63) are never read by
     // the slab reduction; their waves only take part in the staging, which frees MFMA slots for the other workgroup
     const bool skip = diag_tile && wr == 1 && wc < WC / 2;
-    auto mfma_half = [&](int cur, int kk0) {
+    // Fragments one K step ahead of the MFMA burst, barrier in front of a slice's last burst (see tgemm_body).
+    auto rdfrag = [&](int cur, int kk, double (&a)[4], double (&b)[NI]) {
         if (skip) return;
         const double(*tA)[LDS_LD128] = sA[cur];
         const double(*tB)[LDS_LD128] = diag_tile ? sA[cur] : sB[cur];
+        const int krow = kk * 4 + (lane >> 4);
+        const double wv = (WEIGHTED && !PRESCALE) ? sW[cur][krow] : 1.0;
 #pragma unroll
-        for (int kk = kk0; kk < kk0 + 2; ++kk) {
-            const int krow = kk * 4 + (lane >> 4);
-            double a[4], b[NI];
-            const double wv = (WEIGHTED && !PRESCALE) ? sW[cur][krow] : 1.0;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                double t = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
-                a[mi] = (WEIGHTED && !PRESCALE) ? t * wv : t;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+        for (int mi = 0; mi < 4; ++mi) {
+            double t = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
+            a[mi] = (WEIGHTED && !PRESCALE) ? t * wv : t;
         }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
     };
+    auto burst = [&](const double (&a)[4], const double (&b)[NI]) {
+        if (skip) return;
+        __builtin_amdgcn_s_setprio(1);   // see tgemm_body
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    double fa0[4] = {0.0, 0.0, 0.0, 0.0}, fb0[NI] = {}, fa1[4] = {0.0, 0.0, 0.0, 0.0}, fb1[NI] = {};
+    if (nstage > 0) rdfrag(0, 0, fa0, fb0);
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
-        mfma_half(cur, 0);
+        rdfrag(cur, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdfrag(cur, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
             if (s + 2 < nstage) gload(r_begin + (s + 2) * 16);
         }
-        mfma_half(cur, 2);
+        rdfrag(cur, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (s + 1 < nstage) rdfrag(cur ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
@@ -253,32 +271,54 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     lstore(0);
     if (nstage > 1) gload(16);
     __syncthreads();
-    auto mfma_half = [&](int cur, int kk0) {
+    // Operand fragments are fetched from LDS one K step ahead of the MFMA burst that uses them, and the barrier of a
+    // slice sits in front of its last burst, so the first fragment of the next slice is fetched under that burst.
+    auto rdfrag = [&](int cur, int kk, double (&a)[4], double (&b)[NI]) {
+        const int kc = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int kk = kk0; kk < kk0 + 2; ++kk) {
-            const int kc = kk * 4 + (lane >> 4);
-            double a[4], b[NI];
+        for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (!EDGE || ni < nvalid) {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
-                }
-        }
+        for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
     };
+    // Raised wave priority over the MFMA burst only: the SIMD's issue arbiter then prefers a wave whose operands are
+    // ready over the waves that are staging (global loads, LDS writes, address VALU), which otherwise take issue
+    // slots in front of it.  k_tgemm 33.15 -> 31.95 ms at c4; raising it over the LDS operand reads as well gives
+    // nothing, priority 3 the same as 1.  Fragment prefetch on top: 32.1 -> 31.6 ms.
+    auto burst = [&](const double (&a)[4], const double (&b)[NI]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            if (!EDGE || ni < nvalid) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    double fa0[4], fb0[NI], fa1[4], fb1[NI];
+    rdfrag(0, 0, fa0, fb0);
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
-        mfma_half(cur, 0);
+        rdfrag(cur, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdfrag(cur, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
             if (s + 2 < nstage) gload((s + 2) * 16);
         }
-        mfma_half(cur, 2);
+        rdfrag(cur, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (s + 1 < nstage) rdfrag(cur ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        burst(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
