@@ -152,7 +152,8 @@ struct gpz_ctx {
     double *lnbeta_v = nullptr, *phiw_v = nullptr;
     double *slab = nullptr;
     size_t slab_count = 0;
-    int nsplit = 1, rows_per_split = 16;
+    int nsplit = 1, rows_per_split = 16;       // off-diagonal tiles of PHI' W PHI
+    int nsplit_d = 1, rows_per_split_d = 16;   // diagonal tiles (3/4 of the work per row: longer row ranges)
     int nsplit_l = 1, rows_per_split_l = 16;
     // communication buffers
     double *comm1 = nullptr;   // [k * mp*mp | GPZ_NS]
@@ -632,13 +633,26 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
         int target = (c->tr.n_pad / (1024 / npairs > 0 ? 1024 / npairs : 1) >= 16384) ? 1024 : 512;
         if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e);
-        int ns = target / npairs;   // floor: npairs*ns workgroups fill at most two full rounds of 512 resident slots
-        const int max_ns = c->tr.n_pad / 64;
-        if (ns > max_ns) ns = max_ns;
-        if (ns < 1) ns = 1;
-        c->rows_per_split = rup((c->tr.n_pad + ns - 1) / ns, 16);
+        // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 6 of 8 MFMAs per K step):
+        // the pair that minimises max(1/s1, 0.75/s2) with noff*s1 + nt*s2 workgroups inside the target.
+        const int noff = npairs - nt, max_ns = c->tr.n_pad / 64 > 0 ? c->tr.n_pad / 64 : 1;
+        int s1 = 1, s2 = 1;
+        double best = 1e300;
+        for (int a = 1; a <= max_ns && a <= target && noff * a + nt <= (target > npairs ? target : npairs); ++a) {
+            int b = noff ? (target - noff * a) / nt : a;
+            if (b > max_ns) b = max_ns;
+            if (b > a) b = a;
+            if (b < 1) b = 1;
+            const double cost = 1.0 / a > 0.75 / b ? 1.0 / a : 0.75 / b;
+            if (cost < best) { best = cost; s1 = a; s2 = b; }
+        }
+        if (const char *e = getenv("GPZ_SYRK_S1")) s1 = atoi(e) > 0 ? atoi(e) : s1;   // tuning only
+        if (const char *e = getenv("GPZ_SYRK_S2")) s2 = atoi(e) > 0 ? atoi(e) : s2;
+        c->rows_per_split = rup((c->tr.n_pad + s1 - 1) / s1, 16);
         c->nsplit = (c->tr.n_pad + c->rows_per_split - 1) / c->rows_per_split;
-        size_t need = (size_t)c->nsplit * mp * mp;
+        c->rows_per_split_d = rup((c->tr.n_pad + s2 - 1) / s2, 16);
+        c->nsplit_d = (c->tr.n_pad + c->rows_per_split_d - 1) / c->rows_per_split_d;
+        size_t need = (size_t)(c->nsplit > c->nsplit_d ? c->nsplit : c->nsplit_d) * mp * mp;
         size_t need_l = (size_t)c->nsplit_l * c->mq * c->mq;
         c->slab_count = need > need_l ? need : need_l;
         if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
@@ -918,11 +932,11 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         {
             Stage s(c, "syrk");
             launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
-                        c->rows_per_split, c->slab, false);
+                        c->rows_per_split, c->nsplit_d, c->rows_per_split_d, c->slab, false);
         }
         {
             Stage s(c, "syrk_reduce");
-            launch_syrk_reduce(c->st, c->slab, c->nsplit, c->mp, c->comm1 + (size_t)o * c->mp * c->mp, c->mp);
+            launch_syrk_reduce(c->st, c->slab, c->nsplit, c->nsplit_d, c->mp, c->comm1 + (size_t)o * c->mp * c->mp, c->mp);
         }
     }
     {
@@ -953,8 +967,9 @@ static void stage_b(gpz_ctx *c, int o) {
     }
     {
         Stage s(c, "lauum");
-        launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
-        launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
+        launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
+                    true);
+        launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
     }
     {
         Stage s(c, "solve_vectors");
@@ -1792,8 +1807,9 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     launch_zero(c->st, c->Wm, (size_t)mq * mq);
     launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
     for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
-    launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->slab, true);
-    launch_syrk_reduce(c->st, c->slab, c->nsplit_l, mq, c->Sinv, mq);
+    launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
+                    true);
+    launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
     launch_cond_flag(c->st, S, m, alpha0, c->Sinv, mq, m, c->Tmp, c->info);
     int info_h[2] = {0, 0};
     double ld = 0.0;

@@ -18,7 +18,7 @@
 // TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
 // WC = wave columns of the 2 x WC wave grid: WC = 2 -> 4 waves of 64x64 each, WC = 4 -> 8 waves of 64x32 each
 // (64 accumulator registers per wave, 4 waves per SIMD with two workgroups per CU).
-template <bool WEIGHTED, bool EDGE, int WC, bool DIAGT>
+template <bool WEIGHTED, int WC, bool DIAGT>
 __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld, const double *__restrict__ wgt,
                                           int mp, int i0, int j0, int r_begin, int r_end,
                                           double *__restrict__ out, double (*sA)[16][LDS_LD128],
@@ -43,15 +43,18 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     // staging map: a wave reads one full 1 KiB tile row per q
     d2_t ra[Q], rb[Q];
     double rw = 0.0, rwq[PRESCALE ? Q : 1];
+    // Edge tiles (mp not a multiple of 128): columns >= mp are read from the last valid column pair instead of being
+    // zero-filled; they only feed accumulators whose rows / columns the guarded store below drops, so the K loop is
+    // the same for every tile.  (c is the same for every q: NT is a multiple of 64.)
+    const int ca = min(i0 + (tid & 63) * 2, mp - 2), cb = min(j0 + (tid & 63) * 2, mp - 2);
     auto gload = [&](int r0) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
             const double *src = Phi + (size_t)(r0 + row) * ld;
-            ra[q] = (!EDGE || i0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + i0 + c) : (d2_t){0.0, 0.0};
-            if (!diag_tile)
-                rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(src + j0 + c) : (d2_t){0.0, 0.0};
+            ra[q] = *reinterpret_cast<const d2_t *>(src + ca);
+            if (!diag_tile) rb[q] = *reinterpret_cast<const d2_t *>(src + cb);
             if (PRESCALE) rwq[q] = wgt[r0 + row];
         }
         if (WEIGHTED && !PRESCALE && tid < 16) rw = wgt[r0 + tid];
@@ -78,34 +81,49 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         if (nstage > 1) gload(r_begin + 16);
     }
     __syncthreads();
-    // diagonal tiles: the wave blocks strictly below the diagonal (rows 64..127 x columns 0..63) are never read by
-    // the slab reduction; their waves only take part in the staging, which frees MFMA slots for the other workgroup
-    const bool skip = diag_tile && wr == 1 && wc < WC / 2;
     // Fragments one K step ahead of the MFMA burst, barrier in front of a slice's last burst (see tgemm_body).
-    auto rdfrag = [&](int cur, int kk, double (&a)[4], double (&b)[NI]) {
-        if (skip) return;
+    // Diagonal tiles: only the 64x64 blocks (0,0), (0,1), (1,1) are wanted.  Each block is dealt over all eight waves
+    // as 16x32 strips (wave -> strip row dr, strip half dh), so a wave runs 6 MFMAs per K step on 2 A and 4 B fragments
+    // and every SIMD carries the same 3/4 of an off-diagonal tile's work (k_syrk splits the rows accordingly).
+    static_assert(!DIAGT || NI == 2, "diagonal-tile wave roles are written for the 2 x 4 wave grid");
+    constexpr int NA = DIAGT ? 3 : 4, NB = DIAGT ? 4 : NI;   // fragment registers (diagonal: 2 A + weight, 4 B)
+    const int dr = DIAGT ? wave >> 1 : 0, dh = DIAGT ? wave & 1 : 0;
+    auto rdfrag = [&](int cur, int kk, double (&a)[NA], double (&b)[NB]) {
         const double(*tA)[LDS_LD128] = sA[cur];
-        const double(*tB)[LDS_LD128] = diag_tile ? sA[cur] : sB[cur];
         const int krow = kk * 4 + (lane >> 4);
-        const double wv = (WEIGHTED && !PRESCALE) ? sW[cur][krow] : 1.0;
+        if (DIAGT) {
+            if (WEIGHTED) a[2] = sW[cur][krow];   // applied in burst(): a multiply here would wait for the LDS data at once
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            double t = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
-            a[mi] = (WEIGHTED && !PRESCALE) ? t * wv : t;
+            for (int h = 0; h < 2; ++h) a[h] = tA[krow][h * 64 + dr * 16 + (lane & 15)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = tA[krow][(q >> 1) * 64 + dh * 32 + (q & 1) * 16 + (lane & 15)];
+        } else {
+            const double(*tB)[LDS_LD128] = sB[cur];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
         }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
     };
-    auto burst = [&](const double (&a)[4], const double (&b)[NI]) {
-        if (skip) return;
+    auto burst = [&](const double (&a)[NA], const double (&b)[NB]) {
         __builtin_amdgcn_s_setprio(1);   // see tgemm_body
+        if (DIAGT) {
+            const double a0 = WEIGHTED ? a[0] * a[2] : a[0], a1 = WEIGHTED ? a[1] * a[2] : a[1];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < 2; ++ni) acc[0][ni] = MFMA_F64(a0, b[ni], acc[0][ni]);        // block (0,0)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+            for (int ni = 0; ni < 2; ++ni) acc[1][ni] = MFMA_F64(a0, b[2 + ni], acc[1][ni]);    // block (0,1)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[2][ni] = MFMA_F64(a1, b[2 + ni], acc[2][ni]);    // block (1,1)
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
-    double fa0[4] = {0.0, 0.0, 0.0, 0.0}, fb0[NI] = {}, fa1[4] = {0.0, 0.0, 0.0, 0.0}, fb1[NI] = {};
+    double fa0[NA] = {}, fb0[NB] = {}, fa1[NA] = {}, fb1[NB] = {};
     if (nstage > 0) rdfrag(0, 0, fa0, fb0);
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
@@ -133,14 +151,16 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     }
 
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < (DIAGT ? 3 : 4); ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
+            const int col = DIAGT ? j0 + (mi == 0 ? 0 : 64) + dh * 32 + ni * 16 + (lane & 15)
+                                  : j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
-                if (!EDGE || (row < mp && col < mp)) out[(size_t)row * mp + col] = acc[mi][ni][r];
+                const int row = DIAGT ? i0 + (mi == 2 ? 64 : 0) + dr * 16 + (lane >> 4) + 4 * r
+                                      : i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
+                if (row < mp && col < mp) out[(size_t)row * mp + col] = acc[mi][ni][r];
             }
         }
 }
@@ -148,7 +168,8 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 template <bool WEIGHTED, bool TRI, int WC>
 __global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict__ Phi, int ld,
                                                        const double *__restrict__ wgt, int n_rows, int mp,
-                                                       int ntile, int rows_per_split,
+                                                       int ntile, int nsplit, int rows_per_split,
+                                                       int nsplit_d, int rows_per_split_d,
                                                        double *__restrict__ slab) {
     __shared__ double sA[2][16][LDS_LD128];
     __shared__ double sB[2][16][LDS_LD128];
@@ -159,40 +180,53 @@ __global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict_
     // PHI at the same time, so a slice is fetched once per split instead of once per tile.
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
     const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int pair = lb % npairs;
-    const int split = lb / npairs;
-    // decode pair -> (ti <= tj), row-major over the upper triangle
-    int ti = 0, rem = pair;
-    while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
-    const int tj = ti + rem;
+    // Off-diagonal tiles take nsplit row ranges of rows_per_split rows; diagonal tiles cost 3/4 as much per row and
+    // take nsplit_d longer ranges (rows_per_split_d).  Enumeration: group g = the noff off-diagonal tiles of row range
+    // g followed by an even share of the ntile*nsplit_d diagonal workgroups, so every contiguous stretch of logical
+    // blocks (= every XCD) carries the same mix.
+    const int noff = npairs - ntile, ndiag = ntile * nsplit_d;
+    auto gstart = [&](int g) { return g * noff + g * ndiag / nsplit; };   // all products < 2^31 (grid < 2^16 groups)
+    int g = (int)((unsigned)lb * (unsigned)nsplit / (unsigned)(noff * nsplit + ndiag));
+    g = g > nsplit - 1 ? nsplit - 1 : g;
+    while (g > 0 && gstart(g) > lb) --g;
+    while (g + 1 < nsplit && gstart(g + 1) <= lb) ++g;
+    const int within = lb - gstart(g);
+    int ti, tj, split, rps;
+    if (within < noff) {
+        split = g;
+        rps = rows_per_split;
+        int rem = within;   // row-major over the strict upper triangle
+        ti = 0;
+        while (rem >= ntile - 1 - ti) { rem -= ntile - 1 - ti; ++ti; }
+        tj = ti + 1 + rem;
+    } else {
+        const int q = g * ndiag / nsplit + within - noff;
+        split = q / ntile;
+        rps = rows_per_split_d;
+        ti = tj = q % ntile;
+    }
     const bool diag_tile = (ti == tj);
     const int i0 = ti * 128, j0 = tj * 128;
 
-    int r_begin = split * rows_per_split;
-    int r_end = min(n_rows, r_begin + rows_per_split);
+    int r_begin = split * rps;
+    int r_end = min(n_rows, r_begin + rps);
     if (TRI) r_begin = max(r_begin, j0 & ~15);
     double *out = slab + (size_t)split * mp * mp;
-    // interior tiles take the guard-free body (no exec-mask branches in the K loop)
-    if (diag_tile) {
-        if (j0 + 128 <= mp)
-            syrk_body<WEIGHTED, false, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
-        else
-            syrk_body<WEIGHTED, true, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
-    } else {
-        if (j0 + 128 <= mp)
-            syrk_body<WEIGHTED, false, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
-        else
-            syrk_body<WEIGHTED, true, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
-    }
+    if (diag_tile)
+        syrk_body<WEIGHTED, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+    else
+        syrk_body<WEIGHTED, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
 }
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
-__global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit, int mp, double *__restrict__ S, int lds) {
+__global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, int nsplit_d, int mp,
+                              double *__restrict__ S, int lds) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= mp) return;
     const int ti = i >> 7, tj = j >> 7;
     const bool upper = (ti < tj) || (ti == tj && i <= j);
+    const int nsplit = (ti == tj) ? nsplit_d : nsplit_off;
     const size_t src = upper ? ((size_t)i * mp + j) : ((size_t)j * mp + i);
     const size_t stride = (size_t)mp * mp;
     const double *p = slab + src;
@@ -479,22 +513,25 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
 int gpz_gemm_wave_cols() { return GPZ_GEMM_WC; }
 
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
-                 int nsplit, int rows_per_split, double *slab, bool tri) {
+                 int nsplit, int rows_per_split, int nsplit_d, int rows_per_split_d, double *slab, bool tri) {
     constexpr int WC = GPZ_GEMM_WC;
     const int ntile = (mp + 127) / 128;
-    const int npairs = ntile * (ntile + 1) / 2;
-    dim3 grid(npairs * nsplit), block(128 * WC);
+    const int noff = ntile * (ntile - 1) / 2;
+    dim3 grid(noff * nsplit + ntile * nsplit_d), block(128 * WC);
     if (tri)
-        hipLaunchKernelGGL((k_syrk<false, true, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<false, true, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+                           rows_per_split, nsplit_d, rows_per_split_d, slab);
     else if (wgt)
-        hipLaunchKernelGGL((k_syrk<true, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<true, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+                           rows_per_split, nsplit_d, rows_per_split_d, slab);
     else
-        hipLaunchKernelGGL((k_syrk<false, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, rows_per_split, slab);
+        hipLaunchKernelGGL((k_syrk<false, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+                           rows_per_split, nsplit_d, rows_per_split_d, slab);
 }
 
-void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int mp, double *S, int lds) {
+void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds) {
     dim3 block(256), grid((mp + 255) / 256, mp);
-    hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, mp, S, lds);
+    hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, nsplit_d, mp, S, lds);
 }
 
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_bench.hip -o tools/mfma_f64_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // 16 independent accumulators pinned in registers by inline asm (no accumulator shuffling by the compiler)
@@ -51,9 +52,9 @@ double timeit(F f) {
     (void)hipEventRecord(e0); f(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms;
 }
-int main() {
+int main(int argc, char **argv) {
     double *out; (void)hipMalloc(&out, 256 * 8 * 512 * sizeof(double));
-    const int iters = 4000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 4000;   // 4000: 2-7 ms launches; 40000 shows the sustained (power-limited) rate
     const double mf = 16 * 2.0 * 16 * 16 * 4;      // flops per wave per mfma_loop iteration
     const double ff = 16 * 64 * 2.0;               // flops per wave per fma_loop iteration
     for (int wps : {1, 2, 3, 4}) {                 // waves per SIMD
