@@ -632,7 +632,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     {
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
         int target = (c->tr.n_pad / (1024 / npairs > 0 ? 1024 / npairs : 1) >= 16384) ? 1024 : 512;
-        if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e);
+        if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e) > 0 ? atoi(e) : target;
         // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 6 of 8 MFMAs per K step):
         // the pair that minimises max(1/s1, 0.75/s2) with noff*s1 + nt*s2 workgroups inside the target.
         const int noff = npairs - nt, max_ns = c->tr.n_pad / 64 > 0 ? c->tr.n_pad / 64 : 1;
