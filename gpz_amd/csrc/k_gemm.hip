@@ -8,6 +8,7 @@
 // Tiling: a workgroup is 4 waves (2x2), each wave owns a 64x64 block of the 128x128 output tile as
 // 4x4 MFMA tiles (16 accumulators x 4 f64 = 128 accumulator registers).  Operands are staged
 // global -> registers -> LDS in 16-deep K slices, double buffered, one barrier per slice.
+#include <type_traits>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -268,18 +269,31 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    // A slice: 128 rows x 16 doubles, 8 consecutive lanes cover one 128-byte row segment
+    // A slice: 128 rows x 16 doubles, 8 consecutive lanes cover one 128-byte row segment.
+    // Addressing is kept off the vector ALU (a VALU instruction takes issue cycles from the MFMA pipe of its SIMD:
+    // tools/mfma_f64_operands.hip, 6 v_mov per 8 MFMAs cost 6 %): the global loads use a wave-uniform base pointer
+    // (SGPR pair, advanced by scalar adds) plus one loop-invariant 32-bit byte offset per operand, and the K loop is
+    // unrolled over the two LDS buffers so that every LDS address is a loop-invariant register plus an immediate.
+    // Columns >= mp of the last column tile are read from the last valid pair (never stored, see the epilogue).
     d2_t ra[Q], rb[Q];
-    auto gload = [&](int k0) {
+    const unsigned voa = (unsigned)(((tid >> 3) * ld + (tid & 7) * 2) * 8);
+    const unsigned vob = (unsigned)(((tid >> 6) * ldb + min(j0 + (tid & 63) * 2, mp - 2)) * 8);
+    const size_t qsa = (size_t)(NT / 8) * ld * 8, qsb = (size_t)(NT / 64) * ldb * 8, ksb = (size_t)16 * ldb * 8;
+    const char *pa = reinterpret_cast<const char *>(Phi + (size_t)i0 * ld);
+    const char *pb = reinterpret_cast<const char *>(B);
+    auto gload = [&]() {   // next 16-deep slice
+        // the empty asm keeps the 32 -> 64 bit extension of the offsets in this block, where instruction selection
+        // folds it into the load's (SGPR base + VGPR offset) addressing mode; hoisted out of the loop it would come back
+        // as a 64-bit vector add per load
+        unsigned oa = voa, ob = vob;
+        asm volatile("" : "+v"(oa), "+v"(ob));
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            int idx = q * NT + tid;
-            int arow = idx >> 3, ac = (idx & 7) * 2;
-            ra[q] = *reinterpret_cast<const d2_t *>(Phi + (size_t)(i0 + arow) * ld + k0 + ac);
-            int row = idx >> 6, c = (idx & 63) * 2;
-            rb[q] = (!EDGE || j0 + c < mp) ? *reinterpret_cast<const d2_t *>(B + (size_t)(k0 + row) * ldb + j0 + c)
-                                           : (d2_t){0.0, 0.0};
+            ra[q] = *reinterpret_cast<const d2_t *>(pa + q * qsa + oa);
+            rb[q] = *reinterpret_cast<const d2_t *>(pb + q * qsb + ob);
         }
+        pa += 16 * 8;
+        pb += ksb;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -301,9 +315,9 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 
     // Software pipeline as in syrk_body: loads of slice s+2 issued mid-slice s, LDS writes between the MFMA halves.
     const int nstage = mp / 16;
-    gload(0);
+    gload();
     lstore(0);
-    if (nstage > 1) gload(16);
+    if (nstage > 1) gload();
     __syncthreads();
     // Operand fragments are fetched from LDS one K step ahead of the MFMA burst that uses them, and the barrier of a
     // slice sits in front of its last burst, so the first fragment of the next slice is fetched under that burst.
@@ -330,8 +344,8 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     };
     double fa0[4], fb0[NI], fa1[4], fb1[NI];
     rdfrag(0, 0, fa0, fb0);
-    for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
+    auto stage = [&](auto curc, int s) {
+        constexpr int cur = decltype(curc)::value;
         rdfrag(cur, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         burst(fa0, fb0);
@@ -342,7 +356,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
-            if (s + 2 < nstage) gload((s + 2) * 16);
+            if (s + 2 < nstage) gload();
         }
         rdfrag(cur, 3, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -353,7 +367,13 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         __builtin_amdgcn_sched_barrier(0);
         burst(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 1 < nstage; s += 2) {
+        stage(std::integral_constant<int, 0>{}, s);
+        stage(std::integral_constant<int, 1>{}, s + 1);
     }
+    if (s < nstage) stage(std::integral_constant<int, 0>{}, s);
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
