@@ -48,17 +48,26 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     // zero-filled; they only feed accumulators whose rows / columns the guarded store below drops, so the K loop is
     // the same for every tile.  (c is the same for every q: NT is a multiple of 64.)
     const int ca = min(i0 + (tid & 63) * 2, mp - 2), cb = min(j0 + (tid & 63) * 2, mp - 2);
-    auto gload = [&](int r0) {
+    // No address arithmetic on the vector ALU inside the K loop (see tgemm_body): wave-uniform base pointers advanced by
+    // scalar adds, loop-invariant 32-bit byte offsets, LDS addresses as register + immediate (loop unrolled over the
+    // two buffers).
+    const unsigned voa = (unsigned)(((tid >> 6) * ld + ca) * 8), vob = (unsigned)(((tid >> 6) * ld + cb) * 8);
+    const unsigned vow = (unsigned)((PRESCALE ? (tid >> 6) : (tid & 15)) * 8);
+    const size_t qsp = (size_t)(NT / 64) * ld * 8, ksp = (size_t)16 * ld * 8;
+    const char *pp = reinterpret_cast<const char *>(Phi + (size_t)r_begin * ld);
+    const char *pw = reinterpret_cast<const char *>(WEIGHTED ? wgt + r_begin : nullptr);
+    auto gload = [&]() {   // next 16-row slice
+        unsigned oa = voa, ob = vob, ow = vow;
+        asm volatile("" : "+v"(oa), "+v"(ob), "+v"(ow));   // keeps the offset extension next to the loads (SGPR-base mode)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            int idx = q * NT + tid;
-            int row = idx >> 6, c = (idx & 63) * 2;
-            const double *src = Phi + (size_t)(r0 + row) * ld;
-            ra[q] = *reinterpret_cast<const d2_t *>(src + ca);
-            if (!diag_tile) rb[q] = *reinterpret_cast<const d2_t *>(src + cb);
-            if (PRESCALE) rwq[q] = wgt[r0 + row];
+            ra[q] = *reinterpret_cast<const d2_t *>(pp + q * qsp + oa);
+            if (!diag_tile) rb[q] = *reinterpret_cast<const d2_t *>(pp + q * qsp + ob);
+            if (PRESCALE) rwq[q] = *reinterpret_cast<const double *>(pw + q * (NT / 64) * 8 + ow);
         }
-        if (WEIGHTED && !PRESCALE && tid < 16) rw = wgt[r0 + tid];
+        if (WEIGHTED && !PRESCALE && tid < 16) rw = *reinterpret_cast<const double *>(pw + ow);
+        pp += ksp;
+        if (WEIGHTED) pw += 16 * 8;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -77,9 +86,9 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     // LDS writes sit between the two MFMA halves instead of in front of the barrier.
     const int nstage = (r_end > r_begin) ? (r_end - r_begin) / 16 : 0;
     if (nstage > 0) {
-        gload(r_begin);
+        gload();
         lstore(0);
-        if (nstage > 1) gload(r_begin + 16);
+        if (nstage > 1) gload();
     }
     __syncthreads();
     // Fragments one K step ahead of the MFMA burst, barrier in front of a slice's last burst (see tgemm_body).
@@ -126,8 +135,8 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     };
     double fa0[NA] = {}, fb0[NB] = {}, fa1[NA] = {}, fb1[NB] = {};
     if (nstage > 0) rdfrag(0, 0, fa0, fb0);
-    for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
+    auto stage = [&](auto curc, int s) {
+        constexpr int cur = decltype(curc)::value;
         rdfrag(cur, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         burst(fa0, fb0);
@@ -138,7 +147,7 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nstage) {
             lstore(cur ^ 1);
-            if (s + 2 < nstage) gload(r_begin + (s + 2) * 16);
+            if (s + 2 < nstage) gload();
         }
         rdfrag(cur, 3, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -149,7 +158,13 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         __builtin_amdgcn_sched_barrier(0);
         burst(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 1 < nstage; s += 2) {
+        stage(std::integral_constant<int, 0>{}, s);
+        stage(std::integral_constant<int, 1>{}, s + 1);
     }
+    if (s < nstage) stage(std::integral_constant<int, 0>{}, s);
 
 #pragma unroll
     for (int mi = 0; mi < (DIAGT ? 3 : 4); ++mi)
