@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-end measurement pass on the GPU box (via gpurun): bench lines of every configuration, the rocprofv3 kernel
+# trace and the PMC passes of the default workload.  usage: tools/measure_all.sh <tag>      -> gpurun_out/<tag>/
+set -u
+tag=$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+python bench.py > $O/c4.json 2> $O/c4.err
+python bench.py --config c2 > $O/c2.json 2> $O/c2.err
+python bench.py --config c3 > $O/c3.json 2> $O/c3.err
+python bench.py --rows 125000 --no-cpu-baseline > $O/c4_shard125k.json 2> $O/c4_shard125k.err
+python bench.py --config c5 --rows 250000 --steps 3 --warmup 1 > $O/c5s.json 2> $O/c5s.err
+tools/pmc_run.sh $tag/pmc > $O/pmc_run.log 2>&1
+cd $R
+python tools/pmc_summary.py gpurun_out/$tag/pmc gpurun_out/$tag/pmc_summary.txt > /dev/null 2>&1
+find gpurun_out/$tag/pmc/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+# keep the merged-back payload small: the raw counter CSVs are large
+find gpurun_out/$tag/pmc -name "*.csv" -size +4M -delete
+tail -c 600 $O/c4.json; echo; tail -c 300 $O/c2.json; echo; tail -c 300 $O/c3.json; echo; tail -c 300 $O/c4_shard125k.json
