@@ -436,7 +436,11 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                     vj[o] = (v && o < k) ? v[j + (size_t)m * o] : 0.0;
                     wj[o] = (wv && o < k) ? wv[j + (size_t)m * o] : 0.0;
                 }
-                const double *rj = prm + jj * NP;
+                // R_j's LDS address through a vector register: as a scalar the compiler rebuilds every broadcast-read address
+                // with s_add + v_mov (39 VALU moves per basis and 4 rows at d = 10); a VGPR base takes immediates
+                unsigned rjo = (unsigned)(jj * NP * sizeof(double));
+                asm volatile("" : "+v"(rjo));
+                const double *rj = reinterpret_cast<const double *>(reinterpret_cast<const char *>(prm) + rjo);
                 double q[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) q[r] = 0.0;
