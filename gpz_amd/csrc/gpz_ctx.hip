@@ -688,7 +688,8 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
         if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * (c->nm + 2)))) return bail(rc);
     }
-    if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_SMALL_NWG * GPZ_NS))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_ROWSCAL_MAX_NWG * GPZ_NS))) return bail(rc);
+    static_assert(GPZ_ROWSCAL_MAX_NWG >= GPZ_SMALL_NWG, "partial record buffer");
     if ((rc = c->ar.alloc(&c->rstats, (size_t)GPZ_NS))) return bail(rc);
     if ((rc = c->ar.alloc(&c->spart, (size_t)8))) return bail(rc);
     if ((rc = c->ar.alloc(&c->dGfull, c->kind == GPZ_KIND_COV ? m * c->d * c->d : m * c->d))) return bail(rc);
@@ -1023,7 +1024,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 Stage s(c, "row_scalars");
                 launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->wbeta,
                                    c->tr.n_pad, c->tr.n, c->rowscal, c->partial);
-                launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
+                launch_slab_sum(c->st, c->partial, row_scalars_nwg(c->tr.n), GPZ_NS, c->rstats);
                 HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");

@@ -126,7 +126,12 @@ int launch_moments(hipStream_t st, const MomentArgs &a);
 
 // Fused single-output path: row scalars from the T-GEMM epilogue, then moments with dPHI formed on the fly.
 //   rowscal[i*4 + {0,1,2}] = omega*beta, omega*beta*delta, dbeta   (GPz.m:48,79,93)
-//   partial: GPZ_SMALL_NWG records of GPZ_NS doubles [sum c*delta, sum omega*delta^2, sum LL, sum dbeta, ...]
+//   partial: row_scalars_nwg(n) records of GPZ_NS doubles [sum c*delta, sum omega*delta^2, sum LL, sum dbeta, ...]
+#define GPZ_ROWSCAL_MAX_NWG 1024
+inline int row_scalars_nwg(int n) {   // one workgroup per 512 rows, 128 .. 1024 (the kernel is bound by load latency)
+    const int w = (n + 511) / 512;
+    return w < 128 ? 128 : (w > GPZ_ROWSCAL_MAX_NWG ? GPZ_ROWSCAL_MAX_NWG : w);
+}
 void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
                         const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
                         double *rowscal, double *partial);

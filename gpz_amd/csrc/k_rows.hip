@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_row_scalars(const double *__restrict__ 
 void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
                         const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
                         double *rowscal, double *partial) {
-    hipLaunchKernelGGL(k_row_scalars, dim3(GPZ_SMALL_NWG), dim3(256), 0, st, nupart, nslots, phiw, y, omega, lnbeta, wbeta,
+    hipLaunchKernelGGL(k_row_scalars, dim3(row_scalars_nwg(n)), dim3(256), 0, st, nupart, nslots, phiw, y, omega, lnbeta, wbeta,
                        n_pad, n, rowscal, partial);
 }
 
