@@ -398,8 +398,11 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                                                         double *__restrict__ slab, int nm,
                                                         const double *__restrict__ Psir, const double *__restrict__ Mr,
                                                         const double *__restrict__ G2, const int *__restrict__ chunktab) {
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    const int chunk = blockIdx.x;
+    // Column group fastest in a 1-D grid: the workgroups that read the same rows of PHI / T are dispatched together
+    // and visit those DRAM pages at about the same time (c4: 4.66 -> 4.55 ms against chunk-fastest order)
+    const int ncg = (m + 255) >> 8;
+    const int j = (int)(blockIdx.x % ncg) * 256 + threadIdx.x;
+    const int chunk = blockIdx.x / ncg;
     const bool act = j < m;
     const int jc = act ? j : 0;
     double p[D];
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
     } while (0)
 
 int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
-    dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
+    dim3 g((unsigned)((a.m + 255) / 256) * (unsigned)a.nchunk), b(256);
     if (a.kind == GPZ_KIND_COV) {
         switch (a.d) {
             case 1: MOMF(GPZ_KIND_COV, 1, 0, 1); break;
