@@ -26,6 +26,15 @@ from .api import GPzContext, Model
 # --------------------------------------------------------------------------------------------------
 # minFunc: L-BFGS + strong Wolfe
 # --------------------------------------------------------------------------------------------------
+def _vdot(a, b):
+    """Inner product of two optimiser vectors.  NumPy vectors go through einsum, not BLAS: a threaded ddot on a 10^5-vector
+    costs milliseconds where the BLAS pool is wider than the cores the process may use (18 ms against 50 us on the
+    8-core build container), and minFunc's iteration is a dozen such products."""
+    if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
+        return float(np.einsum("i,i->", a, b))
+    return float(a @ b)
+
+
 def _legal(v):
     """isLegal.m: real, no NaN, no Inf."""
     if isinstance(v, DevVec):
@@ -186,7 +195,7 @@ def _armijo(fun, x, t, d, f, fr, g, gtd, c1, prog_tol):
         elif not _legal(g_new):
             t = _polyinterp([(0.0, f, gtd), (t, f_new, None)], 0.0, t)
         else:
-            t = _polyinterp([(0.0, f, gtd), (t, f_new, float(g_new @ d))], 0.0, t)
+            t = _polyinterp([(0.0, f, gtd), (t, f_new, _vdot(g_new, d))], 0.0, t)
         if t < temp * 1e-3:
             t = temp * 1e-3
         elif t > temp * 0.6:
@@ -203,7 +212,7 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
     function value and gradient at x + t*d and the number of evaluations."""
     f_new, g_new = fun(x + t * d)
     evals = 1
-    gtd_new = float(g_new @ d) if _legal(g_new) else float("nan")
+    gtd_new = _vdot(g_new, d) if _legal(g_new) else float("nan")
     ls_iter = 0
     t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
     nrm_d = _amax(d)
@@ -232,7 +241,7 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
         f_prev, g_prev, gtd_prev = f_new, g_new, gtd_new
         f_new, g_new = fun(x + t * d)
         evals += 1
-        gtd_new = float(g_new @ d) if _legal(g_new) else float("nan")
+        gtd_new = _vdot(g_new, d) if _legal(g_new) else float("nan")
         ls_iter += 1
     if ls_iter == max_ls:
         bracket = [[0.0, f, g], [t, f_new, g_new]]
@@ -245,7 +254,7 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
         if not (_legal(bracket[0][1]) and _legal(bracket[1][1]) and _legal(bracket[0][2]) and _legal(bracket[1][2])):
             t = 0.5 * (b0 + b1)
         else:
-            t = _polyinterp([(b0, bracket[0][1], float(bracket[0][2] @ d)), (b1, bracket[1][1], float(bracket[1][2] @ d))])
+            t = _polyinterp([(b0, bracket[0][1], _vdot(bracket[0][2], d)), (b1, bracket[1][1], _vdot(bracket[1][2], d))])
         bmax, bmin = max(b0, b1), min(b0, b1)
         if min(bmax - t, t - bmin) / (bmax - bmin) < 0.1:
             if insuf or t >= bmax or t <= bmin:
@@ -257,7 +266,7 @@ def _wolfe(fun, x, t, d, f, g, gtd, c1, c2, max_ls, prog_tol):
             insuf = False
         f_new, g_new = fun(x + t * d)
         evals += 1
-        gtd_new = float(g_new @ d) if _legal(g_new) else float("nan")
+        gtd_new = _vdot(g_new, d) if _legal(g_new) else float("nan")
         ls_iter += 1
         armijo = f_new < f + c1 * t * gtd
         if not armijo or f_new >= f_lo:
@@ -321,7 +330,7 @@ class _LBFGS:
         return self.add(g - g_old, t * d)
 
     def add(self, y, s):
-        ys = float(y @ s)
+        ys = _vdot(y, s)
         if ys <= 1e-10:
             return False
         if self.count < self.cap:
@@ -331,7 +340,7 @@ class _LBFGS:
             self.start = (self.start + 1) % self.cap
             self.end = (self.end + 1) % self.cap
         self.S[self.end] = s; self.Y[self.end] = y; self.YS[self.end] = ys
-        self.hdiag = ys / float(y @ y)
+        self.hdiag = ys / _vdot(y, y)
         return True
 
     def direction(self, g):
@@ -339,11 +348,11 @@ class _LBFGS:
         d = -g.copy()
         al = {}
         for i in reversed(idx):
-            al[i] = float(self.S[i] @ d) / self.YS[i]
+            al[i] = _vdot(self.S[i], d) / self.YS[i]
             d -= al[i] * self.Y[i]
         d *= self.hdiag
         for i in idx:
-            be = float(self.Y[i] @ d) / self.YS[i]
+            be = _vdot(self.Y[i], d) / self.YS[i]
             d += self.S[i] * (al[i] - be)
         return d
 
@@ -378,7 +387,7 @@ def minfunc_lbfgs(fun, x0, max_iter=200, output_fcn=None, corrections=100, opt_t
         if not _legal(d):
             exitflag, msg = -3, "Step direction is illegal"
             break
-        gtd = float(g @ d)
+        gtd = _vdot(g, d)
         if gtd > -prog_tol:
             exitflag, msg = 2, "Directional Derivative below progTol"
             break
