@@ -98,21 +98,38 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
     Xs, ys = X[:rows], y[:rows]
     oms = None if omega is None else omega[:rows]
     psis = synth_psi(cfg, np.arange(rows)) if cfg.get("psi") else None
-    t0 = time.perf_counter()
-    ref = O.GPz(theta, Omodel, Xs, ys, psis, oms)
-    t_all = time.perf_counter() - t0
-    # the m^3 part does not scale with n: time it alone
-    S = np.eye(model.m) + np.ones((model.m, model.m)) * 1e-3
-    t0 = time.perf_counter()
-    O.inv_logdet(S)
-    t_svd = time.perf_counter() - t0
-    scale = cfg["n"] / rows
-    t_full = (t_all - t_svd) * scale + t_svd
+    # BLAS threads = the cores this process may actually use (affinity mask and cgroup quota): the default pool is sized
+    # by the machine's core count, and on a quota-limited box that oversubscription halves the dgemm rate
+    # (GPU box: 256 logical CPUs, quota 16 -> 714 GFLOP/s with the default 64 threads, 1406 with 16)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except Exception:
+        pass
     try:
         import threadpoolctl
-        nthreads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+        limiter = threadpoolctl.threadpool_limits(limits=usable, user_api="blas")
     except Exception:
-        nthreads = os.cpu_count()
+        import contextlib
+        limiter = contextlib.nullcontext()
+    with limiter:
+        t0 = time.perf_counter()
+        ref = O.GPz(theta, Omodel, Xs, ys, psis, oms)
+        t_all = time.perf_counter() - t0
+        # the m^3 part does not scale with n: time it alone
+        S = np.eye(model.m) + np.ones((model.m, model.m)) * 1e-3
+        t0 = time.perf_counter()
+        O.inv_logdet(S)
+        t_svd = time.perf_counter() - t0
+        try:
+            import threadpoolctl
+            nthreads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] + [1])
+        except Exception:
+            nthreads = usable
+    scale = cfg["n"] / rows
+    t_full = (t_all - t_svd) * scale + t_svd
     return ref, dict(value=1.0 / t_full, unit="evals/s", cores=int(nthreads), kind="port",
                      sample=f"oracle GPz() as-written on the first {rows} of {cfg['n']} rows: {t_all:.1f} s measured "
                             f"(of which {t_svd:.2f} s is the m^3 SVD inverse), row-dependent part scaled x{scale:.1f}")
@@ -233,7 +250,7 @@ def main():
             "finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rows = max(2000, min(n, n // 32 if n >= 200000 else n // 4))   # ~20 s of CPU work at c4
+            rows = max(2000, min(n, n // 8 if n >= 200000 else n))        # ~13 s of CPU work at c4 (16 BLAS threads), the whole problem at c2 / c3
             if cfg.get("psi"):
                 rows = 60                                                  # per-pair d x d loops in NumPy: ~1e5 pairs
             ref, cb = cpu_baseline(cfg, model, theta0, X, y, omega, rows)
