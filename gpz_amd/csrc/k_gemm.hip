@@ -3,11 +3,14 @@
 //   k_syrk        S = PHI' * diag(w) * PHI   (GPz.m:63-65, upper 128x128 tiles, split over rows)
 //   k_syrk_reduce sum the row-split slabs, mirror to the lower triangle
 //   k_tgemm       T = PHI * B,  B = [inv(SIGMA) | w]   (GPz.m:69,72,77 in one product)
-//   k_gemm_small  generic strided C = beta*C + alpha*A*B for the m x m factorisation steps
+//   k_trtri_level one level of the recursive triangular inverse (64x64 tile GEMMs on the structurally non-zero K range)
 //
-// Tiling: a workgroup is 4 waves (2x2), each wave owns a 64x64 block of the 128x128 output tile as
-// 4x4 MFMA tiles (16 accumulators x 4 f64 = 128 accumulator registers).  Operands are staged
-// global -> registers -> LDS in 16-deep K slices, double buffered, one barrier per slice.
+// Tiling: a workgroup is 8 waves (2 x 4), each wave owns a 64x32 block of the 128x128 output tile as 4x2 MFMA tiles
+// (8 accumulators x 4 f64 = 64 accumulator registers; 128 VGPRs per lane, four waves per SIMD with two workgroups per
+// CU).  Operands are staged global -> registers -> LDS in 16-deep K slices, double buffered, one barrier per slice.
+// The K loops keep the vector ALU for the MFMAs: a VALU instruction of any wave takes issue cycles the MFMA pipe of
+// that SIMD does not get back (tools/mfma_f64_operands.hip), so addresses live in SGPR base pointers, loop-invariant
+// offsets and immediates.
 #include <type_traits>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
