@@ -830,3 +830,24 @@ def test_many_nan_patterns_single_launch(method, d, k, psi):
     assert rel(g, ref.grad) <= tol
     for key in ("trainRMSE", "trainLL", "validRMSE", "validLL"):
         assert abs(stats[key] - ref.stats[key]) <= 1e-9 * max(1.0, abs(ref.stats[key]))
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("psi,nanfrac", [(False, 0.0), (True, 0.0), (False, 0.4), (True, 0.4)])
+def test_hip_path_against_the_50_digit_reference(method, psi, nanfrac):
+    """The HIP path judged by tests/mp_reference.py (mpmath, 50 digits; objective from the model's formulas, gradient by
+    differencing at that precision) instead of by the fp64 oracle: SURVEY.md §8c pin 5."""
+    import mp_reference as R
+    n, d, m, k = 14, 2, 3, 1
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=5, psi=psi, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    f_mp = float(R.nlogml(theta, model.method, m, d, k, True, X, Y, Psi, om))
+    g_mp = np.array([float(v) for v in R.gradient(theta, model.method, m, d, k, True, X, Y, Psi, om)])
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, om)
+    try:
+        f, g = ctx.eval(theta)
+    finally:
+        ctx.close()
+    cond = O.GPz(theta, model, X, Y, Psi, om).cond
+    assert abs(f - f_mp) <= 1e-12 * abs(f_mp)
+    assert np.max(np.abs(g - g_mp)) <= max(1e-11, 50 * cond * 2.2e-16) * np.max(np.abs(g_mp))

@@ -151,6 +151,61 @@ def test_device_lbfgs_direction_matches_two_loop(p, corr, steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mf_mem_p64_c3", "mf_mem_p513_c7", "mf_mem_p900_c100"])
+def test_device_lbfgs_memory_matches_the_restated_reference(name):
+    """gpz_lbfgs_add / gpz_lbfgs_direction (k_lbfgs.hip) replay the fixtures of oracle/minfunc_oracle.py — lbfgsAdd.m's ring
+    (wrapping, rejected pairs) and lbfgsProd.m / mex/lbfgsProdC.c:46-88's product — not the package's own host two-loop."""
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dev = host._LBFGSDevice(int(z["p"]), int(z["corrections"]))
+    n_added = 0
+    for it in range(z["T"].size):
+        g, g_old = z["G"][it + 1], z["G"][it]
+        added = dev.add_step(host.DevVec.from_host(g), host.DevVec.from_host(g_old), float(z["T"][it]),
+                             host.DevVec.from_host(z["D"][it]))
+        assert added == bool(z["added"][it]), it
+        n_added += int(added)
+        if n_added:
+            dd = dev.direction(host.DevVec.from_host(g)).host()
+            assert rel(dd, z["directions"][it]) < 1e-10, it
+    dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mf_run_gpz_VD", "mf_run_gpz_VC"])
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_minfunc_trajectory_through_the_hip_path_matches_the_restated_reference(name, device_resident):
+    """minFunc('lbfgs') as restated in oracle/minfunc_oracle.py on the oracle's objective (fixture) against the package's
+    driver on the HIP objective: same step lengths, function values and evaluation counts per iteration."""
+    import os
+    import gpz_amd
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = gpz_amd.Model(m=int(z["m"]), d=int(z["d"]), k=1, method=str(z["method"]), heteroscedastic=True)
+    ctx = gpz_amd.GPzContext(model, z["X"], z["Y"])
+    its = []
+
+    def out(x, kind, i, evals, f, t, gtd, g, d, opt):
+        if kind == "iter":
+            its.append((t, f, evals))
+        return False
+    if device_resident:
+        fun = lambda th: (lambda r: (r[0], host.DevVec(r[1])))(ctx.eval_dev(th.t))
+        x0 = host.DevVec.from_host(z["x0"])
+    else:
+        fun, x0 = ctx.eval, z["x0"]
+    x, f, flag, evals, msg = host.minfunc_lbfgs(fun, x0, max_iter=int(z["max_iter"]), output_fcn=out)
+    ctx.close()
+    if device_resident:
+        x = x.host()
+    assert evals == int(z["funcCount"]) and [e for _, _, e in its] == list(z["funcCounts"][1:])
+    assert np.allclose([t for t, _, _ in its], z["steps"], rtol=1e-5)
+    assert np.allclose([v for _, v, _ in its], z["fval"][1:], rtol=1e-7, atol=1e-10)
+    assert rel(x, z["x"]) < 1e-4
+
+
+@pytest.mark.gpu
 def test_devvec_reductions():
     rng = np.random.default_rng(3)
     a = rng.standard_normal(50001); b = rng.standard_normal(50001)

@@ -287,3 +287,51 @@ def test_pinv_golden_regression(name):
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     Xi, ld = O.inv_logdet(z["S"])
     assert np.linalg.matrix_rank(Xi) == int(z["rank"]) and rel(Xi, z["Xi"]) < 1e-9 and abs(ld - float(z["logdet"])) < 1e-9
+
+
+# ---- independent evaluations of the objective AND of the gradient (SURVEY.md §8c pin 5) ----------------------------
+# tests/mp_reference.py shares no code with the oracle: one general ln PHI expression instead of the reference's four
+# branches, LU solve + determinant instead of the SVD inverse, and the gradient by differencing at 50 digits (mpmath) or by
+# autograd (torch fp64) instead of the hand-derived blocks of GPz.m:89-231.
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("psi,nanfrac", [(False, 0.0), (True, 0.0), (False, 0.4), (True, 0.4)])
+def test_mpmath_50_digit_objective_and_gradient(method, psi, nanfrac):
+    import mp_reference as R
+    n, d, m, k = 14, 2, 3, 1
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=5, psi=psi, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    r = O.GPz(theta, model, X, Y, Psi, om)
+    f = R.nlogml(theta, model.method, m, d, k, True, X, Y, Psi, om)
+    assert abs(float(f) - r.nlogML) <= 1e-13 * abs(float(f))
+    g = np.array([float(v) for v in R.gradient(theta, model.method, m, d, k, True, X, Y, Psi, om)])
+    assert np.max(np.abs(g - r.grad)) <= max(1e-12, 50 * r.cond * 2.2e-16) * np.max(np.abs(g))
+
+
+@pytest.mark.parametrize("method,hetero,k", [("VD", False, 1), ("VC", False, 2), ("VL", True, 2)])
+def test_mpmath_50_digit_homoscedastic_and_multi_output(method, hetero, k):
+    import mp_reference as R
+    n, d, m = 12, 2, 3
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, hetero, seed=15)
+    r = O.GPz(theta, model, X, Y)
+    f = R.nlogml(theta, model.method, m, d, k, hetero, X, Y)
+    g = np.array([float(v) for v in R.gradient(theta, model.method, m, d, k, hetero, X, Y)])
+    assert abs(float(f) - r.nlogML) <= 1e-13 * abs(float(f))
+    assert np.max(np.abs(g - r.grad)) <= max(1e-12, 50 * r.cond * 2.2e-16) * np.max(np.abs(g))
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("hetero", [True, False])
+@pytest.mark.parametrize("psi,nanfrac,k", [(False, 0.0, 1), (True, 0.0, 2), (False, 0.3, 2), (True, 0.3, 1)])
+def test_torch_autograd_gradient(method, hetero, psi, nanfrac, k):
+    import torch
+    import mp_reference as R
+    n, d, m = 150, 3, 6
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, hetero, seed=25, psi=psi, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    r = O.GPz(theta, model, X, Y, Psi, om)
+    th = torch.tensor(theta, requires_grad=True)
+    f = R.torch_nlogml(th, model.method, m, d, k, hetero, X, Y, Psi, om)
+    f.backward()
+    g = th.grad.numpy()
+    assert abs(f.item() - r.nlogML) <= 1e-12 * abs(r.nlogML)
+    assert np.max(np.abs(g - r.grad)) <= max(1e-11, 50 * r.cond * 2.2e-16) * np.max(np.abs(g))

@@ -19,7 +19,7 @@ for f in ("sq", "sq2", "fetch", "write"):
     for k, cs in load(base + f + "/p_counter_collection.csv").items():
         for c, v in cs.items():
             data.setdefault(k, {})[c] = sum(v) / len(v)
-keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue"))]
+keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_"))]
 with open(dst, "w") as out:
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
               "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X; one counter group per pass; tools/pmc_run.sh)\n"
