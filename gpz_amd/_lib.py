@@ -75,6 +75,18 @@ SYMBOLS = {
     "gpz_inv_logdet": (C.c_int, [c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_int32_p]),
     "gpz_dxy": (C.c_int, [c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
     "gpz_nan_groups": (C.c_int, [c_double_p, C.c_int64, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
+    "gpz_mgpu_create": (C.c_int, [C.POINTER(gpz_desc), C.c_int32, c_int32_p, C.c_int32, C.c_int64, c_double_p, c_double_p,
+                                  c_double_p, C.c_int32, c_double_p, c_uint8_p, c_uint8_p, C.POINTER(C.c_void_p)]),
+    "gpz_mgpu_destroy": (None, [C.c_void_p]),
+    "gpz_mgpu_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_mgpu_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "gpz_mgpu_size": (C.c_int32, [C.c_void_p]),
+    "gpz_mgpu_theta_len": (C.c_int64, [C.c_void_p]),
+    "gpz_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "gpz_device_count": (C.c_int, []),
+    "gpz_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "gpz_ctx_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "gpz_rccl_origin": (C.c_char_p, []),
     "gpz_last_error": (C.c_char_p, []),
     "gpz_version": (C.c_int, []),
 }

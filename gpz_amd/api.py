@@ -229,19 +229,135 @@ class GPzContext:
         return {names[i].decode(): (ms[i], int(calls[i])) for i in range(min(n, cap))}
 
 
+class GPzMulti:
+    """The same closure on several GPUs behind ONE synchronous call (gpz_mgpu_* of the C ABI): the library splits the
+    training-selected rows into contiguous blocks, one per device, drives every device from its own host thread and
+    all-reduces the m x m / m x (d^2+d) partials with RCCL itself — no torch.distributed, no Python in the evaluation.
+    What a single MATLAB process reaches through the MEX gateway (minFunc.m:314 calls funObj once and waits).
+
+    n_gpus None/0: every device of the node.  reducer "loopback": all shards on ONE device with the library's own
+    rank-ordered reducer — how the sharded path is exercised on single-GPU machines."""
+
+    def __init__(self, model, X, Y, Psi=None, omega=None, training=None, validation=None, n_gpus=None, devices=None,
+                 reducer="rccl", dtype="f64"):
+        lib = _lib.load()
+        X = _f64(X, 2)
+        Y = _f64(Y, 2)
+        n_tot = X.shape[0]
+        if X.shape[1] != model.d or Y.shape != (n_tot, model.k):
+            raise ValueError("X must be n x d and Y n x k")
+        om = _f64(omega, 2)
+        if om is not None and om.shape != (n_tot, 1):
+            raise ValueError("omega must be n x 1")
+        psi, psi_kind = None, 0
+        if Psi is not None:
+            psi = _f64(Psi)
+            psi_kind = 2 if psi.ndim == 3 else 1
+        self._tr = _mask(training, n_tot)
+        self._va = _mask(validation, n_tot)
+        if reducer not in ("rccl", "loopback"):
+            raise ValueError("reducer must be 'rccl' or 'loopback'")
+        dev = None
+        if devices is not None:
+            dev = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+            n_gpus = dev.size
+        self.model = model
+        self._desc = _desc(model, 0, None, 0, 1, dtype)
+        h = C.c_void_p()
+        _lib.check(lib.gpz_mgpu_create(
+            C.byref(self._desc), int(n_gpus or 0), None if dev is None else dev.ctypes.data_as(_lib.c_int32_p),
+            1 if reducer == "loopback" else 0, n_tot, _lib.dptr(X), _lib.dptr(Y), _lib.dptr(psi), psi_kind, _lib.dptr(om),
+            None if self._tr is None else self._tr.ctypes.data_as(_lib.c_uint8_p),
+            None if self._va is None else self._va.ctypes.data_as(_lib.c_uint8_p), C.byref(h)))
+        self._h, self._lib = h, lib
+        self.n_gpus = int(lib.gpz_mgpu_size(h))
+        self.p = int(lib.gpz_mgpu_theta_len(h))
+        self.rows_per_gpu = [int(lib.gpz_n_train(lib.gpz_mgpu_ctx(h, r))) for r in range(self.n_gpus)]
+        self.n_train = sum(self.rows_per_gpu)
+        self.stats, self.info, self.n_global = {}, 0, self.n_train
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpz_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self, theta):
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        if theta.size != self.p:
+            raise ValueError(f"theta must have {self.p} elements")
+        f = C.c_double()
+        g = np.empty(self.p)
+        st = (C.c_double * 4)(float("nan"), float("nan"), float("nan"), float("nan"))
+        dg = (C.c_double * 2)()
+        _lib.check(self._lib.gpz_mgpu_eval(self._h, _lib.dptr(theta), C.byref(f), _lib.dptr(g), st, dg))
+        self.stats = {"trainRMSE": st[0], "trainLL": st[1]}
+        if self._va is not None:
+            self.stats.update(validRMSE=st[2], validLL=st[3])
+        self.info, self.n_global = int(dg[0]), int(dg[1])
+        return f.value, g
+
+    def solve(self, theta):
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        if theta.size != self.p:
+            raise ValueError(f"theta must have {self.p} elements")
+        m, k = self.model.m, self.model.k
+        w = np.empty((m, k), order="F")
+        iS = np.empty((m, m, k), order="F")
+        part = np.empty(k)
+        _lib.check(self._lib.gpz_mgpu_solve(self._h, _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(part)))
+        return w, iS, part
+
+    def _each(self):
+        return [self._lib.gpz_mgpu_ctx(self._h, r) for r in range(self.n_gpus)]
+
+    def enable_timing(self, on=True):
+        for c in self._each():
+            _lib.check(self._lib.gpz_ctx_enable_timing(c, 1 if on else 0))
+
+    def reset_timings(self):
+        for c in self._each():
+            _lib.check(self._lib.gpz_ctx_reset_timings(c))
+
+    def set_pinv_mode(self, mode):
+        for c in self._each():
+            _lib.check(self._lib.gpz_ctx_set_pinv_mode(c, int(mode)))
+
+    def timings(self, rank=0):
+        """{stage: (total_ms, calls)} of one rank (HIP events on that device's stream)."""
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        calls = (C.c_int64 * cap)()
+        n = self._lib.gpz_ctx_timings(self._lib.gpz_mgpu_ctx(self._h, rank), names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], int(calls[i])) for i in range(min(n, cap))}
+
+
+def device_count():
+    return int(_lib.load().gpz_device_count())
+
+
 _cache = {}
 
 
 def _ctx_for(model, X, Y, Psi, omega, training, validation):
-    """One context per closure: keyed on the identity of the data arrays (the MEX shim keys on mxArray
-    pointers the same way)."""
+    """One context per closure, keyed on the identity of the model and of the data arrays.  The arrays are treated as
+    immutable while cached (MATLAB's value semantics: a modified array is a new array there): editing X, Y, omega, the
+    masks or the model IN PLACE between calls is not seen — call ``reset()`` after doing that.  The least recently
+    created context is evicted once four are alive."""
     def ident(a):
         return None if a is None else (id(a), getattr(a, "shape", None))
-    key = (id(model), ident(X), ident(Y), ident(Psi), ident(omega), ident(training), ident(validation))
+    key = (id(model), model.m, model.d, model.k, model.method, bool(model.heteroscedastic),
+           ident(X), ident(Y), ident(Psi), ident(omega), ident(training), ident(validation))
     ctx = _cache.get(key)
     if ctx is None:
         if len(_cache) >= 4:
-            _, old = _cache.popitem()
+            old = _cache.pop(next(iter(_cache)))        # FIFO: dicts keep insertion order
             old[0].close()
         ctx = (GPzContext(model, X, Y, Psi, omega, training, validation), (X, Y, Psi, omega, training, validation))
         _cache[key] = ctx

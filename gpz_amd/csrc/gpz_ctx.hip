@@ -41,6 +41,16 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *gpz_last_error(void) { return g_err.c_str(); }
+// the same error channel for the other host-side translation units (gpz_mgpu.hip)
+int gpz_fail(int code, const char *fmt, ...) {
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
 extern "C" int gpz_version(void) { return GPZ_VERSION; }
 
 static int method_id_of(const char *m) {
@@ -179,6 +189,8 @@ struct gpz_ctx {
     double *out_h = nullptr, *theta_h = nullptr;   // pinned
     gpz_allreduce_fn ar_fn = nullptr;
     void *ar_user = nullptr;
+    void *priv = nullptr;                 // owned by whoever attached it (the RCCL communicator of gpz_ctx_init_rccl),
+    void (*priv_free)(void *) = nullptr;  // released with the context
     bool timing = false;
     StageTimer tm;
     bool phi_valid = false;
@@ -483,7 +495,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
             }
             c->pats_fixed = true;
         } else if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
-        c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan;
+        // dtype f32 selects the fp32 pair kernels only where EVERY rank does: a given pattern table means some rank holds
+        // missing values (it takes the fp64 route and posts one record block per pattern), so nobody may take the fp32 route
+        c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan && !table;
     }
     if (desc->dtype != GPZ_F64 && desc->dtype != GPZ_F32) return fail(GPZ_ERR_ARG, "dtype must be GPZ_F64 or GPZ_F32");
     if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1)
@@ -705,11 +719,18 @@ extern "C" void gpz_ctx_destroy(gpz_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
+    if (c->priv && c->priv_free) c->priv_free(c->priv);
     c->ar.release();
     if (c->out_h) (void)hipHostFree(c->out_h);
     if (c->theta_h) (void)hipHostFree(c->theta_h);
     for (hipEvent_t e : c->tm.pool) (void)hipEventDestroy(e);
     delete c;
+}
+
+void gpz_ctx_attach_private(gpz_ctx *c, void *priv, void (*free_fn)(void *)) {
+    if (c->priv && c->priv_free) c->priv_free(c->priv);
+    c->priv = priv;
+    c->priv_free = free_fn;
 }
 
 extern "C" int gpz_ctx_set_allreduce(gpz_ctx *c, gpz_allreduce_fn fn, void *user) {

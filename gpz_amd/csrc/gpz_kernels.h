@@ -3,6 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- host-side helpers shared by gpz_ctx.hip and gpz_mgpu.hip ------------------------------------------------
+struct gpz_ctx;
+int gpz_fail(int code, const char *fmt, ...);                      // sets gpz_last_error() of the calling thread, returns code
+void gpz_ctx_attach_private(gpz_ctx *c, void *priv, void (*free_fn)(void *));   // freed by gpz_ctx_destroy
+
 // ---- theta unpacking (getPHI.m:24-40,117,122; GPz.m:28,32,50,98-101) -------------------------
 // Device parameter block produced by k_unpack from the raw theta vector.
 struct GpzParams {

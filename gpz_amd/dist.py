@@ -85,12 +85,33 @@ class _CudaBuf:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def make_allreduce(group=None, device="cuda"):
-    """Build the C-ABI all-reduce hook (gpz_allreduce_fn) on top of torch.distributed.
+def init_rccl(ctx, rank, world, device, group=None):
+    """Give a sharded context its own RCCL communicator INSIDE the library (gpz_rccl_unique_id / gpz_ctx_init_rccl): the
+    two all-reduces of an evaluation are then ncclAllReduce calls issued by the library on its own stream — no Python,
+    no GIL, no ctypes trampoline in the evaluation.  torch.distributed is used once, to ship rank 0's 128-byte id."""
+    import torch.distributed as dist
+    from . import _lib
+    lib = _lib.load()
+    idbuf = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.gpz_rccl_unique_id(idbuf))
+    box = [idbuf.raw if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    idbuf = C.create_string_buffer(box[0], 128)
+    _lib.check(lib.gpz_ctx_init_rccl(ctx._h, idbuf, int(rank), int(world), int(device)))
+    ctx._cb = None            # the Python hook (if any) is no longer referenced by the library
+    return lib.gpz_rccl_origin().decode()
 
-    device "cuda": ``buf`` is a device pointer; the tensor view is all-reduced with the process group's
-    backend (RCCL) on the current stream — the library runs on the same stream, so ordering is implicit.
-    device "cpu": ``buf`` is a host pointer (used by the gloo tests)."""
+
+def make_allreduce(group=None, device="cuda", device_index=None):
+    """Build the C-ABI all-reduce hook (gpz_allreduce_fn) on top of torch.distributed (the alternative to init_rccl:
+    any backend torch.distributed offers, e.g. gloo for the CPU tests and for two ranks that share one GPU).
+
+    device "cuda": ``buf`` is a device pointer; the tensor view is all-reduced with the process group's backend on the
+    stream the library passes (the context's stream), so the collective is ordered with the library's kernels whatever
+    torch's current stream is.  device "cpu": ``buf`` is a host pointer (used by the gloo tests).
+    The hook object owns its tensor views; make one hook per context and drop it with the context."""
     import torch
     import torch.distributed as dist
     views = {}   # the library all-reduces the same two buffers every evaluation: build each tensor view once
@@ -103,9 +124,16 @@ def make_allreduce(group=None, device="cuda"):
                     arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
                     t = torch.from_numpy(arr)
                 else:
-                    t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+                    idx = torch.cuda.current_device() if device_index is None else device_index
+                    t = torch.as_tensor(_CudaBuf(buf, count), device=torch.device("cuda", idx))
+                    if t.data_ptr() != buf:
+                        raise RuntimeError("device buffer was copied instead of viewed: wrong device index for the hook")
                 views[(buf, count)] = t
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if device != "cpu" and stream:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return 0
         except Exception as e:  # never unwind through the C frame
             print("gpz_amd.dist allreduce hook failed:", repr(e), flush=True)

@@ -19,6 +19,11 @@
  *   gpz_inv_logdet      [Xi,logdet] = inv_logdet(X)         GPz/inv_logdet.m:1
  *   gpz_dxy             D = Dxy(X,Y)                        GPz/Dxy.m:1
  *   gpz_nan_groups      the NaN-pattern grouping loop       GPz/getPHI.m:43-54 (== GPz.m:118-129)
+ *   gpz_mgpu_*          the same closure / calls on all GPUs of the node behind one synchronous call
+ *                       (minFunc_2012/minFunc/minFunc.m:314 calls funObj once and waits)
+ *
+ * Limits: 1 <= d <= 20 (the reference has none, getPHI.m:69-98 is generic; wider inputs return GPZ_ERR_UNSUPPORTED),
+ * k <= 8 outputs.
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):
  *   - all matrices are column-major double; masks are 1 byte per row (MATLAB logical);
@@ -50,7 +55,7 @@ extern "C" {
 #define GPZ_ERR_COMM        -4   /* the all-reduce hook failed */
 #define GPZ_ERR_UNSUPPORTED -5   /* valid in the reference, not built yet (see DESIGN.md scope table) */
 
-#define GPZ_VERSION 1
+#define GPZ_VERSION 2
 
 typedef struct gpz_ctx gpz_ctx;
 
@@ -195,6 +200,44 @@ int gpz_dxy(const double *X, int64_t nx, const double *Y, int64_t ny, int32_t d,
 /* Group id per row = rank (by first occurrence) of the row's NaN pattern; returns the number of
  * groups in *n_groups.  Bit-exact with the greedy loop of getPHI.m:43-54. */
 int gpz_nan_groups(const double *X, int64_t n, int32_t d, int32_t device, int32_t *group_id, int32_t *n_groups);
+
+/* ---- all GPUs of the node behind ONE synchronous call (SURVEY.md 8b "threading", 8e) -------------------------------
+ * The reference calls [f,g] = funObj(x) from one MATLAB process and blocks on it (minFunc/minFunc.m:314,
+ * WolfeLineSearch.m:34,114,194; closure at GPz/train.m:40).  gpz_mgpu_create takes the same arguments as gpz_ctx_create
+ * (the whole, unsharded data set), splits the training-selected rows and the validation rows into contiguous balanced
+ * blocks, one per device, and keeps one context per device; gpz_mgpu_eval / gpz_mgpu_solve then have the semantics of
+ * gpz_eval / gpz_solve.  Inside, one host thread per device drives that device's stream and the two all-reduces of an
+ * evaluation are RCCL calls (ncclCommInitAll communicators) on the library's device buffers: only m x m and
+ * m x (d^2+d) partials cross xGMI.  desc->device / stream / rank / world are ignored.
+ *   n_gpus   <= 0: every device of the node (hipGetDeviceCount)
+ *   devices  NULL: 0 .. n_gpus-1 (loopback: all 0)
+ *   reducer  GPZ_REDUCER_RCCL, or GPZ_REDUCER_LOOPBACK: an in-library rank-ordered reducer for shards that share one
+ *            device (RCCL refuses duplicate devices) - the way the sharded path is tested on single-GPU machines. */
+#define GPZ_REDUCER_RCCL     0
+#define GPZ_REDUCER_LOOPBACK 1
+typedef struct gpz_mgpu gpz_mgpu;
+int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32_t *devices, int32_t reducer, int64_t n_tot,
+                    const double *X, const double *Y, const double *Psi, int32_t psi_kind, const double *omega,
+                    const uint8_t *training, const uint8_t *validation, gpz_mgpu **out);
+void gpz_mgpu_destroy(gpz_mgpu *h);
+int gpz_mgpu_eval(gpz_mgpu *h, const double *theta, double *f, double *g, double stats[4], double diag[2]);
+int gpz_mgpu_solve(gpz_mgpu *h, const double *theta, double *w, double *iSigma_w, double *nlogML_partial);
+int32_t gpz_mgpu_size(const gpz_mgpu *h);
+int64_t gpz_mgpu_theta_len(const gpz_mgpu *h);
+/* the context of one rank, for gpz_n_train / gpz_ctx_enable_timing / gpz_ctx_timings / gpz_ctx_set_pinv_mode (apply
+ * settings to every rank); owned by the handle - never destroy it. */
+gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t rank);
+int gpz_device_count(void);
+
+/* ---- one rank per PROCESS (torchrun / mpirun launchers): RCCL inside the library instead of a caller-supplied hook.
+ * Rank 0 calls gpz_rccl_unique_id and ships the 128 bytes to the other ranks by any out-of-band means; every rank then
+ * calls gpz_ctx_init_rccl on its sharded context (collective: returns when all `world` ranks have called).  The
+ * communicator is destroyed with the context.  gpz_rccl_origin: which RCCL the library bound to (dlopen at first use:
+ * one the process already carries, else librccl.so.1 from the library path). */
+#define GPZ_RCCL_ID_BYTES 128
+int gpz_rccl_unique_id(void *id128);
+int gpz_ctx_init_rccl(gpz_ctx *ctx, const void *id128, int32_t rank, int32_t world, int32_t device);
+const char *gpz_rccl_origin(void);
 
 const char *gpz_last_error(void);
 int gpz_version(void);

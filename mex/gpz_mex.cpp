@@ -1,13 +1,22 @@
 // gpz_mex.cpp — MEX gateway between MATLAB and libgpz_hip.so (pure marshalling, no arithmetic).
 //
-// Build on a machine that has MATLAB (not available in the build image, so this file is source only):
-//     mex -R2018a gpz_mex.cpp -I../include -L../gpz_amd/lib -lgpz_hip
-// Same gateway convention as the reference's own MEX files (minFunc_2012/minFunc/mex/lbfgsProdC.c:7).
+// Build on a machine that has MATLAB (not available in the build image; tests/test_mex_gateway.py compiles this file
+// against the declarations-only header tests/stubs/mex.h and runs it against a stand-in MEX runtime on the GPU box):
+//     mex -R2017b gpz_mex.cpp -I../include -L../gpz_amd/lib -lgpz_hip
+// Same gateway convention as the reference's own MEX files (minFunc_2012/minFunc/mex/lbfgsProdC.c:7); input types are
+// checked and reported with mexErrMsg* like lbfgsProdC.c:24-25; outputs come from mxCreate* (lbfgsProdC.c:43); prhs is
+// never written (the reference's lbfgsAddC.c:30-33 does write into its inputs, knowingly).
 //
-//   gpz_mex('create', model, X, Y, Psi, omega, training, validation)   once per closure (train.m:40)
-//   [f, g, stats] = gpz_mex('eval', theta)                             GPz.m nargout<=2
-//   [w, iSigma_w, part] = gpz_mex('solve', theta)                      GPz.m nargout>2 (GPz.m:84-87)
-//   PHI = gpz_mex('phi')                                               5th output of GPz.m:1
+//   [f, g, stats] = gpz_mex('eval',  theta, model, X, Y, Psi, omega, training, validation)   GPz.m nargout<=2
+//   [w, iSigma_w, part] = gpz_mex('solve', theta, model, X, Y, Psi, omega, training, validation)   GPz.m:84-87
+//        The closure's data (train.m:40) lives on the GPUs between calls.  Every call hands the closure's arguments
+//        over again — MATLAB passes shared-data copies, so this costs nothing — and the gateway compares them with
+//        what the live context was built from: model fields, array sizes, DATA POINTERS (copy-on-write gives a changed
+//        array a new pointer) and 256 strided samples of every array (a pointer re-used by the allocator for different
+//        data).  Anything different rebuilds the context.  model.n_gpus (optional) = number of GPUs, default all of
+//        the node; the rows are sharded across them and reduced with RCCL inside the library (gpz_mgpu_*).
+//        model.dtype = 'f32' (optional) selects the fp32 per-pair factorisations of GC/VC with input noise.
+//   PHI = gpz_mex('phi')                                               5th output of GPz.m:1 (after eval / solve)
 //   [PHI, lnBeta_i, N] = gpz_mex('getphi', model, theta, X, Psi)       getPHI.m:1 (rows already selected)
 //   [mu,nu,beta_i,gamma,PHI] = gpz_mex('predict', model, theta, w, iSigma_w, priors, X, Psi)
 //                                                  one NaN-pattern group of predict.m:60-69: predictFull / predictNoisy /
@@ -16,40 +25,64 @@
 //   [Xi, logdet] = gpz_mex('inv_logdet', A)                            inv_logdet.m:1
 //   D = gpz_mex('dxy', X, Y)                                           Dxy.m:1
 //   gpz_mex('pinv_mode', mode)                                         branch of inv_logdet.m:7-12 (0 auto, 1 always, -1 never)
-//   gpz_mex('reset')
-// model.dtype = 'f32' (optional field) selects the fp32 per-pair factorisations of GC/VC with input noise.
+//   n = gpz_mex('gpus')                                                GPUs the live context runs on (0: none)
+//   n = gpz_mex('builds')                                              how many times a device context was (re)built so far
+//   gpz_mex('reset')                                                   drop the device context (clear global / new data)
+#include <stdint.h>
 #include <string.h>
 #include "mex.h"
 #include "gpz_hip.h"
 
-static gpz_ctx *g_ctx = NULL;
-static int g_m = 0, g_k = 0;
+#define NARR 6                        /* X, Y, Psi, omega, training, validation */
+#define NSAMP 256
+
+typedef struct {
+    int32_t d, m, k, hetero, dtype, n_gpus;
+    char method[4];
+    const void *ptr[NARR];
+    size_t bytes[NARR];
+    mwSize rows[NARR];
+    uint64_t sum[NARR];
+} closure_key;
+
+static gpz_mgpu *g_mg = NULL;
+static closure_key g_key;
+static int g_m = 0, g_k = 0, g_pinv = 0, g_locked = 0, g_builds = 0;
 
 static void cleanup(void) {
-    if (g_ctx) { gpz_ctx_destroy(g_ctx); g_ctx = NULL; }
+    if (g_mg) { gpz_mgpu_destroy(g_mg); g_mg = NULL; }
 }
 static const double *opt(const mxArray *a) { return (a && !mxIsEmpty(a)) ? mxGetPr(a) : NULL; }
 static const uint8_t *optmask(const mxArray *a) {
     if (!a || mxIsEmpty(a)) return NULL;
-    if (!mxIsLogical(a)) mexErrMsgIdAndTxt("gpz:type", "masks must be logical");
+    if (!mxIsLogical(a)) mexErrMsgIdAndTxt("gpz:type", "training / validation must be logical");
     return (const uint8_t *)mxGetLogicals(a);
 }
+static void need_double(const mxArray *a, const char *what, int allow_empty) {
+    if (!a || (mxIsEmpty(a) && allow_empty)) return;
+    if (!mxIsDouble(a) || mxIsComplex(a) || mxIsEmpty(a)) mexErrMsgIdAndTxt("gpz:type", "%s must be a real double array", what);
+}
 static double field(const mxArray *s, const char *name) {
-    const mxArray *f = mxGetField(s, 0, name);
+    const mxArray *f = mxIsStruct(s) ? mxGetField(s, 0, name) : NULL;
     if (!f) mexErrMsgIdAndTxt("gpz:model", "model.%s missing", name);
     return mxGetScalar(f);
 }
 
-static gpz_desc desc_of(const mxArray *model) {
+static gpz_desc desc_of(const mxArray *model, int32_t *n_gpus) {
     gpz_desc d;
     memset(&d, 0, sizeof d);
     d.d = (int32_t)field(model, "d"); d.m = (int32_t)field(model, "m"); d.k = (int32_t)field(model, "k");
     d.heteroscedastic = (int32_t)field(model, "heteroscedastic");
-    mxGetString(mxGetField(model, 0, "method"), d.method, sizeof d.method);
+    const mxArray *me = mxGetField(model, 0, "method");
+    if (!me || mxGetString(me, d.method, sizeof d.method)) mexErrMsgIdAndTxt("gpz:model", "model.method missing");
     d.world = 1;
     const mxArray *dt = mxGetField(model, 0, "dtype");
     char buf[8] = "";
     if (dt && !mxGetString(dt, buf, sizeof buf) && !strcmp(buf, "f32")) d.dtype = GPZ_F32;
+    if (n_gpus) {
+        const mxArray *ng = mxGetField(model, 0, "n_gpus");
+        *n_gpus = (ng && !mxIsEmpty(ng)) ? (int32_t)mxGetScalar(ng) : 0;       /* 0: every GPU of the node */
+    }
     return d;
 }
 static int psi_kind_of(const mxArray *Psi) {   /* fixPsi.m layouts: [] / n x d / d x d x n */
@@ -63,14 +96,76 @@ static int has_nan(const mxArray *X) {
 }
 #define CHECK(call, id) do { if (call) mexErrMsgIdAndTxt(id, "%s", gpz_last_error()); } while (0)
 
+/* What the live context was built from.  Bitwise sampling: NaN payloads compare like any other bits. */
+static void key_of(const mxArray *model, const mxArray *const *arr, closure_key *key) {
+    memset(key, 0, sizeof *key);
+    gpz_desc d = desc_of(model, &key->n_gpus);
+    key->d = d.d; key->m = d.m; key->k = d.k; key->hetero = d.heteroscedastic; key->dtype = d.dtype;
+    memcpy(key->method, d.method, sizeof key->method);
+    for (int q = 0; q < NARR; ++q) {
+        const mxArray *a = arr[q];
+        if (!a || mxIsEmpty(a)) continue;
+        const size_t n = mxGetNumberOfElements(a), es = mxGetElementSize(a);
+        const unsigned char *p = (const unsigned char *)mxGetData(a);
+        key->ptr[q] = p;
+        key->bytes[q] = n * es;
+        key->rows[q] = mxGetM(a);
+        const size_t step = n > NSAMP ? n / NSAMP : 1;
+        uint64_t h = 1469598103934665603ull;
+        for (size_t e = 0; e < n; e += step)
+            for (size_t b = 0; b < es; ++b) { h ^= p[e * es + b]; h *= 1099511628211ull; }
+        for (size_t b = 0; b < es; ++b) { h ^= p[(n - 1) * es + b]; h *= 1099511628211ull; }
+        key->sum[q] = h;
+    }
+}
+
+/* (Re)build the device context when the closure's arguments differ from the live one's.  args: model, X, Y, Psi, omega,
+ * training, validation  (GPz.m:1's own argument order after theta). */
+static void ensure_context(const mxArray *const *args) {
+    const mxArray *model = args[0];
+    closure_key key;
+    key_of(model, args + 1, &key);
+    if (g_mg && !memcmp(&key, &g_key, sizeof key)) return;
+    cleanup();
+    const mxArray *X = args[1], *Y = args[2], *Psi = args[3], *om = args[4];
+    need_double(X, "X", 0); need_double(Y, "Y", 0); need_double(Psi, "Psi", 1); need_double(om, "omega", 1);
+    int32_t n_gpus = 0;
+    gpz_desc d = desc_of(model, &n_gpus);
+    const mwSize n = mxGetM(X);
+    if (mxGetN(X) != (mwSize)d.d || mxGetM(Y) != n || mxGetN(Y) != (mwSize)d.k)
+        mexErrMsgIdAndTxt("gpz:size", "X must be n x model.d and Y n x model.k");
+    for (int q = 4; q <= 6; ++q)
+        if (args[q] && !mxIsEmpty(args[q]) && mxGetNumberOfElements(args[q]) < n)
+            mexErrMsgIdAndTxt("gpz:size", "omega / training / validation must have one entry per row of X");
+    if (gpz_mgpu_create(&d, n_gpus, NULL, GPZ_REDUCER_RCCL, (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi),
+                        opt(om), optmask(args[5]), optmask(args[6]), &g_mg))
+        mexErrMsgIdAndTxt("gpz:create", "%s", gpz_last_error());
+    g_key = key;
+    ++g_builds;
+    g_m = d.m; g_k = d.k;
+    if (g_pinv)
+        for (int32_t r = 0; r < gpz_mgpu_size(g_mg); ++r) (void)gpz_ctx_set_pinv_mode(gpz_mgpu_ctx(g_mg, r), g_pinv);
+    if (!g_locked) { mexLock(); mexAtExit(cleanup); g_locked = 1; }
+}
+
+static const double *theta_of(const mxArray *th) {
+    const mwSize p = (mwSize)gpz_mgpu_theta_len(g_mg);
+    if (!mxIsDouble(th) || mxIsComplex(th) || mxGetNumberOfElements(th) != p)
+        mexErrMsgIdAndTxt("gpz:theta", "theta must be a real double vector of %d elements", (int)p);
+    return mxGetPr(th);
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     char cmd[16];
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gpz:usage", "first argument: command");
     if (!strcmp(cmd, "reset")) { cleanup(); return; }
+    if (!strcmp(cmd, "builds")) { plhs[0] = mxCreateDoubleScalar((double)g_builds); return; }
+    if (!strcmp(cmd, "gpus")) { plhs[0] = mxCreateDoubleScalar(g_mg ? (double)gpz_mgpu_size(g_mg) : 0.0); return; }
     /* ---- stand-alone entries (no context) ---- */
     if (!strcmp(cmd, "getphi")) {
         if (nrhs != 5) mexErrMsgIdAndTxt("gpz:usage", "getphi needs model,theta,X,Psi");
-        gpz_desc d = desc_of(prhs[1]);
+        gpz_desc d = desc_of(prhs[1], NULL);
+        need_double(prhs[2], "theta", 0); need_double(prhs[3], "X", 0); need_double(prhs[4], "Psi", 1);
         const mwSize ns = mxGetM(prhs[3]);
         plhs[0] = mxCreateDoubleMatrix(ns, d.m, mxREAL);
         mxArray *lb = mxCreateDoubleMatrix(ns, d.k, mxREAL), *N = nlhs > 2 ? mxCreateDoubleMatrix(ns, d.m, mxREAL) : NULL;
@@ -82,8 +177,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     if (!strcmp(cmd, "predict")) {
         if (nrhs != 8) mexErrMsgIdAndTxt("gpz:usage", "predict needs model,theta,w,iSigma_w,priors,X,Psi");
-        gpz_desc d = desc_of(prhs[1]);
+        gpz_desc d = desc_of(prhs[1], NULL);
         const mxArray *X = prhs[6], *Psi = prhs[7];
+        need_double(X, "X", 0); need_double(Psi, "Psi", 1);
         const mwSize ns = mxGetM(X);
         mxArray *o[5];
         for (int q = 0; q < 4; ++q) o[q] = mxCreateDoubleMatrix(ns, d.k, mxREAL);   /* mu nu beta_i gamma (gamma = 0 for predictFull) */
@@ -104,14 +200,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     if (!strcmp(cmd, "prior")) {
         if (nrhs != 5) mexErrMsgIdAndTxt("gpz:usage", "prior needs model,theta,X,Psi");
-        gpz_desc d = desc_of(prhs[1]);
+        gpz_desc d = desc_of(prhs[1], NULL);
+        need_double(prhs[3], "X", 0);
         plhs[0] = mxCreateDoubleMatrix(1, d.m, mxREAL);
         CHECK(gpz_prior(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetM(prhs[3]), opt(prhs[4]), psi_kind_of(prhs[4]),
                         mxGetPr(plhs[0]), NULL), "gpz:prior");
         return;
     }
     if (!strcmp(cmd, "inv_logdet")) {
+        if (nrhs != 2) mexErrMsgIdAndTxt("gpz:usage", "inv_logdet needs a matrix");
+        need_double(prhs[1], "X", 0);
         const mwSize m = mxGetM(prhs[1]);
+        if (mxGetN(prhs[1]) != m) mexErrMsgIdAndTxt("gpz:size", "inv_logdet: the matrix must be square");
         double ld = 0.0;
         plhs[0] = mxCreateDoubleMatrix(m, m, mxREAL);
         CHECK(gpz_inv_logdet(mxGetPr(prhs[1]), (int32_t)m, 0, mxGetPr(plhs[0]), &ld, NULL), "gpz:inv_logdet");
@@ -119,60 +219,67 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         return;
     }
     if (!strcmp(cmd, "dxy")) {
+        if (nrhs != 3) mexErrMsgIdAndTxt("gpz:usage", "dxy needs X,Y");
+        need_double(prhs[1], "X", 0); need_double(prhs[2], "Y", 0);
+        if (mxGetN(prhs[1]) != mxGetN(prhs[2])) mexErrMsgIdAndTxt("gpz:size", "dxy: X and Y need the same number of columns");
         plhs[0] = mxCreateDoubleMatrix(mxGetM(prhs[1]), mxGetM(prhs[2]), mxREAL);
         CHECK(gpz_dxy(mxGetPr(prhs[1]), (int64_t)mxGetM(prhs[1]), mxGetPr(prhs[2]), (int64_t)mxGetM(prhs[2]),
                       (int32_t)mxGetN(prhs[1]), 0, mxGetPr(plhs[0])), "gpz:dxy");
         return;
     }
-    if (!strcmp(cmd, "create")) {
-        if (nrhs != 8) mexErrMsgIdAndTxt("gpz:usage", "create needs model,X,Y,Psi,omega,training,validation");
-        cleanup();
-        gpz_desc d = desc_of(prhs[1]);
-        const mxArray *Psi = prhs[4];
-        int psi_kind = psi_kind_of(Psi);
-        if (gpz_ctx_create(&d, (int64_t)mxGetM(prhs[2]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), opt(Psi), psi_kind,
-                           opt(prhs[5]), optmask(prhs[6]), optmask(prhs[7]), &g_ctx))
-            mexErrMsgIdAndTxt("gpz:create", "%s", gpz_last_error());
-        g_m = d.m; g_k = d.k;
-        mexLock();
-        mexAtExit(cleanup);
-        return;
-    }
-    if (!g_ctx) mexErrMsgIdAndTxt("gpz:state", "call gpz_mex('create', ...) first");
-    if (!strcmp(cmd, "eval")) {
-        mwSize p = (mwSize)gpz_theta_len(g_ctx);
-        if (nrhs != 2 || !mxIsDouble(prhs[1]) || mxGetNumberOfElements(prhs[1]) != p)
-            mexErrMsgIdAndTxt("gpz:theta", "theta must be a double vector of %d elements", (int)p);
-        double f;
-        plhs[1 < nlhs ? 1 : 0] = NULL;
-        mxArray *g = mxCreateDoubleMatrix(p, 1, mxREAL);
-        mxArray *st = mxCreateDoubleMatrix(4, 1, mxREAL);
-        mxGetPr(st)[2] = mxGetNaN(); mxGetPr(st)[3] = mxGetNaN();
-        if (gpz_eval(g_ctx, mxGetPr(prhs[1]), &f, mxGetPr(g), mxGetPr(st), NULL))
-            mexErrMsgIdAndTxt("gpz:eval", "%s", gpz_last_error());
-        plhs[0] = mxCreateDoubleScalar(f);
-        if (nlhs > 1) plhs[1] = g; else mxDestroyArray(g);
-        if (nlhs > 2) plhs[2] = st; else mxDestroyArray(st);
-        return;
-    }
-    if (!strcmp(cmd, "solve")) {
-        mwSize dims[3] = {(mwSize)g_m, (mwSize)g_m, (mwSize)g_k};
-        plhs[0] = mxCreateDoubleMatrix(g_m, g_k, mxREAL);
-        mxArray *iS = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
-        mxArray *part = mxCreateDoubleMatrix(1, g_k, mxREAL);
-        if (gpz_solve(g_ctx, mxGetPr(prhs[1]), mxGetPr(plhs[0]), mxGetPr(iS), mxGetPr(part)))
-            mexErrMsgIdAndTxt("gpz:solve", "%s", gpz_last_error());
-        if (nlhs > 1) plhs[1] = iS; else mxDestroyArray(iS);
-        if (nlhs > 2) plhs[2] = part; else mxDestroyArray(part);
-        return;
-    }
     if (!strcmp(cmd, "pinv_mode")) {
-        CHECK(gpz_ctx_set_pinv_mode(g_ctx, (int)mxGetScalar(prhs[1])), "gpz:pinv_mode");
+        if (nrhs != 2) mexErrMsgIdAndTxt("gpz:usage", "pinv_mode needs a mode");
+        g_pinv = (int)mxGetScalar(prhs[1]);
+        if (g_pinv < -1 || g_pinv > 1) { g_pinv = 0; mexErrMsgIdAndTxt("gpz:usage", "pinv_mode: -1, 0 or 1"); }
+        if (g_mg)
+            for (int32_t r = 0; r < gpz_mgpu_size(g_mg); ++r) CHECK(gpz_ctx_set_pinv_mode(gpz_mgpu_ctx(g_mg, r), g_pinv), "gpz:pinv_mode");
+        return;
+    }
+    if (!strcmp(cmd, "eval") || !strcmp(cmd, "solve")) {
+        if (nrhs != 9) mexErrMsgIdAndTxt("gpz:usage", "%s needs theta,model,X,Y,Psi,omega,training,validation", cmd);
+        ensure_context(prhs + 2);
+        const double *theta = theta_of(prhs[1]);
+        if (cmd[0] == 'e') {
+            const mwSize p = (mwSize)gpz_mgpu_theta_len(g_mg);
+            double f;
+            mxArray *g = mxCreateDoubleMatrix(p, 1, mxREAL);
+            mxArray *st = mxCreateDoubleMatrix(4, 1, mxREAL);
+            mxGetPr(st)[2] = mxGetNaN(); mxGetPr(st)[3] = mxGetNaN();
+            if (gpz_mgpu_eval(g_mg, theta, &f, mxGetPr(g), mxGetPr(st), NULL))
+                mexErrMsgIdAndTxt("gpz:eval", "%s", gpz_last_error());
+            plhs[0] = mxCreateDoubleScalar(f);
+            if (nlhs > 1) plhs[1] = g; else mxDestroyArray(g);
+            if (nlhs > 2) plhs[2] = st; else mxDestroyArray(st);
+        } else {
+            mwSize dims[3] = {(mwSize)g_m, (mwSize)g_m, (mwSize)g_k};
+            plhs[0] = mxCreateDoubleMatrix(g_m, g_k, mxREAL);
+            mxArray *iS = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+            mxArray *part = mxCreateDoubleMatrix(1, g_k, mxREAL);
+            if (gpz_mgpu_solve(g_mg, theta, mxGetPr(plhs[0]), mxGetPr(iS), mxGetPr(part)))
+                mexErrMsgIdAndTxt("gpz:solve", "%s", gpz_last_error());
+            if (nlhs > 1) plhs[1] = iS; else mxDestroyArray(iS);
+            if (nlhs > 2) plhs[2] = part; else mxDestroyArray(part);
+        }
         return;
     }
     if (!strcmp(cmd, "phi")) {
-        plhs[0] = mxCreateDoubleMatrix((mwSize)gpz_n_train(g_ctx), g_m, mxREAL);
-        if (gpz_get_phi(g_ctx, mxGetPr(plhs[0]))) mexErrMsgIdAndTxt("gpz:phi", "%s", gpz_last_error());
+        if (!g_mg) mexErrMsgIdAndTxt("gpz:state", "no live context: call eval or solve first");
+        /* the shards hold contiguous row blocks of the training selection, in rank order */
+        mwSize n = 0;
+        for (int32_t r = 0; r < gpz_mgpu_size(g_mg); ++r) n += (mwSize)gpz_n_train(gpz_mgpu_ctx(g_mg, r));
+        plhs[0] = mxCreateDoubleMatrix(n, g_m, mxREAL);
+        double *out = mxGetPr(plhs[0]);
+        mwSize r0 = 0;
+        for (int32_t r = 0; r < gpz_mgpu_size(g_mg); ++r) {
+            gpz_ctx *c = gpz_mgpu_ctx(g_mg, r);
+            const mwSize nr = (mwSize)gpz_n_train(c);
+            if (!nr) continue;
+            mxArray *blk = mxCreateDoubleMatrix(nr, g_m, mxREAL);
+            if (gpz_get_phi(c, mxGetPr(blk))) mexErrMsgIdAndTxt("gpz:phi", "%s", gpz_last_error());
+            for (int j = 0; j < g_m; ++j) memcpy(out + (size_t)j * n + r0, mxGetPr(blk) + (size_t)j * nr, nr * sizeof(double));
+            mxDestroyArray(blk);
+            r0 += nr;
+        }
         return;
     }
     mexErrMsgIdAndTxt("gpz:usage", "unknown command '%s'", cmd);

@@ -851,3 +851,116 @@ def test_hip_path_against_the_50_digit_reference(method, psi, nanfrac):
     cond = O.GPz(theta, model, X, Y, Psi, om).cond
     assert abs(f - f_mp) <= 1e-12 * abs(f_mp)
     assert np.max(np.abs(g - g_mp)) <= max(1e-11, 50 * cond * 2.2e-16) * np.max(np.abs(g_mp))
+
+
+# ---- all GPUs behind one synchronous C call (gpz_mgpu_*, gpz_mgpu.hip) and RCCL inside the library ---------------
+def test_inlibrary_rccl_single_rank_is_bit_identical():
+    """gpz_rccl_unique_id + gpz_ctx_init_rccl: a context that believes it is rank 0 of 2 gets a ONE-rank RCCL communicator
+    created and used inside the library (ncclCommInitRank / ncclAllReduce on the library's device buffers and stream, no
+    Python in the evaluation).  A one-rank all-reduce is the identity, so f and g must equal the plain evaluation of the
+    same rows bit for bit — which also shows the collectives are ordered correctly with the kernels around them."""
+    import ctypes as C
+    model, theta, X, Y, _, rng = make_problem(5000, 10, 96, 1, "VC", True, seed=41)
+    om = rng.random((5000, 1)) + 0.5
+    a = gpz_amd.GPzContext(model, X, Y, None, om, rank=0, world=2)
+    lib = _lib.load()
+    idbuf = C.create_string_buffer(128)
+    _lib.check(lib.gpz_rccl_unique_id(idbuf))
+    _lib.check(lib.gpz_ctx_init_rccl(a._h, idbuf, 0, 1, 0))
+    assert lib.gpz_rccl_origin().decode() != ""
+    fa, ga = a.eval(theta)
+    fa2, ga2 = a.eval(theta)
+    wa, iSa, pa = a.solve(theta)
+    a.close()
+    b = gpz_amd.GPzContext(model, X, Y, None, om)
+    fb, gb = b.eval(theta)
+    wb, iSb, pb = b.solve(theta)
+    b.close()
+    assert fa == fb and np.array_equal(ga, gb) and fa2 == fa and np.array_equal(ga2, ga)
+    assert np.array_equal(wa, wb) and np.array_equal(iSa, iSb) and np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("method,psi,nanfrac,k", [("VC", False, 0.0, 1), ("VD", True, 0.3, 2), ("VC", True, 0.0, 1),
+                                                    ("GC", False, 0.3, 2), ("VC", True, 0.3, 1), ("GL", False, 0.0, 1)])
+@pytest.mark.parametrize("shards", [2, 3])
+def test_mgpu_loopback_matches_oracle_and_unsharded(method, psi, nanfrac, k, shards):
+    """gpz_mgpu_create / gpz_mgpu_eval / gpz_mgpu_solve: the library shards the rows itself, runs one host thread and one
+    stream per shard and reduces the partials at the two exchange points; here all shards live on this box's one GPU and
+    the in-library rank-ordered reducer stands in for RCCL (which refuses duplicate devices).  Against the oracle on the
+    unsharded problem, with weights, a training mask and validation rows."""
+    n = 3001
+    model, theta, X, Y, Psi, rng = make_problem(n, 6, 40, k, method, True, seed=33, psi=psi, nanfrac=nanfrac)
+    r2 = np.random.default_rng(1)
+    om = r2.random((n, 1)) + 0.5
+    tr = r2.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    r4 = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr, nargout=4)
+    tol = grad_tol(ref.cond)
+    mg = gpz_amd.GPzMulti(model, X, Y, Psi, om, tr, ~tr, n_gpus=shards, reducer="loopback")
+    try:
+        assert mg.n_gpus == shards and sum(mg.rows_per_gpu) == int(tr.sum())
+        assert max(mg.rows_per_gpu) - min(mg.rows_per_gpu) <= 1
+        f, g = mg.eval(theta)
+        f2, g2 = mg.eval(theta)
+        w, iS, part = mg.solve(theta)
+        stats = dict(mg.stats)
+        assert mg.n_global == int(tr.sum())
+    finally:
+        mg.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= tol
+    assert f2 == f and np.array_equal(g2, g)                                # deterministic reducer: repeatable bitwise
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+    assert rel(w, r4.w) <= tol and rel(iS, r4.iSigma_w) <= tol and rel(part, r4.nlogML) <= FTOL
+    one = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
+    f1, g1 = one.eval(theta)
+    one.close()
+    assert abs(f - f1) <= 1e-12 * abs(f1) and rel(g, g1) <= max(1e-10, tol / 50)
+
+
+def test_mgpu_one_device_equals_plain_context_bitwise():
+    model, theta, X, Y, _, rng = make_problem(4000, 5, 33, 1, "VC", True, seed=43)
+    mg = gpz_amd.GPzMulti(model, X, Y, n_gpus=1)
+    f, g = mg.eval(theta)
+    mg.enable_timing(True)
+    mg.eval(theta)
+    assert mg.timings(0)["tgemm"][1] == 1
+    mg.close()
+    one = gpz_amd.GPzContext(model, X, Y)
+    f1, g1 = one.eval(theta)
+    one.close()
+    assert f == f1 and np.array_equal(g, g1)
+
+
+def test_mgpu_c4_shaped_shards_against_oracle():
+    """c4's shape (d = 10, m = 1000, VC, heteroscedastic) on 8 loopback shards of a row subsample: the partition the
+    8-GPU run uses, with the MFMA contractions and the blocked Cholesky at their full m."""
+    import bench
+    model, theta, X, y, omega = _bench_problem("c4", n=20000)
+    ref = O.GPz(theta, O.Model(m=model.m, d=model.d, k=1, method="VC", heteroscedastic=True), X, y)
+    mg = gpz_amd.GPzMulti(model, X, y, n_gpus=8, reducer="loopback")
+    f, g = mg.eval(theta)
+    mg.close()
+    one = gpz_amd.GPzContext(model, X, y)
+    f1, g1 = one.eval(theta)
+    one.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+    assert abs(f - f1) <= 1e-10 * max(1.0, abs(f1)) and rel(g, g1) <= grad_tol(ref.cond) / 50      # the same sums, regrouped
+
+
+def test_mgpu_refuses_bad_layouts_loudly():
+    model, theta, X, Y, _, rng = make_problem(50, 3, 4, 1, "VD", True, seed=2)
+    with pytest.raises(_lib.GpzError):                       # RCCL needs distinct devices
+        gpz_amd.GPzMulti(model, X, Y, devices=[0, 0])
+    with pytest.raises(_lib.GpzError):                       # fewer training rows than shards
+        gpz_amd.GPzMulti(model, X[:3], Y[:3], n_gpus=4, reducer="loopback")
+    with pytest.raises(_lib.GpzError):                       # a device that is not there
+        gpz_amd.GPzMulti(model, X, Y, devices=[gpz_amd.device_count() + 3])
+    mg = gpz_amd.GPzMulti(model, X, Y, n_gpus=2, reducer="loopback")
+    with pytest.raises(ValueError):
+        mg.eval(theta[:-1])
+    f, g = mg.eval(np.full_like(theta, np.nan))              # numerical breakdown is a value, not an error, on every rank
+    assert np.isnan(f) and np.isnan(g).all()
+    f, g = mg.eval(theta)                                    # and the handle is still usable afterwards
+    assert np.isfinite(f)
+    mg.close()

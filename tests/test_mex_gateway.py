@@ -1,0 +1,232 @@
+"""mex/gpz_mex.cpp — the MATLAB side of the drop-in boundary — compiled and EXECUTED without MATLAB.
+
+tests/stubs/mex.h declares the part of the MEX C API the gateway uses (documented MATLAB signatures);
+tests/stubs/mex_runtime.cpp implements it on heap arrays and adds a small driver.  The gateway is compiled unchanged,
+linked against libgpz_hip.so, and called the way mex/GPz.m calls it; on the GPU box its results are compared with the
+oracle.  Gateway convention checked: minFunc_2012/minFunc/mex/lbfgsProdC.c:7 (mexFunction signature), :24-25 (argument
+checks reported with mexErrMsg*), :43 (outputs from mxCreate*)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import make_problem, rel, grad_tol
+from oracle import gpz_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUBS = os.path.join(ROOT, "tests", "stubs")
+TWIN = os.path.join(ROOT, "build", "libgpz_mex_twin.so")
+SRCS = [os.path.join(ROOT, "mex", "gpz_mex.cpp"), os.path.join(STUBS, "mex_runtime.cpp")]
+
+
+def test_gateway_compiles_against_the_mex_api_declarations():
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + STUBS,
+                        "-I" + os.path.join(ROOT, "include"), SRCS[0]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def _twin():
+    from gpz_amd import _lib
+    _lib.load()          # the package's loading order (torch's bundled HIP runtime first, see _lib.load) before the twin pulls libgpz_hip.so in
+    libdir = os.path.join(ROOT, "gpz_amd", "lib")
+    deps = SRCS + [os.path.join(STUBS, "mex.h"), os.path.join(ROOT, "include", "gpz_hip.h")]
+    if not os.path.exists(TWIN) or any(os.path.getmtime(s) > os.path.getmtime(TWIN) for s in deps):
+        os.makedirs(os.path.dirname(TWIN), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wall", "-I" + STUBS,
+                               "-I" + os.path.join(ROOT, "include"), *SRCS, "-L" + libdir, "-lgpz_hip",
+                               "-Wl,-rpath," + libdir, "-o", TWIN])
+    lib = C.CDLL(TWIN)
+    vp, sz = C.c_void_p, C.c_size_t
+    for name, res, args in [("mexrt_double", vp, [vp, C.c_int, C.POINTER(sz)]), ("mexrt_logical", vp, [vp, sz]),
+                            ("mexrt_string", vp, [C.c_char_p]), ("mexrt_struct", vp, []),
+                            ("mexrt_set_field", None, [vp, C.c_char_p, vp]), ("mexrt_ndim", C.c_int, [vp]),
+                            ("mexrt_dim", sz, [vp, C.c_int]), ("mexrt_call", C.c_int, [C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+                            ("mexrt_last_error", C.c_char_p, []), ("mexrt_last_id", C.c_char_p, []),
+                            ("mexrt_locks", C.c_int, []), ("mexrt_unload", None, []), ("mxDestroyArray", None, [vp]),
+                            ("mxGetPr", vp, [vp]), ("mxGetNumberOfElements", sz, [vp])]:
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    return lib
+
+
+class MexError(Exception):
+    def __init__(self, ident, msg):
+        super().__init__(f"{ident}: {msg}")
+        self.ident = ident
+
+
+class Mex:
+    """Marshals NumPy values the way MATLAB hands them to a MEX file and calls the gateway."""
+
+    def __init__(self):
+        self.lib = _twin()
+        self.held = {}      # id(ndarray) -> (mxArray, ndarray): a MATLAB variable keeps its data pointer between calls
+
+    def hold(self, *arrays):
+        for a in arrays:
+            if a is not None:
+                self.held[id(a)] = (self._in(a), a)
+
+    def poke(self, a, flat_index, value):
+        """Write into the held mxArray of ``a`` in place (what MATLAB may do to an unshared variable)."""
+        p = self.held[id(a)][0]
+        C.cast(self.lib.mxGetPr(p), C.POINTER(C.c_double))[flat_index] = value
+
+    def release(self):
+        for p, _ in self.held.values():
+            self.lib.mxDestroyArray(p)
+        self.held = {}
+
+    def _in(self, v):
+        L = self.lib
+        if v is None:
+            return L.mexrt_double(None, 2, (C.c_size_t * 2)(0, 0))
+        if isinstance(v, str):
+            return L.mexrt_string(v.encode())
+        if isinstance(v, dict):
+            s = L.mexrt_struct()
+            for key, val in v.items():
+                L.mexrt_set_field(s, key.encode(), self._in(val))
+            return s
+        a = np.asarray(v)
+        if a.dtype == bool:
+            a = np.ascontiguousarray(a.ravel().astype(np.uint8))
+            return L.mexrt_logical(a.ctypes.data, a.size)
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim < 2:
+            a = a.reshape(-1, 1) if a.ndim == 1 else a.reshape(1, 1)
+        f = np.asfortranarray(a)
+        return L.mexrt_double(f.ctypes.data, f.ndim, (C.c_size_t * f.ndim)(*f.shape))
+
+    def _out(self, p):
+        L = self.lib
+        shape = tuple(L.mexrt_dim(p, q) for q in range(L.mexrt_ndim(p)))
+        n = L.mxGetNumberOfElements(p)
+        buf = np.ctypeslib.as_array(C.cast(L.mxGetPr(p), C.POINTER(C.c_double)), shape=(n,)).copy() if n else np.zeros(0)
+        return buf.reshape(shape, order="F")
+
+    def __call__(self, nlhs, *args):
+        L = self.lib
+        owned = [None if id(a) in self.held else self._in(a) for a in args]
+        prhs = (C.c_void_p * len(args))(*[self.held[id(a)][0] if o is None else o for a, o in zip(args, owned)])
+        plhs = (C.c_void_p * max(nlhs, 1))()
+        rc = L.mexrt_call(nlhs, plhs, len(args), prhs)
+        for p in owned:
+            if p is not None:
+                L.mxDestroyArray(p)
+        if rc:
+            raise MexError(L.mexrt_last_id().decode(), L.mexrt_last_error().decode())
+        outs = [self._out(plhs[q]) for q in range(max(nlhs, 1)) if plhs[q]]
+        for q in range(max(nlhs, 1)):
+            if plhs[q]:
+                L.mxDestroyArray(plhs[q])
+        return outs[0] if nlhs <= 1 and outs else outs
+
+
+def model_struct(model, **extra):
+    s = {"m": float(model.m), "d": float(model.d), "k": float(model.k), "method": model.method,
+         "heteroscedastic": bool(model.heteroscedastic)}
+    s.update(extra)
+    return s
+
+
+def test_gateway_links_and_rejects_bad_calls_without_a_gpu():
+    mex = Mex()
+    assert mex(1, "gpus") == 0.0
+    mex(0, "reset")
+    for args, ident in [(("nonsense",), "gpz:usage"), (("eval", np.zeros(3)), "gpz:usage"), (("dxy", np.zeros((2, 2))), "gpz:usage"),
+                        (("inv_logdet", np.zeros((2, 3))), "gpz:size"), (("phi",), "gpz:state"), (("pinv_mode", 5.0), "gpz:usage"),
+                        (("dxy", np.zeros((2, 2)), np.zeros((2, 3))), "gpz:size"),
+                        (("eval", np.zeros(3), {"m": 2.0}, None, None, None, None, None, None), "gpz:model")]:
+        with pytest.raises(MexError) as e:
+            mex(1, *args)
+        assert e.value.ident == ident, (args[0], e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,psi,nanfrac,k", [("VC", False, 0.0, 1), ("VD", True, 0.3, 2), ("GC", True, 0.0, 1)])
+def test_gateway_eval_solve_phi_match_the_oracle(method, psi, nanfrac, k):
+    """What mex/GPz.m does for [f,g] = GPz(theta,...) (globals from stats), [~,~,w,iSigma_w,PHI] = GPz(...) and the
+    closure-change detection: new omega values in a NEW array of the same size must rebuild the device context."""
+    n = 1500
+    model, theta, X, Y, Psi, rng = make_problem(n, 5, 24, k, method, True, seed=51, psi=psi, nanfrac=nanfrac)
+    r2 = np.random.default_rng(4)
+    om = r2.random((n, 1)) + 0.5
+    tr = r2.random(n) < 0.75
+    ms = model_struct(model)
+    mex = Mex()
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    tol = grad_tol(ref.cond)
+    f, g, st = mex(3, "eval", theta, ms, X, Y, Psi, om, tr, ~tr)
+    assert mex(1, "gpus") == 1.0 and mex.lib.mexrt_locks() == 1
+    assert f.shape == (1, 1) and g.shape == (theta.size, 1) and st.shape == (4, 1)
+    assert abs(f[0, 0] - ref.nlogML) <= 1e-8 * abs(ref.nlogML) and rel(g.ravel(), ref.grad) <= tol
+    for q, key in enumerate(["trainRMSE", "trainLL", "validRMSE", "validLL"]):
+        assert abs(st[q, 0] - ref.stats[key]) <= 1e-10 * max(1.0, abs(ref.stats[key]))
+    f_again = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, ~tr)          # nlhs = 1: only f comes back
+    assert f_again[0, 0] == f[0, 0]
+    r4 = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr, nargout=5)
+    w, iS, part = mex(3, "solve", theta, ms, X, Y, Psi, om, tr, ~tr)
+    assert w.shape == (model.m, k) and iS.shape == (model.m, model.m, k) and part.shape == (1, k)
+    assert rel(w, r4.w) <= tol and rel(iS, r4.iSigma_w) <= tol and rel(part.ravel(), r4.nlogML) <= 1e-8
+    PHI = mex(1, "phi")
+    assert PHI.shape == (int(tr.sum()), model.m) and rel(PHI, r4.PHI) <= 1e-10
+    # closure change: other weights, other masks, other model -> the live context must not be reused
+    om2 = om * (1.0 + r2.random((n, 1)))
+    ref2 = O.GPz(theta, model, X, Y, Psi, om2, tr, ~tr)
+    f2 = mex(1, "eval", theta, ms, X, Y, Psi, om2, tr, ~tr)
+    assert abs(f2[0, 0] - ref2.nlogML) <= 1e-8 * abs(ref2.nlogML) and f2[0, 0] != f[0, 0]
+    tr3 = r2.random(n) < 0.75
+    ref3 = O.GPz(theta, model, X, Y, Psi, om2, tr3, None)
+    f3, g3, st3 = mex(3, "eval", theta, ms, X, Y, Psi, om2, tr3, None)
+    assert abs(f3[0, 0] - ref3.nlogML) <= 1e-8 * abs(ref3.nlogML) and np.isnan(st3[2:, 0]).all()
+    with pytest.raises(MexError) as e:
+        mex(1, "eval", theta[:-1], ms, X, Y, Psi, om2, tr3, None)
+    assert e.value.ident == "gpz:theta"
+    with pytest.raises(MexError) as e:
+        mex(1, "solve", theta[:-1], ms, X, Y, Psi, om2, tr3, None)
+    assert e.value.ident == "gpz:theta"
+    with pytest.raises(MexError) as e:
+        mex(1, "eval", theta, ms, X.astype(np.float64)[:, :-1], Y, None, None, None, None)
+    assert e.value.ident == "gpz:size"
+    mex(0, "reset")
+    assert mex(1, "gpus") == 0.0
+    # a closure whose arrays keep their data pointers (MATLAB variables between minFunc iterations): ONE build, however
+    # many evaluations; an in-place edit of a sampled element, or another model field, is seen and rebuilds
+    mex.hold(X, Y, Psi, om, tr)
+    b0 = mex(1, "builds")[0, 0]
+    fa = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    fb = mex(1, "eval", theta + 1e-3, ms, X, Y, Psi, om, tr, None)
+    mex(3, "solve", theta, ms, X, Y, Psi, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 1 and fa[0, 0] != fb[0, 0]
+    hit = next(i for i in np.flatnonzero(tr) if i % (n // 256) == 0)       # a training row among the 256 sampled elements
+    mex.poke(om, int(hit), om[hit, 0] * 3.0)
+    fc = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 2 and fc[0, 0] != fa[0, 0]
+    if model.heteroscedastic:
+        ms2 = dict(ms, heteroscedastic=False)
+        with pytest.raises(MexError) as e:          # theta is now too long for the model: the context was rebuilt for it
+            mex(1, "eval", theta, ms2, X, Y, Psi, om, tr, None)
+        assert e.value.ident == "gpz:theta" and mex(1, "builds")[0, 0] == b0 + 3
+    mex.release()
+    mex(0, "reset")
+    mex.lib.mexrt_unload()
+
+
+@pytest.mark.gpu
+def test_gateway_standalone_entries():
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((30, 30))
+    A = A @ A.T + 30 * np.eye(30)
+    mex = Mex()
+    Xi, ld = mex(2, "inv_logdet", A)
+    Xr, lr = O.inv_logdet(A)
+    assert rel(Xi, Xr) <= 1e-10 and abs(ld[0, 0] - lr) <= 1e-10 * abs(lr)
+    P, Q = rng.standard_normal((40, 4)), rng.standard_normal((9, 4))
+    assert rel(mex(1, "dxy", P, Q), O.Dxy(P, Q)) <= 1e-12
+    model, theta, X, Y, Psi, _ = make_problem(200, 4, 12, 1, "VC", True, seed=3)
+    PHI, lnb, N = mex(3, "getphi", model_struct(model), theta, X, None)
+    out = O.getPHI(X, None, theta, model, None)
+    assert rel(PHI, out[0]) <= 1e-10 and rel(lnb, out[2]) <= 1e-12
