@@ -31,67 +31,111 @@
 
 #define LT(r, c) ((r) * ((r) + 1) / 2 + (c))
 
-// In-place Cholesky of a packed lower triangle (column by column, dot-product form); *hl = sum ln L_cc.
+// ---- packed fp32 arithmetic ------------------------------------------------------------------------------------------
+// A plain v_fma_f32 retires 64 FMAs per 4 cycles and SIMD (78.6 TFLOP/s on the chip); the 157 TFLOP/s fp32 vector peak
+// is v_pk_fma_f32, two FMAs per lane on an even-aligned register pair, with op_sel picking either half of an operand
+// for both results (a free broadcast).  Everything O(D^3) below therefore works on ROW PAIRS of the lower triangle:
+// column c holds the pairs t = c/2 .. D/2-1 = rows (2t, 2t+1).  For odd c the first pair starts one row above the
+// diagonal; that slot is junk during the factorisation (never read as a row-c value) and is set to zero in the inverse
+// factor, where whole columns enter dot products.  D(D+2)/4 pairs instead of D(D+1)/2 scalars: 110 vs 210 at D = 20.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 sp(float x) {
+    f2 r;
+    r.x = x;
+    r.y = x;
+    return r;
+}
+// first pair of column c:  c*H - sum_{q<c} floor(q/2)  (closed form: the unroller must see plain arithmetic)
+constexpr int p2base(int H, int c) { return c * H - ((c & 1) ? (c / 2) * (c / 2) : (c / 2) * (c / 2 - 1)); }
+#define P2(t, c) (p2base(D / 2, (c)) + (t) - (c) / 2)
+#define NP2_OF(D) p2base((D) / 2, (D))
+
+// In-place Cholesky, left-looking by columns.  rd[c] = 1 / L_cc (the rsq every column needs anyway), *hl = sum ln L_cc.
 template <int D>
-__device__ __forceinline__ void chol32(float (&M)[D * (D + 1) / 2], float *hl) {
+__device__ __forceinline__ void chol2(f2 (&M)[NP2_OF(D)], float (&rd)[D], float *hl) {
+    constexpr int H = D / 2;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        float p = M[LT(c, c)];
 #pragma unroll
-        for (int q = 0; q < c; ++q) p = fmaf(-M[LT(c, q)], M[LT(c, q)], p);
-        const float inv = __builtin_amdgcn_rsqf(p);                 // 1/sqrt(p), 1 ulp
-        const float dd = p * inv;
-        M[LT(c, c)] = dd;
-        s += __logf(dd);
+        for (int t = c / 2; t < H; ++t) {
+            f2 a = M[P2(t, c)];
 #pragma unroll
-        for (int r = c + 1; r < D; ++r) {
-            float t = M[LT(r, c)];
-#pragma unroll
-            for (int q = 0; q < c; ++q) t = fmaf(-M[LT(r, q)], M[LT(c, q)], t);
-            M[LT(r, c)] = t * inv;
+            for (int q = 0; q < c; ++q) a -= M[P2(t, q)] * sp(M[P2(c / 2, q)][c & 1]);      // L[., q] * L[c][q]
+            M[P2(t, c)] = a;
         }
+        const float p = M[P2(c / 2, c)][c & 1];
+        const float inv = __builtin_amdgcn_rsqf(p);                                         // 1/sqrt(p), 1 ulp
+        rd[c] = inv;
+        s += __logf(p);
+#pragma unroll
+        for (int t = c / 2; t < H; ++t) M[P2(t, c)] *= sp(inv);
     }
-    *hl = s;
+    *hl = 0.5f * s;
 }
 
-// L <- inv(L) in place.  First the diagonal is replaced by its reciprocals (every later division becomes a multiply),
-// then ascending columns: column c reads only columns >= c of L.
+// L <- W = inv(L) in place, ascending columns: column c of W is the forward substitution of e_c, done right-looking so
+// that every update is a packed column operation; it reads columns >= c of L, which are still untouched.
 template <int D>
-__device__ __forceinline__ void trinv32(float (&L)[D * (D + 1) / 2]) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) L[LT(c, c)] = __builtin_amdgcn_rcpf(L[LT(c, c)]);
+__device__ __forceinline__ void trinv2(f2 (&L)[NP2_OF(D)], const float (&rd)[D]) {
+    constexpr int H = D / 2;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        const float wcc = L[LT(c, c)];
+        f2 x[H];
+        float wc[D];
 #pragma unroll
-        for (int r = c + 1; r < D; ++r) {
-            float s = L[LT(r, c)] * wcc;
+        for (int t = c / 2; t < H; ++t) x[t] = sp(0.f);
 #pragma unroll
-            for (int q = c + 1; q < r; ++q) s = fmaf(L[LT(r, q)], L[LT(q, c)], s);   // L[q][c] already holds W[q][c]
-            L[LT(r, c)] = -s * L[LT(r, r)];
+        for (int q = c; q < D; ++q) {
+            const float wq = (q == c) ? rd[c] : -x[q / 2][q & 1] * rd[q];
+            wc[q] = wq;
+#pragma unroll
+            for (int t = (q + 1) / 2; t < H; ++t) x[t] += L[P2(t, q)] * sp(wq);             // rows > q (a finished row rides along)
+        }
+#pragma unroll
+        for (int t = c / 2; t < H; ++t) {
+            f2 o;
+            o.x = (2 * t >= c) ? wc[2 * t] : 0.f;                                           // the slot above the diagonal: zero
+            o.y = wc[2 * t + 1];
+            L[P2(t, c)] = o;
         }
     }
 }
 
-// Stage [S | p] of JB basis functions into LDS.  DIAG: S = R_j' packed lower (S(r,c) = R_j[c][r], c <= r) from the QR
-// records Rc (k_prep_cov: row a of R at a*de - a(a-1)/2, de = padded dimension of the parameter block); else
-// S = Sigma_j packed lower.  Padding dimensions (>= d) are identity.
+// Stage the pair-matrix parameters and the centres of JB basis functions into LDS.
+//   DIAG: the QR factor R_j by columns, row k of the stage = column k of R as D/2 row pairs (R[2t][k], R[2t+1][k]), zero
+//         below the diagonal (Rc: k_prep_cov's records, row a of R at a*de - a(a-1)/2, de = padded dimension of the
+//         parameter block);  else: Sigma_j in the row-pair layout above.  Padding dimensions (>= d) are identity.
 template <int D, int JB, bool DIAG>
 __device__ __forceinline__ void stage_params(int tid, int nt, int j0, int m, int d, int de, const double *__restrict__ Sig,
                                              const double *__restrict__ Rc, const double *__restrict__ P,
-                                             float (*sS)[D * (D + 1) / 2], double (*sP)[D]) {
-    constexpr int NP = D * (D + 1) / 2;
-    for (int e = tid; e < JB * NP; e += nt) {
-        const int jj = e / NP, q = e % NP, j = min(j0 + jj, m - 1);
-        int r = 0;
-        while ((r + 1) * (r + 2) / 2 <= q) ++r;
-        const int c = q - r * (r + 1) / 2;
-        float v;
-        if (r >= d) v = (r == c) ? 1.0f : 0.0f;
-        else if (DIAG) v = (float)Rc[(size_t)j * (de * (de + 1) / 2 + de) + (c * de - c * (c - 1) / 2) + (r - c)];   // R[c][r]
-        else v = (float)Sig[(size_t)j * d * d + r * d + c];
-        (&sS[0][0])[e] = v;
+                                             f2 (*sS)[D * D / 2], double (*sP)[D]) {
+    constexpr int H = D / 2;
+    if (DIAG) {
+        for (int e = tid; e < JB * D * D; e += nt) {
+            const int jj = e / (D * D), q = e % (D * D), k = q / D, r = q % D, j = min(j0 + jj, m - 1);
+            float v;
+            if (r > k) v = 0.f;
+            else if (k >= d) v = (r == k) ? 1.0f : 0.0f;
+            else v = (float)Rc[(size_t)j * (de * (de + 1) / 2 + de) + (r * de - r * (r - 1) / 2) + (k - r)];   // R[r][k]
+            ((float *)&sS[jj][0])[q] = v;
+        }
+    } else {
+        constexpr int NP2 = NP2_OF(D);
+        for (int e = tid; e < JB * NP2 * 2; e += nt) {
+            const int jj = e / (NP2 * 2), q = e % (NP2 * 2), pe = q >> 1, j = min(j0 + jj, m - 1);
+            int c = 0, b = 0;                                   // column of pair pe: base(c) = c*H - (c even ? a(a-1) : a*a), a = c/2
+            for (int cn = 1; cn < D; ++cn) {
+                const int a = cn / 2, bn = cn * H - ((cn & 1) ? a * a : a * (a - 1));
+                if (bn <= pe) { c = cn; b = bn; }
+            }
+            const int r = 2 * (pe - b + c / 2) + (q & 1);
+            float v;
+            if (r < c) v = 0.f;
+            else if (r >= d) v = (r == c) ? 1.0f : 0.0f;
+            else v = (float)Sig[(size_t)j * d * d + r * d + c];
+            ((float *)&sS[jj][0])[q] = v;
+        }
     }
     for (int e = tid; e < JB * D; e += nt) {
         const int jj = e / D, c = e % D, j = min(j0 + jj, m - 1);
@@ -99,31 +143,60 @@ __device__ __forceinline__ void stage_params(int tid, int nt, int j0, int m, int
     }
 }
 
-// The pair matrix in packed lower form.  DIAG: A = I + R diag(psi) R',  A(r,c) = delta_rc + sum_{k>=r} R[r][k] psi_k R[c][k];
+// The pair matrix in the row-pair layout.  DIAG: A = I + R diag(psi) R' = I + sum_k psi_k r_k r_k' (r_k = column k of R);
 // else M = Sigma_j + Psi_i (getPHI.m:84, GPz.m:170).
 template <int D, bool DIAG>
-__device__ __forceinline__ void pair_matrix(const float *__restrict__ S, const float (&pd)[DIAG ? D : 1],
-                                            const float *__restrict__ PsiT, long ldp, unsigned ic,
-                                            float (&M)[D * (D + 1) / 2]) {
+__device__ __forceinline__ void pair_matrix2(const f2 *__restrict__ S, const float (&pd)[DIAG ? D : 1],
+                                             const float *__restrict__ PsiT, long ldp, unsigned ic, f2 (&M)[NP2_OF(D)]) {
+    constexpr int H = D / 2;
     if (DIAG) {
 #pragma unroll
-        for (int r = 0; r < D; ++r)
+        for (int e = 0; e < NP2_OF(D); ++e) M[e] = sp(0.f);
 #pragma unroll
-            for (int c = 0; c <= r; ++c) M[LT(r, c)] = (r == c) ? 1.0f : 0.0f;
+        for (int c = 0; c < D; ++c) M[P2(c / 2, c)][c & 1] = 1.0f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
+            f2 s[H], g[H];
 #pragma unroll
-            for (int r = 0; r <= k; ++r) {
-                const float t = S[LT(k, r)] * pd[k];                                   // R[r][k] psi_k
-#pragma unroll
-                for (int c = 0; c <= r; ++c) M[LT(r, c)] = fmaf(t, S[LT(k, c)], M[LT(r, c)]);
+            for (int t = 0; t <= k / 2; ++t) {
+                s[t] = S[k * H + t];
+                g[t] = s[t] * sp(pd[k]);                                               // psi_k R[., k]
             }
+#pragma unroll
+            for (int c = 0; c <= k; ++c)
+#pragma unroll
+                for (int t = c / 2; t <= k / 2; ++t) M[P2(t, c)] += s[t] * sp(g[c / 2][c & 1]);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) M[LT(r, c)] = S[LT(r, c)] + PsiT[(size_t)LT(r, c) * ldp + ic];
+            for (int t = c / 2; t < H; ++t) {
+                f2 ps;
+                ps.x = (2 * t >= c) ? PsiT[(size_t)LT(2 * t, c) * ldp + ic] : 0.f;
+                ps.y = PsiT[(size_t)LT(2 * t + 1, c) * ldp + ic];
+                M[P2(t, c)] = S[P2(t, c)] + ps;
+            }
+    }
+}
+
+// z = Delta (full Psi) or R Delta (whitened), as row pairs; Delta is formed in fp64.
+template <int D, bool DIAG>
+__device__ __forceinline__ void delta2(const f2 *__restrict__ S, const float (&dl)[D], f2 (&z)[D / 2]) {
+    constexpr int H = D / 2;
+    if (DIAG) {
+#pragma unroll
+        for (int t = 0; t < H; ++t) z[t] = sp(0.f);
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int t = 0; t <= k / 2; ++t) z[t] += S[k * H + t] * sp(dl[k]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            z[t].x = dl[2 * t];
+            z[t].y = dl[2 * t + 1];
+        }
     }
 }
 
@@ -135,9 +208,9 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
                                                     const double *__restrict__ P, const double *__restrict__ Sig,
                                                     const double *__restrict__ Rc, const double *__restrict__ lnS,
                                                     double *__restrict__ Phi, int ld, int jgroup) {
-    constexpr int NP = D * (D + 1) / 2;
+    constexpr int H = D / 2;
     constexpr int JB = 8;
-    __shared__ float sS[JB][NP];
+    __shared__ f2 sS[JB][D * D / 2];
     __shared__ double sP[JB][D];
     __shared__ double sL[JB];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -161,32 +234,22 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
         for (int jj = 0; jj < JB; ++jj) {
             const int j = j0 + jj;
             if (j >= jhi) break;
-            float M[NP];
-            pair_matrix<D, DIAG>(sS[jj], pd, PsiT, ldp, ic, M);
-            float hl;
-            chol32<D>(M, &hl);
-            float z[D];
-            if (DIAG) {                                                                // z = R Delta
+            f2 M[NP2_OF(D)];
+            pair_matrix2<D, DIAG>(sS[jj], pd, PsiT, ldp, ic, M);
+            float hl, rd[D];
+            chol2<D>(M, rd, &hl);
+            float dl[D];
 #pragma unroll
-                for (int r = 0; r < D; ++r) z[r] = 0.f;
+            for (int k = 0; k < D; ++k) dl[k] = (float)(x[k] - sP[jj][k]);
+            f2 z[H];
+            delta2<D, DIAG>(sS[jj], dl, z);
+            float quad = 0.f;
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const float dl = (float)(x[k] - sP[jj][k]);
+            for (int c = 0; c < D; ++c) {                                              // y = L^-1 z, column by column
+                const float yc = z[c / 2][c & 1] * rd[c];
+                quad = fmaf(yc, yc, quad);
 #pragma unroll
-                    for (int r = 0; r <= k; ++r) z[r] = fmaf(sS[jj][LT(k, r)], dl, z[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < D; ++r) z[r] = (float)(x[r] - sP[jj][r]);
-            }
-            float y[D], quad = 0.f;
-#pragma unroll
-            for (int r = 0; r < D; ++r) {                                              // y = L^-1 z
-                float s = z[r];
-#pragma unroll
-                for (int c = 0; c < r; ++c) s = fmaf(-M[LT(r, c)], y[c], s);
-                y[r] = s * __builtin_amdgcn_rcpf(M[LT(r, r)]);
-                quad = fmaf(y[r], y[r], quad);
+                for (int t = (c + 1) / 2; t < H; ++t) z[t] -= M[P2(t, c)] * sp(yc);
             }
             // getPHI.m:86:  -1/2 quad + 1/2 ln|Sigma_j| - 1/2 ln|M|;  whitened: the two log-determinants collapse to -1/2 ln|A|
             const double lp = DIAG ? (-0.5 * (double)quad - (double)hl) : (-0.5 * (double)quad + 0.5 * sL[jj] - (double)hl);
@@ -238,10 +301,11 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
                                                        const double *__restrict__ Rc, int rows_per_chunk,
                                                        double *__restrict__ slab, int nrec) {
     constexpr int NP = D * (D + 1) / 2;
+    constexpr int H = D / 2;
     constexpr int JB = 8;
     constexpr int NV = 3 + D + NP;                     // values reduced per pair: [dp, r1, r2 | dp*u (D) | dp*(uu' - Minv) (NP)]
     constexpr int NG = (NV + 31) / 32;                 // groups of 32 values
-    __shared__ float sS[JB][NP];
+    __shared__ f2 sS[JB][D * D / 2];
     __shared__ double sP[JB][D];
     __shared__ double acc[JB][NG * 32];
     const int lane = threadIdx.x;
@@ -276,40 +340,30 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
             }
             if (!act) { dpd = 0.0; q1 = 0.0; q2 = 0.0; }
             const float dp = (float)dpd;
-            float L[NP];
-            pair_matrix<D, DIAG>(sS[jj], pd, PsiT, ldp, ic, L);
-            float hl;
-            chol32<D>(L, &hl);
-            trinv32<D>(L);                                                             // L now holds W = inv(L)
+            f2 L[NP2_OF(D)];
+            pair_matrix2<D, DIAG>(sS[jj], pd, PsiT, ldp, ic, L);
+            float hl, rd[D];
+            chol2<D>(L, rd, &hl);
+            trinv2<D>(L, rd);                                                          // L now holds W = inv(L)
             float u[D];
             {
-                float y[D];
+                float dl[D];
 #pragma unroll
-                for (int r = 0; r < D; ++r) y[r] = 0.f;
-                float z[D];                                                            // z = Delta, or R Delta (whitened)
+                for (int c = 0; c < D; ++c) dl[c] = (c < d) ? (float)(Xr[(size_t)ic * de + c] - sP[jj][c]) : 0.f;   // Delta formed in fp64
+                f2 z[H], y[H];
+                delta2<D, DIAG>(sS[jj], dl, z);                                        // z = Delta, or R Delta (whitened)
 #pragma unroll
-                for (int r = 0; r < D; ++r) z[r] = 0.f;
+                for (int t = 0; t < H; ++t) y[t] = sp(0.f);
 #pragma unroll
-                for (int c = 0; c < D; ++c) {                                          // Delta formed in fp64
-                    const float dl = (c < d) ? (float)(Xr[(size_t)ic * de + c] - sP[jj][c]) : 0.f;
-                    if (DIAG) {
+                for (int c = 0; c < D; ++c)                                            // y = W z
 #pragma unroll
-                        for (int r = 0; r <= c; ++r) z[r] = fmaf(sS[jj][LT(c, r)], dl, z[r]);
-                    } else {
-                        z[c] = dl;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < D; ++c) {                                          // y = W z
-#pragma unroll
-                    for (int r = c; r < D; ++r) y[r] = fmaf(L[LT(r, c)], z[c], y[r]);
-                }
+                    for (int t = c / 2; t < H; ++t) y[t] += L[P2(t, c)] * sp(z[c / 2][c & 1]);
 #pragma unroll
                 for (int a = 0; a < D; ++a) {                                          // u = W' y = M^-1 Delta
-                    float s = 0.f;
+                    f2 s2 = L[P2(a / 2, a)] * y[a / 2];
 #pragma unroll
-                    for (int q = a; q < D; ++q) s = fmaf(L[LT(q, a)], y[q], s);
-                    u[a] = s;
+                    for (int t = a / 2 + 1; t < H; ++t) s2 += L[P2(t, a)] * y[t];
+                    u[a] = s2.x + s2.y;
                 }
             }
             // Values in record order, pushed 32 at a time through the wave reduction and added to the fp64
@@ -333,10 +387,10 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
             for (int a = 0; a < D; ++a)
 #pragma unroll
                 for (int b = 0; b <= a; ++b) {
-                    float mi = 0.f;
+                    f2 m2 = L[P2(a / 2, a)] * L[P2(a / 2, b)];                         // Minv(a,b) = sum_q W[q][a] W[q][b]
 #pragma unroll
-                    for (int q = a; q < D; ++q) mi = fmaf(L[LT(q, a)], L[LT(q, b)], mi);   // Minv(a,b) = sum_q W[q][a] W[q][b]
-                    push(dp * (u[a] * u[b] - mi));                                     // GPz.m:174
+                    for (int t = a / 2 + 1; t < H; ++t) m2 += L[P2(t, a)] * L[P2(t, b)];
+                    push(dp * (u[a] * u[b] - (m2.x + m2.y)));                          // GPz.m:174
                 }
 #pragma unroll
             for (int e = NV; e < NG * 32; ++e) push(0.f);

@@ -1,10 +1,12 @@
 """Summarise the counter passes written by tools/pmc_run.sh into a text file under profiles/.
-usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/<name>.txt"""
+usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/<name>.txt ["bench arguments and workload, for the header"]"""
 import collections
 import csv
 import sys
 
 base, dst = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+what = sys.argv[3] if len(sys.argv) > 3 else ("--steps 2 --warmup 1 --no-cpu-baseline\n"
+                                              "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X")
 
 
 def load(path):
@@ -21,8 +23,7 @@ for f in ("sq", "sq2", "fetch", "write"):
             data.setdefault(k, {})[c] = sum(v) / len(v)
 keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_"))]
 with open(dst, "w") as out:
-    out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
-              "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X; one counter group per pass; tools/pmc_run.sh)\n"
+    out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py " + what + "; one counter group per pass; tools/pmc_run.sh)\n"
               "# per-launch averages.  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles;\n"
               "# SQ_VALU_MFMA_BUSY_CYCLES in cycles (= 64 x N_mfma for v_mfma_f64_16x16x4_f64); GRBM_GUI_ACTIVE is summed over\n"
               "# the 8 XCDs (divide by 8 for kernel cycles); FETCH_SIZE / WRITE_SIZE in KB at the L2 fabric side; FETCH_SIZE reads\n"
