@@ -128,11 +128,41 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
             nthreads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] + [1])
         except Exception:
             nthreads = usable
+        vec = None
+        if not cfg.get("psi"):
+            # mode (ii) of BASELINE.md section 5: the same mathematics written the vectorised way (one GEMM per row chunk
+            # for the whitened differences, two n m^2 products, Cholesky inverse) - oracle/gpz_vectorised.py
+            from oracle import gpz_vectorised as V
+            t0 = time.perf_counter()
+            fv, gv = V.GPz(theta, Omodel, Xs, ys, oms)
+            t_vec = time.perf_counter() - t0
+            Sv = S.copy()
+            t0 = time.perf_counter()
+            import scipy.linalg as sla
+            sla.cho_solve(sla.cho_factor(Sv, lower=True), np.eye(model.m))
+            t_chol = time.perf_counter() - t0
+            vec = dict(value=1.0 / ((t_vec - t_chol) * cfg["n"] / rows + t_chol), unit="evals/s",
+                       agrees_with_as_written=bool(abs(fv - ref.nlogML) <= 1e-9 * abs(ref.nlogML)
+                                                   and np.max(np.abs(gv - ref.grad)) <= 1e-6 * np.max(np.abs(ref.grad))),
+                       sample=f"oracle/gpz_vectorised.py on the same {rows} rows: {t_vec:.1f} s measured (of which "
+                              f"{t_chol:.2f} s is the m^3 Cholesky inverse), row-dependent part scaled x{cfg['n'] / rows:.1f}")
     scale = cfg["n"] / rows
     t_full = (t_all - t_svd) * scale + t_svd
-    return ref, dict(value=1.0 / t_full, unit="evals/s", cores=int(nthreads), kind="port",
-                     sample=f"oracle GPz() as-written on the first {rows} of {cfg['n']} rows: {t_all:.1f} s measured "
-                            f"(of which {t_svd:.2f} s is the m^3 SVD inverse), row-dependent part scaled x{scale:.1f}")
+    blas = "unknown"
+    try:
+        import threadpoolctl
+        for p_ in threadpoolctl.threadpool_info():
+            if p_.get("user_api") == "blas":
+                blas = f"{p_.get('internal_api')} {p_.get('version')} ({p_.get('threading_layer', '')}, {p_.get('architecture', '')})"
+    except Exception:
+        pass
+    out = dict(value=1.0 / t_full, unit="evals/s", cores=int(nthreads), kind="port", mode="as-written",
+               host_cpu_count=os.cpu_count(), usable_cores=usable, blas=blas,
+               sample=f"oracle GPz() as-written on the first {rows} of {cfg['n']} rows: {t_all:.1f} s measured "
+                      f"(of which {t_svd:.2f} s is the m^3 SVD inverse), row-dependent part scaled x{scale:.1f}")
+    if vec:
+        out["vectorised"] = vec
+    return ref, out
 
 
 def main():
@@ -143,6 +173,8 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="override the row count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--validation", type=float, default=0.0,
+                    help="fraction of the rows turned into validation rows (GPz.m:239-261 priced inside the step; SURVEY 8d: c2 with 0.15)")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +206,12 @@ def main():
     n = cfg["n"]
     stream = torch.cuda.current_stream().cuda_stream
     dtype = cfg.get("dtype", "f64")
+    tr_mask = va_mask = None
+    if args.validation > 0.0:
+        if use_dist:
+            raise SystemExit("--validation is a single-GPU measurement")
+        va_mask = np.random.default_rng(6).random(n) < args.validation
+        tr_mask = ~va_mask
     if use_dist:
         Xs, ys, oms, trs, _ = gdist.shard_rows(rank, world, X, y, omega)
         rows, _ = gdist.shard_index(rank, world, n)
@@ -182,7 +220,7 @@ def main():
                                  rank=rank, world=world, allreduce=gdist.make_allreduce(), dtype=dtype)
     else:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
-        ctx = gpz_amd.GPzContext(model, X, y, psi, omega, None, None, device=local_rank, stream=stream or None, dtype=dtype)
+        ctx = gpz_amd.GPzContext(model, X, y, psi, omega, tr_mask, va_mask, device=local_rank, stream=stream or None, dtype=dtype)
     del psi
     n_local = ctx.n_train
 
@@ -200,9 +238,11 @@ def main():
     ctx.reset_timings()
     barrier()
     t0 = time.perf_counter()
-    fs = []
+    fs, step_s = [], []
     for i in range(args.steps):
-        f, g = ctx.eval(thetas[args.warmup + i])
+        ts = time.perf_counter()
+        f, g = ctx.eval(thetas[args.warmup + i])     # synchronous: returns with f, g on the host
+        step_s.append(time.perf_counter() - ts)
         fs.append(f)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -230,17 +270,20 @@ def main():
         out = {
             "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "median_ms_per_step": float(np.median(step_s) * 1e3), "median_evals_per_s": float(1.0 / np.median(step_s)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations", "data": "synthetic",
             "config": {"workload": f"{args.config}: n={n} d={cfg['d']} m={m} method={cfg['method']} heteroscedastic k=1"
                                    + (" omega=(1+y-min y)^-2" if cfg["omega"] else "")
-                                   + (" Psi=diag cubes dtype=f32" if cfg.get("psi") else ""),
+                                   + (" Psi=diag cubes dtype=f32" if cfg.get("psi") else "")
+                                   + (f" validation={int(va_mask.sum())} rows (training {n_local})" if va_mask is not None else ""),
                        "rows_per_gpu": n_local, "sharding": f"rows/{world} + RCCL all-reduce of m x m and m x d partials"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)",
                          "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / F64_MFMA_PEAK_TFLOPS,
                          "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not args.n else None,
+                         "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
                          "avg_ms": tg_avg, "ubench_ceiling": F64_MFMA_UBENCH_TFLOPS,
                          "frac_of_ubench": ach / F64_MFMA_UBENCH_TFLOPS},
@@ -249,7 +292,7 @@ def main():
                         "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
             "finite": finite,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and va_mask is None:
             rows = max(2000, min(n, n // 8 if n >= 200000 else n))        # ~13 s of CPU work at c4 (16 BLAS threads), the whole problem at c2 / c3
             if cfg.get("psi"):
                 rows = 60                                                  # per-pair d x d loops in NumPy: ~1e5 pairs

@@ -335,3 +335,16 @@ def test_torch_autograd_gradient(method, hetero, psi, nanfrac, k):
     g = th.grad.numpy()
     assert abs(f.item() - r.nlogML) <= 1e-12 * abs(r.nlogML)
     assert np.max(np.abs(g - r.grad)) <= max(1e-11, 50 * r.cond * 2.2e-16) * np.max(np.abs(g))
+
+
+@pytest.mark.parametrize("method,hetero,weights", [("VC", True, True), ("VD", True, False), ("VC", False, False), ("VD", False, True)])
+def test_vectorised_baseline_matches_the_statement_level_oracle(method, hetero, weights):
+    """oracle/gpz_vectorised.py (the "vectorised CPU" mode bench.py times next to the as-written one) is the same function."""
+    from oracle import gpz_vectorised as V
+    from helpers import make_problem
+    model, theta, X, Y, _, rng = make_problem(700, 6, 30, 1, method, hetero, seed=5)
+    om = rng.random((700, 1)) + 0.5 if weights else None
+    ref = O.GPz(theta, model, X, Y, None, om)
+    f, g = V.GPz(theta, model, X, Y, om, chunk=256)
+    assert abs(f - ref.nlogML) <= 1e-11 * abs(ref.nlogML)
+    assert np.max(np.abs(g - ref.grad)) <= max(1e-10, 50 * ref.cond * 2.2e-16) * np.max(np.abs(ref.grad))
