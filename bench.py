@@ -206,6 +206,7 @@ def main():
     n = cfg["n"]
     stream = torch.cuda.current_stream().cuda_stream
     dtype = cfg.get("dtype", "f64")
+    comm = "none"
     tr_mask = va_mask = None
     if args.validation > 0.0:
         if use_dist:
@@ -216,8 +217,14 @@ def main():
         Xs, ys, oms, trs, _ = gdist.shard_rows(rank, world, X, y, omega)
         rows, _ = gdist.shard_index(rank, world, n)
         psi = synth_psi(cfg, rows) if cfg.get("psi") else None
+        # The two all-reduces of an evaluation: RCCL called INSIDE the library on its own communicator (gpz_ctx_init_rccl; no
+        # Python between the kernels) - GPZ_BENCH_COMM=torch selects the torch.distributed hook instead (any backend, e.g.
+        # gloo for two ranks sharing one GPU).
+        comm = os.environ.get("GPZ_BENCH_COMM", "rccl" if backend == "nccl" else "torch")
         ctx = gpz_amd.GPzContext(model, Xs, ys, psi, oms, trs, None, device=local_rank, stream=stream or None,
-                                 rank=rank, world=world, allreduce=gdist.make_allreduce(), dtype=dtype)
+                                 rank=rank, world=world, allreduce=gdist.make_allreduce() if comm == "torch" else None, dtype=dtype)
+        if comm != "torch":
+            gdist.init_rccl(ctx, rank, world, local_rank)
     else:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
         ctx = gpz_amd.GPzContext(model, X, y, psi, omega, tr_mask, va_mask, device=local_rank, stream=stream or None, dtype=dtype)
@@ -277,7 +284,9 @@ def main():
                                    + (" omega=(1+y-min y)^-2" if cfg["omega"] else "")
                                    + (" Psi=diag cubes dtype=f32" if cfg.get("psi") else "")
                                    + (f" validation={int(va_mask.sum())} rows (training {n_local})" if va_mask is not None else ""),
-                       "rows_per_gpu": n_local, "sharding": f"rows/{world} + RCCL all-reduce of m x m and m x d partials"
+                       "rows_per_gpu": n_local, "sharding": (f"rows/{world} + all-reduce of the m x m and m x (d^2+d) partials: "
+                                                              + ("RCCL inside the library (gpz_ctx_init_rccl)" if comm != "torch"
+                                                                 else f"torch.distributed hook ({backend})"))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)",
                          "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1069,7 +1069,6 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 if (nch < 1) nch = 1;   // a rank without training rows still writes its (zero) records
                 const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
                 nch = (c->tr.n + rpc - 1) / rpc;
-            if (nch < 1) nch = 1;
                 if (nch < 1) nch = 1;
                 if (c->psi_miss) {   // one launch over all NaN patterns, one record set per pattern
                     launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,

@@ -1,11 +1,13 @@
-// theta unpacking and the PHI build  (getPHI.m:24-40, 60-125), no-Psi / no-missing branch.
+// theta unpacking and the PHI build  (getPHI.m:24-40, 60-125), no-Psi / no-missing branch (+ diagonal Psi, + missing
+// dimensions for the diagonal kinds).
 //
-// Thread mapping: lanes run along ROWS (samples).  Each thread keeps R rows of X in registers and
-// walks over all basis functions; the per-basis parameters (centre p_j, length-scale matrix Gamma_j)
-// are wave-uniform, so they reach the VALU as scalar (SGPR) operands through the scalar cache.
-// Every 16 basis functions the wave transposes its R x 64 x 16 block through LDS and writes PHI
-// row-major (128 contiguous bytes per row).  The heteroscedastic noise model ln beta_i = b + PHI v
-// (getPHI.m:116-125) is a per-thread running sum, so PHI is touched once.
+// Thread mapping: lanes run along ROWS (samples).  Each thread keeps R rows of X in registers and walks over all basis
+// functions.  Diagonal kinds: the per-basis parameters (centre p_j, squared length scales) are wave-uniform and reach
+// the VALU as scalar (SGPR) operands.  Covariance kinds: [R_j | R_j p_j] of EIGHT basis functions (Gamma_j = Q_j R_j,
+// k_prep_cov) are staged in LDS per workgroup and read back as broadcast ds_reads through a VGPR base + immediates, each
+// read feeding the thread's R rows, software-pipelined row by row of R_j under sched_barrier.  Every 8 (cov) / 16 (diag)
+// basis functions the wave transposes its block through LDS and writes PHI row-major.  The heteroscedastic noise model
+// ln beta_i = b + PHI v (getPHI.m:116-125) is a per-thread running sum, so PHI is touched once.
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 

@@ -462,22 +462,32 @@ def getOmega(Y, method="balanced", binWidth=None):
     return np.ones((Y.size, 1))
 
 
-def sample(n, trainSplit, validSplit, testSplit, rng=None):
-    """sample.m: random boolean training / validation / testing masks."""
+def sample(n, trainSample, validSample, testSample, rng=None):
+    """[training,validation,testing] = sample(n,trainSample,validSample,testSample)   (sample.m).
+    trainSample < 1: the three arguments are FRACTIONS of n (validation and testing rounded up, training capped by what
+    is left, sample.m:3-7 - they are not renormalised); otherwise they are row COUNTS (demo_photoz.m:49).  The masks
+    are taken from one random permutation in the order validation, testing, training (sample.m:15-17)."""
     rng = rng or np.random.default_rng()
-    tot = trainSplit + validSplit + testSplit
-    perm = rng.permutation(n)
-    nt, nv = int(math.ceil(n * trainSplit / tot)), int(math.ceil(n * validSplit / tot))
+    if trainSample < 1:
+        validSample = int(math.ceil(n * validSample))
+        testSample = int(math.ceil(n * testSample))
+        trainSample = min(int(math.ceil(n * trainSample)), n - testSample - validSample)
+    trainSample, validSample, testSample = int(trainSample), int(validSample), int(testSample)
+    r = rng.permutation(n)
     tr = np.zeros(n, bool); va = np.zeros(n, bool); te = np.zeros(n, bool)
-    tr[perm[:nt]] = True; va[perm[nt:nt + nv]] = True; te[perm[nt + nv:]] = True
+    va[r[:validSample]] = True
+    te[r[validSample:validSample + testSample]] = True
+    tr[r[validSample + testSample:validSample + testSample + trainSample]] = True
     return tr, va, te
 
 
-def metrics(Y, mu, sigma, f):
-    """metrics.m: cumulative metric f(Y - mu-errors) over samples sorted by predictive variance."""
-    order = np.argsort(np.asarray(sigma).ravel())
-    Ys, ms = np.asarray(Y).ravel()[order], np.asarray(mu).ravel()[order]
-    return np.array([f(Ys[:q + 1], ms[:q + 1]) for q in range(Ys.size)])
+def metrics(y, mu, sigma, fun):
+    """scores = metrics(y,mu,sigma,fun)   (metrics.m): samples sorted by predictive variance, fun(y,mu,sigma) evaluated
+    element-wise on the sorted vectors, running mean cumsum(.)./(1:n)'."""
+    y, mu, sigma = (np.asarray(a, dtype=np.float64).ravel() for a in (y, mu, sigma))
+    order = np.argsort(sigma, kind="stable")
+    vals = np.asarray(fun(y[order], mu[order], sigma[order]), dtype=np.float64).ravel()
+    return np.cumsum(vals) / np.arange(1, y.size + 1)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -241,3 +241,20 @@ def test_device_resident_training_matches_host_training():
     mu_a = gpz_amd.predict(X, ma, selection=te)[0]; mu_b = gpz_amd.predict(X, mb, selection=te)[0]
     ra = math.sqrt(np.mean((mu_a[:, 0] - Y[te, 0]) ** 2)); rb = math.sqrt(np.mean((mu_b[:, 0] - Y[te, 0]) ** 2))
     assert rb < 0.2 and abs(ra - rb) < 0.02
+
+
+def test_sample_and_metrics_follow_the_reference_semantics():
+    """sample.m:3-17: fractions are NOT renormalised and counts are accepted (demo_photoz.m:49); metrics.m: fun(y,mu,sigma)
+    element-wise on the variance-sorted vectors, running mean."""
+    tr, va, te = host.sample(1000, 0.2, 0.2, 0.2, np.random.default_rng(0))
+    assert (tr.sum(), va.sum(), te.sum()) == (200, 200, 200) and not (tr & va).any() and not (tr & te).any() and not (va & te).any()
+    tr, va, te = host.sample(1000, 0.9, 0.2, 0.2, np.random.default_rng(0))          # training capped by what is left
+    assert (tr.sum(), va.sum(), te.sum()) == (600, 200, 200)
+    tr, va, te = host.sample(50000, 10000, 10000, 10000, np.random.default_rng(0))   # row counts
+    assert (tr.sum(), va.sum(), te.sum()) == (10000, 10000, 10000)
+    rng = np.random.default_rng(1)
+    y, mu, sg = rng.standard_normal(200), rng.standard_normal(200), rng.random(200)
+    sc = host.metrics(y, mu, sg, lambda y_, mu_, s_: (y_ - mu_) ** 2 / (1 + s_))    # a three-argument lambda like demo_photoz.m:86-88
+    o = np.argsort(sg, kind="stable")
+    want = np.cumsum((y[o] - mu[o]) ** 2 / (1 + sg[o])) / np.arange(1, 201)
+    assert sc.shape == (200,) and np.allclose(sc, want, rtol=1e-14, atol=0)
