@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
     __shared__ f2 sS[JB][D * D / 2];
     __shared__ double sP[JB][D];
     __shared__ double sL[JB];
+    __shared__ double sOut[JB][256];                   // the JB results of every row, written out as one 64-byte run per row
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n;
     const unsigned ic = (unsigned)(act ? i : 0);
@@ -253,7 +254,21 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
             }
             // getPHI.m:86:  -1/2 quad + 1/2 ln|Sigma_j| - 1/2 ln|M|;  whitened: the two log-determinants collapse to -1/2 ln|A|
             const double lp = DIAG ? (-0.5 * (double)quad - (double)hl) : (-0.5 * (double)quad + 0.5 * sL[jj] - (double)hl);
-            if (act) Phi[(size_t)i * ld + j] = exp(lp);
+            sOut[jj][threadIdx.x] = exp(lp);
+        }
+        if (act) {                                      // (own column of sOut: no barrier needed)
+            double *dst = Phi + (size_t)i * ld + j0;
+            if (j0 + JB <= jhi) {                       // ld is a multiple of 16, j0 of 8: 16-byte aligned
+#pragma unroll
+                for (int q = 0; q < JB / 2; ++q) {
+                    d2_t o;
+                    o.x = sOut[2 * q][threadIdx.x];
+                    o.y = sOut[2 * q + 1][threadIdx.x];
+                    reinterpret_cast<d2_t *>(dst)[q] = o;
+                }
+            } else {
+                for (int jj = 0; j0 + jj < jhi; ++jj) dst[jj] = sOut[jj][threadIdx.x];
+            }
         }
     }
 }
@@ -308,6 +323,7 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
     __shared__ f2 sS[JB][D * D / 2];
     __shared__ double sP[JB][D];
     __shared__ double acc[JB][NG * 32];
+    __shared__ double sPh[JB][64], sTt[JB][64];        // PHI / T of the wave's 64 rows x JB basis functions
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x, j0 = blockIdx.y * JB;
     stage_params<D, JB, DIAG>(lane, 64, j0, m, d, de, Sig, Rc, P, sS, sP);
@@ -325,11 +341,25 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
         }
         double ob = 0.0, cc = 0.0, db = 0.0;
         if (rowscal) { const double *rs = rowscal + (size_t)ic * 4; ob = rs[0]; cc = rs[1]; db = rs[2]; }
+        {   // this row's PHI / T entries of the JB basis functions: 64 contiguous bytes each, read ONCE as 16-byte loads and
+            // parked in LDS (one 8-byte load per basis function touched a different cache line per lane every time:
+            // 8.6 x the algorithmic bytes at the fabric).  ld is a multiple of 16 and j0 of 8: aligned, inside the row.
+            const d2_t *pr = reinterpret_cast<const d2_t *>(Phi + (size_t)ic * ld + j0);
+            const d2_t *tr = reinterpret_cast<const d2_t *>(T + (size_t)ic * ld + j0);
+            d2_t pv[JB / 2], tv[JB / 2];
+#pragma unroll
+            for (int q = 0; q < JB / 2; ++q) { pv[q] = pr[q]; tv[q] = tr[q]; }
+#pragma unroll
+            for (int q = 0; q < JB / 2; ++q) {
+                sPh[2 * q][lane] = pv[q].x; sPh[2 * q + 1][lane] = pv[q].y;
+                sTt[2 * q][lane] = tv[q].x; sTt[2 * q + 1][lane] = tv[q].y;
+            }
+        }
 #pragma unroll 1
         for (int jj = 0; jj < JB; ++jj) {
             const int j = j0 + jj;
             if (j >= m) break;
-            const double ph = Phi[(size_t)ic * ld + j], tt = T[(size_t)ic * ld + j];
+            const double ph = sPh[jj][lane], tt = sTt[jj][lane];   // same lane wrote it: no barrier needed
             double dpd, q1 = 0.0, q2 = 0.0;
             if (rowscal) {
                 dpd = (-ob * tt - cc * w[j] + db * (v ? v[j] : 0.0)) * ph;           // GPz.m:72,90,106,113
