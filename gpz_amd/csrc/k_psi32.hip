@@ -79,26 +79,35 @@ __device__ __forceinline__ void chol2(f2 (&M)[NP2_OF(D)], float (&rd)[D], float 
 template <int D>
 __device__ __forceinline__ void trinv2(f2 (&L)[NP2_OF(D)], const float (&rd)[D]) {
     constexpr int H = D / 2;
+    f2 rd2[H];                                               // (1/L_2t,2t, 1/L_2t+1,2t+1)
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+        rd2[t].x = rd[2 * t];
+        rd2[t].y = rd[2 * t + 1];
+    }
+    // The diagonal of L is not read again (rd holds its reciprocals): zero it, so that the packed update below leaves the
+    // finished row of an even column alone.
+#pragma unroll
+    for (int c = 0; c < D; ++c) L[P2(c / 2, c)][c & 1] = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        f2 x[H];
-        float wc[D];
+        // x = -(partial sums), started at -e_c: then w_q = -x_q / L_qq holds for q = c as well, and the slot above the
+        // diagonal of an odd column comes out as zero.  Every q is ONE packed multiply that writes a whole pair (for even
+        // q only its lower half is final and is used; the pair of odd q is the finished one) - no half-register inserts.
+        f2 x[H], wv[H];
 #pragma unroll
         for (int t = c / 2; t < H; ++t) x[t] = sp(0.f);
+        x[c / 2][c & 1] = -1.0f;
 #pragma unroll
         for (int q = c; q < D; ++q) {
-            const float wq = (q == c) ? rd[c] : -x[q / 2][q & 1] * rd[q];
-            wc[q] = wq;
+            const f2 wp = -x[q / 2] * rd2[q / 2];
+            if (q & 1) wv[q / 2] = wp;
+            const float wq = wp[q & 1];
 #pragma unroll
-            for (int t = (q + 1) / 2; t < H; ++t) x[t] += L[P2(t, q)] * sp(wq);             // rows > q (a finished row rides along)
+            for (int t = (q + 1) / 2; t < H; ++t) x[t] += L[P2(t, q)] * sp(wq);             // rows > q (and q itself, times the zeroed diagonal)
         }
 #pragma unroll
-        for (int t = c / 2; t < H; ++t) {
-            f2 o;
-            o.x = (2 * t >= c) ? wc[2 * t] : 0.f;                                           // the slot above the diagonal: zero
-            o.y = wc[2 * t + 1];
-            L[P2(t, c)] = o;
-        }
+        for (int t = c / 2; t < H; ++t) L[P2(t, c)] = wv[t];
     }
 }
 
