@@ -256,6 +256,9 @@ void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned
 // prediction with input noise (predictDiag.m:75-125 / predictCov.m:70-132) and the getPrior iteration (getPrior.m:7-20)
 void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,
                        const double *iSig, double *tab, int rec);
+int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
+                             const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                             long pairs_per_chunk, double *part);   // k_psi.hip: 2 <= d <= 10, else -1
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
                           const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part);

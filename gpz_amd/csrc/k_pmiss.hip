@@ -165,33 +165,49 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
 
 // sums[3][k][n_pad] += over the pairs of the chunk:  Z = exp(lnZ + lnNo_q(x)) * T2(row, qq)
 //   lnNo_q = -1/2 sum_o (x - cij)^2/(Cij [+ psi]) [- 1/2 sum_o ln(Cij + psi)]                                  :176-178 / :260-263
+// One WAVE per row, lanes along the pairs of the chunk (T2 is read coalesced, the 3k sums are reduced over the wave at
+// the end): a NaN-pattern group is often a few dozen rows, and with one THREAD per row the chunk's 512 pairs were a
+// serial chain of 512 exp / divide iterations per launch (1 ms per launch whatever the group's size).
 __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr, const double *__restrict__ Psir, int de,
                                                    int n, long n_pad, int ld, int d, int k, unsigned obs, int npq,
                                                    const double *__restrict__ T2, const double *__restrict__ rec, int nrec,
                                                    double *__restrict__ sums) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double x[20], ps[20];
-    for (int c = 0; c < d; ++c) {
-        x[c] = Xr[(size_t)i * de + c];
-        ps[c] = Psir ? Psir[(size_t)i * de + c] : 0.0;
+    __shared__ double sx[4][20], sps[4][20];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + wave;
+    const bool live = i < n;
+    if (live && lane < d) {
+        sx[wave][lane] = Xr[(size_t)i * de + lane];
+        sps[wave][lane] = Psir ? Psir[(size_t)i * de + lane] : 0.0;
     }
+    __syncthreads();
+    if (!live) return;
     double acc[24];
-    for (int e = 0; e < 3 * k; ++e) acc[e] = 0.0;
-    for (int qq = 0; qq < npq; ++qq) {
+#pragma unroll
+    for (int e = 0; e < 24; ++e) acc[e] = 0.0;
+    for (int qq = lane; qq < npq; qq += 64) {
         const double *r = rec + (size_t)qq * nrec;
         double qd = 0.0, ls = 0.0;
         for (int c = 0; c < d; ++c) {
             if (!((obs >> c) & 1u)) continue;
-            const double s = r[d + c] + ps[c];
-            const double dl = x[c] - r[c];
+            const double s = r[d + c] + sps[wave][c];
+            const double dl = sx[wave][c] - r[c];
             qd += dl * dl / s;
             if (Psir) ls += log(s);
         }
         const double Z = exp(r[2 * d] - 0.5 * qd - 0.5 * ls) * T2[(size_t)i * ld + qq];
-        for (int e = 0; e < 3 * k; ++e) acc[e] = fma(Z, r[2 * d + 1 + e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < 3 * k) acc[e] = fma(Z, r[2 * d + 1 + e], acc[e]);
     }
-    for (int e = 0; e < 3 * k; ++e) sums[(size_t)e * n_pad + i] += acc[e];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) {
+        if (e >= 3 * k) break;
+        double v = acc[e];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) sums[(size_t)e * n_pad + i] += v;
+    }
 }
 
 void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
@@ -219,6 +235,6 @@ void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int 
 }
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
                      unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums) {
-    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
+    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
                        npq, T2, rec, nrec, sums);
 }

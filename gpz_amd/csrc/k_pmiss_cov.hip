@@ -256,30 +256,40 @@ __global__ void k_pmc_pairs(PmcPat pt, int m, int de, int k, const double *__res
 
 // part[chunk][3k][ldx]: sums over the pairs of a chunk of  Z_q(row) * weights,
 //   Z = exp(lnZ) * sum_l N(X_hat(row,l) - cij ; Cij + Psi_hat_l(row)) Pio(row,l)     (:190-201 / :300-313)
-__global__ void k_pmc_accum(PmcPat pt, int row0, int nrows, int m, int ld, int k, long npairs, long pairs_per_chunk,
-                            const double *__restrict__ rec, int nrec, const double *__restrict__ tab, int ntab,
-                            const double *__restrict__ Pio, const double *__restrict__ Xhat,
-                            const double *__restrict__ Phat, long ldx, double *__restrict__ part) {
-    const int rr = blockIdx.x * blockDim.x + threadIdx.x;
-    const int chunk = blockIdx.y;
-    if (rr >= nrows) return;
+// One WAVE per (row, pair chunk), lanes along the m components l of the inner sum (reduced over the wave per pair): a
+// NaN-pattern group is often a handful of rows, and with one thread per row a launch kept ten lanes busy for seconds.
+__global__ __launch_bounds__(64) void k_pmc_accum(PmcPat pt, int row0, int nrows, int m, int ld, int k, long npairs,
+                                                  long pairs_per_chunk, const double *__restrict__ rec, int nrec,
+                                                  const double *__restrict__ tab, int ntab, const double *__restrict__ Pio,
+                                                  const double *__restrict__ Xhat, const double *__restrict__ Phat, long ldx,
+                                                  double *__restrict__ part) {
+    const int rr = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
     const int d = pt.d;
     double acc[24], S[GDM * GDM], dl[GDM];
-    for (int e = 0; e < 3 * k; ++e) acc[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 24; ++e) acc[e] = 0.0;
     const long q0 = (long)chunk * pairs_per_chunk, q1 = min(npairs, q0 + pairs_per_chunk);
     for (long q = q0; q < q1; ++q) {
         const double *t = tab + (size_t)q * ntab;
         double ec = 0.0;
-        for (int l = 0; l < m; ++l) {
+        for (int l = lane; l < m; l += 64) {
             pmc_add_phat(S, t, pt, Phat ? Phat + ((size_t)rr * m + l) * d * d : nullptr, rec + (size_t)l * nrec);
             const double *xh = Xhat + ((size_t)rr * m + l) * d;
             for (int a = 0; a < d; ++a) dl[a] = xh[a] - t[d * d + a];
             ec += exp(pmc_lognorm(S, dl, d)) * Pio[(size_t)rr * ld + l];
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ec += __shfl_xor(ec, off, 64);
         const double Z = exp(t[d * d + d]) * ec;
-        for (int e = 0; e < 3 * k; ++e) acc[e] = fma(Z, t[d * d + d + 1 + e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < 3 * k) acc[e] = fma(Z, t[d * d + d + 1 + e], acc[e]);
     }
-    for (int e = 0; e < 3 * k; ++e) part[((size_t)chunk * 3 * k + e) * ldx + row0 + rr] = acc[e];
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < 3 * k) part[((size_t)chunk * 3 * k + e) * ldx + row0 + rr] = acc[e];
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -318,7 +328,7 @@ void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, in
         launch_pm_pio(st, Ex, ld, nr, m, priors, Pio);
         hipLaunchKernelGGL(k_pmc_phi, dim3((m + 63) / 64, nr), dim3(64), 0, st, pt, nr, m, ld, de, P, Sig, (const double *)rec,
                            nrec, (const double *)Pio, (const double *)Xhat, (const double *)(Psi3 ? Phat : nullptr), Phi, row0);
-        hipLaunchKernelGGL(k_pmc_accum, dim3((nr + 63) / 64, nchunk), dim3(64), 0, st, pt, row0, nr, m, ld, k, npairs,
+        hipLaunchKernelGGL(k_pmc_accum, dim3(nr, nchunk), dim3(64), 0, st, pt, row0, nr, m, ld, k, npairs,
                            pairs_per_chunk, (const double *)rec, nrec, (const double *)tab, ntab, (const double *)Pio,
                            (const double *)Xhat, (const double *)(Psi3 ? Phat : nullptr), ldx, part);
     }

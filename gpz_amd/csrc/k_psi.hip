@@ -299,4 +299,86 @@ int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int l
     return 0;
 }
 
+// predictNoisy, covariance kinds (predictCov.m:70-132): one thread per sample, the pairs [p0, p1) of this chunk; partial sums
+// part[chunk][3][k][ldx] — the register-resident twin of k_predict_noisy's covariance branch (k_gen.hip): Psi_i and the pair
+// matrix Cij + Psi_i are packed triangles with compile-time indices, the pair record (uniform over the wave) is read through
+// the scalar cache.  tab record: [lnz | cij (d) | Cij (d x d)].
+template <int D>
+__global__ __launch_bounds__(64) void k_predict_noisy_cov(int n, long ldx, int m, int de, int k, const double *__restrict__ Xr,
+                                                           const double *__restrict__ Psi3, const double *__restrict__ tab,
+                                                           int rec, const double *__restrict__ w, const double *__restrict__ v,
+                                                           const double *__restrict__ iS, long pairs_per_chunk,
+                                                           double *__restrict__ part) {
+    constexpr int NP = D * (D + 1) / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < n;
+    const int ic = act ? i : n - 1;
+    const long npair = (long)m * (m + 1) / 2;
+    const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
+    double x[D], ps[NP];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = Xr[(size_t)ic * de + c];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) ps[LT(r, c)] = Psi3[(size_t)ic * D * D + r + D * c];
+    double ga[8], vl[8], nu[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);   // (a, b) of the first pair, then walk
+    while (a * (a + 1) / 2 > p0) --a;
+    while ((a + 1) * (a + 2) / 2 <= p0) ++a;
+    long b = p0 - a * (a + 1) / 2;
+#pragma unroll 1
+    for (long e = p0; e < p1; ++e) {
+        const double *t = tab + (size_t)e * rec;
+        double M[NP];
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) M[LT(r, c)] = t[1 + D + r * D + c] + ps[LT(r, c)];    // Cij + Psi        predictCov.m:109
+        double hl;
+        chol_packed<D>(M, &hl);
+        double q = 0.0, y[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double s = x[r] - t[1 + r];
+#pragma unroll
+            for (int c = 0; c < r; ++c) s = fma(-M[LT(r, c)], y[c], s);
+            y[r] = s / M[LT(r, r)];
+            q = fma(y[r], y[r], q);
+        }
+        const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] - 0.5 * q - hl);                    // :111, 2x in the loop (:113-119)
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < k) {
+                ga[o] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o]);
+                vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o]);
+                nu[o] = fma(z, iS[a + (size_t)m * b + (size_t)m * m * o], nu[o]);
+            }
+        if (++b > a) { ++a; b = 0; }
+    }
+    if (act) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < k) {
+                part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
+                part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
+                part[(((size_t)blockIdx.y * 3 + 2) * k + o) * ldx + i] = nu[o];
+            }
+    }
+}
+
+int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
+                             const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                             long pairs_per_chunk, double *part) {
+    if (n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;
+#define PN_CASE(DD)                                                                                                        \
+    hipLaunchKernelGGL((k_predict_noisy_cov<DD>), dim3((n + 63) / 64, nchunk), dim3(64), 0, st, n, ldx, m, de, k, Xr, Psi3, tab, \
+                       rec, w, v, iS, pairs_per_chunk, part)
+    PSI_CASES(PN_CASE)
+#undef PN_CASE
+    return 0;
+}
+
 bool psi_fast_path_available(int d) { return d >= 2 && d <= 10; }
