@@ -586,11 +586,14 @@ def init(X, Y, method, m, heteroscedastic=True, normalize=True, omega=None, trai
 
 
 def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=None, validation=None, Psi=None,
-          verbose=True, device=0, device_resident=False, dtype="f64"):
+          verbose=True, device=0, device_resident=False, dtype="f64", n_gpus=None, reducer="rccl"):
     """model = train(model,X,Y,...)   (train.m + callBack.m): L-BFGS on the negative log marginal likelihood with
     per-iteration statistics, best-on-validation tracking and early stopping after maxAttempts non-improving
     iterations.  device_resident=True keeps theta, the gradient, the search direction and the L-BFGS memory on the GPU
-    (gpz_eval_dev + gpz_lbfgs_*): per evaluation only f and the statistics cross PCIe."""
+    (gpz_eval_dev + gpz_lbfgs_*): per evaluation only f and the statistics cross PCIe.
+    n_gpus (0 = every GPU of the node): the closure is evaluated on several GPUs behind one synchronous call (GPzMulti /
+    gpz_mgpu_*: rows sharded, RCCL inside the library) - what the MEX gateway does for a MATLAB train.m; reducer
+    "loopback" puts the shards on one GPU (single-GPU machines)."""
     X = np.asarray(X, dtype=np.float64); Y = np.asarray(Y, dtype=np.float64)
     if Y.ndim == 1:
         Y = Y[:, None]
@@ -601,8 +604,14 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
     training_only = validation is None or not np.asarray(validation).any()
     state = {"best_theta": model.sets["best"]["theta"].copy(), "best_valid": model.sets["best"].get("LL", -np.inf),
              "attempts": 0, "tic": time.time()}
-    ctx = GPzContext(model, Xn, Yc, PsiN, omega, training, None if training_only else validation, device=device,
-                     dtype=dtype)
+    if n_gpus is not None:
+        if device_resident:
+            raise ValueError("device_resident optimiser vectors live on one GPU: use it without n_gpus")
+        ctx = api.GPzMulti(model, Xn, Yc, PsiN, omega, training, None if training_only else validation, n_gpus=n_gpus,
+                           reducer=reducer, dtype=dtype)
+    else:
+        ctx = GPzContext(model, Xn, Yc, PsiN, omega, training, None if training_only else validation, device=device,
+                         dtype=dtype)
 
     def fun(theta):
         if isinstance(theta, DevVec):

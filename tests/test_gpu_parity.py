@@ -992,6 +992,24 @@ def test_mgpu_loopback_matches_oracle_and_unsharded(method, psi, nanfrac, k, sha
     assert abs(f - f1) <= 1e-12 * abs(f1) and rel(g, g1) <= max(1e-10, tol / 50)
 
 
+def test_mgpu_loopback_f32_pair_path():
+    """dtype = f32 (the fp32 per-pair factorisations of config 5's path) through the native multi-GPU driver: the ranks agree
+    on the Psi form through the first exchange point (psi32_agree) and sum whitened records."""
+    n, d, m = 900, 8, 12
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, 1, "VC", True, seed=71, psi=True)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    Psi = np.zeros((d, d, n)); Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.2, (d, n))
+    ref = O.GPz(theta, model, X, Y, Psi)
+    mg = gpz_amd.GPzMulti(model, X, Y, Psi, n_gpus=3, reducer="loopback", dtype="f32")
+    f, g = mg.eval(theta)
+    mg.close()
+    one = gpz_amd.GPzContext(model, X, Y, Psi, dtype="f32")
+    f1, g1 = one.eval(theta)
+    one.close()
+    assert abs(f - ref.nlogML) <= F32_FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= F32_GTOL
+    assert abs(f - f1) <= 1e-6 * abs(f1) and rel(g, g1) <= 1e-5
+
+
 def test_mgpu_one_device_equals_plain_context_bitwise():
     model, theta, X, Y, _, rng = make_problem(4000, 5, 33, 1, "VC", True, seed=43)
     mg = gpz_amd.GPzMulti(model, X, Y, n_gpus=1)

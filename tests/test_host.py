@@ -258,3 +258,24 @@ def test_sample_and_metrics_follow_the_reference_semantics():
     o = np.argsort(sg, kind="stable")
     want = np.cumsum((y[o] - mu[o]) ** 2 / (1 + sg[o])) / np.arange(1, 201)
     assert sc.shape == (200,) and np.allclose(sc, want, rtol=1e-14, atol=0)
+
+
+@pytest.mark.gpu
+def test_train_over_three_loopback_shards_reproduces_the_single_context_run():
+    """train(..., n_gpus=3, reducer="loopback"): init -> L-BFGS -> re-solve with the closure evaluated by gpz_mgpu_* (rows
+    sharded by the library, partials reduced at the two exchange points).  The same run on one context must take the same
+    steps: identical evaluation count, objective and parameters to rounding of the regrouped sums."""
+    import gpz_amd
+    X, Y = _sinc_data(1500)
+    rng = np.random.default_rng(3)
+    tr, va, te = gpz_amd.sample(X.shape[0], 0.7, 0.15, 0.15, rng)
+    base = gpz_amd.init(X, Y, "VL", 12, training=tr, rng=np.random.default_rng(4))
+    import copy
+    m1 = gpz_amd.train(copy.deepcopy(base), X, Y, maxIter=25, training=tr, validation=va, verbose=False)
+    m3 = gpz_amd.train(copy.deepcopy(base), X, Y, maxIter=25, training=tr, validation=va, verbose=False, n_gpus=3,
+                       reducer="loopback")
+    assert m1.train_info["funEvals"] == m3.train_info["funEvals"]
+    assert abs(m1.train_info["f"] - m3.train_info["f"]) <= 1e-9 * abs(m1.train_info["f"])
+    for name in ("last", "best"):
+        assert rel(m3.sets[name]["theta"], m1.sets[name]["theta"]) <= 1e-7
+        assert rel(m3.sets[name]["w"], m1.sets[name]["w"]) <= 1e-6

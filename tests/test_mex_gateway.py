@@ -216,6 +216,29 @@ def test_gateway_eval_solve_phi_match_the_oracle(method, psi, nanfrac, k):
 
 
 @pytest.mark.gpu
+def test_gateway_optional_model_fields():
+    """model.n_gpus and model.dtype (optional fields of the model struct): n_gpus = 1 is honoured, more GPUs than the box has is
+    an error from the library reported through mexErrMsgIdAndTxt, dtype = 'f32' selects the fp32 pair kernels."""
+    import gpz_amd
+    n, d, m = 600, 6, 10
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, 1, "VC", True, seed=61, psi=True)
+    from test_gpu_parity import _well_conditioned_gamma
+    theta = _well_conditioned_gamma(model, theta, rng)
+    mex = Mex()
+    f64 = mex(1, "eval", theta, model_struct(model, n_gpus=1.0), X, Y, Psi, None, None, None)
+    assert mex(1, "gpus") == 1.0
+    f32 = mex(1, "eval", theta, model_struct(model, n_gpus=1.0, dtype="f32"), X, Y, Psi, None, None, None)
+    ref = O.GPz(theta, model, X, Y, Psi)
+    assert abs(f64[0, 0] - ref.nlogML) <= 1e-8 * abs(ref.nlogML)
+    assert abs(f32[0, 0] - ref.nlogML) <= 1e-4 * abs(ref.nlogML) and f32[0, 0] != f64[0, 0]
+    with pytest.raises(MexError) as e:
+        mex(1, "eval", theta, model_struct(model, n_gpus=float(gpz_amd.device_count() + 2)), X, Y, Psi, None, None, None)
+    assert e.value.ident == "gpz:create"
+    mex(0, "reset")
+    mex.lib.mexrt_unload()
+
+
+@pytest.mark.gpu
 def test_gateway_standalone_entries():
     rng = np.random.default_rng(2)
     A = rng.standard_normal((30, 30))
