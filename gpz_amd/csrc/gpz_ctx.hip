@@ -1037,8 +1037,9 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         else stage_b(c, o);
         {
             Stage s(c, "tgemm");
+            // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip)
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
-                         c->phiw, c->m, c->m + o);
+                         c->phiw, c->m, c->m + o, c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
         }
         if (fused) {
             {

@@ -69,7 +69,7 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol);
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands = false);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
 #ifndef GPZ_CH_NB

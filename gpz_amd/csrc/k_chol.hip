@@ -7,6 +7,7 @@
 // 2*sum(log(diag(L))).  The matrix is padded with an identity block to a multiple of 32 so every
 // panel is full.  A non-positive pivot is reported through *info (results are NaN then); the
 // rank-truncating branch of inv_logdet.m:7-12 is not reproduced ("deviations").
+#include <stdlib.h>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void k_gemv(const double *__restrict__ M, int 
 
 // Bext (mp x mp row-major) = [ inv(SIGMA) | w in column m+out | 0 ];  dgi = diag(inv(SIGMA)).
 __global__ void k_fill_bext(const double *__restrict__ Sinv, int ldsi, const double *__restrict__ w, int m, int mp,
-                            int out, double *__restrict__ Bext, double *__restrict__ dgi) {
+                            int out, double *__restrict__ Bext, double *__restrict__ dgi, int round32) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= mp) return;
     double v = 0.0;
@@ -238,9 +239,11 @@ __global__ void k_fill_bext(const double *__restrict__ Sinv, int ldsi, const dou
         if (j < m) v = Sinv[(size_t)i * ldsi + j];
         else if (j == m + out) v = w[i];
     }
-    Bext[(size_t)i * mp + j] = v;
+    // round32: experiment switch (tools/f32_operand_experiment.py) - the B operand of the T-GEMM as an fp32-operand MFMA would see it
+    Bext[(size_t)i * mp + j] = round32 ? (double)(float)v : v;
     if (i == j && i < m) dgi[i] = v;
 }
+static int bext_round32() { return getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0; }
 
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda) {
     hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda);
@@ -264,7 +267,7 @@ void launch_zero(hipStream_t st, double *p, size_t count) {
 
 void launch_fill_bext(hipStream_t st, const double *Sinv, int ldsi, const double *w, int m, int mp, int out,
                       double *Bext, double *dgi) {
-    hipLaunchKernelGGL(k_fill_bext, dim3((mp + 255) / 256, mp), dim3(256), 0, st, Sinv, ldsi, w, m, mp, out, Bext, dgi);
+    hipLaunchKernelGGL(k_fill_bext, dim3((mp + 255) / 256, mp), dim3(256), 0, st, Sinv, ldsi, w, m, mp, out, Bext, dgi, bext_round32());
 }
 
 void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const double *S, int lds, const double *alpha,
@@ -278,5 +281,5 @@ void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const dou
     // dwda = -inv(SIGMA) * (alpha .* w)          (GPz.m:71)
     hipLaunchKernelGGL(k_gemv, dim3(nwg), dim3(256), 0, st, Sinv, ldsi, m, (const double *)w, 1L, alpha, -1.0, dwda);
     hipLaunchKernelGGL(k_fill_bext, dim3((mp + 255) / 256, mp), dim3(256), 0, st, Sinv, ldsi, (const double *)w, m, mp,
-                       out, Bext, dgi);
+                       out, Bext, dgi, bext_round32());
 }

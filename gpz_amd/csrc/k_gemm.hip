@@ -15,6 +15,34 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
+// Operand type of a contraction.  double: v_mfma_f64_16x16x4_f64, accumulators in fp64.  float (dtype = f32 with the fp32
+// pair kernels active, BASELINE config 5): the operands are rounded to fp32 while they are staged into LDS (half the LDS
+// traffic) and multiplied on v_mfma_f32_16x16x4_f32 (same 16x16x4 fragment layout, twice the rate); the fp32 accumulators
+// are FLUSHED into fp64 accumulators every GPZ_F32_FLUSH K slices (16 * GPZ_F32_FLUSH products per element), so the
+// accumulation error stays at the level of the operand rounding (tools/f32_operand_experiment.py: rounding PHI and
+// [inv(SIGMA)|w] to fp32 moves f by 2.4e-10 and g by 3.6e-7 of max|g| on a 250 000-row shard of config 5).
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+#define GPZ_F32_FLUSH 8
+template <typename OT> struct MfmaOf;
+template <> struct MfmaOf<double> {
+    typedef d4_t acc_t;
+    typedef d2_t pair_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return MFMA_F64(a, b, c); }
+};
+template <> struct MfmaOf<float> {
+    typedef f4_t acc_t;
+    typedef f2_t pair_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+template <typename OT>
+__device__ __forceinline__ typename MfmaOf<OT>::pair_t to_pair(const d2_t v) {
+    typename MfmaOf<OT>::pair_t r;
+    r.x = (OT)v.x;
+    r.y = (OT)v.y;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // S = PHI' W PHI
 // ---------------------------------------------------------------------------------------------
@@ -269,10 +297,10 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, i
 // Optional fused epilogue (nupart != nullptr):
 //   nupart[(ct*WC + wc)*n_pad + row] = sum over this wave's columns (< m) of PHI[row][col]*T[row][col]   (GPz.m:69)
 //   phiw[row] = T[row][mcol]  (= (PHI w)_row, GPz.m:77)
-template <bool EDGE, int WC>
+template <bool EDGE, int WC, typename OT>
 __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int ld, const double *__restrict__ B,
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
-                                           double (*sA)[128][18], double (*sB)[16][LDS_LD128],
+                                           OT (*sA)[128][18], OT (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
                                            long n_pad, int ct) {
     constexpr int NT = 128 * WC;
@@ -281,11 +309,15 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
 
-    d4_t acc[4][NI];
+    // fp32 operands: K = m here (a few thousand products per element), where fp32 accumulation adds an error of the size of the
+    // operand rounding itself (both ~ eps32 * sqrt(K) * rms|term|): no fp64 master sums, the result is converted at the end.
+    typedef typename MfmaOf<OT>::acc_t acc_t;
+    typedef typename MfmaOf<OT>::pair_t pair_t;
+    acc_t acc[4][NI];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NI; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
 
     // A slice: 128 rows x 16 doubles, 8 consecutive lanes cover one 128-byte row segment.
     // Addressing is kept off the vector ALU (a VALU instruction takes issue cycles from the MFMA pipe of its SIMD:
@@ -318,9 +350,9 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         for (int q = 0; q < Q; ++q) {
             int idx = q * NT + tid;
             int arow = idx >> 3, ac = (idx & 7) * 2;
-            *reinterpret_cast<d2_t *>(&sA[buf][arow][ac]) = ra[q];
+            *reinterpret_cast<pair_t *>(&sA[buf][arow][ac]) = to_pair<OT>(ra[q]);
             int row = idx >> 6, c = (idx & 63) * 2;
-            *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
+            *reinterpret_cast<pair_t *>(&sB[buf][row][c]) = to_pair<OT>(rb[q]);
         }
     };
 
@@ -339,7 +371,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     __syncthreads();
     // Operand fragments are fetched from LDS one K step ahead of the MFMA burst that uses them, and the barrier of a
     // slice sits in front of its last burst, so the first fragment of the next slice is fetched under that burst.
-    auto rdfrag = [&](int cur, int kk, double (&a)[4], double (&b)[NI]) {
+    auto rdfrag = [&](int cur, int kk, OT (&a)[4], OT (&b)[NI]) {
         const int kc = kk * 4 + (lane >> 4);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
@@ -350,17 +382,17 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     // ready over the waves that are staging (global loads, LDS writes, address VALU), which otherwise take issue
     // slots in front of it.  k_tgemm 33.15 -> 31.95 ms at c4; raising it over the LDS operand reads as well gives
     // nothing, priority 3 the same as 1.  Fragment prefetch on top: 32.1 -> 31.6 ms.
-    auto burst = [&](const double (&a)[4], const double (&b)[NI]) {
+    auto burst = [&](const OT (&a)[4], const OT (&b)[NI]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
             if (!EDGE || ni < nvalid) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MfmaOf<OT>::run(a[mi], b[ni], acc[mi][ni]);
             }
         __builtin_amdgcn_s_setprio(0);
     };
-    double fa0[4], fb0[NI], fa1[4], fb1[NI];
+    OT fa0[4], fb0[NI], fa1[4], fb1[NI];
     rdfrag(0, 0, fa0, fb0);
     auto stage = [&](auto curc, int s) {
         constexpr int cur = decltype(curc)::value;
@@ -392,6 +424,9 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         stage(std::integral_constant<int, 1>{}, s + 1);
     }
     if (s < nstage) stage(std::integral_constant<int, 0>{}, s);
+    auto res = [&](int mi, int ni, int r) -> double { return (double)acc[mi][ni][r]; };
+    // row of accumulator register r inside a 16x16 tile: the f64 instruction deals rows (lane >> 4) + 4r, the f32 one 4(lane >> 4) + r
+    auto crow = [&](int r) -> int { return std::is_same<OT, float>::value ? 4 * (lane >> 4) + r : (lane >> 4) + 4 * r; };
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -401,8 +436,8 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
             if (!EDGE || col < mp) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
-                    T[(size_t)row * ldt + col] = acc[mi][ni][r];
+                    const int row = i0 + wr * 64 + mi * 16 + crow(r);
+                    T[(size_t)row * ldt + col] = res(mi, ni, r);
                 }
             }
         }
@@ -412,13 +447,13 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
+                const int row = i0 + wr * 64 + mi * 16 + crow(r);
                 double p = 0.0;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
-                    if (col < m) p = fma(Phi[(size_t)row * ld + col], acc[mi][ni][r], p);
-                    if (col == mcol) phiw[row] = acc[mi][ni][r];
+                    if (col < m) p = fma(Phi[(size_t)row * ld + col], res(mi, ni, r), p);
+                    if (col == mcol) phiw[row] = res(mi, ni, r);
                 }
                 // sum over the 16 lanes that share this row (lane & 15 runs over columns)
                 p += __shfl_xor(p, 1, 64);
@@ -430,14 +465,14 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     }
 }
 
-template <int WC>
+template <int WC, typename OT>
 __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict__ Phi, int ld,
                                                         const double *__restrict__ B, int ldb,
                                                         double *__restrict__ T, int ldt, int mp, int nct,
                                                         double *__restrict__ nupart, double *__restrict__ phiw, int m,
                                                         int mcol, long n_pad) {
-    __shared__ double sA[2][128][18];
-    __shared__ double sB[2][16][LDS_LD128];
+    __shared__ OT sA[2][128][18];
+    __shared__ OT sB[2][16][LDS_LD128];
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
     // logical tiles, so the 8 column tiles of a row panel run back to back on one XCD and the 1 MB PHI panel is
     // fetched from HBM once instead of once per XCD.  Bijective for any grid size; affects speed only.
@@ -446,9 +481,9 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
-        tgemm_body<false, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
     else
-        tgemm_body<true, WC>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -573,12 +608,16 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 }
 
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol) {
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands) {
     constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
     dim3 grid((n_pad / 128) * nct), block(128 * WC);
-    hipLaunchKernelGGL(k_tgemm<WC>, grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
-                       (long)n_pad);
+    if (f32_operands)
+        hipLaunchKernelGGL((k_tgemm<WC, float>), grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
+                           (long)n_pad);
+    else
+        hipLaunchKernelGGL((k_tgemm<WC, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
+                           (long)n_pad);
 }
 
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs) {

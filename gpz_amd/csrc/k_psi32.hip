@@ -26,6 +26,7 @@
 // PsiT: packed lower triangle of Psi_i, element-major (PsiT[e * ldp + i]) so the lanes of a wave read consecutive
 // floats; DIAG: Psi_i is diagonal for every row (what fixPsi.m builds from per-dimension variances) and PsiT holds
 // only the D diagonals.
+#include <stdlib.h>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
                                                     const float *__restrict__ PsiT, long ldp, int n, int m,
                                                     const double *__restrict__ P, const double *__restrict__ Sig,
                                                     const double *__restrict__ Rc, const double *__restrict__ lnS,
-                                                    double *__restrict__ Phi, int ld, int jgroup) {
+                                                    double *__restrict__ Phi, int ld, int jgroup, int round32) {
     constexpr int H = D / 2;
     constexpr int JB = 8;
     __shared__ f2 sS[JB][D * D / 2];
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(256) void k_psi32_phi(const double *__restrict__ Xr
             }
             // getPHI.m:86:  -1/2 quad + 1/2 ln|Sigma_j| - 1/2 ln|M|;  whitened: the two log-determinants collapse to -1/2 ln|A|
             const double lp = DIAG ? (-0.5 * (double)quad - (double)hl) : (-0.5 * (double)quad + 0.5 * sL[jj] - (double)hl);
-            sOut[jj][threadIdx.x] = exp(lp);
+            // round32: experiment switch (tools/f32_operand_experiment.py) - PHI rounded to fp32 as an fp32-operand MFMA would see it
+            sOut[jj][threadIdx.x] = round32 ? (double)(float)exp(lp) : exp(lp);
         }
         if (act) {                                      // (own column of sOut: no barrier needed)
             double *dst = Phi + (size_t)i * ld + j0;
@@ -567,14 +569,15 @@ int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const floa
     const int jgroup = (((m + ng - 1) / ng) + 7) / 8 * 8;
     ng = (m + jgroup - 1) / jgroup;
     const dim3 grid(nrb, ng);
+    const int round32 = getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0;   // tools/f32_operand_experiment.py
 #define PHI_CASE(DD)                                                                                                     \
     do {                                                                                                                 \
         if (diag)                                                                                                        \
             hipLaunchKernelGGL((k_psi32_phi<DD, true>), grid, dim3(256), 0, st, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, lnS, Phi, \
-                               ld, jgroup);                                                                              \
+                               ld, jgroup, round32);                                                                              \
         else                                                                                                             \
             hipLaunchKernelGGL((k_psi32_phi<DD, false>), grid, dim3(256), 0, st, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, lnS, Phi, \
-                               ld, jgroup);                                                                              \
+                               ld, jgroup, round32);                                                                              \
     } while (0)
     PSI32_CASES(PHI_CASE)
 #undef PHI_CASE
