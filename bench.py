@@ -279,7 +279,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "median_ms_per_step": float(np.median(step_s) * 1e3), "median_evals_per_s": float(1.0 / np.median(step_s)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations", "data": "synthetic",
+            "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations + f32-operand MFMA contractions (fp64 master sums)",
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: n={n} d={cfg['d']} m={m} method={cfg['method']} heteroscedastic k=1"
                                    + (" omega=(1+y-min y)^-2" if cfg["omega"] else "")
                                    + (" Psi=diag cubes dtype=f32" if cfg.get("psi") else "")
@@ -301,6 +302,20 @@ def main():
                         "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
             "finite": finite,
         }
+        if cfg.get("psi"):
+            # config 5: the dominant kernels are the fp32 per-pair factorisations (VALU), not the GEMMs.  Algorithmic work per
+            # (sample, basis) pair at D = 20, whitened form: PHI 3480 FMA, moments 6370 FMA, 2 flops each.
+            mo_ms, mo_calls = tim.get("moments", (0.0, 0))
+            mo_avg = mo_ms / max(1, mo_calls)
+            pairs = float(n_local) * m
+            ach_mo = pairs * 6370 * 2 / (mo_avg * 1e-3) / 1e12 if mo_avg > 0 else 0.0
+            ach_ph = pairs * 3480 * 2 / (ph_avg * 1e-3) / 1e12 if ph_avg > 0 else 0.0
+            out["roofline_f32_pair_kernels"] = {
+                "bound": "fp32 VALU (157.3 TFLOP/s spec = the fp32 MFMA rate; one wave per SIMD issues ~1 instruction per 6 cycles, "
+                         "tools/fp32_valu_bench.hip)",
+                "peak": 157.3, "unit": "TFLOP/s",
+                "k_psi32_moments": {"achieved": ach_mo, "frac": ach_mo / 157.3, "avg_ms": mo_avg, "flops_per_pair": 12740},
+                "k_psi32_phi (+ fill, row dots)": {"achieved": ach_ph, "frac": ach_ph / 157.3, "avg_ms": ph_avg, "flops_per_pair": 6960}}
         if world == 1 and not args.no_cpu_baseline and va_mask is None:
             rows = max(2000, min(n, n // 8 if n >= 200000 else n))        # ~13 s of CPU work at c4 (16 BLAS threads), the whole problem at c2 / c3
             if cfg.get("psi"):

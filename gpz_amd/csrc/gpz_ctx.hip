@@ -954,7 +954,8 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         {
             Stage s(c, "syrk");
             launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
-                        c->rows_per_split, c->nsplit_d, c->rows_per_split_d, c->slab, false);
+                        c->rows_per_split, c->nsplit_d, c->rows_per_split_d, c->slab, false,
+                        c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));   // config 5: fp32-operand MFMAs, fp64 master sums
         }
         {
             Stage s(c, "syrk_reduce");

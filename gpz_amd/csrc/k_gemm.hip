@@ -50,11 +50,11 @@ __device__ __forceinline__ typename MfmaOf<OT>::pair_t to_pair(const d2_t v) {
 // TRI: rows < tj*128 contribute nothing (PHI is lower triangular: used for inv(L)' * inv(L)).
 // WC = wave columns of the 2 x WC wave grid: WC = 2 -> 4 waves of 64x64 each, WC = 4 -> 8 waves of 64x32 each
 // (64 accumulator registers per wave, 4 waves per SIMD with two workgroups per CU).
-template <bool WEIGHTED, int WC, bool DIAGT>
+template <bool WEIGHTED, int WC, bool DIAGT, typename OT>
 __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld, const double *__restrict__ wgt,
                                           int mp, int i0, int j0, int r_begin, int r_end,
-                                          double *__restrict__ out, double (*sA)[16][LDS_LD128],
-                                          double (*sB)[16][LDS_LD128], double (*sW)[16]) {
+                                          double *__restrict__ out, OT (*sA)[16][LDS_LD128],
+                                          OT (*sB)[16][LDS_LD128], OT (*sW)[16]) {
     constexpr int NT = 128 * WC;          // threads
     constexpr int NI = 8 / WC;            // 16-column MFMA tiles per wave
     constexpr int Q = 1024 / NT;          // double2 per thread per operand slice (16 x 128 doubles)
@@ -66,11 +66,34 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
 
-    d4_t acc[4][NI];
+    // fp32 operands: K = rows here (thousands of POSITIVE products per element), where an fp32 running sum loses
+    // eps32 * sqrt(K/3) - far more than the operand rounding, which averages out.  The fp32 accumulators are therefore
+    // flushed into fp64 master sums every GPZ_F32_FLUSH slices (128 rows); the master costs 64 more registers, so this
+    // variant runs two waves per SIMD instead of four.
+    constexpr bool F32 = std::is_same<OT, float>::value;
+    typedef typename MfmaOf<OT>::acc_t acc_t;
+    typedef typename MfmaOf<OT>::pair_t pair_t;
+    acc_t acc[4][NI];
+    d4_t acc64[F32 ? 4 : 1][F32 ? NI : 1];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NI; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NI; ++b) {
+            acc[a][b] = (acc_t){0, 0, 0, 0};
+            if (F32) acc64[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        }
+    auto flush = [&]() {
+        if constexpr (F32) {
+#pragma unroll
+            for (int a = 0; a < (DIAGT ? 3 : 4); ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc64[a][b][r] += (double)acc[a][b][r];
+                    acc[a][b] = (acc_t){0, 0, 0, 0};
+                }
+        }
+    };
 
     // staging map: a wave reads one full 1 KiB tile row per q
     d2_t ra[Q], rb[Q];
@@ -106,10 +129,10 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
             int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
             if (PRESCALE) { ra[q].x *= rwq[q]; ra[q].y *= rwq[q]; }
-            *reinterpret_cast<d2_t *>(&sA[buf][row][c]) = ra[q];
-            if (!diag_tile) *reinterpret_cast<d2_t *>(&sB[buf][row][c]) = rb[q];
+            *reinterpret_cast<pair_t *>(&sA[buf][row][c]) = to_pair<OT>(ra[q]);
+            if (!diag_tile) *reinterpret_cast<pair_t *>(&sB[buf][row][c]) = to_pair<OT>(rb[q]);
         }
-        if (WEIGHTED && !PRESCALE && tid < 16) sW[buf][tid] = rw;
+        if (WEIGHTED && !PRESCALE && tid < 16) sW[buf][tid] = (OT)rw;
     };
 
     // Software pipeline: the global loads of slice s+2 are issued in the middle of slice s, right after slice s+1
@@ -129,8 +152,8 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     static_assert(!DIAGT || NI == 2, "diagonal-tile wave roles are written for the 2 x 4 wave grid");
     constexpr int NA = DIAGT ? 3 : 4, NB = DIAGT ? 4 : NI;   // fragment registers (diagonal: 2 A + weight, 4 B)
     const int dr = DIAGT ? wave >> 1 : 0, dh = DIAGT ? wave & 1 : 0;
-    auto rdfrag = [&](int cur, int kk, double (&a)[NA], double (&b)[NB]) {
-        const double(*tA)[LDS_LD128] = sA[cur];
+    auto rdfrag = [&](int cur, int kk, OT (&a)[NA], OT (&b)[NB]) {
+        const OT(*tA)[LDS_LD128] = sA[cur];
         const int krow = kk * 4 + (lane >> 4);
         if (DIAGT) {
             if (WEIGHTED) a[2] = sW[cur][krow];   // applied in burst(): a multiply here would wait for the LDS data at once
@@ -139,32 +162,32 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
 #pragma unroll
             for (int q = 0; q < 4; ++q) b[q] = tA[krow][(q >> 1) * 64 + dh * 32 + (q & 1) * 16 + (lane & 15)];
         } else {
-            const double(*tB)[LDS_LD128] = sB[cur];
+            const OT(*tB)[LDS_LD128] = sB[cur];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) a[mi] = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni] = tB[krow][wc * (16 * NI) + ni * 16 + (lane & 15)];
         }
     };
-    auto burst = [&](const double (&a)[NA], const double (&b)[NB]) {
+    auto burst = [&](const OT (&a)[NA], const OT (&b)[NB]) {
         __builtin_amdgcn_s_setprio(1);   // see tgemm_body
         if (DIAGT) {
-            const double a0 = WEIGHTED ? a[0] * a[2] : a[0], a1 = WEIGHTED ? a[1] * a[2] : a[1];
+            const OT a0 = WEIGHTED ? a[0] * a[2] : a[0], a1 = WEIGHTED ? a[1] * a[2] : a[1];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[0][ni] = MFMA_F64(a0, b[ni], acc[0][ni]);        // block (0,0)
+            for (int ni = 0; ni < 2; ++ni) acc[0][ni] = MfmaOf<OT>::run(a0, b[ni], acc[0][ni]);        // block (0,0)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[1][ni] = MFMA_F64(a0, b[2 + ni], acc[1][ni]);    // block (0,1)
+            for (int ni = 0; ni < 2; ++ni) acc[1][ni] = MfmaOf<OT>::run(a0, b[2 + ni], acc[1][ni]);    // block (0,1)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[2][ni] = MFMA_F64(a1, b[2 + ni], acc[2][ni]);    // block (1,1)
+            for (int ni = 0; ni < 2; ++ni) acc[2][ni] = MfmaOf<OT>::run(a1, b[2 + ni], acc[2][ni]);    // block (1,1)
         } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MfmaOf<OT>::run(a[mi], b[ni], acc[mi][ni]);
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    double fa0[NA] = {}, fb0[NB] = {}, fa1[NA] = {}, fb1[NB] = {};
+    OT fa0[NA] = {}, fb0[NB] = {}, fa1[NA] = {}, fb1[NB] = {};
     if (nstage > 0) rdfrag(0, 0, fa0, fb0);
     auto stage = [&](auto curc, int s) {
         constexpr int cur = decltype(curc)::value;
@@ -194,8 +217,16 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     for (; s + 1 < nstage; s += 2) {
         stage(std::integral_constant<int, 0>{}, s);
         stage(std::integral_constant<int, 1>{}, s + 1);
+        if (F32 && ((s + 2) % GPZ_F32_FLUSH) == 0) flush();
     }
     if (s < nstage) stage(std::integral_constant<int, 0>{}, s);
+    flush();
+    auto res = [&](int mi, int ni, int r) -> double {
+        if constexpr (F32) return acc64[mi][ni][r];
+        else return acc[mi][ni][r];
+    };
+    // row of accumulator register r inside a 16x16 tile: the f64 instruction deals rows (lane >> 4) + 4r, the f32 one 4(lane >> 4) + r
+    auto crow = [&](int r) -> int { return F32 ? 4 * (lane >> 4) + r : (lane >> 4) + 4 * r; };
 
 #pragma unroll
     for (int mi = 0; mi < (DIAGT ? 3 : 4); ++mi)
@@ -205,22 +236,19 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
                                   : j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = DIAGT ? i0 + (mi == 2 ? 64 : 0) + dr * 16 + (lane >> 4) + 4 * r
-                                      : i0 + wr * 64 + mi * 16 + (lane >> 4) + 4 * r;
-                if (row < mp && col < mp) out[(size_t)row * mp + col] = acc[mi][ni][r];
+                const int row = DIAGT ? i0 + (mi == 2 ? 64 : 0) + dr * 16 + crow(r) : i0 + wr * 64 + mi * 16 + crow(r);
+                if (row < mp && col < mp) out[(size_t)row * mp + col] = res(mi, ni, r);
             }
         }
 }
 
-template <bool WEIGHTED, bool TRI, int WC>
-__global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict__ Phi, int ld,
-                                                       const double *__restrict__ wgt, int n_rows, int mp,
-                                                       int ntile, int nsplit, int rows_per_split,
-                                                       int nsplit_d, int rows_per_split_d,
-                                                       double *__restrict__ slab) {
-    __shared__ double sA[2][16][LDS_LD128];
-    __shared__ double sB[2][16][LDS_LD128];
-    __shared__ double sW[2][16];
+template <bool WEIGHTED, bool TRI, int WC, typename OT>
+__global__ __launch_bounds__(128 * WC, (std::is_same<OT, float>::value ? 2 : WC)) void k_syrk(
+    const double *__restrict__ Phi, int ld, const double *__restrict__ wgt, int n_rows, int mp, int ntile, int nsplit,
+    int rows_per_split, int nsplit_d, int rows_per_split_d, double *__restrict__ slab) {
+    __shared__ OT sA[2][16][LDS_LD128];
+    __shared__ OT sB[2][16][LDS_LD128];
+    __shared__ OT sW[2][16];
 
     const int npairs = ntile * (ntile + 1) / 2;
     // XCD-aware remap (see k_tgemm): the tiles of one row split run on one XCD and walk the same 16-row slices of
@@ -260,9 +288,9 @@ __global__ __launch_bounds__(128 * WC, WC) void k_syrk(const double *__restrict_
     if (TRI) r_begin = max(r_begin, j0 & ~15);
     double *out = slab + (size_t)split * mp * mp;
     if (diag_tile)
-        syrk_body<WEIGHTED, WC, true>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+        syrk_body<WEIGHTED, WC, true, OT>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
     else
-        syrk_body<WEIGHTED, WC, false>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
+        syrk_body<WEIGHTED, WC, false, OT>(Phi, ld, wgt, mp, i0, j0, r_begin, r_end, out, sA, sB, sW);
 }
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
@@ -586,19 +614,23 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
 int gpz_gemm_wave_cols() { return GPZ_GEMM_WC; }
 
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
-                 int nsplit, int rows_per_split, int nsplit_d, int rows_per_split_d, double *slab, bool tri) {
+                 int nsplit, int rows_per_split, int nsplit_d, int rows_per_split_d, double *slab, bool tri,
+                 bool f32_operands) {
     constexpr int WC = GPZ_GEMM_WC;
     const int ntile = (mp + 127) / 128;
     const int noff = ntile * (ntile - 1) / 2;
     dim3 grid(noff * nsplit + ntile * nsplit_d), block(128 * WC);
     if (tri)
-        hipLaunchKernelGGL((k_syrk<false, true, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+        hipLaunchKernelGGL((k_syrk<false, true, WC, double>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+                           rows_per_split, nsplit_d, rows_per_split_d, slab);
+    else if (wgt && f32_operands)
+        hipLaunchKernelGGL((k_syrk<true, false, WC, float>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
                            rows_per_split, nsplit_d, rows_per_split_d, slab);
     else if (wgt)
-        hipLaunchKernelGGL((k_syrk<true, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+        hipLaunchKernelGGL((k_syrk<true, false, WC, double>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
                            rows_per_split, nsplit_d, rows_per_split_d, slab);
     else
-        hipLaunchKernelGGL((k_syrk<false, false, WC>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
+        hipLaunchKernelGGL((k_syrk<false, false, WC, double>), grid, block, 0, st, Phi, ld, wgt, n_rows, mp, ntile, nsplit,
                            rows_per_split, nsplit_d, rows_per_split_d, slab);
 }
 
