@@ -224,7 +224,18 @@ def main():
         ctx = gpz_amd.GPzContext(model, Xs, ys, psi, oms, trs, None, device=local_rank, stream=stream or None,
                                  rank=rank, world=world, allreduce=gdist.make_allreduce() if comm == "torch" else None, dtype=dtype)
         if comm != "torch":
-            gdist.init_rccl(ctx, rank, world, local_rank)
+            try:
+                gdist.init_rccl(ctx, rank, world, local_rank)
+                ok = 1
+            except Exception as e:   # every rank must take the same route: agree on it
+                print(f"rank {rank}: RCCL inside the library unavailable ({e!r}); falling back to the torch.distributed hook",
+                      file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm = "torch"
+                ctx.set_allreduce(gdist.make_allreduce())
     else:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
         ctx = gpz_amd.GPzContext(model, X, y, psi, omega, tr_mask, va_mask, device=local_rank, stream=stream or None, dtype=dtype)

@@ -138,6 +138,11 @@ class GPzContext:
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             _lib.check(lib.gpz_ctx_set_allreduce(h, self._cb, None))
 
+    def set_allreduce(self, allreduce):
+        """Install (or replace) the caller-supplied all-reduce hook of a sharded context (gpz_ctx_set_allreduce)."""
+        self._cb = _lib.ALLREDUCE_FN(allreduce)
+        _lib.check(self._lib.gpz_ctx_set_allreduce(self._h, self._cb, None))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.gpz_ctx_destroy(self._h)

@@ -93,11 +93,18 @@ def init_rccl(ctx, rank, world, device, group=None):
     from . import _lib
     lib = _lib.load()
     idbuf = C.create_string_buffer(128)
+    box = [None]
     if rank == 0:
-        _lib.check(lib.gpz_rccl_unique_id(idbuf))
-    box = [idbuf.raw if rank == 0 else None]
+        # a failure on rank 0 (no RCCL to bind) must reach every rank through the broadcast, or they wait in it for ever
+        try:
+            _lib.check(lib.gpz_rccl_unique_id(idbuf))
+            box = [idbuf.raw]
+        except Exception as e:
+            box = [repr(e)]
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
+    if not isinstance(box[0], bytes):
+        raise RuntimeError(f"gpz_rccl_unique_id failed on rank 0: {box[0]}")
     idbuf = C.create_string_buffer(box[0], 128)
     _lib.check(lib.gpz_ctx_init_rccl(ctx._h, idbuf, int(rank), int(world), int(device)))
     ctx._cb = None            # the Python hook (if any) is no longer referenced by the library
