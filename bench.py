@@ -34,6 +34,7 @@ CONFIGS = {
     "c5": dict(n=2_000_000, d=20, m=2000, method="VC", omega=None, psi=True, dtype="f32"),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (datasheet f64 matrix = f64 vector rate)
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 F64_MFMA_UBENCH_TFLOPS = 77.7  # tools/mfma_f64_bench.hip on this pool's MI355X: back-to-back v_mfma_f64_16x16x4_f64, >=3 waves/SIMD
 
 
@@ -300,9 +301,10 @@ def main():
                                                               + ("RCCL inside the library (gpz_ctx_init_rccl)" if comm != "torch"
                                                                  else f"torch.distributed hook ({backend})"))
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)",
-                         "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F64_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)"
+                                                    + (" on fp32-operand MFMAs" if cfg.get("psi") else ""),
+                         "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS if cfg.get("psi") else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / (F32_MFMA_PEAK_TFLOPS if cfg.get("psi") else F64_MFMA_PEAK_TFLOPS),
                          "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not args.n else None,
                          "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
