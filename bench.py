@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="override the row count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--native-mgpu", type=int, default=0, metavar="K",
+                    help="single process, K shards behind gpz_mgpu_* (one host thread per shard, reduction inside the library): RCCL over "
+                         "K GPUs when the node has them, else all K shards on GPU 0 with the loopback reducer (measures the driver's "
+                         "threading, not scaling)")
     ap.add_argument("--validation", type=float, default=0.0,
                     help="fraction of the rows turned into validation rows (GPz.m:239-261 priced inside the step; SURVEY 8d: c2 with 0.15)")
     args = ap.parse_args()
@@ -237,11 +241,17 @@ def main():
             if int(flag.item()) == 0:
                 comm = "torch"
                 ctx.set_allreduce(gdist.make_allreduce())
+    elif args.native_mgpu > 0:
+        psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
+        K = args.native_mgpu
+        reducer = "rccl" if gpz_amd.device_count() >= K else "loopback"
+        ctx = gpz_amd.GPzMulti(model, X, y, psi, omega, tr_mask, va_mask, n_gpus=K, reducer=reducer, dtype=dtype)
+        comm = f"gpz_mgpu x{K} ({reducer})"
     else:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
         ctx = gpz_amd.GPzContext(model, X, y, psi, omega, tr_mask, va_mask, device=local_rank, stream=stream or None, dtype=dtype)
     del psi
-    n_local = ctx.n_train
+    n_local = ctx.rows_per_gpu[0] if args.native_mgpu > 0 else ctx.n_train
 
     prng = np.random.default_rng(3)
     thetas = [theta0 + 1e-3 * prng.standard_normal(theta0.size) for _ in range(args.steps + args.warmup)]
@@ -288,7 +298,7 @@ def main():
         phi_gbs = 8.0 * (n_local * cfg["d"] + n_local * m) / (ph_avg * 1e-3) / 1e9 if ph_avg > 0 else 0.0
         out = {
             "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": (args.native_mgpu if (args.native_mgpu > 0 and "rccl" in comm) else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "median_ms_per_step": float(np.median(step_s) * 1e3), "median_evals_per_s": float(1.0 / np.median(step_s)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations + f32-operand MFMA contractions (fp64 master sums)",
@@ -300,7 +310,8 @@ def main():
                        "rows_per_gpu": n_local, "sharding": (f"rows/{world} + all-reduce of the m x m and m x (d^2+d) partials: "
                                                               + ("RCCL inside the library (gpz_ctx_init_rccl)" if comm != "torch"
                                                                  else f"torch.distributed hook ({backend})"))
-                       if world > 1 else "single GPU"},
+                       if world > 1 else (f"one process, {comm}: rows/{args.native_mgpu} per shard, one host thread per shard, "
+                                          "reduction inside the library" if args.native_mgpu > 0 else "single GPU")},
             "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)"
                                                     + (" on fp32-operand MFMAs" if cfg.get("psi") else ""),
                          "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS if cfg.get("psi") else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -329,7 +340,7 @@ def main():
                 "peak": 157.3, "unit": "TFLOP/s",
                 "k_psi32_moments": {"achieved": ach_mo, "frac": ach_mo / 157.3, "avg_ms": mo_avg, "flops_per_pair": 12740},
                 "k_psi32_phi (+ fill, row dots)": {"achieved": ach_ph, "frac": ach_ph / 157.3, "avg_ms": ph_avg, "flops_per_pair": 6960}}
-        if world == 1 and not args.no_cpu_baseline and va_mask is None:
+        if world == 1 and not args.no_cpu_baseline and va_mask is None and args.native_mgpu == 0:
             rows = max(2000, min(n, n // 8 if n >= 200000 else n))        # ~13 s of CPU work at c4 (16 BLAS threads), the whole problem at c2 / c3
             if cfg.get("psi"):
                 rows = 60                                                  # per-pair d x d loops in NumPy: ~1e5 pairs
