@@ -70,9 +70,12 @@ typedef struct gpz_desc {
     void   *stream;           /* hipStream_t to run on; NULL = null stream */
     int32_t rank;             /* this shard's rank (0 when unsharded) */
     int32_t world;            /* number of row shards (1 when unsharded) */
-    int32_t dtype;            /* GPZ_F64 (0, default) or GPZ_F32: precision flag of the path.  f32 selects
-                               * fp32 per-(sample, basis) factorisations for GC/VC with input noise (BASELINE config 5);
-                               * every other stage, theta, f and g stay fp64 */
+    int32_t dtype;            /* GPZ_F64 (0, default) or GPZ_F32: precision flag of the path.  f32 applies to
+                               * GC/VC with input noise and no missing values (BASELINE config 5): fp32 per-(sample, basis)
+                               * factorisations, and the two MFMA contractions on fp32-rounded operands (PHI'W PHI with fp64
+                               * master sums, PHI*inv(SIGMA) with fp32 accumulation).  Delta, ln PHI, PHI, every sum over
+                               * rows, the m x m stage, theta, f and g stay fp64; every other configuration ignores the
+                               * flag and runs the fp64 path bit for bit.  Gates: 1e-4 on f, 1e-3 on g (of max|g|) */
     int32_t reserved[3];
 } gpz_desc;
 #define GPZ_F64 0
