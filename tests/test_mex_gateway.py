@@ -253,3 +253,35 @@ def test_gateway_standalone_entries():
     PHI, lnb, N = mex(3, "getphi", model_struct(model), theta, X, None)
     out = O.getPHI(X, None, theta, model, None)
     assert rel(PHI, out[0]) <= 1e-10 and rel(lnb, out[2]) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["VD", "GC"])
+def test_gateway_predict_and_prior_entries(method):
+    """gpz_mex('predict', ...) per NaN-pattern group as mex/predictDiag.m / predictCov.m call it (all four branches picked from
+    what X and Psi contain) and gpz_mex('prior', ...) as mex/getPrior.m calls it, against the Python mirror, which the parity
+    tests check against the oracle's predictDiag.m / predictCov.m / getPrior.m restatements."""
+    import gpz_amd
+    n, d, m = 300, 4, 10
+    model, theta, X, Y, _, rng = make_problem(600, d, m, 1, method, True, seed=77)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    w, iS, _ = ctx.solve(theta)
+    ctx.close()
+    priors = gpz_amd.getPrior(X, None, theta, model)
+    model.sets = {"best": {"theta": theta, "w": w, "iSigma_w": iS, "priors": priors}}
+    Xs = rng.standard_normal((n, d))
+    Xn = Xs.copy(); Xn[:, 1] = np.nan                                           # ONE pattern: dimension 1 missing everywhere
+    if method[1] == "C":
+        Psi = np.zeros((d, d, n)); Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.05, (d, n))
+    else:
+        Psi = rng.gamma(1.0, 0.05, (n, d))
+    ms = model_struct(model)
+    mex = Mex()
+    pr = mex(1, "prior", ms, theta, X, None)
+    assert pr.shape == (1, m) and rel(pr.ravel(), priors) <= 1e-12
+    for XX, PP in ((Xs, None), (Xs, Psi), (Xn, None), (Xn, Psi)):
+        mu, nu, beta_i, gamma, PHI = mex(5, "predict", ms, theta, w, iS, priors, XX, PP)
+        ref = gpz_amd.predict(XX, model, Psi=PP)                                # mu, sigma, nu, beta_i, gamma, PHI, ...
+        assert mu.shape == (n, 1) and PHI.shape == (n, m)
+        assert rel(mu, ref[0]) <= 1e-12 and rel(nu, ref[2]) <= 1e-12 and rel(beta_i, ref[3]) <= 1e-12
+        assert np.max(np.abs(gamma - ref[4])) <= 1e-12 * max(1.0, np.max(np.abs(ref[4]))) and rel(PHI, ref[5]) <= 1e-12
