@@ -84,6 +84,8 @@ SYMBOLS = {
     "gpz_mgpu_theta_len": (C.c_int64, [C.c_void_p]),
     "gpz_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "gpz_device_count": (C.c_int, []),
+    "gpz_mgpu_predict": (C.c_int, [C.POINTER(gpz_desc), C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                  C.c_int64, c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "gpz_ctx_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "gpz_rccl_origin": (C.c_char_p, []),

@@ -477,10 +477,12 @@ def nan_groups(X, device=0):
     return gid, int(ng.value)
 
 
-def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
+def predict(X, model, whichSet="best", Psi=None, selection=None, device=0, n_gpus=None):
     """[mu,sigma,nu,beta_i,gamma,PHI,w,iSigma_w] = predict(X,model,...)   (predict.m:1).  Rows are grouped by NaN
     pattern as predict.m:45-57 does; a group without missing values runs predictFull / predictNoisy, a group with
-    missing values predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337)."""
+    missing values predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337).
+    n_gpus (0 = every GPU of the node): every group's rows are split into contiguous blocks over the GPUs
+    (gpz_mgpu_predict; more blocks than GPUs = several blocks per GPU)."""
     lib = _lib.load()
     X = np.asarray(X, dtype=np.float64)
     psi = None if Psi is None else np.asarray(Psi, dtype=np.float64)
@@ -514,7 +516,14 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0):
         Pg = None if psin is None else np.asfortranarray(psin[:, :, idx] if cube else psin[idx])
         o_mu = np.empty((ng, k), order="F"); o_nu = np.empty((ng, k), order="F"); o_be = np.empty((ng, k), order="F")
         o_ga = np.zeros((ng, k), order="F"); o_ph = np.empty((ng, m), order="F")
-        if not missing[idx[0]].any():
+        if n_gpus is not None:
+            pri = st.get("priors")
+            pri = np.full(m, 1.0 / m) if pri is None else np.ascontiguousarray(np.asarray(pri, dtype=np.float64).ravel())
+            _lib.check(lib.gpz_mgpu_predict(C.byref(ds), int(n_gpus), None, _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS),
+                                            _lib.dptr(pri), _lib.dptr(Xg), ng, _lib.dptr(Pg),
+                                            0 if Pg is None else (2 if cube else 1), _lib.dptr(o_mu), _lib.dptr(o_nu),
+                                            _lib.dptr(o_be), _lib.dptr(o_ga), _lib.dptr(o_ph)))
+        elif not missing[idx[0]].any():
             if Pg is None:                                           # predictFull, gamma = 0 (predictDiag.m:74)
                 _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xg), ng,
                                                 _lib.dptr(o_mu), _lib.dptr(o_nu), _lib.dptr(o_be), _lib.dptr(o_ph)))

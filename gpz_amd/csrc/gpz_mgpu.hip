@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -488,6 +489,84 @@ extern "C" int gpz_mgpu_solve(gpz_mgpu *h, const double *theta, double *w, doubl
     h->out_iS = iSigma_w;
     h->out_part = nlogML_partial;
     return run_command(h, 2, theta);
+}
+
+// ---- prediction over several GPUs ------------------------------------------------------------------------------------------
+// The rows of one NaN-pattern group are independent (predict.m:60-69 calls predictDiag / predictCov per group; inside, every
+// sample is a row of PHI and a row of the pairwise sums): contiguous row blocks go to the devices, each block through the
+// single-device entry its content selects (predictFull / predictNoisy / predictMissing / predictNoisyMissing, the choice of
+// predictDiag.m:39-55), one host thread per block.  Results are those of the single-device call, row for row.
+extern "C" int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int32_t *devices, const double *theta, const double *w,
+                                const double *iSigma_w, const double *priors, const double *Xs, int64_t ns, const double *Psi,
+                                int32_t psi_kind, double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
+    if (!desc || !theta || !w || !iSigma_w || !Xs || ns < 1 || !mu || !nu || !beta_i)
+        return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_predict: null argument");
+    if ((Psi != nullptr) != (psi_kind != 0)) return gpz_fail(GPZ_ERR_ARG, "Psi and psi_kind disagree");
+    const int ndev = gpz_device_count();
+    if (ndev < 1) return gpz_fail(GPZ_ERR_HIP, "no HIP device");
+    if (n_gpus <= 0) n_gpus = ndev;
+    const int d = desc->d, k = desc->k, m = desc->m;
+    bool miss = false;
+    for (int c = 0; c < d && !miss; ++c) { const double xv = Xs[(size_t)c * ns]; miss = xv != xv; }   // the group's pattern: first row (predictDiag.m:3)
+    if (miss && (!priors || !gamma)) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_predict: missing values need priors and gamma");
+    if (psi_kind && !gamma) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_predict: input noise needs gamma");
+    int nblk = n_gpus;
+    if ((int64_t)nblk > ns) nblk = (int)ns;
+    std::vector<int> dev(nblk);
+    for (int r = 0; r < nblk; ++r) {
+        dev[r] = devices ? devices[r] : r % ndev;
+        if (dev[r] < 0 || dev[r] >= ndev) return gpz_fail(GPZ_ERR_ARG, "device %d not present (%d devices)", dev[r], ndev);
+    }
+    std::vector<int> rc(nblk, 0);
+    std::vector<std::string> err(nblk);
+    auto work = [&](int r) {
+        int64_t lo, hi;
+        shard_bounds(ns, r, nblk, &lo, &hi);
+        const int64_t nr = hi - lo;
+        std::vector<double> Xb((size_t)nr * d), Pb, o_mu((size_t)nr * k), o_nu((size_t)nr * k), o_be((size_t)nr * k), o_ga((size_t)nr * k), o_phi;
+        for (int c = 0; c < d; ++c) memcpy(&Xb[(size_t)c * nr], Xs + (size_t)c * ns + lo, (size_t)nr * sizeof(double));
+        if (psi_kind == 1) {
+            Pb.resize((size_t)nr * d);
+            for (int c = 0; c < d; ++c) memcpy(&Pb[(size_t)c * nr], Psi + (size_t)c * ns + lo, (size_t)nr * sizeof(double));
+        } else if (psi_kind == 2) {
+            Pb.assign(Psi + (size_t)lo * d * d, Psi + (size_t)hi * d * d);
+        }
+        if (PHI) o_phi.resize((size_t)nr * m);
+        gpz_desc dr = *desc;
+        dr.device = dev[r];
+        dr.stream = nullptr;
+        int e;
+        if (miss)
+            e = gpz_predict_missing(&dr, theta, w, iSigma_w, priors, Xb.data(), nr, psi_kind ? Pb.data() : nullptr, psi_kind,
+                                    o_mu.data(), o_nu.data(), o_be.data(), o_ga.data(), PHI ? o_phi.data() : nullptr);
+        else if (psi_kind)
+            e = gpz_predict_noisy(&dr, theta, w, iSigma_w, Xb.data(), nr, Pb.data(), psi_kind, o_mu.data(), o_nu.data(),
+                                  o_be.data(), o_ga.data(), PHI ? o_phi.data() : nullptr);
+        else {
+            e = gpz_predict_full(&dr, theta, w, iSigma_w, Xb.data(), nr, o_mu.data(), o_nu.data(), o_be.data(),
+                                 PHI ? o_phi.data() : nullptr);
+            std::fill(o_ga.begin(), o_ga.end(), 0.0);                       // predictFull has no gamma term
+        }
+        rc[r] = e;
+        if (e) { err[r] = gpz_last_error(); return; }
+        for (int o = 0; o < k; ++o) {
+            memcpy(mu + (size_t)o * ns + lo, &o_mu[(size_t)o * nr], (size_t)nr * sizeof(double));
+            memcpy(nu + (size_t)o * ns + lo, &o_nu[(size_t)o * nr], (size_t)nr * sizeof(double));
+            memcpy(beta_i + (size_t)o * ns + lo, &o_be[(size_t)o * nr], (size_t)nr * sizeof(double));
+            if (gamma) memcpy(gamma + (size_t)o * ns + lo, &o_ga[(size_t)o * nr], (size_t)nr * sizeof(double));
+        }
+        if (PHI)
+            for (int j = 0; j < m; ++j) memcpy(PHI + (size_t)j * ns + lo, &o_phi[(size_t)j * nr], (size_t)nr * sizeof(double));
+    };
+    if (nblk == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < nblk; ++r) th.emplace_back(work, r);
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < nblk; ++r)
+        if (rc[r]) return gpz_fail(rc[r], "block %d (device %d): %s", r, dev[r], err[r].c_str());
+    return GPZ_OK;
 }
 
 extern "C" int32_t gpz_mgpu_size(const gpz_mgpu *h) { return h ? h->n : -1; }

@@ -231,6 +231,15 @@ int64_t gpz_mgpu_theta_len(const gpz_mgpu *h);
  * settings to every rank); owned by the handle - never destroy it. */
 gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t rank);
 int gpz_device_count(void);
+/* Prediction of ONE NaN-pattern group (predict.m:60-69) over several GPUs: the rows are independent, so contiguous row blocks go
+ * to the devices, each through the single-device entry its content selects — gpz_predict_full / _noisy / _missing, the choice
+ * predictDiag.m:39-55 makes from X (pattern of the first row) and Psi.  Arguments as in those entries (priors and gamma may be
+ * NULL when the group has neither missing values nor input noise: gamma is then not written / written as 0); results equal the
+ * single-device call row for row.  n_gpus <= 0: every device; devices NULL: 0 .. n_gpus-1 (cyclic when n_gpus exceeds the node:
+ * several blocks per device, which is how single-GPU machines exercise the path). */
+int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int32_t *devices, const double *theta, const double *w,
+                     const double *iSigma_w, const double *priors, const double *Xs, int64_t ns, const double *Psi,
+                     int32_t psi_kind, double *mu, double *nu, double *beta_i, double *gamma, double *PHI);
 
 /* ---- one rank per PROCESS (torchrun / mpirun launchers): RCCL inside the library instead of a caller-supplied hook.
  * Rank 0 calls gpz_rccl_unique_id and ships the 128 bytes to the other ranks by any out-of-band means; every rank then

@@ -177,7 +177,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     if (!strcmp(cmd, "predict")) {
         if (nrhs != 8) mexErrMsgIdAndTxt("gpz:usage", "predict needs model,theta,w,iSigma_w,priors,X,Psi");
-        gpz_desc d = desc_of(prhs[1], NULL);
+        int32_t n_gpus = 0;
+        gpz_desc d = desc_of(prhs[1], &n_gpus);
         const mxArray *X = prhs[6], *Psi = prhs[7];
         need_double(X, "X", 0); need_double(Psi, "Psi", 1);
         const mwSize ns = mxGetM(X);
@@ -185,15 +186,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         for (int q = 0; q < 4; ++q) o[q] = mxCreateDoubleMatrix(ns, d.k, mxREAL);   /* mu nu beta_i gamma (gamma = 0 for predictFull) */
         o[4] = mxCreateDoubleMatrix(ns, d.m, mxREAL);
         const double *th = mxGetPr(prhs[2]), *w = mxGetPr(prhs[3]), *iS = mxGetPr(prhs[4]);
-        if (has_nan(X))
-            CHECK(gpz_predict_missing(&d, th, w, iS, mxGetPr(prhs[5]), mxGetPr(X), (int64_t)ns, opt(Psi), psi_kind_of(Psi),
-                                      mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3]), mxGetPr(o[4])), "gpz:predict");
-        else if (psi_kind_of(Psi))
-            CHECK(gpz_predict_noisy(&d, th, w, iS, mxGetPr(X), (int64_t)ns, mxGetPr(Psi), psi_kind_of(Psi), mxGetPr(o[0]),
-                                    mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3]), mxGetPr(o[4])), "gpz:predict");
-        else
-            CHECK(gpz_predict_full(&d, th, w, iS, mxGetPr(X), (int64_t)ns, mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]),
-                                   mxGetPr(o[4])), "gpz:predict");
+        /* the rows of a group are independent: contiguous blocks over model.n_gpus GPUs (default all), each through the entry
+         * its content selects (predictFull / predictNoisy / predictMissing / predictNoisyMissing, predictDiag.m:39-55) */
+        CHECK(gpz_mgpu_predict(&d, n_gpus, NULL, th, w, iS, opt(prhs[5]), mxGetPr(X), (int64_t)ns, opt(Psi), psi_kind_of(Psi),
+                               mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3]), mxGetPr(o[4])), "gpz:predict");
         for (int q = 0; q < 5; ++q)
             if (q < nlhs || q == 0) plhs[q] = o[q]; else mxDestroyArray(o[q]);
         return;

@@ -1056,3 +1056,26 @@ def test_mgpu_refuses_bad_layouts_loudly():
     f, g = mg.eval(theta)                                    # and the handle is still usable afterwards
     assert np.isfinite(f)
     mg.close()
+
+
+@pytest.mark.parametrize("method", ["VD", "VC"])
+def test_predict_over_row_blocks_equals_the_single_device_call(method):
+    """gpz_mgpu_predict: every NaN-pattern group's rows split into contiguous blocks (three blocks on this box's one GPU), each
+    block through the entry its content selects; all four branches and several patterns.  Row for row the single-device results."""
+    n, d, m = 700, 4, 9
+    model, theta, X, Y, _, rng = make_problem(500, d, m, 2, method, True, seed=91)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    w, iS, _ = ctx.solve(theta)
+    ctx.close()
+    model.sets = {"best": {"theta": theta, "w": w, "iSigma_w": iS, "priors": gpz_amd.getPrior(X, None, theta, model)}}
+    Xs = rng.standard_normal((n, d))
+    Xn = Xs.copy(); Xn[rng.random((n, d)) < 0.2] = np.nan; Xn[:, 0] = Xs[:, 0]
+    if method[1] == "C":
+        Psi = np.zeros((d, d, n)); Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.05, (d, n))
+    else:
+        Psi = rng.gamma(1.0, 0.05, (n, d))
+    for XX, PP in ((Xs, None), (Xs, Psi), (Xn, None), (Xn, Psi)):
+        one = gpz_amd.predict(XX, model, Psi=PP)
+        many = gpz_amd.predict(XX, model, Psi=PP, n_gpus=3)
+        for a, b in zip(one[:6], many[:6]):
+            assert np.array_equal(a, b)
