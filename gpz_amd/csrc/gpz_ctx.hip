@@ -1694,14 +1694,19 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     double *No = nullptr, *Pio = nullptr, *B = nullptr, *T = nullptr, *wd = nullptr, *iSd = nullptr, *prd = nullptr,
            *rec = nullptr, *sums = nullptr, *phiw = nullptr, *outb = nullptr, *tmp = nullptr;
     const int nrec = 2 * d + 1 + 3 * (int)k;
+    // pair chunks of cw * mp pairs: a NaN-pattern group is often a few dozen rows, and then the launches per chunk are what it
+    // costs - wider chunks, fewer of them, as far as the chunk's T (np x width) stays under 2 GB
+    int cw = 8;
+    while (cw > 1 && (double)np * (double)(cw * mp) * 8.0 > 2e9) cw >>= 1;
+    const size_t width = (size_t)cw * mp;
     if (!rc) rc = c->ar.alloc(&No, np * mp);
     if (!rc) rc = c->ar.alloc(&Pio, np * mp);
-    if (!rc) rc = c->ar.alloc(&B, mp * mp);
-    if (!rc) rc = c->ar.alloc(&T, np * mp);
+    if (!rc) rc = c->ar.alloc(&B, mp * width);
+    if (!rc) rc = c->ar.alloc(&T, np * (width > mp ? width : mp));
     if (!rc) rc = c->ar.alloc(&wd, m * k);
     if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
     if (!rc) rc = c->ar.alloc(&prd, m);
-    if (!rc) rc = c->ar.alloc(&rec, mp * nrec);
+    if (!rc) rc = c->ar.alloc(&rec, width * nrec);
     if (!rc) rc = c->ar.alloc(&sums, 3 * k * np);
     if (!rc) rc = c->ar.alloc(&phiw, np * k);
     if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
@@ -1723,12 +1728,13 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
                           c->lnbeta, nullptr, phiw);
         launch_zero(c->st, sums, 3 * k * np);
         const long npairs = (long)m * (m + 1) / 2;
-        for (long q0 = 0; q0 < npairs; q0 += (long)mp) {                                     // predictDiag.m:170-200
-            const int npq = (int)((npairs - q0 < (long)mp) ? npairs - q0 : (long)mp);
-            launch_pm_pairtab(c->st, q0, npairs, c->m, (int)mp, d, de, c->k, obs, c->has_psi ? 1 : 0, c->pr.P, c->pr.G, wd,
-                              c->hetero ? c->pr.v : nullptr, iSd, B, rec, nrec);
-            launch_tgemm(c->st, Pio, (int)mp, B, (int)mp, T, (int)np, (int)mp, nullptr, nullptr, c->m, -1);
-            launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)mp, d, c->k, obs, npq, T, rec, nrec, sums);
+        for (long q0 = 0; q0 < npairs; q0 += (long)width) {                                  // predictDiag.m:170-200
+            const int npq = (int)((npairs - q0 < (long)width) ? npairs - q0 : (long)width);
+            launch_pm_pairtab(c->st, q0, npairs, c->m, (int)mp, (int)width, d, de, c->k, obs, c->has_psi ? 1 : 0, c->pr.P,
+                              c->pr.G, wd, c->hetero ? c->pr.v : nullptr, iSd, B, rec, nrec);
+            launch_tgemm(c->st, Pio, (int)mp, B, (int)width, T, (int)np, (int)width, nullptr, nullptr, c->m, -1, false, (int)mp,
+                         (int)width);
+            launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)width, d, c->k, obs, npq, T, rec, nrec, sums);
         }
         launch_predict_noisy_final(c->st, sums, (long)np, n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
                                    outb + 2 * k * np);

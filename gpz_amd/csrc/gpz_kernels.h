@@ -70,7 +70,7 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol, bool f32_operands = false);
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands = false, int kdim = 0, int ldt = 0);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
 #ifndef GPZ_CH_NB
@@ -281,9 +281,9 @@ void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, in
 void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B);
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
                    const double *G, double *Phi);
-void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs, int has_psi,
-                       const double *P, const double *G, const double *w, const double *v, const double *iS, double *B,
-                       double *rec, int nrec);
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned obs,
+                       int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
+                       double *B, double *rec, int nrec);
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
                      unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums);
 

@@ -330,7 +330,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            OT (*sA)[128][18], OT (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
-                                           long n_pad, int ct) {
+                                           long n_pad, int ct, int kdim) {
     constexpr int NT = 128 * WC;
     constexpr int NI = 8 / WC;
     constexpr int Q = 1024 / NT;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     }
 
     // Software pipeline as in syrk_body: loads of slice s+2 issued mid-slice s, LDS writes between the MFMA halves.
-    const int nstage = mp / 16;
+    const int nstage = kdim / 16;        // K (= mp for the evaluation's T = PHI*[inv(SIGMA)|w]; the output may be wider: mp columns)
     gload();
     lstore(0);
     if (nstage > 1) gload();
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
                                                         const double *__restrict__ B, int ldb,
                                                         double *__restrict__ T, int ldt, int mp, int nct,
                                                         double *__restrict__ nupart, double *__restrict__ phiw, int m,
-                                                        int mcol, long n_pad) {
+                                                        int mcol, long n_pad, int kdim) {
     __shared__ OT sA[2][128][18];
     __shared__ OT sB[2][16][LDS_LD128];
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
@@ -509,9 +509,9 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
-        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim);
     else
-        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct);
+        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -639,17 +639,21 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
     hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, nsplit_d, mp, S, lds);
 }
 
+// T (n_pad x mp, row stride ldt) = PHI (n_pad x kdim, row stride ld) * B (kdim x mp, row stride ldb).  kdim = 0: the square case
+// of the evaluation (K = mp, ldt = ld).  kdim % 16 == 0.
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol, bool f32_operands) {
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands, int kdim, int ldt) {
     constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
+    if (kdim <= 0) kdim = mp;
+    if (ldt <= 0) ldt = ld;
     dim3 grid((n_pad / 128) * nct), block(128 * WC);
     if (f32_operands)
-        hipLaunchKernelGGL((k_tgemm<WC, float>), grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
-                           (long)n_pad);
+        hipLaunchKernelGGL((k_tgemm<WC, float>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
+                           (long)n_pad, kdim);
     else
-        hipLaunchKernelGGL((k_tgemm<WC, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ld, mp, nct, nupart, phiw, m, mcol,
-                           (long)n_pad);
+        hipLaunchKernelGGL((k_tgemm<WC, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
+                           (long)n_pad, kdim);
 }
 
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs) {

@@ -99,16 +99,16 @@ __device__ __forceinline__ void pair_of(long q, int *pi, int *pj) {
 //           [- 1/2 sum_o ln Cij when there is no input noise: the x-independent part of No,                    :178]
 //     c2  = 2 for j < i, 1 for j == i (2x inside the loop, minus 1x for the diagonal term after it,            :191-199)
 // Columns past the last pair are zero (B) / c2 = 0 (rec).
-__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs,
+__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int ldb, int d, int de, int k, unsigned obs,
                                                     int has_psi, const double *__restrict__ P,
                                                     const double *__restrict__ G, const double *__restrict__ w,
                                                     const double *__restrict__ v, const double *__restrict__ iS,
                                                     double *__restrict__ B, double *__restrict__ rec, int nrec) {
-    const int qq = blockIdx.x;
+    const int qq = blockIdx.x;                      // pair within the chunk: gridDim.x = chunk width = ldb (row stride of B)
     const long q = q0 + qq;
     double *r = rec + (size_t)qq * nrec;
     if (q >= npairs) {
-        for (int l = threadIdx.x; l < ld; l += 256) B[(size_t)l * ld + qq] = 0.0;
+        for (int l = threadIdx.x; l < ld; l += 256) B[(size_t)l * ldb + qq] = 0.0;
         for (int e = threadIdx.x; e < nrec; e += 256) r[e] = (e >= d && e < 2 * d) ? 1.0 : 0.0;
         return;
     }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
             }
             val = exp(-0.5 * qd - 0.5 * ls);
         }
-        B[(size_t)l * ld + qq] = val;
+        B[(size_t)l * ldb + qq] = val;
     }
     if (threadIdx.x == 0) {
         double lz = 0.0, qd = 0.0, ls = 0.0, lo = 0.0;
@@ -227,11 +227,12 @@ void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, i
     hipLaunchKernelGGL(k_pm_phi, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, No, T1, ld, n, n_pad, m, d, de, G,
                        Phi);
 }
-void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int d, int de, int k, unsigned obs, int has_psi,
-                       const double *P, const double *G, const double *w, const double *v, const double *iS, double *B,
-                       double *rec, int nrec) {
-    hipLaunchKernelGGL(k_pm_pairtab, dim3(ld), dim3(256), 0, st, q0, npairs, m, ld, d, de, k, obs, has_psi, P, G, w, v, iS, B,
-                       rec, nrec);
+// width = number of pairs of the chunk = row stride of B (ld rows: the K dimension of the following T-GEMM)
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned obs,
+                       int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
+                       double *B, double *rec, int nrec) {
+    hipLaunchKernelGGL(k_pm_pairtab, dim3(width), dim3(256), 0, st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
+                       iS, B, rec, nrec);
 }
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
                      unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums) {
