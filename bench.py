@@ -169,8 +169,8 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)       # >= 20 calls after 3 warm-ups
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="override the row count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
