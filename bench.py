@@ -4,9 +4,16 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2]
 
 A "step" is one gpz_eval: theta on the host -> [f, grad, 4 statistics] on the host, data resident in HBM.
-Metric (BASELINE.json): objective+gradient evaluations per second, whole job.  With N>1 the script is
-launched by torch.distributed.run, one rank per GPU; the n rows of the SAME problem are sharded across ranks
-(strong scaling) and the m x m / m x d partials are all-reduced over RCCL (gpz_amd/dist.py).
+Metric (BASELINE.json): objective+gradient evaluations per second, whole job.  N > 1 shards the n rows of the SAME
+problem (strong scaling); only the m x m / m x (d^2+d) partials are all-reduced over RCCL.  Two launch forms:
+  * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: one rank per process, RCCL communicator
+    created INSIDE the library from a unique id shipped once by torch.distributed (gpz_ctx_init_rccl);
+  * `python bench.py --gpus N` (no launcher, WORLD_SIZE unset): ONE process, the library drives the N devices itself
+    (gpz_mgpu_*: a host thread + stream + context per device, ncclCommInitAll) — the form a MATLAB host uses
+    (minFunc.m:314 calls funObj once and waits).
+Either way the run FAILS (non-zero exit) when the node has fewer than N GPUs or the launcher's world size is not N;
+nothing degrades silently to fewer devices.  `--native-mgpu K` is the separate single-GPU test form: K shards on one
+device with the library's loopback reducer (measures the driver's threading, not scaling; reports n_gpus = 1).
 
 Workloads (synthetic data per SURVEY.md §8d):
     c4  n=1e6 d=10 m=1000 VC heteroscedastic fp64   <- the configuration the metric's target is quoted on (default)
@@ -186,16 +193,29 @@ def main():
     import gpz_amd
     from gpz_amd import dist as gdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) >= 1 and "RANK" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # GPZ_DIST_BACKEND=gloo lets two ranks share one GPU (single-GPU boxes: RCCL refuses duplicate devices)
+    # GPZ_DIST_BACKEND=gloo lets two ranks share one GPU (single-GPU boxes: RCCL refuses duplicate devices) - a test form
     backend = os.environ.get("GPZ_DIST_BACKEND", "nccl")
+    ndev = gpz_amd.device_count()
+    if launched and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+                         f"{world}-rank run as {args.gpus} GPUs")
+    if args.gpus > ndev and not (launched and backend != "nccl"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {ndev} GPU(s); refusing to run on fewer devices "
+                         "(use --native-mgpu K for the single-GPU loopback form)")
+    if args.native_mgpu > 0 and (launched and world > 1 or args.gpus > 1):
+        raise SystemExit("--native-mgpu is the single-GPU loopback form: do not combine it with --gpus N or a launcher")
+    native = (not launched or world == 1) and args.gpus > 1          # one process, N devices, RCCL inside the library
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1
+    use_dist = launched and world > 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,9 +232,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dtype = cfg.get("dtype", "f64")
     comm = "none"
+    rccl_origin = None
     tr_mask = va_mask = None
     if args.validation > 0.0:
-        if use_dist:
+        if use_dist or native:
             raise SystemExit("--validation is a single-GPU measurement")
         va_mask = np.random.default_rng(6).random(n) < args.validation
         tr_mask = ~va_mask
@@ -230,7 +251,7 @@ def main():
                                  rank=rank, world=world, allreduce=gdist.make_allreduce() if comm == "torch" else None, dtype=dtype)
         if comm != "torch":
             try:
-                gdist.init_rccl(ctx, rank, world, local_rank)
+                rccl_origin = gdist.init_rccl(ctx, rank, world, local_rank)
                 ok = 1
             except Exception as e:   # every rank must take the same route: agree on it
                 print(f"rank {rank}: RCCL inside the library unavailable ({e!r}); falling back to the torch.distributed hook",
@@ -241,17 +262,23 @@ def main():
             if int(flag.item()) == 0:
                 comm = "torch"
                 ctx.set_allreduce(gdist.make_allreduce())
-    elif args.native_mgpu > 0:
+    elif native or args.native_mgpu > 0:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
-        K = args.native_mgpu
-        reducer = "rccl" if gpz_amd.device_count() >= K else "loopback"
+        K = args.gpus if native else args.native_mgpu
+        reducer = "rccl" if native else "loopback"
         ctx = gpz_amd.GPzMulti(model, X, y, psi, omega, tr_mask, va_mask, n_gpus=K, reducer=reducer, dtype=dtype)
+        if native and ctx.n_gpus != args.gpus:
+            raise SystemExit(f"bench.py: asked for {args.gpus} GPUs, the library reports {ctx.n_gpus}")
         comm = f"gpz_mgpu x{K} ({reducer})"
+        if native:
+            rccl_origin = gpz_amd.rccl_origin()
     else:
         psi = synth_psi(cfg, np.arange(n)) if cfg.get("psi") else None
         ctx = gpz_amd.GPzContext(model, X, y, psi, omega, tr_mask, va_mask, device=local_rank, stream=stream or None, dtype=dtype)
     del psi
-    n_local = ctx.rows_per_gpu[0] if args.native_mgpu > 0 else ctx.n_train
+    multi = native or args.native_mgpu > 0
+    n_local = ctx.rows_per_gpu[0] if multi else ctx.n_train
+    n_gpus_used = ctx.n_gpus if native else world
 
     prng = np.random.default_rng(3)
     thetas = [theta0 + 1e-3 * prng.standard_normal(theta0.size) for _ in range(args.steps + args.warmup)]
@@ -280,6 +307,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tim = ctx.timings()
+    per_rank = None
+    if multi:
+        per_rank = [{"rank": r, "rows": ctx.rows_per_gpu[r],
+                     "stage_ms_per_eval": {k: v[0] / args.steps for k, v in ctx.timings(r).items()}} for r in range(ctx.n_gpus)]
+    elif use_dist:
+        mine = {"rank": rank, "rows": n_local, "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}}
+        per_rank = [None] * world if rank == 0 else None
+        dist.gather_object(mine, per_rank, dst=0)
     finite = bool(np.isfinite(fs).all() and np.isfinite(g).all())
 
     out = None
@@ -298,7 +333,7 @@ def main():
         phi_gbs = 8.0 * (n_local * cfg["d"] + n_local * m) / (ph_avg * 1e-3) / 1e9 if ph_avg > 0 else 0.0
         out = {
             "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",
-            "n_gpus": (args.native_mgpu if (args.native_mgpu > 0 and "rccl" in comm) else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": n_gpus_used, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "median_ms_per_step": float(np.median(step_s) * 1e3), "median_evals_per_s": float(1.0 / np.median(step_s)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if dtype == "f64" else "f64 + f32 per-pair factorisations + f32-operand MFMA contractions (fp64 master sums)",
@@ -310,14 +345,18 @@ def main():
                        "rows_per_gpu": n_local, "sharding": (f"rows/{world} + all-reduce of the m x m and m x (d^2+d) partials: "
                                                               + ("RCCL inside the library (gpz_ctx_init_rccl)" if comm != "torch"
                                                                  else f"torch.distributed hook ({backend})"))
-                       if world > 1 else (f"one process, {comm}: rows/{args.native_mgpu} per shard, one host thread per shard, "
-                                          "reduction inside the library" if args.native_mgpu > 0 else "single GPU")},
+                       if world > 1 else (f"one process, {comm}: rows/{ctx.n_gpus} per shard, one host thread per shard, "
+                                          "reduction inside the library" if multi else "single GPU"),
+                       "launch": ("torch.distributed.run, one rank per GPU" if use_dist else
+                                  "one process, gpz_mgpu_* drives every device" if native else
+                                  "one process, loopback shards on one device" if multi else "one process, one device"),
+                       "rccl": rccl_origin},
             "roofline": {"bound": "mfma", "kernel": "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)"
                                                     + (" on fp32-operand MFMAs" if cfg.get("psi") else ""),
                          "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS if cfg.get("psi") else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / (F32_MFMA_PEAK_TFLOPS if cfg.get("psi") else F64_MFMA_PEAK_TFLOPS),
-                         "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not args.n else None,
-                         "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not args.n else None,
+                         "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not multi and not args.n else None,
+                         "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
                          "avg_ms": tg_avg, "ubench_ceiling": F64_MFMA_UBENCH_TFLOPS,
                          "frac_of_ubench": ach / F64_MFMA_UBENCH_TFLOPS},
@@ -325,7 +364,11 @@ def main():
                         "phi_build_GBs_algorithmic": phi_gbs, "phi_build_avg_ms": ph_avg,
                         "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
             "finite": finite,
+            # bitwise fingerprint of the last step's result (same theta sequence for every launch form)
+            "check": {"f_last": float(fs[-1]).hex(), "g_sum": float(np.sum(g)).hex(), "g_absmax": float(np.max(np.abs(g))).hex()},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if cfg.get("psi"):
             # config 5: the dominant kernels are the fp32 per-pair factorisations (VALU), not the GEMMs.  Algorithmic work per
             # (sample, basis) pair at D = 20, whitened form: PHI 3480 FMA, moments 6370 FMA, 2 flops each.
@@ -334,13 +377,19 @@ def main():
             pairs = float(n_local) * m
             ach_mo = pairs * 6370 * 2 / (mo_avg * 1e-3) / 1e12 if mo_avg > 0 else 0.0
             ach_ph = pairs * 3480 * 2 / (ph_avg * 1e-3) / 1e12 if ph_avg > 0 else 0.0
-            out["roofline_f32_pair_kernels"] = {
-                "bound": "fp32 VALU (157.3 TFLOP/s spec = the fp32 MFMA rate; one wave per SIMD issues ~1 instruction per 6 cycles, "
-                         "tools/fp32_valu_bench.hip)",
+            pair = {
+                "bound": "fp32 VALU (157.3 TFLOP/s spec = the fp32 MFMA rate; tools/fp32_valu_bench.hip has the issue rates per occupancy)",
                 "peak": 157.3, "unit": "TFLOP/s",
                 "k_psi32_moments": {"achieved": ach_mo, "frac": ach_mo / 157.3, "avg_ms": mo_avg, "flops_per_pair": 12740},
                 "k_psi32_phi (+ fill, row dots)": {"achieved": ach_ph, "frac": ach_ph / 157.3, "avg_ms": ph_avg, "flops_per_pair": 6960}}
-        if world == 1 and not args.no_cpu_baseline and va_mask is None and args.native_mgpu == 0:
+            # the dominant kernel of this configuration is the moment kernel, not a GEMM: it is the top-level roofline
+            out["roofline_gemm"] = out["roofline"]
+            out["roofline"] = {"bound": "valu", "kernel": "k_psi32_moments (per-(sample, basis) d x d factorisations, 12740 flops/pair)",
+                               "achieved": ach_mo, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_mo / F32_MFMA_PEAK_TFLOPS,
+                               "traffic": (pmc_traffic(args.config) or {}).get("moments_bytes_per_launch") if world == 1 and not multi and not args.n else None,
+                               "avg_ms": mo_avg}
+            out["roofline_f32_pair_kernels"] = pair
+        if world == 1 and not args.no_cpu_baseline and va_mask is None and not multi:
             rows = max(2000, min(n, n // 8 if n >= 200000 else n))        # ~13 s of CPU work at c4 (16 BLAS threads), the whole problem at c2 / c3
             if cfg.get("psi"):
                 rows = 60                                                  # per-pair d x d loops in NumPy: ~1e5 pairs

@@ -43,6 +43,7 @@ SYMBOLS = {
     "gpz_ctx_destroy": (None, [C.c_void_p]),
     "gpz_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "gpz_theta_len": (C.c_int64, [C.c_void_p]),
+    "gpz_theta_len_of": (C.c_int64, [C.POINTER(gpz_desc)]),
     "gpz_n_train": (C.c_int64, [C.c_void_p]),
     "gpz_n_valid": (C.c_int64, [C.c_void_p]),
     "gpz_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
@@ -81,6 +82,8 @@ SYMBOLS = {
     "gpz_mgpu_eval": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_mgpu_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "gpz_mgpu_size": (C.c_int32, [C.c_void_p]),
+    "gpz_mgpu_alive": (C.c_int32, [C.c_void_p]),
+    "gpz_mgpu_debug_fail_at": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gpz_mgpu_theta_len": (C.c_int64, [C.c_void_p]),
     "gpz_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "gpz_device_count": (C.c_int, []),

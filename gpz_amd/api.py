@@ -321,6 +321,15 @@ class GPzMulti:
     def _each(self):
         return [self._lib.gpz_mgpu_ctx(self._h, r) for r in range(self.n_gpus)]
 
+    @property
+    def alive(self):
+        """False once a rank failed inside a call with the RCCL reducer (communicators aborted): re-create the handle."""
+        return bool(self._lib.gpz_mgpu_alive(self._h))
+
+    def debug_fail_at(self, rank, exchange):
+        """Test hook (gpz_mgpu_debug_fail_at): the next call fails on `rank` at exchange point 1 or 2."""
+        _lib.check(self._lib.gpz_mgpu_debug_fail_at(self._h, int(rank), int(exchange)))
+
     def enable_timing(self, on=True):
         for c in self._each():
             _lib.check(self._lib.gpz_ctx_enable_timing(c, 1 if on else 0))
@@ -345,6 +354,12 @@ class GPzMulti:
 
 def device_count():
     return int(_lib.load().gpz_device_count())
+
+
+def rccl_origin():
+    """Which RCCL the library bound to (dlopen at first use): '' when none was needed or found."""
+    o = _lib.load().gpz_rccl_origin()
+    return o.decode() if o else ""
 
 
 _cache = {}

@@ -740,6 +740,12 @@ extern "C" int gpz_ctx_set_allreduce(gpz_ctx *c, gpz_allreduce_fn fn, void *user
     return GPZ_OK;
 }
 extern "C" int64_t gpz_theta_len(const gpz_ctx *c) { return c ? c->p : -1; }
+extern "C" int64_t gpz_theta_len_of(const gpz_desc *ds) {
+    if (!ds || ds->d < 1 || ds->m < 1 || ds->k < 1) return -1;
+    const int mid = method_id_of(ds->method);
+    if (mid < 0) return -1;
+    return (int64_t)ds->m * ds->d + g_dim_of(mid, ds->m, ds->d) + (int64_t)ds->m * ds->k + ds->k + (ds->heteroscedastic ? 2LL * ds->m * ds->k : 0);
+}
 extern "C" int64_t gpz_n_train(const gpz_ctx *c) { return c ? c->tr.n : -1; }
 extern "C" int64_t gpz_n_valid(const gpz_ctx *c) { return c ? c->va.n : -1; }
 

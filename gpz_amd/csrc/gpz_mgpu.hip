@@ -32,11 +32,14 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,6 +59,8 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string where;
 };
+static std::string g_rccl_why;
+static const char *rccl_why() { return g_rccl_why.empty() ? "no diagnostic" : g_rccl_why.c_str(); }
 
 static RcclApi *rccl_api() {
     static std::mutex mu;
@@ -69,12 +74,17 @@ static RcclApi *rccl_api() {
     for (const char *n : names)                      // an RCCL the process already carries (e.g. PyTorch's)
         if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) { api.where = std::string(n) + " (already loaded)"; break; }
     if (!h)
-        for (int q = 1; q >= 0 && !h; --q)
+        for (int q = 1; q >= 0 && !h; --q) {
+            (void)dlerror();
             if ((h = dlopen(names[q], RTLD_NOW | RTLD_LOCAL))) api.where = names[q];
+            else if (const char *e = dlerror()) g_rccl_why += std::string(g_rccl_why.empty() ? "" : "; ") + e;   // read ONCE: dlerror() clears itself
+        }
     if (!h) return nullptr;
+    g_rccl_why.clear();
 #define BIND(f)                                                    \
+    (void)dlerror();                                               \
     api.f = (decltype(api.f))dlsym(h, "nccl" #f);                  \
-    if (!api.f) return nullptr;
+    if (!api.f) { const char *e = dlerror(); g_rccl_why = std::string("nccl" #f ": ") + (e ? e : "symbol not found"); return nullptr; }
     BIND(GetUniqueId) BIND(CommInitRank) BIND(CommInitAll) BIND(CommDestroy) BIND(CommAbort) BIND(AllReduce) BIND(GetErrorString)
 #undef BIND
     api.handle = h;
@@ -101,7 +111,7 @@ static void rank_comm_free(void *p) {
 extern "C" int gpz_rccl_unique_id(void *id128) {
     if (!id128) return gpz_fail(GPZ_ERR_ARG, "gpz_rccl_unique_id: null argument");
     RcclApi *api = rccl_api();
-    if (!api) return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1): %s", dlerror() ? dlerror() : "");
+    if (!api) return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1): %s", rccl_why());
     ncclUniqueId id;
     ncclResult_t r = api->GetUniqueId(&id);
     if (r != ncclSuccess) return gpz_fail(GPZ_ERR_COMM, "ncclGetUniqueId: %s", api->GetErrorString(r));
@@ -113,7 +123,7 @@ extern "C" int gpz_rccl_unique_id(void *id128) {
 extern "C" int gpz_ctx_init_rccl(gpz_ctx *ctx, const void *id128, int32_t rank, int32_t world, int32_t device) {
     if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return gpz_fail(GPZ_ERR_ARG, "gpz_ctx_init_rccl: bad argument");
     RcclApi *api = rccl_api();
-    if (!api) return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1)");
+    if (!api) return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1): %s", rccl_why());
     if (hipSetDevice(device) != hipSuccess) return gpz_fail(GPZ_ERR_HIP, "hipSetDevice(%d) failed", device);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
@@ -179,6 +189,7 @@ struct gpz_mgpu;
 struct RankSlot {
     gpz_mgpu *h = nullptr;
     int rank = 0;
+    int exchange = 0;                              // all-reduces seen in the current command (1 = [PHI'W PHI | ...], 2 = gradient records)
 };
 
 struct gpz_mgpu {
@@ -203,6 +214,14 @@ struct gpz_mgpu {
     std::vector<int> rc;
     std::vector<std::string> err;
     double *out_w = nullptr, *out_iS = nullptr, *out_part = nullptr;
+    // failure handling (RCCL reducer): a rank that fails before or at an exchange point would leave the others inside
+    // ncclAllReduce for ever, so the failing rank's thread aborts every communicator of the handle (ncclCommAbort ends
+    // the in-flight collectives) and the handle is dead from then on: later calls return GPZ_ERR_COMM.  Enqueues hold
+    // comm_mu shared, the abort holds it exclusively, so no thread enqueues on a communicator that is being freed.
+    std::shared_mutex comm_mu;
+    std::atomic<bool> dead{false};
+    std::string dead_why;
+    int inject_rank = -1, inject_exchange = 0;     // gpz_mgpu_debug_fail_at (tests)
     // loopback reducer
     Barrier bar;
     std::vector<double *> lb_ptr;
@@ -212,8 +231,15 @@ struct gpz_mgpu {
 static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
     RankSlot *s = (RankSlot *)user;
     gpz_mgpu *h = s->h;
+    ++s->exchange;
+    if (h->inject_rank == s->rank && h->inject_exchange == s->exchange) {     // injected failure of this rank at this exchange point
+        if (h->reducer == GPZ_REDUCER_LOOPBACK) h->bar.poison();
+        return 1;
+    }
     if (h->reducer == GPZ_REDUCER_RCCL) {
         RcclApi *api = rccl_api();
+        std::shared_lock<std::shared_mutex> lk(h->comm_mu);
+        if (h->dead.load() || !h->comms[s->rank]) return 1;
         return api->AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comms[s->rank], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
     }
     // loopback: every rank's contribution complete -> rank 0 sums in rank order into all buffers -> everyone continues
@@ -234,6 +260,18 @@ static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
     return ok;
 }
 
+// RCCL reducer, after a failure on one rank: end every in-flight collective of the handle and mark it dead.
+static void abort_comms(gpz_mgpu *h, int r, const char *why) {
+    std::unique_lock<std::shared_mutex> lk(h->comm_mu);
+    if (h->dead.exchange(true)) return;
+    h->dead_why = std::string("rank ") + std::to_string(r) + ": " + (why ? why : "");
+    RcclApi *api = h->comms.empty() ? nullptr : rccl_api();
+    for (ncclComm_t &c : h->comms) {
+        if (api && c) (void)api->CommAbort(c);     // frees the communicator as well: never destroyed again
+        c = nullptr;
+    }
+}
+
 static void worker_main(gpz_mgpu *h, int r) {
     (void)hipSetDevice(h->dev[r]);
     unsigned long seen = 0;
@@ -249,6 +287,7 @@ static void worker_main(gpz_mgpu *h, int r) {
         }
         if (cmd == 3) return;
         int rc = 0;
+        h->slots[r].exchange = 0;
         if (cmd == 1)
             rc = gpz_eval(h->ctx[r], theta, &h->f[r], h->g[r].data(), &h->stats[4 * r], &h->diag[2 * r]);
         else if (cmd == 2)
@@ -258,6 +297,7 @@ static void worker_main(gpz_mgpu *h, int r) {
         if (rc) {
             h->err[r] = gpz_last_error();
             h->bar.poison();                        // loopback: do not leave the other ranks at an exchange point
+            if (h->reducer == GPZ_REDUCER_RCCL && h->n > 1) abort_comms(h, r, h->err[r].c_str());   // RCCL: nor inside ncclAllReduce
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
@@ -267,6 +307,9 @@ static void worker_main(gpz_mgpu *h, int r) {
 }
 
 static int run_command(gpz_mgpu *h, int cmd, const double *theta) {
+    if (h->dead.load())
+        return gpz_fail(GPZ_ERR_COMM, "this multi-GPU handle is dead: its communicators were aborted after a failure (%s); destroy it and "
+                                      "create a new one", h->dead_why.c_str());
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->cmd = cmd;
@@ -280,6 +323,7 @@ static int run_command(gpz_mgpu *h, int cmd, const double *theta) {
         h->cv_done.wait(lk, [&] { return h->pending == 0; });
     }
     h->bar.reset();
+    h->inject_rank = -1;                            // an injected failure fires once
     for (int r = 0; r < h->n; ++r)
         if (h->rc[r]) return gpz_fail(h->rc[r], "rank %d (device %d): %s", r, h->dev[r], h->err[r].c_str());
     return GPZ_OK;
@@ -429,7 +473,7 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
     h->k = k;
     if (n_gpus > 1 && reducer == GPZ_REDUCER_RCCL) {
         RcclApi *api = rccl_api();
-        if (!api) { mgpu_free(h); return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1)"); }
+        if (!api) { mgpu_free(h); return gpz_fail(GPZ_ERR_COMM, "RCCL not found (librccl.so.1): %s", rccl_why()); }
         h->comms.assign(n_gpus, nullptr);
         ncclResult_t r = api->CommInitAll(h->comms.data(), n_gpus, h->dev.data());
         if (r != ncclSuccess) {
@@ -510,7 +554,13 @@ extern "C" int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int3
     for (int c = 0; c < d && !miss; ++c) { const double xv = Xs[(size_t)c * ns]; miss = xv != xv; }   // the group's pattern: first row (predictDiag.m:3)
     if (miss && (!priors || !gamma)) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_predict: missing values need priors and gamma");
     if (psi_kind && !gamma) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_predict: input noise needs gamma");
+    // A block costs a thread, a temporary context on its device and an upload of theta, w and iSigma_w (m*m*k doubles): only
+    // worth it for a few thousand rows.  NaN-pattern groups are often a few dozen rows (predict.m:45-57) — those run as ONE
+    // block on the first device.  An explicit device list keeps the caller's split (tests).
+    int64_t min_rows = 4096;
+    if (const char *e = getenv("GPZ_PREDICT_MIN_ROWS_PER_BLOCK")) min_rows = std::max<int64_t>(1, atoll(e));   // tests: split small groups too
     int nblk = n_gpus;
+    if (!devices) nblk = (int)std::min<int64_t>(n_gpus, std::max<int64_t>(1, ns / min_rows));
     if ((int64_t)nblk > ns) nblk = (int)ns;
     std::vector<int> dev(nblk);
     for (int r = 0; r < nblk; ++r) {
@@ -569,6 +619,14 @@ extern "C" int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int3
     return GPZ_OK;
 }
 
+extern "C" int gpz_mgpu_debug_fail_at(gpz_mgpu *h, int32_t rank, int32_t exchange) {
+    if (!h || rank < 0 || rank >= h->n || exchange < 1 || exchange > 2) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_debug_fail_at: bad argument");
+    if (h->n < 2) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_debug_fail_at: a one-shard handle has no exchange point");
+    h->inject_rank = rank;
+    h->inject_exchange = exchange;
+    return GPZ_OK;
+}
+extern "C" int32_t gpz_mgpu_alive(const gpz_mgpu *h) { return (h && !h->dead.load()) ? 1 : 0; }
 extern "C" int32_t gpz_mgpu_size(const gpz_mgpu *h) { return h ? h->n : -1; }
 extern "C" int64_t gpz_mgpu_theta_len(const gpz_mgpu *h) { return h ? h->p : -1; }
 extern "C" gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t rank) { return (h && rank >= 0 && rank < h->n) ? h->ctx[rank] : nullptr; }

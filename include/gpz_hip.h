@@ -108,8 +108,9 @@ int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const double *X,
 void gpz_ctx_destroy(gpz_ctx *ctx);
 int  gpz_ctx_set_allreduce(gpz_ctx *ctx, gpz_allreduce_fn fn, void *user);
 
-/* numel(theta) for this context's model. */
+/* numel(theta) for this context's model / for a model description (init.m:65-97; -1: bad description). */
 int64_t gpz_theta_len(const gpz_ctx *ctx);
+int64_t gpz_theta_len_of(const gpz_desc *desc);
 /* rows selected by the training / validation mask on this rank. */
 int64_t gpz_n_train(const gpz_ctx *ctx);
 int64_t gpz_n_valid(const gpz_ctx *ctx);
@@ -226,6 +227,13 @@ void gpz_mgpu_destroy(gpz_mgpu *h);
 int gpz_mgpu_eval(gpz_mgpu *h, const double *theta, double *f, double *g, double stats[4], double diag[2]);
 int gpz_mgpu_solve(gpz_mgpu *h, const double *theta, double *w, double *iSigma_w, double *nlogML_partial);
 int32_t gpz_mgpu_size(const gpz_mgpu *h);
+/* Failure of one rank inside a call (HIP error, allocation failure, a failed exchange): with GPZ_REDUCER_RCCL the other ranks would
+ * wait inside ncclAllReduce for ever, so the failing rank aborts every communicator of the handle (ncclCommAbort); the call returns
+ * that rank's error and the handle is DEAD: gpz_mgpu_alive returns 0 and every later gpz_mgpu_eval / _solve returns GPZ_ERR_COMM until
+ * the handle is destroyed and re-created.  (The loopback reducer releases its barrier instead and stays usable.)
+ * gpz_mgpu_debug_fail_at: test hook - the next call fails on `rank` at its exchange point `exchange` (1 or 2), once. */
+int32_t gpz_mgpu_alive(const gpz_mgpu *h);
+int gpz_mgpu_debug_fail_at(gpz_mgpu *h, int32_t rank, int32_t exchange);
 int64_t gpz_mgpu_theta_len(const gpz_mgpu *h);
 /* the context of one rank, for gpz_n_train / gpz_ctx_enable_timing / gpz_ctx_timings / gpz_ctx_set_pinv_mode (apply
  * settings to every rank); owned by the handle - never destroy it. */

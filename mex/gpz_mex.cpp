@@ -11,10 +11,14 @@
 //   [w, iSigma_w, part] = gpz_mex('solve', theta, model, X, Y, Psi, omega, training, validation)   GPz.m:84-87
 //        The closure's data (train.m:40) lives on the GPUs between calls.  Every call hands the closure's arguments
 //        over again — MATLAB passes shared-data copies, so this costs nothing — and the gateway compares them with
-//        what the live context was built from: model fields, array sizes, DATA POINTERS (copy-on-write gives a changed
-//        array a new pointer) and 256 strided samples of every array (a pointer re-used by the allocator for different
-//        data).  Anything different rebuilds the context.  model.n_gpus (optional) = number of GPUs, default all of
-//        the node; the rows are sharded across them and reduced with RCCL inside the library (gpz_mgpu_*).
+//        what the live context was built from: model fields, array sizes, data pointers, and the CONTENT of the arrays:
+//        Y, omega, training and validation are hashed completely on every call (MATLAB edits an unshared variable in
+//        place and keeps its pointer — `training(bad) = false` between two train() calls must not evaluate on stale
+//        device data; 18 MB at n = 1e6, ~2 ms), X and Psi (the big ones: 6.4 GB at config 5) by 256 strided samples plus
+//        pointer and size — after editing X or Psi in place call gpz_mex('reset').  Anything different rebuilds the
+//        context.  model.n_gpus (optional) = number of GPUs, default all of the node; the rows are sharded across them
+//        and reduced with RCCL inside the library (gpz_mgpu_*); model.reducer = 'loopback' (optional) puts model.n_gpus
+//        shards on ONE device with the library's own reducer (single-GPU hosts, tests).
 //        model.dtype = 'f32' (optional) selects the fp32 per-pair factorisations of GC/VC with input noise.
 //   PHI = gpz_mex('phi')                                               5th output of GPz.m:1 (after eval / solve)
 //   [PHI, lnBeta_i, N] = gpz_mex('getphi', model, theta, X, Psi)       getPHI.m:1 (rows already selected)
@@ -37,7 +41,7 @@
 #define NSAMP 256
 
 typedef struct {
-    int32_t d, m, k, hetero, dtype, n_gpus;
+    int32_t d, m, k, hetero, dtype, n_gpus, reducer;
     char method[4];
     const void *ptr[NARR];
     size_t bytes[NARR];
@@ -68,6 +72,16 @@ static double field(const mxArray *s, const char *name) {
     return mxGetScalar(f);
 }
 
+static int32_t reducer_of(const mxArray *model) {
+    const mxArray *r = mxIsStruct(model) ? mxGetField(model, 0, "reducer") : NULL;
+    char buf[16] = "";
+    if (!r || mxIsEmpty(r)) return GPZ_REDUCER_RCCL;
+    if (mxGetString(r, buf, sizeof buf)) mexErrMsgIdAndTxt("gpz:model", "model.reducer must be 'rccl' or 'loopback'");
+    if (!strcmp(buf, "loopback")) return GPZ_REDUCER_LOOPBACK;
+    if (!strcmp(buf, "rccl")) return GPZ_REDUCER_RCCL;
+    mexErrMsgIdAndTxt("gpz:model", "model.reducer must be 'rccl' or 'loopback'");
+    return GPZ_REDUCER_RCCL;
+}
 static gpz_desc desc_of(const mxArray *model, int32_t *n_gpus) {
     gpz_desc d;
     memset(&d, 0, sizeof d);
@@ -96,10 +110,35 @@ static int has_nan(const mxArray *X) {
 }
 #define CHECK(call, id) do { if (call) mexErrMsgIdAndTxt(id, "%s", gpz_last_error()); } while (0)
 
-/* What the live context was built from.  Bitwise sampling: NaN payloads compare like any other bits. */
+/* 64-bit content hash, four independent lanes of 8-byte words (memory-bound: ~2 ms for the 18 MB of n-sized arrays at n = 1e6). */
+static uint64_t hash_bytes(const unsigned char *p, size_t nbytes) {
+    uint64_t h[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+    const size_t nw = nbytes / 8;
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4)
+        for (int l = 0; l < 4; ++l) {
+            uint64_t w;
+            memcpy(&w, p + (i + l) * 8, 8);
+            h[l] = (h[l] ^ w) * 0x100000001B3ull;
+            h[l] ^= h[l] >> 29;
+        }
+    for (; i < nw; ++i) {
+        uint64_t w;
+        memcpy(&w, p + i * 8, 8);
+        h[0] = (h[0] ^ w) * 0x100000001B3ull;
+        h[0] ^= h[0] >> 29;
+    }
+    for (size_t b = nw * 8; b < nbytes; ++b) h[1] = (h[1] ^ p[b]) * 0x100000001B3ull;
+    return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]) + nbytes;
+}
+
+/* What the live context was built from.  Bitwise: NaN payloads compare like any other bits.  q: 0 X, 1 Y, 2 Psi, 3 omega,
+ * 4 training, 5 validation — X and Psi are sampled, the n-sized arrays are hashed completely (an in-place edit of ONE mask
+ * element must rebuild the context). */
 static void key_of(const mxArray *model, const mxArray *const *arr, closure_key *key) {
     memset(key, 0, sizeof *key);
     gpz_desc d = desc_of(model, &key->n_gpus);
+    key->reducer = reducer_of(model);
     key->d = d.d; key->m = d.m; key->k = d.k; key->hetero = d.heteroscedastic; key->dtype = d.dtype;
     memcpy(key->method, d.method, sizeof key->method);
     for (int q = 0; q < NARR; ++q) {
@@ -110,6 +149,7 @@ static void key_of(const mxArray *model, const mxArray *const *arr, closure_key 
         key->ptr[q] = p;
         key->bytes[q] = n * es;
         key->rows[q] = mxGetM(a);
+        if (q != 0 && q != 2) { key->sum[q] = hash_bytes(p, n * es); continue; }
         const size_t step = n > NSAMP ? n / NSAMP : 1;
         uint64_t h = 1469598103934665603ull;
         for (size_t e = 0; e < n; e += step)
@@ -137,7 +177,7 @@ static void ensure_context(const mxArray *const *args) {
     for (int q = 4; q <= 6; ++q)
         if (args[q] && !mxIsEmpty(args[q]) && mxGetNumberOfElements(args[q]) < n)
             mexErrMsgIdAndTxt("gpz:size", "omega / training / validation must have one entry per row of X");
-    if (gpz_mgpu_create(&d, n_gpus, NULL, GPZ_REDUCER_RCCL, (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi),
+    if (gpz_mgpu_create(&d, n_gpus, NULL, reducer_of(model), (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi),
                         opt(om), optmask(args[5]), optmask(args[6]), &g_mg))
         mexErrMsgIdAndTxt("gpz:create", "%s", gpz_last_error());
     g_key = key;
@@ -155,6 +195,30 @@ static const double *theta_of(const mxArray *th) {
     return mxGetPr(th);
 }
 
+/* Stand-alone entries: theta / w / iSigma_w / priors / X / Psi must have the sizes the model implies — a short theta would be an
+ * out-of-bounds host read inside the library. */
+static void need_numel(const mxArray *a, size_t want, const char *what) {
+    if (!a || !mxIsDouble(a) || mxIsComplex(a) || mxGetNumberOfElements(a) != want)
+        mexErrMsgIdAndTxt("gpz:size", "%s must be a real double array of %d elements", what, (int)want);
+}
+static void need_theta(const gpz_desc *d, const mxArray *th) {
+    const int64_t p = gpz_theta_len_of(d);
+    if (p < 0) mexErrMsgIdAndTxt("gpz:model", "model.d / m / k / method do not describe a GPz model");
+    if (!th || !mxIsDouble(th) || mxIsComplex(th) || mxGetNumberOfElements(th) != (size_t)p)
+        mexErrMsgIdAndTxt("gpz:theta", "theta must be a real double vector of %d elements", (int)p);
+}
+static void need_rows(const gpz_desc *d, const mxArray *X, const mxArray *Psi) {
+    need_double(X, "X", 0); need_double(Psi, "Psi", 1);
+    if (mxGetN(X) != (mwSize)d->d) mexErrMsgIdAndTxt("gpz:size", "X must be n x model.d");
+    const int kind = psi_kind_of(Psi);
+    const size_t ns = mxGetM(X), dd = (size_t)d->d;
+    if (kind == 1 && (mxGetM(Psi) != ns || mxGetN(Psi) != dd)) mexErrMsgIdAndTxt("gpz:size", "Psi must be n x model.d (fixPsi.m:42-53)");
+    if (kind == 2) {
+        const mwSize *dm = mxGetDimensions(Psi);
+        if (dm[0] != dd || dm[1] != dd || dm[2] != ns) mexErrMsgIdAndTxt("gpz:size", "Psi must be d x d x n (fixPsi.m:22-38)");
+    }
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     char cmd[16];
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gpz:usage", "first argument: command");
@@ -165,7 +229,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (!strcmp(cmd, "getphi")) {
         if (nrhs != 5) mexErrMsgIdAndTxt("gpz:usage", "getphi needs model,theta,X,Psi");
         gpz_desc d = desc_of(prhs[1], NULL);
-        need_double(prhs[2], "theta", 0); need_double(prhs[3], "X", 0); need_double(prhs[4], "Psi", 1);
+        need_theta(&d, prhs[2]); need_rows(&d, prhs[3], prhs[4]);
         const mwSize ns = mxGetM(prhs[3]);
         plhs[0] = mxCreateDoubleMatrix(ns, d.m, mxREAL);
         mxArray *lb = mxCreateDoubleMatrix(ns, d.k, mxREAL), *N = nlhs > 2 ? mxCreateDoubleMatrix(ns, d.m, mxREAL) : NULL;
@@ -180,7 +244,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         int32_t n_gpus = 0;
         gpz_desc d = desc_of(prhs[1], &n_gpus);
         const mxArray *X = prhs[6], *Psi = prhs[7];
-        need_double(X, "X", 0); need_double(Psi, "Psi", 1);
+        need_theta(&d, prhs[2]); need_rows(&d, X, Psi);
+        need_numel(prhs[3], (size_t)d.m * d.k, "w");
+        need_numel(prhs[4], (size_t)d.m * d.m * d.k, "iSigma_w");
+        if (prhs[5] && !mxIsEmpty(prhs[5])) need_numel(prhs[5], (size_t)d.m, "priors");
         const mwSize ns = mxGetM(X);
         mxArray *o[5];
         for (int q = 0; q < 4; ++q) o[q] = mxCreateDoubleMatrix(ns, d.k, mxREAL);   /* mu nu beta_i gamma (gamma = 0 for predictFull) */
@@ -197,7 +264,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (!strcmp(cmd, "prior")) {
         if (nrhs != 5) mexErrMsgIdAndTxt("gpz:usage", "prior needs model,theta,X,Psi");
         gpz_desc d = desc_of(prhs[1], NULL);
-        need_double(prhs[3], "X", 0);
+        need_theta(&d, prhs[2]); need_rows(&d, prhs[3], prhs[4]);
         plhs[0] = mxCreateDoubleMatrix(1, d.m, mxREAL);
         CHECK(gpz_prior(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetM(prhs[3]), opt(prhs[4]), psi_kind_of(prhs[4]),
                         mxGetPr(plhs[0]), NULL), "gpz:prior");

@@ -25,6 +25,7 @@ size_t mxGetM(const mxArray *a);
 size_t mxGetN(const mxArray *a);
 size_t mxGetNumberOfElements(const mxArray *a);
 mwSize mxGetNumberOfDimensions(const mxArray *a);
+const mwSize *mxGetDimensions(const mxArray *a);
 size_t mxGetElementSize(const mxArray *a);
 bool mxIsEmpty(const mxArray *a);
 bool mxIsDouble(const mxArray *a);

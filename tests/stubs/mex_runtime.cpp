@@ -59,6 +59,7 @@ size_t mxGetN(const mxArray *a) {          // product of the trailing dimensions
 }
 size_t mxGetNumberOfElements(const mxArray *a) { return numel(a); }
 mwSize mxGetNumberOfDimensions(const mxArray *a) { return a->cls == mxCHAR_CLASS ? 2 : a->dims.size(); }
+const mwSize *mxGetDimensions(const mxArray *a) { return a->dims.data(); }
 size_t mxGetElementSize(const mxArray *a) { return a->cls == mxCHAR_CLASS ? 2 : a->esize; }
 bool mxIsEmpty(const mxArray *a) { return a->cls == mxSTRUCT_CLASS ? false : numel(a) == 0; }
 bool mxIsDouble(const mxArray *a) { return a->cls == mxDOUBLE_CLASS; }

@@ -1059,9 +1059,11 @@ def test_mgpu_refuses_bad_layouts_loudly():
 
 
 @pytest.mark.parametrize("method", ["VD", "VC"])
-def test_predict_over_row_blocks_equals_the_single_device_call(method):
+def test_predict_over_row_blocks_equals_the_single_device_call(method, monkeypatch):
     """gpz_mgpu_predict: every NaN-pattern group's rows split into contiguous blocks (three blocks on this box's one GPU), each
-    block through the entry its content selects; all four branches and several patterns.  Row for row the single-device results."""
+    block through the entry its content selects; all four branches and several patterns.  Row for row the single-device results.
+    (Groups below 4096 rows per block run as one block by default: the threshold is lowered so the split is what is tested.)"""
+    monkeypatch.setenv("GPZ_PREDICT_MIN_ROWS_PER_BLOCK", "5")
     n, d, m = 700, 4, 9
     model, theta, X, Y, _, rng = make_problem(500, d, m, 2, method, True, seed=91)
     ctx = gpz_amd.GPzContext(model, X, Y)

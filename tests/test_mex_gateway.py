@@ -45,7 +45,7 @@ def _twin():
                             ("mexrt_dim", sz, [vp, C.c_int]), ("mexrt_call", C.c_int, [C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]),
                             ("mexrt_last_error", C.c_char_p, []), ("mexrt_last_id", C.c_char_p, []),
                             ("mexrt_locks", C.c_int, []), ("mexrt_unload", None, []), ("mxDestroyArray", None, [vp]),
-                            ("mxGetPr", vp, [vp]), ("mxGetNumberOfElements", sz, [vp])]:
+                            ("mxGetPr", vp, [vp]), ("mxGetData", vp, [vp]), ("mxGetNumberOfElements", sz, [vp])]:
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
     return lib
@@ -73,6 +73,11 @@ class Mex:
         """Write into the held mxArray of ``a`` in place (what MATLAB may do to an unshared variable)."""
         p = self.held[id(a)][0]
         C.cast(self.lib.mxGetPr(p), C.POINTER(C.c_double))[flat_index] = value
+
+    def poke_logical(self, a, flat_index, value):
+        """In-place write into a held logical mxArray (one byte per element)."""
+        p = self.held[id(a)][0]
+        C.cast(self.lib.mxGetData(p), C.POINTER(C.c_uint8))[flat_index] = 1 if value else 0
 
     def release(self):
         for p, _ in self.held.values():
@@ -205,6 +210,20 @@ def test_gateway_eval_solve_phi_match_the_oracle(method, psi, nanfrac, k):
     mex.poke(om, int(hit), om[hit, 0] * 3.0)
     fc = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
     assert mex(1, "builds")[0, 0] == b0 + 2 and fc[0, 0] != fa[0, 0]
+    # the n-sized arrays are hashed COMPLETELY - an in-place edit of ONE element that a strided sample would
+    # miss (MATLAB: training(bad) = false on an unshared variable keeps the pointer) must rebuild the context
+    miss = next(i for i in np.flatnonzero(tr) if i % (n // 256) != 0 and i != n - 1)
+    mex.poke_logical(tr, int(miss), False)
+    tr_edit = tr.copy(); tr_edit[miss] = False
+    om_now = om.copy(); om_now[hit, 0] *= 3.0
+    fd = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    ref_d = O.GPz(theta, model, X, Y, Psi, om_now, tr_edit, None)
+    assert mex(1, "builds")[0, 0] == b0 + 3 and abs(fd[0, 0] - ref_d.nlogML) <= 1e-8 * abs(ref_d.nlogML) and fd[0, 0] != fc[0, 0]
+    miss_y = next(i for i in np.flatnonzero(tr_edit) if i % (Y.size // 256 or 1) != 0 and i != Y.size - 1)
+    mex.poke(Y, int(miss_y), 0.123)
+    fe = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 4 and fe[0, 0] != fd[0, 0]
+    b0 += 2
     if model.heteroscedastic:
         ms2 = dict(ms, heteroscedastic=False)
         with pytest.raises(MexError) as e:          # theta is now too long for the model: the context was rebuilt for it
@@ -235,6 +254,52 @@ def test_gateway_optional_model_fields():
         mex(1, "eval", theta, model_struct(model, n_gpus=float(gpz_amd.device_count() + 2)), X, Y, Psi, None, None, None)
     assert e.value.ident == "gpz:create"
     mex(0, "reset")
+    mex.lib.mexrt_unload()
+
+
+@pytest.mark.gpu
+def test_gateway_reducer_field_and_loopback_shards():
+    """model.reducer = 'loopback': model.n_gpus shards on one device behind the same gateway (single-GPU MATLAB hosts)."""
+    model, theta, X, Y, Psi, rng = make_problem(900, 4, 8, 1, "VD", True, seed=8)
+    mex = Mex()
+    one = mex(2, "eval", theta, model_struct(model, n_gpus=1.0), X, Y, None, None, None, None)
+    three = mex(2, "eval", theta, model_struct(model, n_gpus=3.0, reducer="loopback"), X, Y, None, None, None, None)
+    assert mex(1, "gpus") == 3.0
+    assert abs(one[0][0, 0] - three[0][0, 0]) <= 1e-12 * abs(one[0][0, 0]) and rel(three[1], one[1]) <= 1e-9
+    with pytest.raises(MexError) as e:
+        mex(1, "eval", theta, model_struct(model, reducer="carrier-pigeon"), X, Y, None, None, None, None)
+    assert e.value.ident == "gpz:model"
+    mex(0, "reset")
+    mex.lib.mexrt_unload()
+
+
+@pytest.mark.gpu
+def test_gateway_standalone_entries_validate_their_arguments():
+    """'getphi' / 'predict' / 'prior' must check numel(theta), w, iSigma_w, priors and the shapes of X / Psi
+    against the model before the library reads them (a short theta would be an out-of-bounds host read)."""
+    model, theta, X, Y, _, rng = make_problem(120, 3, 5, 1, "VC", True, seed=12)
+    ms = model_struct(model)
+    m, d = model.m, model.d
+    w, iS, pri = np.zeros((m, 1)), np.eye(m)[:, :, None], np.full(m, 1.0 / m)
+    cube = np.zeros((d, d, X.shape[0]))
+    mex = Mex()
+    bad = [(("getphi", ms, theta[:-1], X, None), "gpz:theta"),
+           (("getphi", ms, theta, X[:, :-1], None), "gpz:size"),
+           (("getphi", ms, theta, X, cube[:, :, :-1]), "gpz:size"),
+           (("getphi", ms, theta, X, np.zeros((X.shape[0], d + 1))), "gpz:size"),
+           (("getphi", dict(ms, method="XX"), theta, X, None), "gpz:model"),
+           (("prior", ms, theta[:-2], X, None), "gpz:theta"),
+           (("prior", ms, theta, X[:, :-1], None), "gpz:size"),
+           (("predict", ms, theta[:-1], w, iS, pri, X, None), "gpz:theta"),
+           (("predict", ms, theta, w[:-1], iS, pri, X, None), "gpz:size"),
+           (("predict", ms, theta, w, iS[:, :-1], pri, X, None), "gpz:size"),
+           (("predict", ms, theta, w, iS, pri[:-1], X, None), "gpz:size"),
+           (("predict", ms, theta, w, iS, pri, X, cube[:-1]), "gpz:size")]
+    for args, ident in bad:
+        with pytest.raises(MexError) as e:
+            mex(1, *args)
+        assert e.value.ident == ident, (args[0], ident, str(e.value))
+    mex(5, "predict", ms, theta, w, iS, None, X, None)        # empty priors are allowed without missing values
     mex.lib.mexrt_unload()
 
 
