@@ -88,11 +88,15 @@ def synth(cfg, n=None):
     return model, theta, X, y, omega
 
 
-def synth_psi(cfg, rows):
-    """Input noise of config 5: Gamma(1, 0.5) variances per dimension as diagonal d x d cubes, built
-    for the given row indices only (the full cube of n = 2e6 rows is 6.4 GB)."""
+def synth_psi(cfg, rows, cube=False):
+    """Input noise of config 5: Gamma(1, 0.5) variances per dimension for the given row indices.  The library takes
+    the n x d variances directly (psi_kind 3 of the C ABI: it builds the diagonal d x d x n cubes of fixPsi.m:27-31 on its side, so the
+    6.4 GB cube of n = 2e6 rows is never materialised on the host); cube=True returns the d x d x n cubes themselves, the layout
+    the oracle takes."""
     d = cfg["d"]
     var = np.random.default_rng(4).gamma(1.0, 0.5, (cfg["n"], d))[rows]
+    if not cube:
+        return np.asfortranarray(var)
     Psi = np.zeros((d, d, var.shape[0]))
     Psi[np.arange(d), np.arange(d), :] = var.T
     return Psi
@@ -105,7 +109,7 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
     Omodel = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
     Xs, ys = X[:rows], y[:rows]
     oms = None if omega is None else omega[:rows]
-    psis = synth_psi(cfg, np.arange(rows)) if cfg.get("psi") else None
+    psis = synth_psi(cfg, np.arange(rows), cube=True) if cfg.get("psi") else None
     # BLAS threads = the cores this process may actually use (affinity mask and cgroup quota): the default pool is sized
     # by the machine's core count, and on a quota-limited box that oversubscription halves the dgemm rate
     # (GPU box: 256 logical CPUs, quota 16 -> 714 GFLOP/s with the default 64 threads, 1406 with 16)

@@ -67,6 +67,16 @@ def _desc(model, device=0, stream=None, rank=0, world=1, dtype="f64"):
     return ds
 
 
+def _psi_kind(model, psi):
+    """psi_kind of the C ABI from the array's shape: n x d for the diagonal kinds (1), d x d x n cubes for GC/VC (2), and
+    n x d per-dimension variances given to GC/VC (3: the diagonal cubes of fixPsi.m:27-31, expanded by the library)."""
+    if psi is None:
+        return 0
+    if psi.ndim == 3:
+        return 2
+    return 3 if str(model.method)[1] == "C" else 1
+
+
 def _f64(a, ndim=None):
     if a is None:
         return None
@@ -111,7 +121,7 @@ class GPzContext:
         psi = None
         if Psi is not None:
             psi = _f64(Psi)
-            psi_kind = 2 if psi.ndim == 3 else 1
+            psi_kind = _psi_kind(model, psi)
         self._tr = _mask(training, n_tot)
         self._va = _mask(validation, n_tot)
         self.model = model
@@ -257,7 +267,7 @@ class GPzMulti:
         psi, psi_kind = None, 0
         if Psi is not None:
             psi = _f64(Psi)
-            psi_kind = 2 if psi.ndim == 3 else 1
+            psi_kind = _psi_kind(model, psi)
         self._tr = _mask(training, n_tot)
         self._va = _mask(validation, n_tot)
         if reducer not in ("rccl", "loopback"):
@@ -426,7 +436,7 @@ def getPHI(X, Psi, theta, model, selection=None, device=0, want_N=False):
     psi_kind = 0
     if psi is not None:
         psi = np.asfortranarray(psi)
-        psi_kind = 2 if psi.ndim == 3 else 1
+        psi_kind = _psi_kind(model, psi)
     theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
     ns = X.shape[0]
     PHI = np.empty((ns, model.m), order="F")
@@ -573,7 +583,7 @@ def getPrior(X, Psi, theta, model, selection=None, device=0, return_iterations=F
     psi_kind = 0
     if psi is not None:
         psi = np.asfortranarray(psi)
-        psi_kind = 2 if psi.ndim == 3 else 1
+        psi_kind = _psi_kind(model, psi)
     theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
     prior = np.empty(model.m)
     it = C.c_int32()

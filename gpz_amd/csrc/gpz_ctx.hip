@@ -204,6 +204,8 @@ struct gpz_ctx {
     bool psi_fast = false;   // gen && Psi && d <= 10 && fp64: register-resident kernels (k_psi.hip), missing dimensions included
     bool psi_miss = false;   // psi_fast with more than one NaN pattern (or a pattern with missing dimensions)
     bool psi32 = false;      // dtype f32 && gen && Psi && no missing dims: fp32 register-resident kernels (k_psi32.hip)
+    int psi_kind_in = 0;     // layout of the caller's Psi: 1 n x d (diagonal kinds), 2 d x d x n cube, 3 n x d variances = diagonal cubes (GC/VC)
+    bool need_psi3 = true;   // keep the fp64 cube on the device (prediction / fp64 pair kernels); the fp32 evaluation path reads PsiT only
     bool psi32_agreed = false;   // sharded runs: the ranks have agreed on diagonal vs full Psi (first evaluation)
     int ngroups = 0, nrec = 0;
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
@@ -345,29 +347,40 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
         for (size_t r = 0; r < idx.size(); ++r) order[pos[hg[r]]++] = (int)r;
         if (int e = c->ar.alloc(&rs.rows_by_group, idx.size() ? idx.size() : 1)) return e;
         if (!idx.empty()) HIPCHK(hipMemcpy(rs.rows_by_group, order.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (Psi) {   // d x d x n_tot cube (fixPsi.m:22-38): Psi(:,:,i) is contiguous
-            std::vector<double> hp(np * (size_t)d * d, 0.0);
-            for (size_t r = 0; r < idx.size(); ++r)
-                memcpy(&hp[r * d * d], Psi + (size_t)idx[r] * d * d, (size_t)d * d * sizeof(double));
-            if (int e = c->ar.alloc(&rs.Psi3, np * d * d)) return e;
-            HIPCHK(hipMemcpy(rs.Psi3, hp.data(), np * d * d * sizeof(double), hipMemcpyHostToDevice));
+        if (Psi) {   // d x d x n_tot cube (fixPsi.m:22-38): Psi(:,:,i) is contiguous; or (psi_kind 3) the n_tot x d variances the
+                     // cubes' diagonals were built from (fixPsi.m:27-31), expanded here instead of by the caller
+            const bool dvar = c->psi_kind_in == 3;
+            auto psi_at = [&](size_t r, int a, int b) -> double {
+                if (dvar) return a == b ? Psi[(size_t)a * n_tot + idx[r]] : 0.0;
+                return Psi[(size_t)idx[r] * d * d + a + (size_t)d * b];
+            };
+            if (c->need_psi3 || !c->psi32) {
+                std::vector<double> hp(np * (size_t)d * d, 0.0);
+                for (size_t r = 0; r < idx.size(); ++r) {
+                    if (dvar) for (int a = 0; a < d; ++a) hp[r * d * d + a + (size_t)d * a] = Psi[(size_t)a * n_tot + idx[r]];
+                    else memcpy(&hp[r * d * d], Psi + (size_t)idx[r] * d * d, (size_t)d * d * sizeof(double));
+                }
+                if (int e = c->ar.alloc(&rs.Psi3, np * d * d)) return e;
+                HIPCHK(hipMemcpy(rs.Psi3, hp.data(), np * d * d * sizeof(double), hipMemcpyHostToDevice));
+            }
             if (c->psi32) {
                 const int D = psi32_pad_dim(d);
                 bool diag = true;
-                for (size_t r = 0; r < idx.size() && diag; ++r)
-                    for (int a = 0; a < d && diag; ++a)
-                        for (int b = 0; b < d; ++b)
-                            if (a != b && hp[r * d * d + a + (size_t)d * b] != 0.0) { diag = false; break; }
+                if (!dvar)
+                    for (size_t r = 0; r < idx.size() && diag; ++r)
+                        for (int a = 0; a < d && diag; ++a)
+                            for (int b = 0; b < d; ++b)
+                                if (a != b && psi_at(r, a, b) != 0.0) { diag = false; break; }
                 rs.psi_diag = diag ? 1 : 0;
                 const size_t ne = diag ? (size_t)D : (size_t)D * (D + 1) / 2;
                 std::vector<float> ht(ne * np, 0.0f);
                 for (size_t r = 0; r < idx.size(); ++r) {
                     if (diag) {
-                        for (int a = 0; a < d; ++a) ht[(size_t)a * np + r] = (float)hp[r * d * d + a + (size_t)d * a];
+                        for (int a = 0; a < d; ++a) ht[(size_t)a * np + r] = (float)psi_at(r, a, a);
                     } else {
                         for (int a = 0; a < d; ++a)
                             for (int b = 0; b <= a; ++b)   // lower triangle of the symmetric Psi(:,:,i): element (a, b)
-                                ht[((size_t)a * (a + 1) / 2 + b) * np + r] = (float)hp[r * d * d + a + (size_t)d * b];
+                                ht[((size_t)a * (a + 1) / 2 + b) * np + r] = (float)psi_at(r, a, b);
                     }
                 }
                 if (int e = c->ar.alloc(&rs.PsiT, ne * np)) return e;
@@ -473,13 +486,16 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
     const gpz_desc *desc = &c->desc;
     int rc = 0;
     if ((Psi != nullptr) != (psi_kind != 0)) return fail(GPZ_ERR_ARG, "Psi and psi_kind disagree");
+    if (psi_kind < 0 || psi_kind > 3) return fail(GPZ_ERR_ARG, "psi_kind must be 0..3");
+    c->psi_kind_in = psi_kind;
     const bool xnan = has_nan(X, n_tot * (int64_t)c->d) != 0;
     // a given pattern table means "the data set has missing values": every rank takes the general path then, also one
     // whose own rows happen to be complete (the second all-reduce carries one record block per pattern)
     const bool table = patterns && n_patterns > 0;
     if (c->kind == GPZ_KIND_COV && (Psi || xnan || table)) {
         // general path: per-pair d x d factorisations (k_gen.hip)
-        if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
+        if (Psi && psi_kind != 2 && psi_kind != 3)
+            return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38) or as n x d variances (psi_kind 3)");
         // the NaN-pattern table is built per rank in first-occurrence order: shards would disagree on the ids and on the
         // size of the second all-reduce, so a sharded run must be given the table of the whole data set
         if (desc->world > 1 && xnan && !table)
@@ -581,6 +597,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         delete c;
         return code;
     };
+    c->need_psi3 = false;          // an evaluation context on the fp32 pair kernels never reads the fp64 cube (6.4 GB at config 5)
     if ((rc = setup_data(c, n_tot, X, Y, Psi, psi_kind, omega, training, validation, patterns, n_patterns))) return bail(rc);
     // moment chunks of the training rows that end at NaN-pattern boundaries: ~n/target rows each (at least min_rows),
     // plus each pattern's range of chunks for the segmented slab sum
@@ -1594,7 +1611,7 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
 static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double *theta, const double *w, const double *iSigma_w,
                                const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                                double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
-    if (Psi && psi_kind != 2) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38)");
+    if (Psi && psi_kind != 2 && psi_kind != 3) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38) or n x d variances (psi_kind 3)");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;

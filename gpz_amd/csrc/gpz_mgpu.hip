@@ -190,6 +190,7 @@ struct RankSlot {
     gpz_mgpu *h = nullptr;
     int rank = 0;
     int exchange = 0;                              // all-reduces seen in the current command (1 = [PHI'W PHI | ...], 2 = gradient records)
+    bool secondary = false;                        // this rank's failure is the echo of another rank's (poisoned barrier / aborted communicator)
 };
 
 struct gpz_mgpu {
@@ -239,13 +240,13 @@ static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
     if (h->reducer == GPZ_REDUCER_RCCL) {
         RcclApi *api = rccl_api();
         std::shared_lock<std::shared_mutex> lk(h->comm_mu);
-        if (h->dead.load() || !h->comms[s->rank]) return 1;
+        if (h->dead.load() || !h->comms[s->rank]) { s->secondary = true; return 1; }
         return api->AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comms[s->rank], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
     }
     // loopback: every rank's contribution complete -> rank 0 sums in rank order into all buffers -> everyone continues
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { h->bar.poison(); return 1; }
     h->lb_ptr[s->rank] = (double *)buf;
-    if (!h->bar.wait()) return 1;
+    if (!h->bar.wait()) { s->secondary = true; return 1; }
     int ok = 0;
     if (s->rank == 0) {
         if (hipMemcpyAsync(h->lb_ptr_d, h->lb_ptr.data(), h->n * sizeof(double *), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
@@ -256,7 +257,7 @@ static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
         if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) ok = 1;
         if (ok) h->bar.poison();
     }
-    if (!h->bar.wait()) return 1;
+    if (!h->bar.wait()) { if (!ok) s->secondary = true; return 1; }
     return ok;
 }
 
@@ -288,6 +289,7 @@ static void worker_main(gpz_mgpu *h, int r) {
         if (cmd == 3) return;
         int rc = 0;
         h->slots[r].exchange = 0;
+        h->slots[r].secondary = false;
         if (cmd == 1)
             rc = gpz_eval(h->ctx[r], theta, &h->f[r], h->g[r].data(), &h->stats[4 * r], &h->diag[2 * r]);
         else if (cmd == 2)
@@ -324,8 +326,10 @@ static int run_command(gpz_mgpu *h, int cmd, const double *theta) {
     }
     h->bar.reset();
     h->inject_rank = -1;                            // an injected failure fires once
-    for (int r = 0; r < h->n; ++r)
-        if (h->rc[r]) return gpz_fail(h->rc[r], "rank %d (device %d): %s", r, h->dev[r], h->err[r].c_str());
+    for (int pass = 0; pass < 2; ++pass)           // the rank whose failure was not the echo of another rank's comes first
+        for (int r = 0; r < h->n; ++r)
+            if (h->rc[r] && (pass == 1 || !h->slots[r].secondary))
+                return gpz_fail(h->rc[r], "rank %d (device %d): %s", r, h->dev[r], h->err[r].c_str());
     return GPZ_OK;
 }
 
@@ -432,7 +436,7 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
             Or.resize((size_t)nr);
             for (int64_t q = 0; q < nr; ++q) Or[q] = omega[rows[q]];
         }
-        if (psi_kind == 1) {
+        if (psi_kind == 1 || psi_kind == 3) {
             Pr.resize((size_t)nr * d);
             for (int c = 0; c < d; ++c)
                 for (int64_t q = 0; q < nr; ++q) Pr[(size_t)c * nr + q] = Psi[(size_t)c * n_tot + rows[q]];
@@ -575,7 +579,7 @@ extern "C" int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int3
         const int64_t nr = hi - lo;
         std::vector<double> Xb((size_t)nr * d), Pb, o_mu((size_t)nr * k), o_nu((size_t)nr * k), o_be((size_t)nr * k), o_ga((size_t)nr * k), o_phi;
         for (int c = 0; c < d; ++c) memcpy(&Xb[(size_t)c * nr], Xs + (size_t)c * ns + lo, (size_t)nr * sizeof(double));
-        if (psi_kind == 1) {
+        if (psi_kind == 1 || psi_kind == 3) {
             Pb.resize((size_t)nr * d);
             for (int c = 0; c < d; ++c) memcpy(&Pb[(size_t)c * nr], Psi + (size_t)c * ns + lo, (size_t)nr * sizeof(double));
         } else if (psi_kind == 2) {

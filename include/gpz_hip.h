@@ -88,7 +88,10 @@ typedef int (*gpz_allreduce_fn)(void *user, void *buf, size_t count, void *strea
 
 /* Build the evaluation context.  X is n_tot x d, Y n_tot x k, omega n_tot x 1 (NULL = ones),
  * training/validation n_tot x 1 logical (NULL = all rows / no validation), all HOST pointers,
- * column-major.  psi_kind: 0 none; 1 = n_tot x d (after fixPsi, diag kinds); 2 = d x d x n_tot cube.
+ * column-major.  psi_kind: 0 none; 1 = n_tot x d (after fixPsi, diag kinds); 2 = d x d x n_tot cube (GC/VC);
+ * 3 = n_tot x d per-dimension variances for GC/VC, meaning the diagonal cubes fixPsi.m:27-31 builds from them
+ * (Psi(:,:,i) = diag(S(i,:))): the library expands them, so the caller never materialises d x d x n (6.4 GB at
+ * n = 2e6, d = 20).  Results are identical to passing that cube with psi_kind 2.
  * When world>1 the arrays hold only this rank's row shard. */
 int gpz_ctx_create(const gpz_desc *desc, int64_t n_tot,
                    const double *X, const double *Y,

@@ -99,8 +99,12 @@ static gpz_desc desc_of(const mxArray *model, int32_t *n_gpus) {
     }
     return d;
 }
-static int psi_kind_of(const mxArray *Psi) {   /* fixPsi.m layouts: [] / n x d / d x d x n */
-    return (!Psi || mxIsEmpty(Psi)) ? 0 : (mxGetNumberOfDimensions(Psi) == 3 ? 2 : 1);
+/* fixPsi.m layouts: [] / n x d / d x d x n; an n x d array handed to GC/VC is the per-dimension variances fixPsi.m:27-31 would
+ * turn into diagonal cubes - psi_kind 3, expanded by the library */
+static int psi_kind_of(const mxArray *Psi, const gpz_desc *d) {
+    if (!Psi || mxIsEmpty(Psi)) return 0;
+    if (mxGetNumberOfDimensions(Psi) == 3) return 2;
+    return d->method[1] == 'C' ? 3 : 1;
 }
 static int has_nan(const mxArray *X) {
     const double *x = mxGetPr(X);
@@ -177,7 +181,7 @@ static void ensure_context(const mxArray *const *args) {
     for (int q = 4; q <= 6; ++q)
         if (args[q] && !mxIsEmpty(args[q]) && mxGetNumberOfElements(args[q]) < n)
             mexErrMsgIdAndTxt("gpz:size", "omega / training / validation must have one entry per row of X");
-    if (gpz_mgpu_create(&d, n_gpus, NULL, reducer_of(model), (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi),
+    if (gpz_mgpu_create(&d, n_gpus, NULL, reducer_of(model), (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi, &d),
                         opt(om), optmask(args[5]), optmask(args[6]), &g_mg))
         mexErrMsgIdAndTxt("gpz:create", "%s", gpz_last_error());
     g_key = key;
@@ -210,9 +214,9 @@ static void need_theta(const gpz_desc *d, const mxArray *th) {
 static void need_rows(const gpz_desc *d, const mxArray *X, const mxArray *Psi) {
     need_double(X, "X", 0); need_double(Psi, "Psi", 1);
     if (mxGetN(X) != (mwSize)d->d) mexErrMsgIdAndTxt("gpz:size", "X must be n x model.d");
-    const int kind = psi_kind_of(Psi);
+    const int kind = psi_kind_of(Psi, d);
     const size_t ns = mxGetM(X), dd = (size_t)d->d;
-    if (kind == 1 && (mxGetM(Psi) != ns || mxGetN(Psi) != dd)) mexErrMsgIdAndTxt("gpz:size", "Psi must be n x model.d (fixPsi.m:42-53)");
+    if ((kind == 1 || kind == 3) && (mxGetM(Psi) != ns || mxGetN(Psi) != dd)) mexErrMsgIdAndTxt("gpz:size", "Psi must be n x model.d (fixPsi.m:42-53)");
     if (kind == 2) {
         const mwSize *dm = mxGetDimensions(Psi);
         if (dm[0] != dd || dm[1] != dd || dm[2] != ns) mexErrMsgIdAndTxt("gpz:size", "Psi must be d x d x n (fixPsi.m:22-38)");
@@ -233,7 +237,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         const mwSize ns = mxGetM(prhs[3]);
         plhs[0] = mxCreateDoubleMatrix(ns, d.m, mxREAL);
         mxArray *lb = mxCreateDoubleMatrix(ns, d.k, mxREAL), *N = nlhs > 2 ? mxCreateDoubleMatrix(ns, d.m, mxREAL) : NULL;
-        CHECK(gpz_phi(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)ns, opt(prhs[4]), psi_kind_of(prhs[4]),
+        CHECK(gpz_phi(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)ns, opt(prhs[4]), psi_kind_of(prhs[4], &d),
                       mxGetPr(plhs[0]), mxGetPr(lb), N ? mxGetPr(N) : NULL), "gpz:getphi");
         if (nlhs > 1) plhs[1] = lb; else mxDestroyArray(lb);
         if (nlhs > 2) plhs[2] = N;
@@ -255,7 +259,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         const double *th = mxGetPr(prhs[2]), *w = mxGetPr(prhs[3]), *iS = mxGetPr(prhs[4]);
         /* the rows of a group are independent: contiguous blocks over model.n_gpus GPUs (default all), each through the entry
          * its content selects (predictFull / predictNoisy / predictMissing / predictNoisyMissing, predictDiag.m:39-55) */
-        CHECK(gpz_mgpu_predict(&d, n_gpus, NULL, th, w, iS, opt(prhs[5]), mxGetPr(X), (int64_t)ns, opt(Psi), psi_kind_of(Psi),
+        CHECK(gpz_mgpu_predict(&d, n_gpus, NULL, th, w, iS, opt(prhs[5]), mxGetPr(X), (int64_t)ns, opt(Psi), psi_kind_of(Psi, &d),
                                mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3]), mxGetPr(o[4])), "gpz:predict");
         for (int q = 0; q < 5; ++q)
             if (q < nlhs || q == 0) plhs[q] = o[q]; else mxDestroyArray(o[q]);
@@ -266,7 +270,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         gpz_desc d = desc_of(prhs[1], NULL);
         need_theta(&d, prhs[2]); need_rows(&d, prhs[3], prhs[4]);
         plhs[0] = mxCreateDoubleMatrix(1, d.m, mxREAL);
-        CHECK(gpz_prior(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetM(prhs[3]), opt(prhs[4]), psi_kind_of(prhs[4]),
+        CHECK(gpz_prior(&d, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetM(prhs[3]), opt(prhs[4]), psi_kind_of(prhs[4], &d),
                         mxGetPr(plhs[0]), NULL), "gpz:prior");
         return;
     }

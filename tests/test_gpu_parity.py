@@ -679,7 +679,7 @@ def test_f32_pair_path_against_oracle(method, shape, diag):
         assert abs(stats[key] - val) <= 1e-4 * max(1.0, abs(val)), key
 
 
-def _c5_problem(n, m=None):
+def _c5_problem(n, m=None, cube=True):
     """bench.py's config 5 (same generator, same theta recipe, diagonal Psi cubes), optionally with fewer rows / bases."""
     import bench
     cfg = dict(bench.CONFIGS["c5"])
@@ -687,7 +687,7 @@ def _c5_problem(n, m=None):
     if m:
         cfg["m"] = m
     model, theta, X, Y, _ = bench.synth(cfg)
-    return cfg, model, theta, X, Y, bench.synth_psi(cfg, np.arange(n))
+    return cfg, model, theta, X, Y, bench.synth_psi(cfg, np.arange(n), cube=cube)
 
 
 def test_c5_shape_on_the_bench_theta_against_oracle():
@@ -732,13 +732,17 @@ def test_c5_full_size_directional_derivative():
     """Config 5 at BASELINE.json's full size on one GPU (n = 2e6, d = 20, m = 2000, VC + diagonal Psi cubes, dtype f32; PHI and
     T are 32 GB each): the gradient must be the derivative of the objective along random directions.  The objective
     carries fp32 rounding of 4e9 pair factorisations, so the step is larger than autoGrad.m:34-45's fp64 step and the
-    gate is the fp32 one (1e-3).  Falls back to the 250 000-row shard of the 8-GPU run when host memory is short
-    (the Psi cubes of 2e6 rows are 6.4 GB, NumPy temporaries a few times that)."""
-    import psutil
-    n = 2_000_000 if psutil.virtual_memory().available > 96e9 else 250_000
-    cfg, model, theta, X, Y, Psi = _c5_problem(n)
-    ctx = gpz_amd.GPzContext(model, X, Y, Psi, dtype="f32")
-    del Psi
+    gate is the fp32 one (1e-3).  The input noise goes down as the n x d per-dimension variances (psi_kind 3: the library
+    builds the diagonal cubes of fixPsi.m:27-31 on its side), so the 6.4 GB d x d x n cube is never materialised and the
+    full size ALWAYS runs - no fallback to a shard."""
+    import bench
+    n = bench.CONFIGS["c5"]["n"]
+    cfg, model, theta, X, Y, var = _c5_problem(n, cube=False)
+    assert n == 2_000_000 and X.shape == (n, 20) and var.shape == (n, 20) and model.m == 2000
+    print(f"c5 full-size test: n = {n}, d = {model.d}, m = {model.m}, Psi as n x d variances (psi_kind 3)", flush=True)
+    ctx = gpz_amd.GPzContext(model, X, Y, var, dtype="f32")
+    del var
+    assert ctx.n_train == n
     try:
         f0, g = ctx.eval(theta)
         assert ctx.info == 0 and np.isfinite(f0) and np.isfinite(g).all()
@@ -751,6 +755,38 @@ def test_c5_full_size_directional_derivative():
             assert abs(fd - g @ u) <= 1e-3 * max(abs(g @ u), scale), (n, fd, g @ u, scale)
     finally:
         ctx.close()
+
+
+def test_psi_variances_layout_is_bitwise_the_diagonal_cube():
+    """psi_kind 3 (n x d variances handed to GC/VC) == psi_kind 2 with the diagonal cubes fixPsi.m:27-31 builds from them: same
+    bits from eval, getPHI and getPrior, fp64 and fp32 paths, sharded and not; and against the oracle on the cube."""
+    n, d, m = 900, 6, 14
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VC", True, seed=404)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    var = rng.gamma(1.0, 0.2, (n, d))
+    cube = np.zeros((d, d, n))
+    cube[np.arange(d), np.arange(d), :] = var.T
+    tr = rng.random(n) < 0.8
+    for dt in ("f64", "f32"):
+        a = gpz_amd.GPzContext(model, X, Y, cube, None, tr, ~tr, dtype=dt)
+        b = gpz_amd.GPzContext(model, X, Y, var, None, tr, ~tr, dtype=dt)
+        fa, ga = a.eval(theta); fb, gb = b.eval(theta)
+        assert fa == fb and np.array_equal(ga, gb) and a.stats == b.stats
+        a.close(); b.close()
+    ma = gpz_amd.GPzMulti(model, X, Y, cube, None, tr, ~tr, n_gpus=3, reducer="loopback", dtype="f32")
+    mb = gpz_amd.GPzMulti(model, X, Y, var, None, tr, ~tr, n_gpus=3, reducer="loopback", dtype="f32")
+    fa, ga = ma.eval(theta); fb, gb = mb.eval(theta)
+    assert fa == fb and np.array_equal(ga, gb)
+    ma.close(); mb.close()
+    pa = gpz_amd.getPHI(X, cube, theta, model, want_N=True); pb = gpz_amd.getPHI(X, var, theta, model, want_N=True)
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[3], pb[3])
+    assert np.array_equal(gpz_amd.getPrior(X, cube, theta, model), gpz_amd.getPrior(X, var, theta, model))
+    ref = O.GPz(theta, model, X, Y, cube, None, tr, ~tr)
+    c = gpz_amd.GPzContext(model, X, Y, var, None, tr, ~tr)
+    f, g = c.eval(theta); c.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+    with pytest.raises(_lib.GpzError):                    # a cube handed to a diagonal kind stays an error
+        gpz_amd.GPzContext(gpz_amd.Model(m=m, d=d, k=1, method="VD"), X, Y, cube)
 
 
 def test_f32_flag_leaves_the_other_paths_in_fp64():

@@ -7,7 +7,7 @@ import numpy as np, gpz_amd, bench
 from oracle import gpz_oracle as O
 cfg = dict(bench.CONFIGS["c5"]); cfg["n"] = 400; cfg["m"] = 200
 model, theta, X, y, omega = bench.synth(cfg)
-Psi = bench.synth_psi(cfg, np.arange(cfg["n"]))
+Psi = bench.synth_psi(cfg, np.arange(cfg["n"]), cube=True)
 om = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
 P, G, *_ = O.unpack_theta(theta, om); Gm = O.expand_gamma(G, om)
 print("cond(Gamma_j'Gamma_j): median %.1e max %.1e" % tuple(np.percentile([np.linalg.cond(Gm[:, :, j].T @ Gm[:, :, j]) for j in range(model.m)], [50, 100])))

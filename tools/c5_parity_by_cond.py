@@ -4,7 +4,7 @@ import numpy as np, gpz_amd, bench
 from oracle import gpz_oracle as O
 cfg = dict(bench.CONFIGS["c5"]); cfg["n"] = int(sys.argv[1]) if len(sys.argv) > 1 else cfg["n"]; rows = 60
 model, theta, X, y, omega = bench.synth(cfg)
-X, y = X[:rows], y[:rows]; Psi = bench.synth_psi(cfg, np.arange(rows))
+X, y = X[:rows], y[:rows]; Psi = bench.synth_psi(cfg, np.arange(rows), cube=True)
 om = O.Model(m=model.m, d=model.d, k=1, method=model.method, heteroscedastic=True)
 P, G, *_ = O.unpack_theta(theta, om); Gm = O.expand_gamma(G, om)
 cond = np.array([np.linalg.cond(Gm[:, :, j].T @ Gm[:, :, j]) for j in range(model.m)])

@@ -11,7 +11,7 @@ import gpz_amd
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 250000
 cfg = dict(bench.CONFIGS["c5"]); cfg["n"] = rows
 model, theta, X, y, _ = bench.synth(cfg)
-Psi = bench.synth_psi(cfg, np.arange(rows))
+Psi = bench.synth_psi(cfg, np.arange(rows), cube=True)
 out = {}
 for tag, env in (("fp64 PHI", None), ("PHI rounded to fp32", "1")):
     if env: os.environ["GPZ_EXPERIMENT_ROUND_PHI32"] = env
