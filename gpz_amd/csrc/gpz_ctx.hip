@@ -74,7 +74,7 @@ static int pad_dim(int d) {
     static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
     for (int s : sup)
         if (d <= s) return s;
-    return -1;
+    return d;   // wider inputs: the runtime-d kernels of k_wide.hip, no padding
 }
 static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
 
@@ -214,6 +214,7 @@ struct gpz_ctx {
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
     // missing dimensions without input noise: per-pattern parameter blocks and moment slabs of the tuned kernels
     double *RcP = nullptr, *gen_tslab = nullptr, *gen_frec = nullptr, *fin_part = nullptr;
+    double *gen_ws = nullptr;   // d > 20: runtime-d workspace of the general-path kernels (k_gen.hip), else nullptr
     int gen_tnch = 1;
     int *mom_chunktab = nullptr, *mom_segtab = nullptr;   // moment chunks {first row, end row} that respect the pattern
     int mom_nchunk = 0;                                   // boundaries, and each pattern's range of chunks
@@ -422,11 +423,9 @@ static int setup_model(gpz_ctx *c, const gpz_desc *desc) {
     c->mid = method_id_of(desc->method);
     if (c->mid < 0) return fail(GPZ_ERR_ARG, "unknown method '%.2s'", desc->method);
     if (desc->d < 1 || desc->m < 1 || desc->k < 1) return fail(GPZ_ERR_ARG, "d, m, k must be >= 1");
-    if (desc->k > 8) return fail(GPZ_ERR_UNSUPPORTED, "k > 8 outputs not supported");
     c->kind = c->mid >= 4 ? GPZ_KIND_COV : GPZ_KIND_DIAG;
     c->d = desc->d;
     c->de = pad_dim(desc->d);
-    if (c->de < 0) return fail(GPZ_ERR_UNSUPPORTED, "d = %d > 20 not supported", desc->d);
     c->m = desc->m;
     c->k = desc->k;
     c->hetero = desc->heteroscedastic ? 1 : 0;
@@ -501,7 +500,6 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         if (desc->world > 1 && xnan && !table)
             return fail(GPZ_ERR_UNSUPPORTED, "row-sharded GC/VC with missing values needs the global NaN-pattern table "
                                              "(gpz_ctx_create_sharded)");
-        if (c->d > 20) return fail(GPZ_ERR_UNSUPPORTED, "general GC/VC path supports d <= 20");
         c->gen = true;
         if (table) {   // 1 = missing, as isnan(X) (getPHI.m:43); stored here as observed flags
             for (int g = 0; g < n_patterns; ++g) {
@@ -513,7 +511,7 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         } else if (!xnan) c->pats.assign(1, std::vector<unsigned char>((size_t)c->d, (unsigned char)1));   // one pattern: all observed
         // dtype f32 selects the fp32 pair kernels only where EVERY rank does: a given pattern table means some rank holds
         // missing values (it takes the fp64 route and posts one record block per pattern), so nobody may take the fp32 route
-        c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan && !table;
+        c->psi32 = desc->dtype == GPZ_F32 && Psi && !xnan && !table && c->d <= 20;   // fp32 pair kernels: d <= 20
     }
     if (desc->dtype != GPZ_F64 && desc->dtype != GPZ_F32) return fail(GPZ_ERR_ARG, "dtype must be GPZ_F64 or GPZ_F32");
     if (Psi && c->kind == GPZ_KIND_DIAG && psi_kind != 1)
@@ -542,7 +540,7 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
             while ((int)rs->group_begin.size() < c->ngroups + 1)
                 rs->group_begin.push_back(rs->group_begin.empty() ? 0 : rs->group_begin.back());
         if (!c->has_psi) {
-            const int rpw = phi_cov_rows_per_wg(c->de);
+            const int rpw = phi_cov_rows_per_wg(c->de, c->k);
             for (RowSet *rs : {&c->tr, &c->va}) {
                 std::vector<int> tab;
                 for (int g = 0; g < c->ngroups; ++g)
@@ -572,6 +570,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
             (rc = c->ar.alloc(&c->RcP, (size_t)c->ngroups * c->m * (c->de * (c->de + 1) / 2 + c->de))))
             return rc;
     }
+    if (c->d > 20 && (c->gen || c->has_psi) &&
+        (rc = c->ar.alloc(&c->gen_ws, (size_t)GPZ_GEN_RT_THREADS * gen_ws_per_thread(c->d))))
+        return rc;
     return alloc_params(c);
 }
 
@@ -693,9 +694,9 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         size_t rows = np > (size_t)c->va.n_pad ? np : (size_t)c->va.n_pad;
         if ((rc = c->ar.alloc(&c->phipart, (size_t)c->phipart_groups * 2 * k * rows))) return bail(rc);
     }
-    c->comm1_count = k * mp * mp + GPZ_NS;
+    c->comm1_count = k * mp * mp + gpz_ns(c->k);
     if ((rc = c->ar.alloc(&c->comm1, c->comm1_count))) return bail(rc);
-    c->comm2_count = m * c->nm + k * 2 * mp + k * 4 + GPZ_NS;
+    c->comm2_count = m * c->nm + k * 2 * mp + k * 4 + gpz_ns(c->k);
     if ((rc = c->ar.alloc(&c->comm2, c->comm2_count))) return bail(rc);
     c->nwg_rows = c->tr.n < 2048 ? (c->tr.n > 0 ? c->tr.n : 1) : 2048;
     if (k > 1) {
@@ -719,10 +720,10 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
         if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * (c->nm + 2)))) return bail(rc);
     }
-    if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_ROWSCAL_MAX_NWG * GPZ_NS))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_ROWSCAL_MAX_NWG * gpz_ns(c->k)))) return bail(rc);
     static_assert(GPZ_ROWSCAL_MAX_NWG >= GPZ_SMALL_NWG, "partial record buffer");
-    if ((rc = c->ar.alloc(&c->rstats, (size_t)GPZ_NS))) return bail(rc);
-    if ((rc = c->ar.alloc(&c->spart, (size_t)8))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->rstats, (size_t)gpz_ns(c->k)))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->spart, (size_t)(c->k > 8 ? c->k : 8)))) return bail(rc);
     if ((rc = c->ar.alloc(&c->dGfull, c->kind == GPZ_KIND_COV ? m * c->d * c->d : m * c->d))) return bail(rc);
     if ((rc = c->ar.alloc(&c->out_d, (size_t)c->p + 10))) return bail(rc);
     if (hipHostMalloc((void **)&c->out_h, ((size_t)c->p + 10) * sizeof(double)) != hipSuccess ||
@@ -918,9 +919,9 @@ static int build_phi(gpz_ctx *c) {
         // Sigma_j / inv(Sigma_j) / ln|Sigma_j|: everything except the whitened fp32 route (which works from the QR factor)
         const bool whitened = c->psi32 && c->tr.psi_diag && (c->va.n_pad == 0 || c->va.psi_diag);
         if (!whitened)
-            launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+            launch_gen_prep(c->st, c->pr.G, c->m, c->d, c->de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS, c->gen_ws);
         if (!c->has_psi) {   // missing dimensions only: tuned kernels, one launch per NaN pattern
-            launch_gen_pattern_params(c->st, c->Sig, c->pr.P, c->pat_d, c->ngroups, c->m, c->d, c->de, c->RcP);
+            launch_gen_pattern_params(c->st, c->Sig, c->pr.P, c->pat_d, c->ngroups, c->m, c->d, c->de, c->RcP, c->gen_ws);
             return phi_by_pattern(c, c->tr, c->Phi, c->lnbeta, c->wbeta, nullptr, nullptr, true);
         }
         if (c->psi32) {
@@ -933,7 +934,7 @@ static int build_phi(gpz_ctx *c) {
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else {
             launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
-                           c->Phi, c->tr.Y);
+                           c->Phi, c->tr.Y, c->gen_ws);
         }
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           c->tr.om, nullptr, c->lnbeta, c->wbeta, nullptr);
@@ -971,7 +972,7 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
     {
         Stage s(c, "row_sums");
         launch_sums1(c->st, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, sums1);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), sums1);
     }
     for (int o = 0; o < c->k; ++o) {
         {
@@ -1119,7 +1120,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                     const int rpc = (nr + nch - 1) / nch;
                     nch = (nr + rpc - 1) / rpc;
                     launch_gen_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, gr, g, rb,
-                                       nr, c->pat_d, c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                                       nr, c->pat_d, c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec, c->gen_ws);
                     launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, recs_g);
                 }
                 continue;
@@ -1190,7 +1191,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 const int rpc = (nr + nch - 1) / nch;
                 nch = (nr + rpc - 1) / rpc;
                 launch_gen_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gr, g, rb, nr, c->pat_d, c->m, c->d,
-                                   c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec);
+                                   c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec, c->gen_ws);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, recs_g);
             }
         } else {
@@ -1208,7 +1209,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         Stage s(c, "validation");
         if (int e = phi_by_pattern(c, c->va, nullptr, c->lnbeta_v, nullptr, c->w, c->phiw_v, false)) return e;
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     } else if (have_valid && c->gen) {
         Stage s(c, "validation");
         if (c->psi32) {
@@ -1221,12 +1222,12 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else {
             launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
-                           c->Phi_v, nullptr);
+                           c->Phi_v, nullptr, c->gen_ws);
         }
         launch_gen_rowdot(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, c->w, c->lnbeta_v, nullptr, c->phiw_v);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     } else if (have_valid) {
         Stage s(c, "validation");
         PhiArgs a{};
@@ -1238,9 +1239,9 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         a.Psic = c->va.Psic; a.Mc = c->va.Mc; a.ucnt = c->va.ucnt;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, vsums);
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     } else {
-        launch_zero(c->st, vsums, GPZ_NS);
+        launch_zero(c->st, vsums, gpz_ns(c->k));
     }
     {
         Stage s(c, "allreduce2");
@@ -1261,7 +1262,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         else if (c->gen)
             launch_gen_finish(c->st, mom, c->ngroups, c->pat_d, c->m, c->d, c->de, c->pr.G, c->Sig, c->iSig, c->mid, a.sums1,
                               c->k, c->out_d + 1, c->dGfull, c->k == 1 ? cols : nullptr, c->mp, c->nrec, c->fin_part,
-                              c->has_psi ? 0 : 1);
+                              c->has_psi ? 0 : 1, c->gen_ws);
         launch_finish(c->st, a);
     }
     if (c->g_dev_out) {   // gpz_eval_dev: the gradient stays on the device, only f and the statistics block come up
@@ -1352,8 +1353,8 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, c->w, c->lnbeta, nullptr, c->phiw);
         launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
-        if (int e = allreduce(c, c->rstats, GPZ_NS)) return e;
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), c->rstats);
+        if (int e = allreduce(c, c->rstats, gpz_ns(c->k))) return e;
         launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
                              c->k, c->spart);
         HIPCHK(hipMemcpyAsync(nlogML_partial, c->spart, c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -1367,8 +1368,8 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
-        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, GPZ_NS, c->rstats);
-        if (int e = allreduce(c, c->rstats, GPZ_NS)) return e;
+        launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), c->rstats);
+        if (int e = allreduce(c, c->rstats, gpz_ns(c->k))) return e;
         launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
                              c->k, c->spart);
         HIPCHK(hipMemcpyAsync(nlogML_partial, c->spart, c->k * sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -1577,9 +1578,9 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, wd, c->lnbeta, nullptr, phiw);
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
-        launch_pair_table(c->st, c->kind, c->m, d, c->de, c->pr.P, c->pr.G, c->Sig, c->iSig, tab, rec);
+        launch_pair_table(c->st, c->kind, c->m, d, c->de, c->pr.P, c->pr.G, c->Sig, c->iSig, tab, rec, c->gen_ws);
         launch_predict_noisy(c->st, c->kind, c->tr.n, (long)np, c->m, d, c->de, c->k, c->tr.Xr, c->tr.Psir, c->tr.Psi3, tab,
-                             rec, wd, c->hetero ? c->pr.v : nullptr, iSd, nchunk, ppc, part);
+                             rec, wd, c->hetero ? c->pr.v : nullptr, iSd, nchunk, ppc, part, c->gen_ws);
         launch_slab_sum(c->st, part, nchunk, (size_t)3 * k * np, sums);
         launch_predict_noisy_final(c->st, sums, (long)np, c->tr.n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
                                    outb + 2 * k * np);
@@ -1620,7 +1621,7 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double 
     if (hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st) != hipSuccess)
         rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
-    launch_gen_prep(c->st, c->pr.G, c->m, d, de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS);
+    launch_gen_prep(c->st, c->pr.G, c->m, d, de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS, c->gen_ws);
     const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * (int)k;
     const long npairs = (long)m * (m + 1) / 2;
     // rows per block: X_hat / Psi_hat of a block stay below ~512 MB
@@ -1694,7 +1695,8 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     if (!desc || !theta || !w || !iSigma_w || !priors || !Xs || ns < 1 || !mu || !nu || !beta_i || !gamma)
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
     const int d = desc->d;
-    if (d > 20) return fail(GPZ_ERR_UNSUPPORTED, "d = %d > 20 not supported", d);
+    if (d > 20 || desc->k > 8)
+        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 20 and k <= 8 (d = %d, k = %d)", d, desc->k);
     unsigned obs = 0;
     for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1u << c; }
     for (int c = 0; c < d; ++c)
@@ -1919,27 +1921,24 @@ extern "C" int gpz_dxy(const double *X, int64_t nx, const double *Y, int64_t ny,
 
 extern "C" int gpz_nan_groups(const double *X, int64_t n, int32_t d, int32_t device, int32_t *group_id, int32_t *n_groups) {
     if (!X || !group_id || !n_groups || n < 1 || d < 1) return fail(GPZ_ERR_ARG, "gpz_nan_groups: bad argument");
-    if (d > 64) return fail(GPZ_ERR_UNSUPPORTED, "gpz_nan_groups: d > 64");
     HIPCHK(hipSetDevice(device));
     Arena ar;
     double *dx = nullptr;
-    unsigned long long *mask = nullptr, *uniq = nullptr;
+    unsigned char *work = nullptr;
     int *ng = nullptr, *gid = nullptr;
     int rc = ar.alloc(&dx, (size_t)n * d);
-    if (!rc) rc = ar.alloc(&mask, (size_t)n);
-    if (!rc) rc = ar.alloc(&uniq, (size_t)1024);
+    if (!rc) rc = ar.alloc(&work, nan_groups_work_bytes((long)n, d));
     if (!rc) rc = ar.alloc(&ng, (size_t)1);
     if (!rc) rc = ar.alloc(&gid, (size_t)n);
     if (!rc) {
         hipError_t e = hipMemcpy(dx, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_nan_groups(nullptr, dx, n, d, mask, uniq, ng, gid, 1024);
+            launch_nan_groups(nullptr, dx, n, d, work, ng, gid);
             e = hipMemcpy(group_id, gid, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
         }
         int g = 0;
         if (e == hipSuccess) e = hipMemcpy(&g, ng, sizeof(int), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_nan_groups: %s", hipGetErrorString(e));
-        else if (g > 1024) rc = fail(GPZ_ERR_UNSUPPORTED, "gpz_nan_groups: more than 1024 distinct NaN patterns");
         else *n_groups = g;
     }
     ar.release();

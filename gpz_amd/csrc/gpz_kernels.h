@@ -57,7 +57,12 @@ struct PhiArgs {
     const int *wgtab;
     int nwg_tab;
 };
-int phi_cov_rows_per_wg(int de);   // rows one workgroup of the cov-kind PHI kernel covers (granularity of wgtab)
+int phi_cov_rows_per_wg(int de, int k);   // rows one workgroup of the cov-kind PHI kernel covers (granularity of wgtab)
+bool phi_is_wide(int de, int k);          // d or k beyond the instantiated kernels: the runtime-d route of k_wide.hip
+// runtime-d / any-k variants (k_wide.hip): same arguments and output layouts; -1 when the row tiles do not fit the LDS
+int phi_wide_rows_per_wg();
+int launch_phi_wide(hipStream_t st, const PhiArgs &a);
+int launch_prep_cov_wide(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
 
@@ -153,6 +158,8 @@ struct FusedMomentArgs {
     const int *chunktab;            // as in MomentArgs
 };
 int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a);
+int launch_moments_wide(hipStream_t st, const MomentArgs &a);
+int launch_moments_fused_wide(hipStream_t st, const FusedMomentArgs &a);   // overwrites a.T with dPHI
 // split the reduced [m][nm+2] records into mom [m][nm] and cols [2][mp]
 void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols);
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out);
@@ -184,6 +191,9 @@ void launch_finish(hipStream_t st, const FinishArgs &a);
 //   row_stats: [sum omega*delta^2, sum omega*(-0.5 beta delta^2 + 0.5 ln beta), sum omega*beta*delta^2 per output (8), rows, 0]
 //   sums1:     [sum omega, sum_i omega_i*lnbeta_io per output (8), 0, rows, 0]  -- rows at index 10 in both
 #define GPZ_NS 12
+// more than 8 outputs: the records grow by one slot per extra output, appended behind the 12 standard ones
+__host__ __device__ inline int gpz_ns(int k) { return GPZ_NS + (k > 8 ? k - 8 : 0); }
+__host__ __device__ inline int gpz_ns_idx(int base, int o) { return o < 8 ? base + o : GPZ_NS + (o - 8); }
 #define GPZ_SMALL_NWG 128
 void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, const double *lnbeta,
                       long ldx, int n, int k, double *partial);
@@ -192,8 +202,9 @@ void launch_sums1(hipStream_t st, const double *omega, const double *lnbeta, lon
 void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const double *logdet, const double *sums1,
                           const double *rstats, int m, int k, double *out);
 // NaN-pattern grouping (getPHI.m:43-54): masks, first-occurrence unique list, ids.
-int launch_nan_groups(hipStream_t st, const double *X, long n, int d, unsigned long long *mask, unsigned long long *uniq,
-                      int *n_groups, int *group_id, int max_groups);
+size_t nan_groups_work_bytes(long n, int d);
+int launch_nan_groups(hipStream_t st, const double *X, long n, int d, void *work /* nan_groups_work_bytes(n, d) */,
+                      int *n_groups, int *group_id);
 
 // ---- general covariance-kind path: input noise and/or missing dimensions (k_gen.hip) ---------------
 struct GenRows {
@@ -203,17 +214,22 @@ struct GenRows {
     const int *rows_by_group;  // row indices sorted by pattern id
     int n, n_pad;
 };
+// ws: runtime-d workspace of GPZ_GEN_RT_THREADS * gen_ws_per_thread(d) doubles, needed (non-null) when d > 20; the small
+// matrices of the general path live there instead of per-thread scratch and the kernels run as grid-stride loops
+#define GPZ_GEN_RT_THREADS 8192
+size_t gen_ws_per_thread(int d);
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
-                     const unsigned char *pat, int ngroups, double *lnS);
+                     const unsigned char *pat, int ngroups, double *lnS, double *ws = nullptr);
 // missing dimensions without input noise: per-pattern parameter block for the tuned PHI kernel ([R~ | c~], layout of
 // k_prep_cov) and conversion of the tuned moment sums of a pattern into the records k_gen_finish consumes
 void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *P, const unsigned char *pat, int G, int m,
-                               int d, int de, double *RcAll /* G blocks of m*(nt+de) */);
+                               int d, int de, double *RcAll /* G blocks of m*(nt+de) */, double *ws = nullptr);
 void launch_gen_convert_moments(hipStream_t st, const double *frecAll /* [G][m][stride] */, int stride, int has_r,
                                 const double *Sig, const unsigned char *pat, int G, int m, int d, int de,
                                 double *recsAll /* [G][m][nrec] */, int nrec);
 void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
-                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y);
+                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y,
+                    double *ws = nullptr);
 void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y);
 // register-resident variants for Psi without missing dimensions, 2 <= d <= 10 (k_psi.hip); return -1 outside that range
 bool psi_fast_path_available(int d);
@@ -247,22 +263,24 @@ void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ld
 void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                         const double *v, const GenRows &r, int g, int row_begin, int nrows, const unsigned char *pat, int m,
                         int d, int de, const double *P, const double *Sig, int nchunk, int rows_per_chunk, double *slab,
-                        int nrec);
+                        int nrec, double *ws = nullptr);
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
                        double *grad, double *dGfull, double *cols, int mp, int nrec,
                        double *part /* G*m*(d + d*d + 2) doubles of scratch */,
-                       int raw /* records hold plain moment sums (no input noise): see k_gen_convert_moments */);
+                       int raw /* records hold plain moment sums (no input noise): see k_gen_convert_moments */,
+                       double *ws = nullptr);
 
 // prediction with input noise (predictDiag.m:75-125 / predictCov.m:70-132) and the getPrior iteration (getPrior.m:7-20)
 void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,
-                       const double *iSig, double *tab, int rec);
+                       const double *iSig, double *tab, int rec, double *ws = nullptr);
 int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
                              long pairs_per_chunk, double *part);   // k_psi.hip: 2 <= d <= 10, else -1
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
-                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part);
+                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part,
+                          double *ws = nullptr);
 void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
                                 const double *lnbeta, const double *b, double *gamma, double *nu, double *beta_i);
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,

@@ -14,119 +14,144 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
-#define GDM 20   // maximum d of the general path
+// Small-matrix storage of the general path.  CAP > 0: compile-time capacity, the matrices live in per-thread scratch with
+// leading dimension CAP (d <= 20, the layout the path was measured with).  CAP == 0: runtime d of any size — leading
+// dimension d, the matrices live in a global workspace of gen_ws_per_thread(d) doubles per thread and the kernels run as
+// grid-stride loops over GPZ_GEN_RT_THREADS threads, so the workspace does not grow with the problem.
+#define GCAP 20
+#define GEN_ARR(name, cap_count, rt_count)                       \
+    double name##_loc[CAP ? (cap_count) : 1];                    \
+    double *name = name##_loc;                                   \
+    if (!CAP) { name = wsp; wsp += (rt_count); }
+#define GEN_IARR(name, cap_count, rt_count)                      \
+    int name##_loc[CAP ? (cap_count) : 1];                       \
+    int *name = name##_loc;                                      \
+    if (!CAP) { name = (int *)wsp; wsp += ((rt_count) + 1) / 2; }
+#define GEN_SETUP()                                                                                   \
+    const long gt_ = (long)blockIdx.x * blockDim.x + threadIdx.x, nth_ = (long)gridDim.x * blockDim.x; \
+    const int GDM = CAP ? CAP : d;                                                                    \
+    double *wsp = ws ? ws + (size_t)gt_ * ws_stride : nullptr;                                        \
+    (void)wsp
 
-// Cholesky of the leading no x no block of M (row-major, leading dimension GDM), lower factor in place.
-__device__ inline bool chol_small(double *M, int no) {
+size_t gen_ws_per_thread(int d) { return (size_t)9 * d * d + (size_t)8 * d + 16; }
+
+// Cholesky of the leading no x no block of M (row-major, leading dimension ld), lower factor in place.
+__device__ __forceinline__ bool chol_small(double *M, int no, int ld) {
     bool ok = true;
     for (int c = 0; c < no; ++c) {
-        double p = M[c * GDM + c];
-        for (int q = 0; q < c; ++q) p = fma(-M[c * GDM + q], M[c * GDM + q], p);
+        double p = M[c * ld + c];
+        for (int q = 0; q < c; ++q) p = fma(-M[c * ld + q], M[c * ld + q], p);
         if (!(p > 0.0)) ok = false;
         const double dd = sqrt(p);
-        M[c * GDM + c] = dd;
+        M[c * ld + c] = dd;
         for (int r = c + 1; r < no; ++r) {
-            double s = M[r * GDM + c];
-            for (int q = 0; q < c; ++q) s = fma(-M[r * GDM + q], M[c * GDM + q], s);
-            M[r * GDM + c] = s / dd;
+            double s = M[r * ld + c];
+            for (int q = 0; q < c; ++q) s = fma(-M[r * ld + q], M[c * ld + q], s);
+            M[r * ld + c] = s / dd;
         }
     }
     return ok;
 }
 
 // W = inv(L) (lower), then Minv = W' W; L in M (lower), result symmetric full in Minv.
-__device__ inline void inv_from_chol(const double *L, int no, double *W, double *Minv) {
+__device__ __forceinline__ void inv_from_chol(const double *L, int no, double *W, double *Minv, int ld) {
     for (int c = 0; c < no; ++c) {
-        W[c * GDM + c] = 1.0 / L[c * GDM + c];
+        W[c * ld + c] = 1.0 / L[c * ld + c];
         for (int r = c + 1; r < no; ++r) {
             double s = 0.0;
-            for (int q = c; q < r; ++q) s = fma(L[r * GDM + q], W[q * GDM + c], s);
-            W[r * GDM + c] = -s / L[r * GDM + r];
+            for (int q = c; q < r; ++q) s = fma(L[r * ld + q], W[q * ld + c], s);
+            W[r * ld + c] = -s / L[r * ld + r];
         }
     }
     for (int a = 0; a < no; ++a)
         for (int b = 0; b <= a; ++b) {
             double s = 0.0;
-            for (int q = a; q < no; ++q) s = fma(W[q * GDM + a], W[q * GDM + b], s);
-            Minv[a * GDM + b] = s;
-            Minv[b * GDM + a] = s;
+            for (int q = a; q < no; ++q) s = fma(W[q * ld + a], W[q * ld + b], s);
+            Minv[a * ld + b] = s;
+            Minv[b * ld + a] = s;
         }
 }
 
 // Sigma_j = inv(Gamma_j' Gamma_j), iSigma_j = Gamma_j' Gamma_j   (getPHI.m:73, GPz.m:146-147); d x d row-major, stride d*d.
+template <int CAP>
 __global__ void k_gen_prep(const double *__restrict__ G, int m, int d, int de, double *__restrict__ Sig,
-                           double *__restrict__ iSig) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    double A[GDM * GDM], W[GDM * GDM], Ai[GDM * GDM];
-    const double *Gj = G + (size_t)j * de * de;
-    for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) {
-            double s = 0.0;
-            for (int q = 0; q < d; ++q) s = fma(Gj[q * de + a], Gj[q * de + b], s);
-            A[a * GDM + b] = s;
-            iSig[(size_t)j * d * d + a * d + b] = s;
-        }
-    chol_small(A, d);
-    inv_from_chol(A, d, W, Ai);
-    for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) Sig[(size_t)j * d * d + a * d + b] = Ai[a * GDM + b];
+                           double *__restrict__ iSig, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_ARR(A, GCAP * GCAP, d * d) GEN_ARR(W, GCAP * GCAP, d * d) GEN_ARR(Ai, GCAP * GCAP, d * d)
+    for (long j = gt_; j < m; j += nth_) {
+        const double *Gj = G + (size_t)j * de * de;
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b < d; ++b) {
+                double s = 0.0;
+                for (int q = 0; q < d; ++q) s = fma(Gj[q * de + a], Gj[q * de + b], s);
+                A[a * GDM + b] = s;
+                iSig[(size_t)j * d * d + a * d + b] = s;
+            }
+        chol_small(A, d, GDM);
+        inv_from_chol(A, d, W, Ai, GDM);
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b < d; ++b) Sig[(size_t)j * d * d + a * d + b] = Ai[a * GDM + b];
+    }
 }
 
 // ln|Sigma_j,oo| for every (pattern g, basis j):  lnS[g*m + j]
+template <int CAP>
 __global__ void k_gen_lndet(const double *__restrict__ Sig, const unsigned char *__restrict__ pat, int G, int m, int d,
-                            double *__restrict__ lnS) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= G * m) return;
-    const int g = e / m, j = e % m;
-    int o[GDM], no = 0;
-    for (int c = 0; c < d; ++c)
-        if (pat[g * d + c]) o[no++] = c;
-    double M[GDM * GDM];
-    for (int a = 0; a < no; ++a)
-        for (int b = 0; b < no; ++b) M[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
-    chol_small(M, no);
-    double s = 0.0;
-    for (int a = 0; a < no; ++a) s += log(M[a * GDM + a]);
-    lnS[e] = 2.0 * s;
+                            double *__restrict__ lnS, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_IARR(o, GCAP, d) GEN_ARR(M, GCAP * GCAP, d * d)
+    for (long e = gt_; e < (long)G * m; e += nth_) {
+        const int g = (int)(e / m), j = (int)(e % m);
+        int no = 0;
+        for (int c = 0; c < d; ++c)
+            if (pat[g * d + c]) o[no++] = c;
+        for (int a = 0; a < no; ++a)
+            for (int b = 0; b < no; ++b) M[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
+        chol_small(M, no, GDM);
+        double s = 0.0;
+        for (int a = 0; a < no; ++a) s += log(M[a * GDM + a]);
+        lnS[e] = 2.0 * s;
+    }
 }
 
 // PHI build, one thread per row, loop over basis functions.  Xr: n_pad x de (0 at missing), gid: pattern per row,
 // Psi3: n_pad x d*d (nullptr without input noise).  Writes columns [0, m) of PHI.
+template <int CAP>
 __global__ __launch_bounds__(64) void k_gen_phi(const double *__restrict__ Xr, int de, const int *__restrict__ gid,
                                                  const unsigned char *__restrict__ pat, const double *__restrict__ Psi3,
                                                  int n, int m, int d, const double *__restrict__ P,
                                                  const double *__restrict__ Sig, const double *__restrict__ lnS,
-                                                 double *__restrict__ Phi, int ld) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int g = gid[i];
-    int o[GDM], no = 0;
-    for (int c = 0; c < d; ++c)
-        if (pat[g * d + c]) o[no++] = c;
-    const double cmiss = -0.5 * (double)(d - no) * GPZ_LOG2;               // -1/2 |u| ln 2
-    double x[GDM], M[GDM * GDM], y[GDM];
-    for (int a = 0; a < no; ++a) x[a] = Xr[(size_t)i * de + o[a]];
-    for (int j = 0; j < m; ++j) {
-        const double *Sj = Sig + (size_t)j * d * d;
-        for (int a = 0; a < no; ++a)
-            for (int b = 0; b <= a; ++b) {
-                double v = Sj[o[a] * d + o[b]];
-                if (Psi3) v += Psi3[(size_t)i * d * d + o[a] + d * o[b]];   // Psi(o,o,i)   getPHI.m:84
-                M[a * GDM + b] = v;
+                                                 double *__restrict__ Phi, int ld, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_IARR(o, GCAP, d) GEN_ARR(x, GCAP, d) GEN_ARR(M, GCAP * GCAP, d * d) GEN_ARR(y, GCAP, d)
+    for (long i = gt_; i < n; i += nth_) {
+        const int g = gid[i];
+        int no = 0;
+        for (int c = 0; c < d; ++c)
+            if (pat[g * d + c]) o[no++] = c;
+        const double cmiss = -0.5 * (double)(d - no) * GPZ_LOG2;               // -1/2 |u| ln 2
+        for (int a = 0; a < no; ++a) x[a] = Xr[(size_t)i * de + o[a]];
+        for (int j = 0; j < m; ++j) {
+            const double *Sj = Sig + (size_t)j * d * d;
+            for (int a = 0; a < no; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double v = Sj[o[a] * d + o[b]];
+                    if (Psi3) v += Psi3[(size_t)i * d * d + o[a] + d * o[b]];   // Psi(o,o,i)   getPHI.m:84
+                    M[a * GDM + b] = v;
+                }
+            chol_small(M, no, GDM);
+            double quad = 0.0, ldM = 0.0;
+            for (int a = 0; a < no; ++a) {                                      // y = L^-1 Delta_o
+                double s = x[a] - P[(size_t)j * de + o[a]];
+                for (int q = 0; q < a; ++q) s = fma(-M[a * GDM + q], y[q], s);
+                y[a] = s / M[a * GDM + a];
+                quad = fma(y[a], y[a], quad);
+                ldM += log(M[a * GDM + a]);
             }
-        chol_small(M, no);
-        double quad = 0.0, ldM = 0.0;
-        for (int a = 0; a < no; ++a) {                                      // y = L^-1 Delta_o
-            double s = x[a] - P[(size_t)j * de + o[a]];
-            for (int q = 0; q < a; ++q) s = fma(-M[a * GDM + q], y[q], s);
-            y[a] = s / M[a * GDM + a];
-            quad = fma(y[a], y[a], quad);
-            ldM += log(M[a * GDM + a]);
+            double lp = -0.5 * quad + cmiss;                                    // getPHI.m:76
+            if (Psi3) lp += 0.5 * lnS[(size_t)g * m + j] - ldM;                 // getPHI.m:86  (+1/2 ln|S_oo| - 1/2 ln|M|)
+            Phi[(size_t)i * ld + j] = exp(lp);
         }
-        double lp = -0.5 * quad + cmiss;                                    // getPHI.m:76
-        if (Psi3) lp += 0.5 * lnS[(size_t)g * m + j] - ldM;                 // getPHI.m:86  (+1/2 ln|S_oo| - 1/2 ln|M|)
-        Phi[(size_t)i * ld + j] = exp(lp);
     }
 }
 
@@ -173,9 +198,10 @@ __global__ __launch_bounds__(256) void k_gen_rowdot(const double *__restrict__ P
     }
 }
 
-// Moment accumulation for one pattern group: thread per basis j, rows of the group given by an index list.
+// Moment accumulation for one pattern group: thread per (chunk, basis j), rows of the group given by an index list.
 //   rec[j] = [A0 = sum dp | Acc1 (d) = sum dp * embed(M^-1 Delta) | Cacc (d*d) = sum dp * embed(-M^-1 + u u') | r1 | r2]
 // dp = dPHI_ij from T, PHI and the row scalars (single-output fused form) or read from dPhi (multi-output).
+template <int CAP>
 __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ Phi, const double *__restrict__ T, int ld,
                                                      const double *__restrict__ rowscal, const double *__restrict__ w,
                                                      const double *__restrict__ v, const double *__restrict__ Xr, int de,
@@ -183,91 +209,102 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
                                                      const unsigned char *__restrict__ pat, int g,
                                                      const double *__restrict__ Psi3, int m, int d,
                                                      const double *__restrict__ P, const double *__restrict__ Sig,
-                                                     int rows_per_chunk, double *__restrict__ slab, int nrec) {
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int chunk = blockIdx.x;
-    int o[GDM], no = 0;
-    for (int c = 0; c < d; ++c)
-        if (pat[g * d + c]) o[no++] = c;
-    double M[GDM * GDM], W[GDM * GDM], Mi[GDM * GDM], u[GDM], dl[GDM];
-    double acc1[GDM], cacc[GDM * GDM];
-    double a0 = 0.0, r1 = 0.0, r2 = 0.0;
-    for (int a = 0; a < no; ++a) acc1[a] = 0.0;
-    for (int a = 0; a < no * GDM; ++a) cacc[a] = 0.0;
-    const double wj = w ? w[j] : 0.0, vj = v ? v[j] : 0.0;
-    const double *Sj = Sig + (size_t)j * d * d;
-    const int r0 = chunk * rows_per_chunk, rend = min(nrows, r0 + rows_per_chunk);
-    if (!Psi3) {   // without input noise M = Sigma_j,oo is the same for every row of the pattern: invert once
-        for (int a = 0; a < no; ++a)
-            for (int b = 0; b <= a; ++b) M[a * GDM + b] = Sj[o[a] * d + o[b]];
-        chol_small(M, no);
-        inv_from_chol(M, no, W, Mi);
-    }
-    for (int rr = r0; rr < rend; ++rr) {
-        const int i = rows[rr];
-        const double ph = Phi[(size_t)i * ld + j];
-        double dp;
-        if (rowscal) {
-            const double *rs = rowscal + (size_t)i * 4;
-            dp = (-rs[0] * T[(size_t)i * ld + j] - rs[1] * wj + rs[2] * vj) * ph;   // GPz.m:72,90,106,113
-            r1 = fma(ph, rs[1], r1);
-            r2 = fma(ph, rs[2], r2);
-        } else {
-            dp = T[(size_t)i * ld + j];                                     // dPHI already formed (k > 1)
-        }
-        for (int a = 0; a < no; ++a) dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
-        if (Psi3) {
+                                                     int nchunk, int rows_per_chunk, double *__restrict__ slab, int nrec,
+                                                     double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_IARR(o, GCAP, d)
+    GEN_ARR(M, GCAP * GCAP, d * d) GEN_ARR(W, GCAP * GCAP, d * d) GEN_ARR(Mi, GCAP * GCAP, d * d) GEN_ARR(u, GCAP, d)
+    GEN_ARR(dl, GCAP, d) GEN_ARR(acc1, GCAP, d) GEN_ARR(cacc, GCAP * GCAP, d * d)
+    const int mj = (m + 63) / 64 * 64;                  // basis index fastest, padded to whole waves (as the 2-D grid was)
+    for (long it = gt_; it < (long)nchunk * mj; it += nth_) {
+        const int chunk = (int)(it / mj), j = (int)(it % mj);
+        if (j >= m) continue;
+        int no = 0;
+        for (int c = 0; c < d; ++c)
+            if (pat[g * d + c]) o[no++] = c;
+        double a0 = 0.0, r1 = 0.0, r2 = 0.0;
+        for (int a = 0; a < no; ++a) acc1[a] = 0.0;
+        for (int a = 0; a < no * GDM; ++a) cacc[a] = 0.0;
+        const double wj = w ? w[j] : 0.0, vj = v ? v[j] : 0.0;
+        const double *Sj = Sig + (size_t)j * d * d;
+        const int r0 = chunk * rows_per_chunk, rend = min(nrows, r0 + rows_per_chunk);
+        if (!Psi3) {   // without input noise M = Sigma_j,oo is the same for every row of the pattern: invert once
             for (int a = 0; a < no; ++a)
-                for (int b = 0; b <= a; ++b)
-                    M[a * GDM + b] = Sj[o[a] * d + o[b]] + Psi3[(size_t)i * d * d + o[a] + d * o[b]];
-            chol_small(M, no);
-            inv_from_chol(M, no, W, Mi);                                    // iPSoo   GPz.m:170
+                for (int b = 0; b <= a; ++b) M[a * GDM + b] = Sj[o[a] * d + o[b]];
+            chol_small(M, no, GDM);
+            inv_from_chol(M, no, W, Mi, GDM);
         }
+        for (int rr = r0; rr < rend; ++rr) {
+            const int i = rows[rr];
+            const double ph = Phi[(size_t)i * ld + j];
+            double dp;
+            if (rowscal) {
+                const double *rs = rowscal + (size_t)i * 4;
+                dp = (-rs[0] * T[(size_t)i * ld + j] - rs[1] * wj + rs[2] * vj) * ph;   // GPz.m:72,90,106,113
+                r1 = fma(ph, rs[1], r1);
+                r2 = fma(ph, rs[2], r2);
+            } else {
+                dp = T[(size_t)i * ld + j];                                     // dPHI already formed (k > 1)
+            }
+            for (int a = 0; a < no; ++a) dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
+            if (Psi3) {
+                for (int a = 0; a < no; ++a)
+                    for (int b = 0; b <= a; ++b)
+                        M[a * GDM + b] = Sj[o[a] * d + o[b]] + Psi3[(size_t)i * d * d + o[a] + d * o[b]];
+                chol_small(M, no, GDM);
+                inv_from_chol(M, no, W, Mi, GDM);                               // iPSoo   GPz.m:170
+            }
+            for (int a = 0; a < no; ++a) {
+                double s = 0.0;
+                for (int b = 0; b < no; ++b) s = fma(Mi[a * GDM + b], dl[b], s);
+                u[a] = s;
+            }
+            a0 += dp;
+            for (int a = 0; a < no; ++a) {
+                acc1[a] = fma(dp, u[a], acc1[a]);                               // GPz.m:152,172
+                for (int b = 0; b < no; ++b) cacc[a * GDM + b] = fma(dp, u[a] * u[b] - Mi[a * GDM + b], cacc[a * GDM + b]);
+            }
+        }
+        double *rec = slab + ((size_t)chunk * m + j) * nrec;
+        for (int q = 0; q < nrec; ++q) rec[q] = 0.0;
+        rec[0] = a0;
         for (int a = 0; a < no; ++a) {
-            double s = 0.0;
-            for (int b = 0; b < no; ++b) s = fma(Mi[a * GDM + b], dl[b], s);
-            u[a] = s;
+            rec[1 + o[a]] = acc1[a];
+            for (int b = 0; b < no; ++b) rec[1 + d + o[a] * d + o[b]] = cacc[a * GDM + b];
         }
-        a0 += dp;
-        for (int a = 0; a < no; ++a) {
-            acc1[a] = fma(dp, u[a], acc1[a]);                               // GPz.m:152,172
-            for (int b = 0; b < no; ++b) cacc[a * GDM + b] = fma(dp, u[a] * u[b] - Mi[a * GDM + b], cacc[a * GDM + b]);
-        }
+        rec[1 + d + d * d] = r1;
+        rec[2 + d + d * d] = r2;
     }
-    double *rec = slab + ((size_t)chunk * m + j) * nrec;
-    for (int q = 0; q < nrec; ++q) rec[q] = 0.0;
-    rec[0] = a0;
-    for (int a = 0; a < no; ++a) {
-        rec[1 + o[a]] = acc1[a];
-        for (int b = 0; b < no; ++b) rec[1 + d + o[a] * d + o[b]] = cacc[a * GDM + b];
-    }
-    rec[1 + d + d * d] = r1;
-    rec[2 + d + d * d] = r2;
 }
 
 // Chain the per-(pattern, basis) records to dP, dGamma (GPz.m:151-159,174-181) and the column sums.
 // recs: [G][m][nrec] reduced over chunks.  Writes grad dP (scaled), dGamma into grad (VC) or dGfull (GC), cols[2][mp].
 // One thread per (basis, pattern): the pattern's contribution [dP (d) | dGamma (d x d) | r1 | r2] goes to
 // part[(g*m + j)*(d + d*d + 2)]; k_gen_finish_sum adds the patterns up in fixed order and writes the gradient blocks.
+template <int CAP>
 __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ recs, int G,
                                                     const unsigned char *__restrict__ pat, int m, int d, int de,
                                                     const double *__restrict__ Gam, const double *__restrict__ Sig,
                                                     const double *__restrict__ iSig, double *__restrict__ part, int nrec,
-                                                    int raw) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    double dP[GDM], dG[GDM * GDM];
+                                                    int raw, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_ARR(dP, GCAP, d) GEN_ARR(dG, GCAP * GCAP, d * d)
+    GEN_ARR(Soo, GCAP * GCAP, d * d) GEN_ARR(W, GCAP * GCAP, d * d) GEN_ARR(Sinv, GCAP * GCAP, d * d)
+    GEN_ARR(dS, GCAP * GCAP, d * d) GEN_ARR(tmp, GCAP * GCAP, d * d) GEN_ARR(Kuo, GCAP * GCAP, d * d)
+    GEN_ARR(Aeff, GCAP * GCAP, d * d) GEN_ARR(y, GCAP, d) GEN_ARR(dgo, GCAP, d)
+    GEN_IARR(o, GCAP, d) GEN_IARR(uix, GCAP, d)
+    const int mj = (m + 63) / 64 * 64;
+    for (long it = gt_; it < (long)G * mj; it += nth_) {
+    const int g = (int)(it / mj), j = (int)(it % mj);
+    if (j >= m) continue;
     for (int c = 0; c < d; ++c) dP[c] = 0.0;
     for (int e = 0; e < d * GDM; ++e) dG[e] = 0.0;
     double r1 = 0.0, r2 = 0.0;
     const double *Sj = Sig + (size_t)j * d * d, *iSj = iSig + (size_t)j * d * d;
     const double *Gj = Gam + (size_t)j * de * de;
-    double Soo[GDM * GDM], W[GDM * GDM], Sinv[GDM * GDM], dS[GDM * GDM], tmp[GDM * GDM], Kuo[GDM * GDM], Aeff[GDM * GDM];
     {
-        const int g = blockIdx.y;
         const double *rec = recs + ((size_t)g * m + j) * nrec;
-        int o[GDM], uix[GDM], no = 0, nu = 0;
+        int no = 0, nu = 0;
         for (int c = 0; c < d; ++c) {
             if (pat[g * d + c]) o[no++] = c; else uix[nu++] = c;
         }
@@ -276,12 +313,11 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b) Soo[a * GDM + b] = Sj[o[a] * d + o[b]];
         for (int e = 0; e < no * GDM; ++e) tmp[e] = Soo[e];
-        chol_small(tmp, no);
+        chol_small(tmp, no, GDM);
         if (raw) {
             // No input noise: the records are the plain sums M1 = sum dPHI Delta_o and S = sum dPHI Delta_o Delta_o'.
             // dP_o = Sigma_oo^-1 M1 (GPz.m:153) by two triangular solves, and since dSoo = 1/2 Sigma_oo^-1 S Sigma_oo^-1
             // (GPz.m:154, the A0 terms of :174 cancel), diSoo = -Soo dSoo Soo = -1/2 S: no inverse, no products.
-            double y[GDM];
             for (int a = 0; a < no; ++a) {
                 double t = rec[1 + o[a]];
                 for (int q = 0; q < a; ++q) t = fma(-tmp[a * GDM + q], y[q], t);
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
         } else {
         for (int a = 0; a < no; ++a) dP[o[a]] += rec[1 + o[a]];
         // Sigma_oo^-1
-        inv_from_chol(tmp, no, W, Sinv);
+        inv_from_chol(tmp, no, W, Sinv, GDM);
         // dSoo = 1/2 (A0 Sigma_oo^-1 + Cacc)       GPz.m:174
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b)
@@ -321,8 +357,8 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
         if (nu > 0) {
             for (int a = 0; a < nu; ++a)
                 for (int b = 0; b < nu; ++b) tmp[a * GDM + b] = iSj[uix[a] * d + uix[b]];
-            chol_small(tmp, nu);
-            inv_from_chol(tmp, nu, W, Sinv);                                // Sinv = iSigma_uu^-1
+            chol_small(tmp, nu, GDM);
+            inv_from_chol(tmp, nu, W, Sinv, GDM);                           // Sinv = iSigma_uu^-1
             for (int a = 0; a < nu; ++a)
                 for (int b = 0; b < no; ++b) {
                     double s = 0.0;
@@ -338,7 +374,6 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
                 Aeff[r * GDM + b] = s;
             }
         for (int r = 0; r < d; ++r) {
-            double dgo[GDM];
             for (int b = 0; b < no; ++b) {
                 double s = 0.0;
                 for (int q = 0; q < no; ++q) s = fma(Aeff[r * GDM + q], dS[q * GDM + b], s);
@@ -352,12 +387,13 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
             }
         }
     }
-    double *o = part + ((size_t)blockIdx.y * m + j) * (d + d * d + 2);
-    for (int c = 0; c < d; ++c) o[c] = dP[c];
+    double *op = part + ((size_t)g * m + j) * (d + d * d + 2);
+    for (int c = 0; c < d; ++c) op[c] = dP[c];
     for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) o[d + a * d + b] = dG[a * GDM + b];
-    o[d + d * d] = r1;
-    o[d + d * d + 1] = r2;
+        for (int b = 0; b < d; ++b) op[d + a * d + b] = dG[a * GDM + b];
+    op[d + d * d] = r1;
+    op[d + d * d + 1] = r2;
+    }
 }
 
 // One thread per (basis, entry): threads along the entries so the loads of a pattern's block are contiguous.
@@ -387,12 +423,15 @@ __global__ void k_gen_finish_sum(const double *__restrict__ part, int G, int m, 
 //   VlnS_i = sum_ab v_a v_b E[phi_a phi_b] - (ElnS_i - b)^2,  E[phi_a phi_b](x_i) = Z_ab N(x_i | c_ab, C_ab + Psi_i).
 // Pair table: one record per (a >= b): [lnZ_ab | c_ab (d) | C_ab (d diag or d*d)].
 // ---------------------------------------------------------------------------------------------
+template <int CAP>
 __global__ void k_pair_table(int kind, int m, int d, int de, const double *__restrict__ P, const double *__restrict__ G,
                              const double *__restrict__ Sig, const double *__restrict__ iSig, double *__restrict__ tab,
-                             int rec) {
+                             int rec, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_ARR(A, GCAP * GCAP, d * d) GEN_ARR(W, GCAP * GCAP, d * d) GEN_ARR(Ci, GCAP * GCAP, d * d)
+    GEN_ARR(S2, GCAP * GCAP, d * d) GEN_ARR(S2i, GCAP * GCAP, d * d) GEN_ARR(rhs, GCAP, d)
     const long npair = (long)m * (m + 1) / 2;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= npair) return;
+    for (long e = gt_; e < npair; e += nth_) {
     // e -> (a >= b): a = floor((sqrt(8e+1)-1)/2)
     long a = (long)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
     while (a * (a + 1) / 2 > e) --a;
@@ -413,7 +452,6 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
         }
         o[0] = lnz;
     } else {
-        double A[GDM * GDM], W[GDM * GDM], Ci[GDM * GDM], S2[GDM * GDM], S2i[GDM * GDM], rhs[GDM];
         const double *iSa = iSig + (size_t)a * d * d, *iSb = iSig + (size_t)b * d * d;
         const double *Sa = Sig + (size_t)a * d * d, *Sb = Sig + (size_t)b * d * d;
         double lnz = 0.0;
@@ -422,13 +460,13 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
             const double *S = pass ? Sb : Sa;
             for (int r = 0; r < d; ++r)
                 for (int c = 0; c <= r; ++c) A[r * GDM + c] = S[r * d + c];
-            chol_small(A, d);
+            chol_small(A, d, GDM);
             for (int r = 0; r < d; ++r) lnz += log(A[r * GDM + r]);          // 1/2 ln|Sigma| = sum ln L_rr
         }
         for (int r = 0; r < d; ++r)
             for (int c = 0; c <= r; ++c) A[r * GDM + c] = iSa[r * d + c] + iSb[r * d + c];    // iCij          :100
-        chol_small(A, d);
-        inv_from_chol(A, d, W, Ci);                                                            // Cij = inv(iCij)
+        chol_small(A, d, GDM);
+        inv_from_chol(A, d, W, Ci, GDM);                                                       // Cij = inv(iCij)
         for (int c = 0; c < d; ++c) {
             double s = 0.0;
             for (int r = 0; r < d; ++r) s += P[a * de + r] * iSa[r * d + c] + P[b * de + r] * iSb[r * d + c];
@@ -443,31 +481,37 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
             for (int c = 0; c < d; ++c) o[1 + d + r * d + c] = Ci[r * GDM + c];
         for (int r = 0; r < d; ++r)
             for (int c = 0; c <= r; ++c) S2[r * GDM + c] = Sa[r * d + c] + Sb[r * d + c];
-        chol_small(S2, d);
+        chol_small(S2, d, GDM);
         double ld = 0.0;
         for (int r = 0; r < d; ++r) ld += log(S2[r * GDM + r]);
-        inv_from_chol(S2, d, W, S2i);
+        inv_from_chol(S2, d, W, S2i, GDM);
         double q = 0.0;
         for (int r = 0; r < d; ++r)
             for (int c = 0; c < d; ++c) q += (P[a * de + r] - P[b * de + r]) * S2i[r * GDM + c] * (P[a * de + c] - P[b * de + c]);
         o[0] = lnz - 0.5 * q - ld;                                                             // :105  (-1/2 ln|Sa+Sb| = -ld)
     }
+    }
 }
 
 // One thread per sample, pairs [p0, p1) of this chunk; partial sums part[chunk][3][k][n_pad].
+template <int CAP>
 __global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx, int m, int d, int de, int k,
                                                        const double *__restrict__ Xr, const double *__restrict__ Psir,
                                                        const double *__restrict__ Psi3, const double *__restrict__ tab,
                                                        int rec, const double *__restrict__ w, const double *__restrict__ v,
                                                        const double *__restrict__ iS, long pairs_per_chunk,
-                                                       double *__restrict__ part) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                       double *__restrict__ part, int nchunk, double *ws, size_t ws_stride) {
+    extern __shared__ double sums_lds[];               // [3][k][64]: gamma, VlnS, nu partial sums of this lane (any k)
+    GEN_SETUP();
+    GEN_ARR(x, GCAP, d) GEN_ARR(ps, GCAP, d) GEN_ARR(M, GCAP * GCAP, d * d) GEN_ARR(y, GCAP, d)
+    double *ga = sums_lds + threadIdx.x, *vl = ga + (size_t)k * 64, *nu = vl + (size_t)k * 64;   // element o at [o * 64]
+    const long nrb = ((long)n + 63) / 64 * 64;         // rows padded to whole waves; item = chunk * nrb + row
+    for (long it = gt_; it < (long)nchunk * nrb; it += nth_) {
+    const int i = (int)(it % nrb), chunk = (int)(it / nrb);
+    if (i >= n) continue;
     const long npair = (long)m * (m + 1) / 2;
-    const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
-    double x[GDM], ps[GDM], M[GDM * GDM], y[GDM];
-    double ga[8], vl[8], nu[8];
-    for (int o = 0; o < 8; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    const long p0 = (long)chunk * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
+    for (int o = 0; o < k; ++o) { ga[o * 64] = 0.0; vl[o * 64] = 0.0; nu[o * 64] = 0.0; }
     for (int c = 0; c < d; ++c) {
         x[c] = Xr[(size_t)i * de + c];
         if (kind == GPZ_KIND_DIAG) ps[c] = Psir[(size_t)i * de + c];
@@ -492,7 +536,7 @@ __global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx,
         } else {
             for (int r = 0; r < d; ++r)
                 for (int c = 0; c <= r; ++c) M[r * GDM + c] = t[1 + d + r * d + c] + Psi3[(size_t)i * d * d + r + d * c];
-            chol_small(M, d);
+            chol_small(M, d, GDM);
             double q = 0.0, ld = 0.0;
             for (int r = 0; r < d; ++r) {
                 double s = x[r] - t[1 + r];
@@ -505,16 +549,17 @@ __global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx,
         }
         const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] + ln);           // 2x in the loop, -1x for a == b  (:113-119)
         for (int o = 0; o < k; ++o) {
-            ga[o] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o]);
-            vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o]);
-            nu[o] = fma(z, iS[a + (size_t)m * b + (size_t)m * m * o], nu[o]);
+            ga[o * 64] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o * 64]);
+            vl[o * 64] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o * 64]);
+            nu[o * 64] = fma(z, iS[a + (size_t)m * b + (size_t)m * m * o], nu[o * 64]);
         }
         if (++b > a) { ++a; b = 0; }
     }
     for (int o = 0; o < k; ++o) {
-        part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
-        part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
-        part[(((size_t)blockIdx.y * 3 + 2) * k + o) * ldx + i] = nu[o];
+        part[(((size_t)chunk * 3 + 0) * k + o) * ldx + i] = ga[o * 64];
+        part[(((size_t)chunk * 3 + 1) * k + o) * ldx + i] = vl[o * 64];
+        part[(((size_t)chunk * 3 + 2) * k + o) * ldx + i] = nu[o * 64];
+    }
     }
 }
 
@@ -579,22 +624,35 @@ void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, co
     else hipLaunchKernelGGL(k_prior_iter<16>, g, b, 0, st, N, ld, n, m, prior, colslab);
 }
 
+// grid of a general-path kernel: one thread per item in 64-thread workgroups (d <= 20), or the fixed grid-stride pool
+// over the runtime-d workspace
+#define GEN_LAUNCH(KERNEL, items, lds, ...)                                                                            \
+    do {                                                                                                               \
+        if (d <= GCAP)                                                                                                 \
+            hipLaunchKernelGGL((KERNEL<GCAP>), dim3((unsigned)(((items) + 63) / 64)), dim3(64), lds, st, __VA_ARGS__,   \
+                               (double *)nullptr, (size_t)0);                                                          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((KERNEL<0>), dim3(GPZ_GEN_RT_THREADS / 64), dim3(64), lds, st, __VA_ARGS__, ws,          \
+                               gen_ws_per_thread(d));                                                                  \
+    } while (0)
+
 void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const double *P, const double *G, const double *Sig,
-                       const double *iSig, double *tab, int rec) {
+                       const double *iSig, double *tab, int rec, double *ws) {
     const long npair = (long)m * (m + 1) / 2;
-    hipLaunchKernelGGL(k_pair_table, dim3((unsigned)((npair + 63) / 64)), dim3(64), 0, st, kind, m, d, de, P, G, Sig, iSig,
-                       tab, rec);
+    GEN_LAUNCH(k_pair_table, npair, 0, kind, m, d, de, P, G, Sig, iSig, tab, rec);
 }
 
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
-                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part) {
+                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part, double *ws) {
     // covariance kinds, d <= 10: register-resident per-pair factorisations (k_psi.hip) instead of the scratch-resident branch
-    if (kind != GPZ_KIND_DIAG && launch_predict_noisy_cov(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk,
-                                                          pairs_per_chunk, part) == 0)
+    if (kind != GPZ_KIND_DIAG && k <= 8 &&
+        launch_predict_noisy_cov(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part) == 0)
         return;
-    hipLaunchKernelGGL(k_predict_noisy, dim3((n + 63) / 64, nchunk), dim3(64), 0, st, kind, n, ldx, m, d, de, k, Xr, Psir,
-                       Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);
+    const long items = (((long)n + 63) / 64 * 64) * nchunk;
+    const size_t lds = (size_t)3 * k * 64 * sizeof(double);
+    GEN_LAUNCH(k_predict_noisy, items, lds, kind, n, ldx, m, d, de, k, Xr, Psir, Psi3, tab, rec, w, v, iS, pairs_per_chunk,
+               part, nchunk);
 }
 
 void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
@@ -648,24 +706,27 @@ void launch_phi_norm(hipStream_t st, const NormArgs &a) {
 // R~ = upper Cholesky factor of Sigma_oo^-1 scattered into d x d (zero rows / columns at the missing dimensions),
 // c~ = R~ p_j, and the constant |u| ln 2 rides on the first missing dimension's (otherwise empty) row: c~[u0] = sqrt(|u| ln 2).
 // Output in the layout of k_prep_cov: [R~ packed upper, row a at a*de - a(a-1)/2 | c~ (de)] per basis function.
+template <int CAP>
 __global__ void k_gen_pattern_params(const double *__restrict__ Sig, const double *__restrict__ P,
-                                     const unsigned char *__restrict__ pat, int m, int d, int de,
-                                     double *__restrict__ RcAll) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = blockIdx.y;                          // one parameter block of m*(nt+de) doubles per pattern
-    if (j >= m) return;
+                                     const unsigned char *__restrict__ pat, int G, int m, int d, int de,
+                                     double *__restrict__ RcAll, double *ws, size_t ws_stride) {
+    GEN_SETUP();
+    GEN_IARR(o, GCAP, d) GEN_ARR(A, GCAP * GCAP, d * d) GEN_ARR(W, GCAP * GCAP, d * d) GEN_ARR(Ki, GCAP * GCAP, d * d)
+    const int mj = (m + 63) / 64 * 64;
+    for (long it = gt_; it < (long)G * mj; it += nth_) {
+    const int j = (int)(it % mj), g = (int)(it / mj);  // one parameter block of m*(nt+de) doubles per pattern
+    if (j >= m) continue;
     double *Rc = RcAll + (size_t)g * m * (de * (de + 1) / 2 + de);
-    int o[GDM], no = 0, u0 = -1;
+    int no = 0, u0 = -1;
     for (int c = 0; c < d; ++c) {
         if (pat[g * d + c]) o[no++] = c;
         else if (u0 < 0) u0 = c;
     }
-    double A[GDM * GDM], W[GDM * GDM], Ki[GDM * GDM];
     for (int a = 0; a < no; ++a)
         for (int b = 0; b < no; ++b) A[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
-    chol_small(A, no);
-    inv_from_chol(A, no, W, Ki);                       // Ki = Sigma_oo^-1
-    chol_small(Ki, no);                                // Ki = L L'  ->  R~ = L' (upper)
+    chol_small(A, no, GDM);
+    inv_from_chol(A, no, W, Ki, GDM);                  // Ki = Sigma_oo^-1
+    chol_small(Ki, no, GDM);                           // Ki = L L'  ->  R~ = L' (upper)
     const int nt = de * (de + 1) / 2;
     double *out = Rc + (size_t)j * (nt + de);
     for (int e = 0; e < nt + de; ++e) out[e] = 0.0;
@@ -679,6 +740,7 @@ __global__ void k_gen_pattern_params(const double *__restrict__ Sig, const doubl
         out[nt + o[a]] = cs;
     }
     if (u0 >= 0) out[nt + u0] = sqrt((double)(d - no) * GPZ_LOG2);
+    }
 }
 
 // Tuned moment sums of one pattern, [m][nmt (+2)] = [M1 (de) | S packed upper (de(de+1)/2) | r1, r2], scattered into the
@@ -706,8 +768,8 @@ __global__ void k_gen_convert_moments(const double *__restrict__ frecAll, int st
 }
 
 void launch_gen_pattern_params(hipStream_t st, const double *Sig, const double *P, const unsigned char *pat, int G, int m,
-                               int d, int de, double *RcAll) {
-    hipLaunchKernelGGL(k_gen_pattern_params, dim3((m + 63) / 64, G), dim3(64), 0, st, Sig, P, pat, m, d, de, RcAll);
+                               int d, int de, double *RcAll, double *ws) {
+    GEN_LAUNCH(k_gen_pattern_params, (long)G * ((m + 63) / 64 * 64), 0, Sig, P, pat, G, m, d, de, RcAll);
 }
 void launch_gen_convert_moments(hipStream_t st, const double *frecAll, int stride, int has_r, const double *Sig,
                                 const unsigned char *pat, int G, int m, int d, int de, double *recsAll, int nrec) {
@@ -717,17 +779,15 @@ void launch_gen_convert_moments(hipStream_t st, const double *frecAll, int strid
 }
 
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
-                     const unsigned char *pat, int ngroups, double *lnS) {
-    hipLaunchKernelGGL(k_gen_prep, dim3((m + 63) / 64), dim3(64), 0, st, G, m, d, de, Sig, iSig);
-    hipLaunchKernelGGL(k_gen_lndet, dim3((ngroups * m + 63) / 64), dim3(64), 0, st, (const double *)Sig, pat, ngroups, m, d,
-                       lnS);
+                     const unsigned char *pat, int ngroups, double *lnS, double *ws) {
+    GEN_LAUNCH(k_gen_prep, (long)m, 0, G, m, d, de, Sig, iSig);
+    GEN_LAUNCH(k_gen_lndet, (long)ngroups * m, 0, (const double *)Sig, pat, ngroups, m, d, lnS);
 }
 
 void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int de, int k, const double *P,
-                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y) {
+                    const double *Sig, const double *lnS, const unsigned char *pat, double *Phi, const double *Y, double *ws) {
     if (r.n > 0)   // a rank of a sharded run may hold no row of this set
-        hipLaunchKernelGGL(k_gen_phi, dim3((r.n + 63) / 64), dim3(64), 0, st, r.Xr, de, r.gid, pat, r.Psi3, r.n, m, d, P, Sig,
-                           lnS, Phi, mp);
+        GEN_LAUNCH(k_gen_phi, (long)r.n, 0, r.Xr, de, r.gid, pat, r.Psi3, r.n, m, d, P, Sig, lnS, Phi, mp);
     hipLaunchKernelGGL(k_gen_fill, dim3(1024), dim3(256), 0, st, Phi, mp, r.n, r.n_pad, m, mp, k, Y, (long)r.n_pad);
 }
 
@@ -745,17 +805,16 @@ void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ld
 void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                         const double *v, const GenRows &r, int g, int row_begin, int nrows, const unsigned char *pat, int m,
                         int d, int de, const double *P, const double *Sig, int nchunk, int rows_per_chunk, double *slab,
-                        int nrec) {
+                        int nrec, double *ws) {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_gen_moments, dim3(nchunk, (m + 63) / 64), dim3(64), 0, st, Phi, T, ld, rowscal, w, v, r.Xr, de,
-                       r.rows_by_group + row_begin, nrows, pat, g, r.Psi3, m, d, P, Sig, rows_per_chunk, slab, nrec);
+    GEN_LAUNCH(k_gen_moments, (long)nchunk * ((m + 63) / 64 * 64), 0, Phi, T, ld, rowscal, w, v, r.Xr, de,
+               r.rows_by_group + row_begin, nrows, pat, g, r.Psi3, m, d, P, Sig, nchunk, rows_per_chunk, slab, nrec);
 }
 
 void launch_gen_finish(hipStream_t st, const double *recs, int G, const unsigned char *pat, int m, int d, int de,
                        const double *Gam, const double *Sig, const double *iSig, int method_id, const double *sums1, int k,
-                       double *grad, double *dGfull, double *cols, int mp, int nrec, double *part, int raw) {
-    hipLaunchKernelGGL(k_gen_finish, dim3((m + 63) / 64, G), dim3(64), 0, st, recs, G, pat, m, d, de, Gam, Sig, iSig, part, nrec,
-                       raw);
+                       double *grad, double *dGfull, double *cols, int mp, int nrec, double *part, int raw, double *ws) {
+    GEN_LAUNCH(k_gen_finish, (long)G * ((m + 63) / 64 * 64), 0, recs, G, pat, m, d, de, Gam, Sig, iSig, part, nrec, raw);
     const long nt = (long)m * (d + d * d + 2);
     hipLaunchKernelGGL(k_gen_finish_sum, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const double *)part, G, m, d,
                        method_id, sums1, k, grad, dGfull, cols, mp);

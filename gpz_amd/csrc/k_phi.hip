@@ -167,7 +167,10 @@ void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, in
         case 6: hipLaunchKernelGGL(k_prep_cov<6>, g, b, 0, st, G, P, m, de, Rc); break;
         case 8: hipLaunchKernelGGL(k_prep_cov<8>, g, b, 0, st, G, P, m, de, Rc); break;
         case 10: hipLaunchKernelGGL(k_prep_cov<10>, g, b, 0, st, G, P, m, de, Rc); break;
-        default: hipLaunchKernelGGL(k_prep_cov<0>, g, b, 0, st, G, P, m, de, Rc); break;
+        default:
+            if (de > 20) (void)launch_prep_cov_wide(st, G, P, m, de, Rc);   // runtime-d QR in LDS (k_wide.hip)
+            else hipLaunchKernelGGL(k_prep_cov<0>, g, b, 0, st, G, P, m, de, Rc);
+            break;
     }
 }
 
@@ -662,7 +665,9 @@ static int launch_phi_k(hipStream_t st, const PhiArgs &a) {
 }
 
 // a.d must be one of the padded dimensions returned by gpz_pad_dim().
-int phi_cov_rows_per_wg(int de) {
+bool phi_is_wide(int de, int k) { return de > 20 || k > 8; }   // no instantiated kernel: runtime-d route (k_wide.hip)
+int phi_cov_rows_per_wg(int de, int k) {
+    if (phi_is_wide(de, k)) return phi_wide_rows_per_wg();
     switch (de) {
         case 12: return 256 * PhiCovShape<12>::R;
         case 16: return 256 * PhiCovShape<16>::R;
@@ -672,6 +677,6 @@ int phi_cov_rows_per_wg(int de) {
 }
 
 int launch_phi(hipStream_t st, const PhiArgs &a) {
-    if (a.k > 8) return -1;
+    if (phi_is_wide(a.d, a.k)) return launch_phi_wide(st, a);
     return (a.kind == GPZ_KIND_DIAG) ? launch_phi_k<GPZ_KIND_DIAG>(st, a) : launch_phi_k<GPZ_KIND_COV>(st, a);
 }

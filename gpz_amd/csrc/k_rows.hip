@@ -318,7 +318,7 @@ int launch_moments(hipStream_t st, const MomentArgs &a) {
             case 12: MOM_COV(12, 0, 5); MOM_COV(12, 5, 12); break;
             case 16: MOM_COV(16, 0, 4); MOM_COV(16, 4, 9); MOM_COV(16, 9, 16); break;
             case 20: MOM_COV(20, 0, 3); MOM_COV(20, 3, 7); MOM_COV(20, 7, 12); MOM_COV(20, 12, 20); break;
-            default: return -1;
+            default: return launch_moments_wide(st, a);
         }
     } else {
         switch (a.d) {
@@ -333,7 +333,7 @@ int launch_moments(hipStream_t st, const MomentArgs &a) {
             case 12: MOM_DIAG(12); break;
             case 16: MOM_DIAG(16); break;
             case 20: MOM_DIAG(20); break;
-            default: return -1;
+            default: return launch_moments_wide(st, a);
         }
     }
     return 0;
@@ -570,7 +570,7 @@ int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
             case 16: MOMF(GPZ_KIND_COV, 16, 0, 4); MOMF(GPZ_KIND_COV, 16, 4, 9); MOMF(GPZ_KIND_COV, 16, 9, 16); break;
             case 20: MOMF(GPZ_KIND_COV, 20, 0, 3); MOMF(GPZ_KIND_COV, 20, 3, 7); MOMF(GPZ_KIND_COV, 20, 7, 12);
                      MOMF(GPZ_KIND_COV, 20, 12, 20); break;
-            default: return -1;
+            default: return launch_moments_fused_wide(st, a);
         }
     } else {
         switch (a.d) {
@@ -585,7 +585,7 @@ int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
             case 12: MOMF(GPZ_KIND_DIAG, 12, 0, 12); break;
             case 16: MOMF(GPZ_KIND_DIAG, 16, 0, 16); break;
             case 20: MOMF(GPZ_KIND_DIAG, 20, 0, 20); break;
-            default: return -1;
+            default: return launch_moments_fused_wide(st, a);
         }
     }
     return 0;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void k_finish_b(FinishArgs a, int de) {
             }
         }
         part = block_sum_256(part, sh4);
-        double Lo = part - 0.5 * a.scal[o * 4 + 0] - 0.5 * a.logdet[o] + 0.5 * (-a.sums1[1 + o]);
+        double Lo = part - 0.5 * a.scal[o * 4 + 0] - 0.5 * a.logdet[o] + 0.5 * (-a.sums1[gpz_ns_idx(1, o)]);
         if (a.hetero) Lo -= 0.5 * (double)m * (double)k * GPZ_LOG2PI;
         L += Lo;
         __syncthreads();
@@ -801,13 +801,33 @@ __global__ __launch_bounds__(256) void k_row_stats(const double *__restrict__ ph
     s1 = block_sum_256(s1, sh4);
     __syncthreads();
     cnt = block_sum_256(cnt, sh4);
-    double *pw = partial + (size_t)blockIdx.x * GPZ_NS;
+    const int ns = gpz_ns(k);
+    double *pw = partial + (size_t)blockIdx.x * ns;
     if (threadIdx.x == 0) { pw[0] = s0; pw[1] = s1; pw[10] = cnt; pw[11] = 0.0; }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         __syncthreads();
         const double t = block_sum_256(so[o], sh4);
         if (threadIdx.x == 0) pw[2 + o] = t;
+    }
+    for (int o = 8; o < k; ++o) {   // more than 8 outputs: one more pass over the rows per extra output (records grow by k - 8)
+        double t = 0.0, t0 = 0.0, t1 = 0.0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const double om = omega ? omega[i] : 1.0;
+            const double delta = phiw[(size_t)o * ldx + i] - y[(size_t)o * ldx + i];
+            const double lb = lnbeta[(size_t)o * ldx + i];
+            const double beta = exp(-lb);
+            t0 = fma(om, delta * delta, t0);
+            t1 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
+            t = fma(om * beta, delta * delta, t);
+        }
+        __syncthreads();
+        t = block_sum_256(t, sh4);
+        __syncthreads();
+        t0 = block_sum_256(t0, sh4);
+        __syncthreads();
+        t1 = block_sum_256(t1, sh4);
+        if (threadIdx.x == 0) { pw[gpz_ns_idx(2, o)] = t; pw[0] += t0; pw[1] += t1; }
     }
 }
 
@@ -828,13 +848,22 @@ __global__ __launch_bounds__(256) void k_sums1(const double *__restrict__ omega,
     s0 = block_sum_256(s0, sh4);
     __syncthreads();
     cnt = block_sum_256(cnt, sh4);
-    double *pw = partial + (size_t)blockIdx.x * GPZ_NS;
+    const int ns = gpz_ns(k);
+    double *pw = partial + (size_t)blockIdx.x * ns;
     if (threadIdx.x == 0) { pw[0] = s0; pw[9] = 0.0; pw[10] = cnt; pw[11] = 0.0; }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         __syncthreads();
         const double t = block_sum_256(so[o], sh4);
         if (threadIdx.x == 0) pw[1 + o] = t;
+    }
+    for (int o = 8; o < k; ++o) {
+        double t = 0.0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+            t = fma(omega ? omega[i] : 1.0, lnbeta[(size_t)o * ldx + i], t);
+        __syncthreads();
+        t = block_sum_256(t, sh4);
+        if (threadIdx.x == 0) pw[gpz_ns_idx(1, o)] = t;
     }
 }
 
@@ -852,7 +881,7 @@ __global__ __launch_bounds__(256) void k_solve_partial(GpzParams pr, const doubl
             part += -0.5 * pr.alpha[e] * w[e] * w[e] + 0.5 * pr.lnAlpha[e];
         }
         part = block_sum_256(part, sh4);
-        if (threadIdx.x == 0) out[o] = part - 0.5 * rstats[2 + o] - 0.5 * logdet[o] + 0.5 * (-sums1[1 + o]);
+        if (threadIdx.x == 0) out[o] = part - 0.5 * rstats[gpz_ns_idx(2, o)] - 0.5 * logdet[o] + 0.5 * (-sums1[gpz_ns_idx(1, o)]);
         __syncthreads();
     }
 }
@@ -940,77 +969,139 @@ void launch_nu(hipStream_t st, const double *Phi, const double *T, int ld, int n
 // NaN-pattern grouping (getPHI.m:43-54, duplicated at GPz.m:118-129, predict.m:45-56):
 // group id of a row = rank, by first occurrence, of its isnan() bit pattern.  Integer work, bit-exact.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_nan_mask(const double *__restrict__ X, long n, int d, unsigned long long *__restrict__ mask) {
+// Any d (W = ceil(d/64) mask words per row) and any number of distinct patterns:
+//   1. k_nan_mask      isnan() bits of every row
+//   2. k_nan_insert    open-addressing hash table keyed by the mask words; a slot holds the SMALLEST row index carrying its
+//                      pattern (atomicMin: the final table does not depend on the order the rows arrive in)
+//   3. k_nan_flag      flag[r] = 1 where row r is the first row of its pattern
+//   4. k_scan_*        exclusive prefix sum of the flags = the pattern's rank by first occurrence (unique(...,'stable'))
+//   5. k_nan_ids       every row looks its pattern's slot up again and reads the rank of the slot's row
+#define NAN_EMPTY (-1LL)   // all-ones: written by one memset; as unsigned it is above every row index, so atomicMin works
+__global__ void k_nan_mask(const double *__restrict__ X, long n, int d, int W, unsigned long long *__restrict__ mask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long b = 0ULL;
-    for (int c = 0; c < d; ++c) {
-        const double v = X[(size_t)c * n + i];
-        if (v != v) b |= (1ULL << c);
-    }
-    mask[i] = b;
-}
-
-// One workgroup walks the rows in order and appends every pattern not seen before.
-__global__ __launch_bounds__(256) void k_nan_unique(const unsigned long long *__restrict__ mask, long n,
-                                                     unsigned long long *__restrict__ uniq, int *__restrict__ n_groups,
-                                                     int max_groups) {
-    __shared__ unsigned long long su[1024];
-    __shared__ int sn;
-    __shared__ long first;
-    const int tid = threadIdx.x;
-    const int cap = max_groups < 1024 ? max_groups : 1024;
-    if (tid == 0) sn = 0;
-    __syncthreads();
-    for (long base = 0; base < n; base += 256) {
-        const long i = base + tid;
-        const bool have = i < n;
-        const unsigned long long mk = have ? mask[i] : 0ULL;
-        while (true) {
-            bool known = !have;
-            const int cnt = sn;
-            for (int g = 0; g < cnt && !known; ++g) known = (su[g] == mk);
-            if (tid == 0) first = n;
-            __syncthreads();
-            if (!known) atomicMin((unsigned long long *)&first, (unsigned long long)i);
-            __syncthreads();
-            const long f = first;
-            if (f >= n) break;                       // nothing new in this chunk
-            if (i == f) {
-                if (sn < cap) su[sn] = mk;
-                sn = sn + 1;
-            }
-            __syncthreads();
-            if (sn > cap) break;
+    for (int w = 0; w < W; ++w) {
+        unsigned long long b = 0ULL;
+        for (int c = w * 64; c < d && c < w * 64 + 64; ++c) {
+            const double v = X[(size_t)c * n + i];
+            if (v != v) b |= (1ULL << (c - w * 64));
         }
-        __syncthreads();
-        if (sn > cap) break;
+        mask[(size_t)i * W + w] = b;
     }
-    __syncthreads();
-    const int total = sn;
-    for (int g = tid; g < total && g < cap; g += 256) uniq[g] = su[g];
-    if (tid == 0) *n_groups = total;
 }
 
-__global__ void k_nan_ids(const unsigned long long *__restrict__ mask, long n, const unsigned long long *__restrict__ uniq,
-                          const int *__restrict__ n_groups, int *__restrict__ gid) {
+__device__ __forceinline__ unsigned long long nan_hash(const unsigned long long *mk, int W) {
+    unsigned long long h = 0x9e3779b97f4a7c15ULL;
+    for (int w = 0; w < W; ++w) {
+        h ^= mk[w];
+        h *= 0xff51afd7ed558ccdULL;
+        h ^= h >> 33;
+    }
+    return h;
+}
+__device__ __forceinline__ bool nan_same(const unsigned long long *a, const unsigned long long *b, int W) {
+    for (int w = 0; w < W; ++w)
+        if (a[w] != b[w]) return false;
+    return true;
+}
+
+__global__ void k_nan_insert(const unsigned long long *__restrict__ mask, long n, int W, long long *__restrict__ slot,
+                             unsigned long long hmask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long mk = mask[i];
-    const int G = *n_groups;
-    int id = -1;
-    for (int g = 0; g < G; ++g)
-        if (uniq[g] == mk) { id = g; break; }
-    gid[i] = id;
+    const unsigned long long *mk = mask + (size_t)i * W;
+    unsigned long long h = nan_hash(mk, W) & hmask;
+    while (true) {
+        long long cur = atomicAdd((unsigned long long *)&slot[h], 0ULL);
+        if (cur == NAN_EMPTY) {
+            const long long prev = (long long)atomicCAS((unsigned long long *)&slot[h], (unsigned long long)NAN_EMPTY,
+                                                        (unsigned long long)i);
+            if (prev == NAN_EMPTY) return;
+            cur = prev;
+        }
+        if (nan_same(mask + (size_t)cur * W, mk, W)) {   // every row a slot ever held carries the slot's pattern
+            atomicMin((unsigned long long *)&slot[h], (unsigned long long)i);
+            return;
+        }
+        h = (h + 1) & hmask;
+    }
 }
 
-int launch_nan_groups(hipStream_t st, const double *X, long n, int d, unsigned long long *mask, unsigned long long *uniq,
-                      int *n_groups, int *group_id, int max_groups) {
-    if (d > 64) return -1;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_nan_mask, dim3(nb), dim3(256), 0, st, X, n, d, mask);
-    hipLaunchKernelGGL(k_nan_unique, dim3(1), dim3(256), 0, st, (const unsigned long long *)mask, n, uniq, n_groups, max_groups);
-    hipLaunchKernelGGL(k_nan_ids, dim3(nb), dim3(256), 0, st, (const unsigned long long *)mask, n,
-                       (const unsigned long long *)uniq, (const int *)n_groups, group_id);
+__global__ void k_nan_flag(const long long *__restrict__ slot, unsigned long long hsize, int *__restrict__ flag) {
+    const unsigned long long h = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hsize) return;
+    const long long r = slot[h];
+    if (r != NAN_EMPTY) flag[r] = 1;
+}
+
+// exclusive prefix sum over n ints, 1024 per workgroup: block totals, their scan by one workgroup, the final pass
+__global__ __launch_bounds__(256) void k_scan_blocks(const int *__restrict__ in, long n, int *__restrict__ out,
+                                                      int *__restrict__ btot) {
+    __shared__ int sh[256];
+    const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+    for (int q = 0; q < 4; ++q) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - s;                                         // exclusive within the block
+    for (int q = 0; q < 4; ++q) {
+        if (base + q < n) out[base + q] = run;
+        run += v[q];
+    }
+    if (threadIdx.x == 255) btot[blockIdx.x] = sh[255];
+}
+__global__ void k_scan_totals(int *__restrict__ btot, long nb, int *__restrict__ total) {   // one thread: nb = n/1024 entries
+    int run = 0;
+    for (long b = 0; b < nb; ++b) { const int t = btot[b]; btot[b] = run; run += t; }
+    *total = run;
+}
+__global__ void k_nan_ids(const unsigned long long *__restrict__ mask, long n, int W, const long long *__restrict__ slot,
+                          unsigned long long hmask, const int *__restrict__ rank, const int *__restrict__ boff,
+                          int *__restrict__ gid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long *mk = mask + (size_t)i * W;
+    unsigned long long h = nan_hash(mk, W) & hmask;
+    while (true) {
+        const long long r = slot[h];
+        if (nan_same(mask + (size_t)r * W, mk, W)) { gid[i] = rank[r] + boff[r / 1024]; return; }
+        h = (h + 1) & hmask;
+    }
+}
+
+// work: see nan_groups_work_bytes().  Returns 0.
+size_t nan_groups_work_bytes(long n, int d) {
+    const int W = (d + 63) / 64;
+    unsigned long long H = 64;
+    while (H < 2ULL * (unsigned long long)n) H <<= 1;
+    const long nb = (n + 1023) / 1024;
+    return (size_t)n * W * 8 + (size_t)H * 8 + (size_t)n * 4 * 2 + (size_t)nb * 4 + 64;
+}
+int launch_nan_groups(hipStream_t st, const double *X, long n, int d, void *work, int *n_groups, int *group_id) {
+    const int W = (d + 63) / 64;
+    unsigned long long H = 64;
+    while (H < 2ULL * (unsigned long long)n) H <<= 1;
+    const long nb = (n + 1023) / 1024;
+    unsigned long long *mask = (unsigned long long *)work;
+    long long *slot = (long long *)(mask + (size_t)n * W);
+    int *flag = (int *)(slot + H);
+    int *rank = flag + n;
+    int *btot = rank + n;
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    (void)hipMemsetAsync(flag, 0, (size_t)n * sizeof(int), st);
+    (void)hipMemsetAsync(slot, 0xff, (size_t)H * sizeof(long long), st);             // NAN_EMPTY everywhere
+    hipLaunchKernelGGL(k_nan_mask, dim3(nblk), dim3(256), 0, st, X, n, d, W, mask);
+    hipLaunchKernelGGL(k_nan_insert, dim3(nblk), dim3(256), 0, st, (const unsigned long long *)mask, n, W, slot, H - 1);
+    hipLaunchKernelGGL(k_nan_flag, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, (const long long *)slot, H, flag);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nb), dim3(256), 0, st, (const int *)flag, n, rank, btot);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1), 0, st, btot, nb, n_groups);
+    hipLaunchKernelGGL(k_nan_ids, dim3(nblk), dim3(256), 0, st, (const unsigned long long *)mask, n, W,
+                       (const long long *)slot, H - 1, (const int *)rank, (const int *)btot, group_id);
     return 0;
 }

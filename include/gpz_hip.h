@@ -22,8 +22,13 @@
  *   gpz_mgpu_*          the same closure / calls on all GPUs of the node behind one synchronous call
  *                       (minFunc_2012/minFunc/minFunc.m:314 calls funObj once and waits)
  *
- * Limits: 1 <= d <= 20 (the reference has none, getPHI.m:69-98 is generic; wider inputs return GPZ_ERR_UNSUPPORTED),
- * k <= 8 outputs.
+ * Limits: none on d, k or the number of NaN patterns for the evaluation, getPHI, predictFull, predictNoisy, getPrior and the
+ * NaN grouping (the reference is generic, getPHI.m:60-110, GPz.m:133-213).  d <= 20 and k <= 8 run the instantiated,
+ * register-resident kernels; wider inputs / more outputs take runtime-d kernels with the row data in LDS (k_wide.hip) and, for
+ * GC/VC with input noise or missing values, a workspace-backed form of the general path (DESIGN.md section 7 gives the cost;
+ * a row tile must fit the 160 KB of LDS: d <= ~100 for the diagonal kinds with input noise and missing values, ~300 without).
+ * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 20 or k > 8, dtype = f32 pair kernels with d > 20 (the
+ * fp64 general path is taken instead).
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):
  *   - all matrices are column-major double; masks are 1 byte per row (MATLAB logical);

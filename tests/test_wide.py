@@ -1,0 +1,142 @@
+"""Inputs wider than the instantiated kernels (d > 20), more than 8 outputs, more than 1024 NaN patterns.
+
+The reference is generic in all three (getPHI.m:60-110 and GPz.m:133-213 loop over columns, predict.m:45-56 groups any number
+of NaN patterns); VERDICT r02 "missing 2" listed them as refusals (`GPZ_ERR_UNSUPPORTED`).  They now run through the
+runtime-d kernels of k_wide.hip (PHI build, moments, QR preparation), the workspace-backed general path of k_gen.hip and the
+hash-based NaN grouping — same gates as the tuned path."""
+import numpy as np
+import pytest
+
+import gpz_amd
+from gpz_amd import _lib
+from oracle import gpz_oracle as O
+from helpers import grad_tol, make_problem, rel
+from test_gpu_parity import FTOL, phi_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _gate(model, theta, X, Y, Psi=None, omega=None, tr=None, va=None, loose=1.0):
+    ref = O.GPz(theta, model, X, Y, Psi, omega, tr, va)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, omega, tr, va)
+    try:
+        f, g = ctx.eval(theta)
+        pt = phi_tol(model, theta)
+        tol = loose * max(grad_tol(ref.cond), pt)
+        assert ctx.info == 0
+        assert abs(f - ref.nlogML) <= max(FTOL, pt) * abs(ref.nlogML), (f, ref.nlogML)
+        assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+        for key, val in ref.stats.items():
+            assert abs(ctx.stats[key] - val) <= max(1e-10, pt) * max(1.0, abs(val)), key
+        r4 = O.GPz(theta, model, X, Y, Psi, omega, tr, va, nargout=4)
+        w, iS, part = ctx.solve(theta)
+        assert rel(w, r4.w) <= tol and rel(iS, r4.iSigma_w) <= tol and rel(part, r4.nlogML) <= max(FTOL, pt)
+        assert rel(ctx.phi(), r4.PHI) <= pt
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("method", ["GL", "VL", "GD", "VD", "GC", "VC"])
+@pytest.mark.parametrize("d,k", [(24, 1), (24, 9), (33, 2)])
+def test_wide_inputs_and_many_outputs(method, d, k):
+    """d = 24 / 33 (a 25-band photometric catalogue is the verdict's example), k = 9: objective, gradient, statistics, solve, PHI
+    against the oracle, with weights and a training / validation split."""
+    n, m = 600, 12
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=1000 + d + k)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    _gate(model, theta, X, Y, None, om, tr, ~tr)
+
+
+@pytest.mark.parametrize("method", ["VD", "GL", "VC", "GC"])
+@pytest.mark.parametrize("psi,nanfrac", [(True, 0.0), (False, 0.3), (True, 0.3)])
+def test_wide_inputs_with_input_noise_and_missing(method, psi, nanfrac):
+    n, d, m, k = 400, 22, 8, 1
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=2000 + d, psi=psi, nanfrac=nanfrac)
+    tr = rng.random(n) < 0.8
+    # GC/VC with input noise: the reference's chain dS -> diS = -Sigma dS Sigma -> dGamma goes through inv(Gamma'Gamma) twice and
+    # loses cond^1.5 * eps; oracle and HIP path run the same formula and differ by that rounding noise
+    loose = 2.0
+    if psi and method[1] == "C":
+        c = phi_tol(model, theta) / (200.0 * 2.2e-16)
+        loose = max(2.0, 10.0 * c ** 1.5 * 2.2e-16 / phi_tol(model, theta))
+    _gate(model, theta, X, Y, Psi, None, tr, ~tr, loose=loose)
+
+
+@pytest.mark.parametrize("method,d,k", [("VD", 5, 10), ("VC", 4, 9), ("GL", 3, 12)])
+def test_many_outputs_on_narrow_inputs(method, d, k):
+    """k > 8 with d inside the instantiated range: the PHI build takes the any-k kernel, the rest is the per-output loop."""
+    model, theta, X, Y, _, rng = make_problem(500, d, 10, k, method, True, seed=3000 + k)
+    _gate(model, theta, X, Y)
+
+
+def test_get_phi_and_predict_full_wide():
+    d, k, m = 26, 2, 9
+    for method in ("VD", "VC"):
+        model, theta, X, Y, _, rng = make_problem(300, d, m, k, method, True, seed=4000)
+        model.muX = rng.standard_normal(d) * 0.1; model.sdX = 1.0 + rng.random(d); model.muY = rng.standard_normal(k)
+        r4 = O.GPz(theta, model, X, Y, nargout=4)
+        model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w}
+        Xs = rng.standard_normal((77, d))
+        ref = O.predict(Xs, model)
+        out = gpz_amd.predict(Xs, model)
+        tol = max(1e-9, phi_tol(model, theta))
+        for i, name in enumerate(("mu", "sigma", "nu", "beta_i")):
+            assert rel(out[i], ref[i]) <= tol, (method, name)
+        got = gpz_amd.getPHI(Xs, None, theta, model, want_N=True)
+        rp = O.getPHI(Xs, None, theta, model, None, want_N=True)
+        for a, b in zip(got, rp):
+            if a is not None and b is not None:
+                assert rel(a, b) <= tol
+
+
+@pytest.mark.parametrize("method", ["VD", "GC"])
+def test_predict_with_input_noise_wide(method):
+    d, k, m = 23, 1, 7
+    model, theta, X, Y, _, rng = make_problem(300, d, m, k, method, True, seed=4100)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w}
+    Xs = rng.standard_normal((40, d))
+    Psi = rng.gamma(1.0, 0.1, (40, d))
+    ref = O.predict_noisy(Xs, Psi, model)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    tol = max(1e-9, phi_tol(model, theta))
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= tol, name
+
+
+@pytest.mark.parametrize("n,d,frac", [(30000, 12, 0.35), (5000, 70, 0.02), (2000, 130, 0.01)])
+def test_nan_groups_many_patterns_and_wide_rows(n, d, frac):
+    """More than 1024 distinct patterns (d = 12 at 35 % missing: ~3000) and more than 64 columns: bit-exact ids."""
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    X[rng.random((n, d)) < frac] = np.nan
+    gid, ng = gpz_amd.nan_groups(X)
+    rg, pats = O.nan_groups(X)
+    assert ng == pats.shape[0] and np.array_equal(gid, rg)
+    if d == 12:
+        assert ng > 1024
+
+
+def test_cov_kind_with_more_than_1024_nan_patterns():
+    """GC with ~1500 NaN patterns in the evaluation (one launch over all patterns, segmented slab sums)."""
+    n, d, m = 6000, 14, 6
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "GC", True, seed=77)
+    X[rng.random((n, d)) < 0.25] = np.nan
+    X[np.isnan(X).all(1), 0] = 0.1
+    _, pats = O.nan_groups(X)
+    assert pats.shape[0] > 1024
+    _gate(model, theta, X, Y, loose=2.0)
+
+
+def test_what_is_still_refused_says_so():
+    """Prediction with missing values keeps d <= 20 and k <= 8 (k_pmiss*.hip hold a row and 3k sums in registers)."""
+    d = 22
+    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "VD", True, seed=5)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = np.full(5, 0.2)
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
+    Xs = rng.standard_normal((10, d)); Xs[:, 3] = np.nan
+    with pytest.raises(_lib.GpzError) as ei:
+        gpz_amd.predict(Xs, model)
+    assert ei.value.code == -5
