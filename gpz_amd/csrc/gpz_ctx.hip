@@ -355,6 +355,16 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
                 if (dvar) return a == b ? Psi[(size_t)a * n_tot + idx[r]] : 0.0;
                 return Psi[(size_t)idx[r] * d * d + a + (size_t)d * b];
             };
+            {   // every Psi_i diagonal?  (what fixPsi.m builds from per-dimension variances; prediction and the fp32 pair kernels
+                // have cheaper forms for it)
+                bool dg = true;
+                if (!dvar)
+                    for (size_t r = 0; r < idx.size() && dg; ++r)
+                        for (int a = 0; a < d && dg; ++a)
+                            for (int b = 0; b < d; ++b)
+                                if (a != b && psi_at(r, a, b) != 0.0) { dg = false; break; }
+                rs.psi_diag = dg ? 1 : 0;
+            }
             if (c->need_psi3 || !c->psi32) {
                 std::vector<double> hp(np * (size_t)d * d, 0.0);
                 for (size_t r = 0; r < idx.size(); ++r) {
@@ -366,13 +376,7 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
             }
             if (c->psi32) {
                 const int D = psi32_pad_dim(d);
-                bool diag = true;
-                if (!dvar)
-                    for (size_t r = 0; r < idx.size() && diag; ++r)
-                        for (int a = 0; a < d && diag; ++a)
-                            for (int b = 0; b < d; ++b)
-                                if (a != b && psi_at(r, a, b) != 0.0) { diag = false; break; }
-                rs.psi_diag = diag ? 1 : 0;
+                const bool diag = rs.psi_diag != 0;
                 const size_t ne = diag ? (size_t)D : (size_t)D * (D + 1) / 2;
                 std::vector<float> ht(ne * np, 0.0f);
                 for (size_t r = 0; r < idx.size(); ++r) {
@@ -1580,7 +1584,8 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
         launch_pair_table(c->st, c->kind, c->m, d, c->de, c->pr.P, c->pr.G, c->Sig, c->iSig, tab, rec, c->gen_ws);
         launch_predict_noisy(c->st, c->kind, c->tr.n, (long)np, c->m, d, c->de, c->k, c->tr.Xr, c->tr.Psir, c->tr.Psi3, tab,
-                             rec, wd, c->hetero ? c->pr.v : nullptr, iSd, nchunk, ppc, part, c->gen_ws);
+                             rec, wd, c->hetero ? c->pr.v : nullptr, iSd, nchunk, ppc, part, c->gen_ws,
+                             (c->tr.psi_diag ? 1 : 0) | (c->mid == 4 ? 2 : 0));
         launch_slab_sum(c->st, part, nchunk, (size_t)3 * k * np, sums);
         launch_predict_noisy_final(c->st, sums, (long)np, c->tr.n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
                                    outb + 2 * k * np);
@@ -1628,8 +1633,12 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double 
     long rb = (1L << 26) / ((long)m * d * d);
     if (rb > n) rb = n;
     if (rb < 1) rb = 1;
+    const bool fast = pmc_fast(d, (int)k);
+    if (fast && rb > 64) rb = 64;   // the register-resident kernels deal the rows of a block over the lanes of a wave
     const int rows_blk = (int)rb;
-    int nchunk = (int)(npairs < 64 ? npairs : 64);
+    // pair chunks = slabs of `part`: one wave per chunk on the register-resident route (fill the chip), 64 otherwise
+    const long want = fast ? 2048 : 64;
+    int nchunk = (int)(npairs < want ? npairs : want);
     const long ppc = (npairs + nchunk - 1) / nchunk;
     nchunk = (int)((npairs + ppc - 1) / ppc);
     double *wd = nullptr, *iSd = nullptr, *prd = nullptr, *rec = nullptr, *tab = nullptr, *Ex = nullptr, *Pio = nullptr,
@@ -1647,6 +1656,8 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double 
     if (!rc) rc = c->ar.alloc(&sums, 3 * k * np);
     if (!rc) rc = c->ar.alloc(&phiw, np * k);
     if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
+    double *work2 = nullptr;
+    if (!rc && fast) rc = c->ar.alloc(&work2, m * ((size_t)d * (d + 1) / 2 + (size_t)d * d + d + 1));
     if (!rc) {
         hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
         if (e == hipSuccess) e = hipMemcpyAsync(iSd, iSigma_w, m * m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
@@ -1657,7 +1668,7 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double 
         launch_zero(c->st, c->Phi, np * mp);
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
         launch_pmc(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, c->Sig, c->iSig, prd, wd,
-                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi);
+                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi, work2);
         launch_slab_sum(c->st, part, nchunk, 3 * k * np, sums);
         launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
                           c->lnbeta, nullptr, phiw);

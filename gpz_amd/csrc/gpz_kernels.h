@@ -276,11 +276,12 @@ void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const dou
                        const double *iSig, double *tab, int rec, double *ws = nullptr);
 int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
-                             long pairs_per_chunk, double *part);   // k_psi.hip: 2 <= d <= 10, else -1
+                             long pairs_per_chunk, double *part,
+                             int flags = 0 /* bit 0: every Psi_i diagonal, bit 1: one covariance for all basis functions (GC) */);   // k_psi.hip: 2 <= d <= 10, else -1
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
                           const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part,
-                          double *ws = nullptr);
+                          double *ws = nullptr, int flags = 0);
 void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
                                 const double *lnbeta, const double *b, double *gamma, double *nu, double *beta_i);
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
@@ -295,7 +296,9 @@ int pmc_rec_len(int d, unsigned obs);
 void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
-                double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi);
+                double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
+                double *work2 = nullptr /* m * (d(d+1)/2 + d*d + d + 1) doubles: enables the register-resident route */);
+bool pmc_fast(int d, int k);   // 2 <= d <= 10, k <= 8: the register-resident kernels (needs rows_blk <= 64)
 void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B);
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
                    const double *G, double *Phi);

@@ -644,10 +644,11 @@ void launch_pair_table(hipStream_t st, int kind, int m, int d, int de, const dou
 
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
-                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part, double *ws) {
+                          const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part, double *ws,
+                          int flags) {
     // covariance kinds, d <= 10: register-resident per-pair factorisations (k_psi.hip) instead of the scratch-resident branch
     if (kind != GPZ_KIND_DIAG && k <= 8 &&
-        launch_predict_noisy_cov(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part) == 0)
+        launch_predict_noisy_cov(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part, flags) == 0)
         return;
     const long items = (((long)n + 63) / 64 * 64) * nchunk;
     const size_t lds = (size_t)3 * k * 64 * sizeof(double);

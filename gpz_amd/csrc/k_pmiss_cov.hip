@@ -108,10 +108,13 @@ __global__ void k_pmc_prep(PmcPat pt, int m, const double *__restrict__ Sig, con
 }
 
 // Per (row, basis): Ex (without the prior), X_hat, and with input noise Psi_hat.   (:167-176 / :260-274)
+// tl != 0: transposed layouts for the register-resident kernels below — X_hat as [row][d][m], Psi_hat as packed lower
+// triangles [row][d(d+1)/2][m] (component index fastest: the lanes of a wave run along the components).
+#define PLT(r, c) ((r) * ((r) + 1) / 2 + (c))
 __global__ void k_pmc_rows(PmcPat pt, int row0, int nrows, int m, int ld, const double *__restrict__ Xr, int de,
                            const double *__restrict__ Psi3, const double *__restrict__ P, const double *__restrict__ Sig,
                            const double *__restrict__ rec, int nrec, double *__restrict__ Ex, double *__restrict__ Xhat,
-                           double *__restrict__ Phat) {
+                           double *__restrict__ Phat, int tl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int rr = blockIdx.y;
     if (i >= m || rr >= nrows) return;
@@ -139,12 +142,13 @@ __global__ void k_pmc_rows(PmcPat pt, int row0, int nrows, int m, int ld, const 
         lp = pmc_lognorm(M, dl, no);
     }
     Ex[(size_t)rr * ld + i] = exp(lp);
-    double *xh = Xhat + ((size_t)rr * m + i) * d;
-    for (int a = 0; a < no; ++a) xh[pt.o[a]] = Xr[(size_t)row * de + pt.o[a]];
+    double *xh = tl ? Xhat + (size_t)rr * d * m + i : Xhat + ((size_t)rr * m + i) * d;
+    const size_t xs = tl ? (size_t)m : 1;
+    for (int a = 0; a < no; ++a) xh[pt.o[a] * xs] = Xr[(size_t)row * de + pt.o[a]];
     for (int c = 0; c < nu; ++c) {
         double s = P[(size_t)i * de + pt.u[c]];
         for (int a = 0; a < no; ++a) s = fma(dl[a], R[a * nu + c], s);
-        xh[pt.u[c]] = s;
+        xh[pt.u[c] * xs] = s;
     }
     if (Phat) {
         // B = T Psi_oo T' in [o u] order, T = [I; R'];  Psi_hat(unshuffle, unshuffle) = B;  Psi_hat(u,u) += CU
@@ -156,7 +160,7 @@ __global__ void k_pmc_rows(PmcPat pt, int row0, int nrows, int m, int ld, const 
                 for (int q = 0; q < no; ++q) s = fma(ps[pt.o[a] + d * pt.o[q]], R[q * nu + c], s);
                 PR[a * GDM + c] = s;
             }
-        double *ph = Phat + ((size_t)rr * m + i) * d * d;
+        double *ph = tl ? Phat + (size_t)rr * (d * (d + 1) / 2) * m + i : Phat + ((size_t)rr * m + i) * d * d;
         for (int a = 0; a < d; ++a)
             for (int b = 0; b < d; ++b) {
                 double v;
@@ -167,10 +171,14 @@ __global__ void k_pmc_rows(PmcPat pt, int row0, int nrows, int m, int ld, const 
                     v = 0.0;
                     for (int q = 0; q < no; ++q) v = fma(R[q * nu + (a - no)], PR[q * GDM + (b - no)], v);
                 }
-                ph[pt.inv[a] * d + pt.inv[b]] = v;
+                if (!tl) ph[pt.inv[a] * d + pt.inv[b]] = v;
+                else if (pt.inv[a] >= pt.inv[b]) ph[(size_t)PLT(pt.inv[a], pt.inv[b]) * m] = v;
             }
         for (int a = 0; a < nu; ++a)
-            for (int c = 0; c < nu; ++c) ph[pt.u[a] * d + pt.u[c]] += CU[a * nu + c];
+            for (int c = 0; c < nu; ++c) {
+                if (!tl) ph[pt.u[a] * d + pt.u[c]] += CU[a * nu + c];
+                else if (pt.u[a] >= pt.u[c]) ph[(size_t)PLT(pt.u[a], pt.u[c]) * m] += CU[a * nu + c];
+            }
     }
 }
 
@@ -292,6 +300,199 @@ __global__ __launch_bounds__(64) void k_pmc_accum(PmcPat pt, int row0, int nrows
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Register-resident form of the two sums above for 2 <= d <= 10 (template D, packed triangles, division-free Cholesky):
+//     out(row, r) = exp(lnZ_r) * sum_l N(X_hat(row,l) - c_r ; C_r + Psi_hat_l(row)) * Pio(row,l)
+// over a table of records r = [C_r (d x d) | c_r (d) | lnZ_r | weights (nw)]:  the basis pairs with their 3k weights
+// (k_pmc_pairs' table -> gamma / VlnS / nu partial sums, predictCov.m:190-201 / :300-313), or the basis functions themselves
+// with C = Sigma_i, c = P_i, lnZ = lnz_i and no weights (PHI, predictCov.m:178-207 / :276-318).
+// Lanes run along the components l.  The density is exp(-1/2 q) * prod 1/L_cc: no log, no sqrt, no divide per triple.
+//
+// Without input noise Psi_hat_l is CU_l on the (u,u) block whatever the row is, so the d x d factorisation is shared by all
+// rows of the NaN-pattern group (k_pmc_sum_s: one wave per chunk of records, the rows looped inside, per-lane partial sums
+// in LDS, lanes re-dealt along the rows for the sum over l).  With input noise it depends on (row, record, component) — the
+// reference's O(n m^3 d^3) — and a wave takes one (row, chunk of records) (k_pmc_sum_n).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pmc_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+template <int D>
+__device__ __forceinline__ void pmc_chol_rd(double (&M)[D * (D + 1) / 2], double (&rd)[D], double *prod_rd) {
+    double prod = 1.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double p = M[PLT(c, c)];
+#pragma unroll
+        for (int q = 0; q < c; ++q) p = fma(-M[PLT(c, q)], M[PLT(c, q)], p);
+        const double inv = pmc_rsqrt(p);
+        rd[c] = inv;
+        prod *= inv;
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double s = M[PLT(r, c)];
+#pragma unroll
+            for (int q = 0; q < c; ++q) s = fma(-M[PLT(r, q)], M[PLT(c, q)], s);
+            M[PLT(r, c)] = s * inv;
+        }
+    }
+    *prod_rd = prod;
+}
+
+// CUT[e][l]: Psi_hat_l without input noise as a packed triangle (CU_l on the (u,u) block, zero elsewhere)
+__global__ void k_pmc_cut(PmcPat pt, int m, const double *__restrict__ rec, int nrec, double *__restrict__ CUT) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= m) return;
+    const int d = pt.d, no = pt.no, nu = pt.nu, np = d * (d + 1) / 2;
+    for (int e = 0; e < np; ++e) CUT[(size_t)e * m + l] = 0.0;
+    const double *CU = rec + (size_t)l * nrec + 2 + no * no + no * nu;
+    for (int a = 0; a < nu; ++a)
+        for (int c = 0; c < nu; ++c)
+            if (pt.u[a] >= pt.u[c]) CUT[(size_t)PLT(pt.u[a], pt.u[c]) * m + l] = CU[a * nu + c];
+}
+// record table of the PHI sum: [Sigma_i (d x d) | P_i (d) | lnz_i]
+__global__ void k_pmc_phitab(int m, int d, int de, const double *__restrict__ P, const double *__restrict__ Sig,
+                             const double *__restrict__ rec, int nrec, double *__restrict__ ptab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double *t = ptab + (size_t)i * (d * d + d + 1);
+    for (int e = 0; e < d * d; ++e) t[e] = Sig[(size_t)i * d * d + e];
+    for (int a = 0; a < d; ++a) t[d * d + a] = P[(size_t)i * de + a];
+    t[d * d + d] = rec[(size_t)i * nrec];
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_pmc_sum_s(int nrows, int row0, int m, int ld, long R, long rec_per_chunk,
+                                                   const double *__restrict__ tab, int ntab, int nw,
+                                                   const double *__restrict__ Pio, const double *__restrict__ XhT,
+                                                   const double *__restrict__ CUT, double *__restrict__ Phi, long ldx,
+                                                   double *__restrict__ part) {
+    constexpr int NP = D * (D + 1) / 2;
+    __shared__ double ecs[64 * 65];
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    const long r0 = (long)chunk * rec_per_chunk, r1 = min(R, r0 + rec_per_chunk);
+    double acc[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) acc[e] = 0.0;
+    for (long r = r0; r < r1; ++r) {
+        const double *t = tab + (size_t)r * ntab;
+        for (int rr = 0; rr < nrows; ++rr) ecs[rr * 65 + lane] = 0.0;
+        for (int l0 = 0; l0 < m; l0 += 64) {
+            const int l = l0 + lane, lc = min(l, m - 1);
+            double M[NP], rd[D], prd;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) M[PLT(a, b)] = t[a * D + b] + CUT[(size_t)PLT(a, b) * m + lc];
+            pmc_chol_rd<D>(M, rd, &prd);
+            for (int rr = 0; rr < nrows; ++rr) {
+                double q = 0.0, y[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double s = XhT[((size_t)rr * D + a) * m + lc] - t[D * D + a];
+#pragma unroll
+                    for (int c = 0; c < a; ++c) s = fma(-M[PLT(a, c)], y[c], s);
+                    y[a] = s * rd[a];
+                    q = fma(y[a], y[a], q);
+                }
+                if (l < m) ecs[rr * 65 + lane] += exp(-0.5 * q) * prd * Pio[(size_t)rr * ld + l];
+            }
+        }
+        __syncthreads();
+        if (lane < nrows) {                      // lanes re-dealt along the rows: the sum over the components, in lane order
+            double ec = 0.0;
+            for (int j = 0; j < 64; ++j) ec += ecs[lane * 65 + j];
+            const double Z = exp(t[D * D + D]) * ec;
+            if (nw == 0) Phi[(size_t)(row0 + lane) * ld + r] = Z;
+#pragma unroll
+            for (int e = 0; e < 24; ++e)
+                if (e < nw) acc[e] = fma(Z, t[D * D + D + 1 + e], acc[e]);
+        }
+        __syncthreads();
+    }
+    if (nw > 0 && lane < nrows) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < nw) part[((size_t)chunk * nw + e) * ldx + row0 + lane] = acc[e];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_pmc_sum_n(int nrows, int row0, int m, int ld, long R, long rec_per_chunk,
+                                                   const double *__restrict__ tab, int ntab, int nw,
+                                                   const double *__restrict__ Pio, const double *__restrict__ XhT,
+                                                   const double *__restrict__ PhT, double *__restrict__ Phi, long ldx,
+                                                   double *__restrict__ part) {
+    constexpr int NP = D * (D + 1) / 2;
+    const int lane = threadIdx.x, rr = blockIdx.x, chunk = blockIdx.y;
+    const long r0 = (long)chunk * rec_per_chunk, r1 = min(R, r0 + rec_per_chunk);
+    double acc[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) acc[e] = 0.0;
+    for (long r = r0; r < r1; ++r) {
+        const double *t = tab + (size_t)r * ntab;
+        double ec = 0.0;
+        for (int l0 = 0; l0 < m; l0 += 64) {
+            const int l = l0 + lane, lc = min(l, m - 1);
+            double M[NP], rd[D], prd;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) M[PLT(a, b)] = t[a * D + b] + PhT[((size_t)rr * NP + PLT(a, b)) * m + lc];
+            pmc_chol_rd<D>(M, rd, &prd);
+            double q = 0.0, y[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                double s = XhT[((size_t)rr * D + a) * m + lc] - t[D * D + a];
+#pragma unroll
+                for (int c = 0; c < a; ++c) s = fma(-M[PLT(a, c)], y[c], s);
+                y[a] = s * rd[a];
+                q = fma(y[a], y[a], q);
+            }
+            if (l < m) ec += exp(-0.5 * q) * prd * Pio[(size_t)rr * ld + l];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ec += __shfl_xor(ec, off, 64);
+        const double Z = exp(t[D * D + D]) * ec;
+        if (nw == 0 && lane == 0) Phi[(size_t)(row0 + rr) * ld + r] = Z;
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < nw) acc[e] = fma(Z, t[D * D + D + 1 + e], acc[e]);
+    }
+    if (nw > 0 && lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e)
+            if (e < nw) part[((size_t)chunk * nw + e) * ldx + row0 + rr] = acc[e];
+    }
+}
+
+// out = the weighted sums (nw > 0, part) or PHI (nw == 0) over the record table; false when d is outside 2..10
+static bool pmc_sum(hipStream_t st, int d, bool noisy, int nrows, int row0, int m, int ld, long R, int nchunk, const double *tab,
+                    int ntab, int nw, const double *Pio, const double *XhT, const double *PsT, double *Phi, long ldx,
+                    double *part) {
+    const long rpc = (R + nchunk - 1) / nchunk;
+    const int nch = (int)((R + rpc - 1) / rpc);
+#define PMC_CASE(DD)                                                                                                      \
+    case DD:                                                                                                              \
+        if (noisy)                                                                                                        \
+            hipLaunchKernelGGL((k_pmc_sum_n<DD>), dim3(nrows, nch), dim3(64), 0, st, nrows, row0, m, ld, R, rpc, tab, ntab, nw, \
+                               Pio, XhT, PsT, Phi, ldx, part);                                                            \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_pmc_sum_s<DD>), dim3(nch), dim3(64), 0, st, nrows, row0, m, ld, R, rpc, tab, ntab, nw, Pio,   \
+                               XhT, PsT, Phi, ldx, part);                                                                 \
+        return true;
+    switch (d) {
+        PMC_CASE(2) PMC_CASE(3) PMC_CASE(4) PMC_CASE(5) PMC_CASE(6) PMC_CASE(7) PMC_CASE(8) PMC_CASE(9) PMC_CASE(10)
+        default: return false;
+    }
+#undef PMC_CASE
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 // One NaN-pattern group.  obs: bit c set = dimension c observed.  Sig/iSig: m x d*d (k_gen_prep).  Work buffers are
 // allocated by the caller: rec (m*nrec), tab (npairs*ntab), Ex/Pio (rows_blk*ld each), Xhat (rows_blk*m*d),
@@ -302,10 +503,13 @@ int pmc_rec_len(int d, unsigned obs) {
     const int nu = d - no;
     return 2 + no * no + no * nu + nu * nu;
 }
+bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // register-resident kernels (rows_blk <= 64 then)
+// work2: m * (d(d+1)/2 + d*d + d + 1) doubles, used by the register-resident route
 void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
-                double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi) {
+                double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
+                double *work2) {
     PmcPat pt;
     pt.d = d; pt.no = 0; pt.nu = 0;
     for (int c = 0; c < d; ++c) {
@@ -318,14 +522,28 @@ void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, in
     for (int a = 0; a < d; ++a) pt.inv[perm[a]] = a;                        // [~,unshuffle] = sort([find(o) find(~o)])
     const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * k;
     const long npairs = (long)m * (m + 1) / 2;
+    const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64;
     hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec);
     hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
                        (const double *)rec, nrec, w, v, iS, tab, ntab);
+    double *CUT = work2, *ptab = work2 ? work2 + (size_t)m * (d * (d + 1) / 2) : nullptr;
+    if (fast) {
+        if (!Psi3) hipLaunchKernelGGL(k_pmc_cut, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, (const double *)rec, nrec, CUT);
+        hipLaunchKernelGGL(k_pmc_phitab, dim3((m + 63) / 64), dim3(64), 0, st, m, d, de, P, Sig, (const double *)rec, nrec, ptab);
+    }
     for (int row0 = 0; row0 < n; row0 += rows_blk) {
         const int nr = (n - row0 < rows_blk) ? n - row0 : rows_blk;
         hipLaunchKernelGGL(k_pmc_rows, dim3((m + 63) / 64, nr), dim3(64), 0, st, pt, row0, nr, m, ld, Xr, de, Psi3, P, Sig,
-                           (const double *)rec, nrec, Ex, Xhat, Psi3 ? Phat : nullptr);
+                           (const double *)rec, nrec, Ex, Xhat, Psi3 ? Phat : nullptr, fast ? 1 : 0);
         launch_pm_pio(st, Ex, ld, nr, m, priors, Pio);
+        if (fast) {
+            const double *PsT = Psi3 ? Phat : CUT;
+            pmc_sum(st, d, Psi3 != nullptr, nr, row0, m, ld, (long)m, m < 256 ? m : 256, ptab, d * d + d + 1, 0, Pio, Xhat, PsT,
+                    Phi, ldx, nullptr);
+            pmc_sum(st, d, Psi3 != nullptr, nr, row0, m, ld, npairs, nchunk, tab, ntab, 3 * k, Pio, Xhat, PsT, nullptr, ldx,
+                    part);
+            continue;
+        }
         hipLaunchKernelGGL(k_pmc_phi, dim3((m + 63) / 64, nr), dim3(64), 0, st, pt, nr, m, ld, de, P, Sig, (const double *)rec,
                            nrec, (const double *)Pio, (const double *)Xhat, (const double *)(Psi3 ? Phat : nullptr), Phi, row0);
         hipLaunchKernelGGL(k_pmc_accum, dim3(nr, nchunk), dim3(64), 0, st, pt, row0, nr, m, ld, k, npairs,

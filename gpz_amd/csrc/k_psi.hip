@@ -13,19 +13,31 @@
 // packed lower triangle, row-major: element (r, c), c <= r, at r(r+1)/2 + c
 #define LT(r, c) ((r) * ((r) + 1) / 2 + (c))
 
-// In-place Cholesky of a packed lower triangle; returns sum(log(diag(L))) = 1/2 ln|M| through *half_logdet.
+// 1/sqrt(p) in fp64 without the library's sqrt + divide (~50 instructions): v_rsq_f64 seed and two Newton steps.
+__device__ __forceinline__ double rsqrt_nr(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
+// In-place Cholesky of a packed lower triangle, division-free: rd[c] = 1 / L_cc (the diagonal slots of M hold L_cc for the
+// callers that read them), *prod_rd = prod_c rd[c] = |M|^-1/2.  A non-positive pivot gives NaN as sqrt() would.
 template <int D>
-__device__ __forceinline__ void chol_packed(double (&M)[D * (D + 1) / 2], double *half_logdet) {
+__device__ __forceinline__ void chol_packed_rd(double (&M)[D * (D + 1) / 2], double (&rd)[D], double *prod_rd) {
     double prod = 1.0;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         double p = M[LT(c, c)];
 #pragma unroll
         for (int q = 0; q < c; ++q) p = fma(-M[LT(c, q)], M[LT(c, q)], p);
-        const double dd = sqrt(p);
-        const double inv = 1.0 / dd;
-        M[LT(c, c)] = dd;
-        prod *= dd;
+        const double inv = rsqrt_nr(p);
+        rd[c] = inv;
+        M[LT(c, c)] = p * inv;
+        prod *= inv;
 #pragma unroll
         for (int r = c + 1; r < D; ++r) {
             double s = M[LT(r, c)];
@@ -34,22 +46,29 @@ __device__ __forceinline__ void chol_packed(double (&M)[D * (D + 1) / 2], double
             M[LT(r, c)] = s * inv;
         }
     }
-    *half_logdet = log(prod);
+    *prod_rd = prod;
+}
+// returns sum(log(diag(L))) = 1/2 ln|M| through *half_logdet.
+template <int D>
+__device__ __forceinline__ void chol_packed(double (&M)[D * (D + 1) / 2], double (&rd)[D], double *half_logdet) {
+    double pr;
+    chol_packed_rd<D>(M, rd, &pr);
+    *half_logdet = -log(pr);
 }
 
 // W = inv(L) (packed lower), Mi = W' W (packed lower, symmetric)
 template <int D>
-__device__ __forceinline__ void inv_packed(const double (&L)[D * (D + 1) / 2], double (&W)[D * (D + 1) / 2],
-                                           double (&Mi)[D * (D + 1) / 2]) {
+__device__ __forceinline__ void inv_packed(const double (&L)[D * (D + 1) / 2], const double (&rd)[D],
+                                           double (&W)[D * (D + 1) / 2], double (&Mi)[D * (D + 1) / 2]) {
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        W[LT(c, c)] = 1.0 / L[LT(c, c)];
+        W[LT(c, c)] = rd[c];
 #pragma unroll
         for (int r = c + 1; r < D; ++r) {
             double s = 0.0;
 #pragma unroll
             for (int q = c; q < r; ++q) s = fma(L[LT(r, q)], W[LT(q, c)], s);
-            W[LT(r, c)] = -s / L[LT(r, r)];
+            W[LT(r, c)] = -s * rd[r];
         }
     }
 #pragma unroll
@@ -136,8 +155,8 @@ __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, 
 #pragma unroll
                 for (int e = 0; e < NP; ++e) M[e] = psi[e] + t[e];             // Psi(o,o,i) + Sigma(o,o)      getPHI.m:84
             }
-            double hl;
-            chol_packed<D>(M, &hl);
+            double hl, rd[D];
+            chol_packed<D>(M, rd, &hl);
             double quad = 0.0;
 #pragma unroll
             for (int r = 0; r < D; ++r) {                                      // y = L^-1 Delta
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(256) void k_psi_phi(const double *__restrict__ Xr, 
                 if (MISS) s *= sel[r];
 #pragma unroll
                 for (int c = 0; c < r; ++c) s = fma(-M[LT(r, c)], y[c], s);
-                y[r] = s / M[LT(r, r)];
+                y[r] = s * rd[r];
                 quad = fma(y[r], y[r], quad);
             }
             const double lns = MISS ? lnS[(size_t)g * m + j] : t[NP + D];
@@ -213,9 +232,9 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
             for (int c = 0; c <= r; ++c) L[LT(r, c)] = sg[LT(r, c)] + ps[r + D * c];     // Sigma + Psi_i    GPz.m:170
         }
         }
-        double hl;
-        chol_packed<D>(L, &hl);
-        inv_packed<D>(L, W, Mi);
+        double hl, rd[D];
+        chol_packed<D>(L, rd, &hl);
+        inv_packed<D>(L, rd, W, Mi);
 #pragma unroll
         for (int a = 0; a < D; ++a) {
             double s = 0.0;
@@ -303,54 +322,71 @@ int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int l
 // part[chunk][3][k][ldx] — the register-resident twin of k_predict_noisy's covariance branch (k_gen.hip): Psi_i and the pair
 // matrix Cij + Psi_i are packed triangles with compile-time indices, the pair record (uniform over the wave) is read through
 // the scalar cache.  tab record: [lnz | cij (d) | Cij (d x d)].
-template <int D>
+//   DIAGPSI  every Psi_i of the call is diagonal (what fixPsi.m builds from per-dimension variances): d instead of d(d+1)/2
+//            registers for it, two waves per SIMD instead of one
+//   SHARED   GC: every basis function has the same covariance, so Cij = Sigma/2 for every pair and the sample's pair matrix
+//            Sigma/2 + Psi_i is factorised ONCE; a pair then costs the forward substitution and one exp
+//   KM       outputs carried in registers (1 or 8)
+// N(x; cij, Cij + Psi_i) = exp(-1/2 q) * prod_c (1 / L_cc): no logarithm, no division, no sqrt per pair.
+template <int D, bool DIAGPSI, bool SHARED, int KM>
 __global__ __launch_bounds__(64) void k_predict_noisy_cov(int n, long ldx, int m, int de, int k, const double *__restrict__ Xr,
                                                            const double *__restrict__ Psi3, const double *__restrict__ tab,
                                                            int rec, const double *__restrict__ w, const double *__restrict__ v,
                                                            const double *__restrict__ iS, long pairs_per_chunk,
                                                            double *__restrict__ part) {
     constexpr int NP = D * (D + 1) / 2;
+    constexpr int NPS = DIAGPSI ? D : NP;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n;
     const int ic = act ? i : n - 1;
     const long npair = (long)m * (m + 1) / 2;
     const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
-    double x[D], ps[NP];
+    double x[D], ps[NPS];
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] = Xr[(size_t)ic * de + c];
 #pragma unroll
-    for (int r = 0; r < D; ++r)
+    for (int r = 0; r < D; ++r) {
+        if (DIAGPSI) ps[r] = Psi3[(size_t)ic * D * D + r + D * r];
+        else {
 #pragma unroll
-        for (int c = 0; c <= r; ++c) ps[LT(r, c)] = Psi3[(size_t)ic * D * D + r + D * c];
-    double ga[8], vl[8], nu[8];
+            for (int c = 0; c <= r; ++c) ps[DIAGPSI ? 0 : LT(r, c)] = Psi3[(size_t)ic * D * D + r + D * c];
+        }
+    }
+    double ga[KM], vl[KM], nu[KM];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    for (int o = 0; o < KM; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
     long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);   // (a, b) of the first pair, then walk
     while (a * (a + 1) / 2 > p0) --a;
     while ((a + 1) * (a + 2) / 2 <= p0) ++a;
     long b = p0 - a * (a + 1) / 2;
-#pragma unroll 1
-    for (long e = p0; e < p1; ++e) {
-        const double *t = tab + (size_t)e * rec;
-        double M[NP];
+    double M[NP], rd[D], prd = 1.0;
+    auto build = [&](const double *t) {
 #pragma unroll
         for (int r = 0; r < D; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) M[LT(r, c)] = t[1 + D + r * D + c] + ps[LT(r, c)];    // Cij + Psi        predictCov.m:109
-        double hl;
-        chol_packed<D>(M, &hl);
+            for (int c = 0; c <= r; ++c) {
+                if (DIAGPSI) M[LT(r, c)] = (r == c) ? t[1 + D + r * D + c] + ps[r] : t[1 + D + r * D + c];
+                else M[LT(r, c)] = t[1 + D + r * D + c] + ps[DIAGPSI ? 0 : LT(r, c)];   // Cij + Psi        predictCov.m:109
+            }
+        chol_packed_rd<D>(M, rd, &prd);
+    };
+    if (SHARED && p0 < p1) build(tab + (size_t)p0 * rec);
+#pragma unroll 1
+    for (long e = p0; e < p1; ++e) {
+        const double *t = tab + (size_t)e * rec;
+        if (!SHARED) build(t);
         double q = 0.0, y[D];
 #pragma unroll
         for (int r = 0; r < D; ++r) {
             double s = x[r] - t[1 + r];
 #pragma unroll
             for (int c = 0; c < r; ++c) s = fma(-M[LT(r, c)], y[c], s);
-            y[r] = s / M[LT(r, r)];
+            y[r] = s * rd[r];
             q = fma(y[r], y[r], q);
         }
-        const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] - 0.5 * q - hl);                    // :111, 2x in the loop (:113-119)
+        const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] - 0.5 * q) * prd;                   // :111, 2x in the loop (:113-119)
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
+        for (int o = 0; o < KM; ++o)
             if (o < k) {
                 ga[o] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o]);
                 vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o]);
@@ -360,7 +396,7 @@ __global__ __launch_bounds__(64) void k_predict_noisy_cov(int n, long ldx, int m
     }
     if (act) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
+        for (int o = 0; o < KM; ++o)
             if (o < k) {
                 part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
                 part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
@@ -369,15 +405,28 @@ __global__ __launch_bounds__(64) void k_predict_noisy_cov(int n, long ldx, int m
     }
 }
 
+// flags: bit 0 = every Psi_i is diagonal, bit 1 = all basis functions share one covariance (GC)
 int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
-                             long pairs_per_chunk, double *part) {
+                             long pairs_per_chunk, double *part, int flags) {
     if (n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;
+    const bool dg = flags & 1, sh = flags & 2;
+#define PN_LAUNCH(DD, DG, SH, KM)                                                                                          \
+    hipLaunchKernelGGL((k_predict_noisy_cov<DD, DG, SH, KM>), dim3((n + 63) / 64, nchunk), dim3(64), 0, st, n, ldx, m, de, k, Xr, \
+                       Psi3, tab, rec, w, v, iS, pairs_per_chunk, part)
 #define PN_CASE(DD)                                                                                                        \
-    hipLaunchKernelGGL((k_predict_noisy_cov<DD>), dim3((n + 63) / 64, nchunk), dim3(64), 0, st, n, ldx, m, de, k, Xr, Psi3, tab, \
-                       rec, w, v, iS, pairs_per_chunk, part)
+    do {                                                                                                                   \
+        if (k == 1) {                                                                                                      \
+            if (dg && sh) PN_LAUNCH(DD, true, true, 1); else if (dg) PN_LAUNCH(DD, true, false, 1);                        \
+            else if (sh) PN_LAUNCH(DD, false, true, 1); else PN_LAUNCH(DD, false, false, 1);                               \
+        } else {                                                                                                           \
+            if (dg && sh) PN_LAUNCH(DD, true, true, 8); else if (dg) PN_LAUNCH(DD, true, false, 8);                        \
+            else if (sh) PN_LAUNCH(DD, false, true, 8); else PN_LAUNCH(DD, false, false, 8);                               \
+        }                                                                                                                  \
+    } while (0)
     PSI_CASES(PN_CASE)
 #undef PN_CASE
+#undef PN_LAUNCH
     return 0;
 }
 

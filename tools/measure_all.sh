@@ -15,12 +15,12 @@ python bench.py --config c5 --rows 250000 --steps 3 --warmup 1 > $O/c5s.json 2> 
 python bench.py --config c2 --validation 0.15 > $O/c2_validation15.json 2> $O/c2_validation15.err
 tools/pmc_run.sh $tag/pmc > $O/pmc_run.log 2>&1
 cd $R
-python tools/pmc_summary.py gpurun_out/$tag/pmc gpurun_out/$tag/pmc_summary.txt > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/$tag/pmc gpurun_out/$tag/pmc_summary.txt --constants gpurun_out/$tag/pmc_constants.json --config c4 > /dev/null 2>&1
 find gpurun_out/$tag/pmc/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 tools/pmc_run.sh $tag/pmc_c5 --config c5 --rows 250000 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_c5_run.log 2>&1
 cd $R
 python tools/pmc_summary.py gpurun_out/$tag/pmc_c5 gpurun_out/$tag/pmc_c5_summary.txt "--config c5 --rows 250000 --steps 2 --warmup 1 --no-cpu-baseline
-# (c5 shard: n=250000 of 2e6, d=20 m=2000 VC hetero + diagonal Psi cubes, dtype f32, 1 x MI355X" > /dev/null 2>&1
+# (c5 shard: n=250000 of 2e6, d=20 m=2000 VC hetero + diagonal Psi cubes, dtype f32, 1 x MI355X" --constants gpurun_out/$tag/pmc_constants.json --config c5 > /dev/null 2>&1
 find gpurun_out/$tag/pmc_c5/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_c5.csv \;
 # keep the merged-back payload small: the raw counter CSVs are large
 find gpurun_out/$tag/pmc -name "*.csv" -size +4M -delete

@@ -1,12 +1,22 @@
-"""Summarise the counter passes written by tools/pmc_run.sh into a text file under profiles/.
-usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/<name>.txt ["bench arguments and workload, for the header"]"""
+"""Summarise the counter passes written by tools/pmc_run.sh into a text file under profiles/, and (optionally) write the
+per-launch fabric-side byte counts bench.py reports as `roofline.traffic` into profiles/pmc_constants.json.
+usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/<name>.txt ["bench arguments and workload, for the header"]
+                                   [--constants profiles/pmc_constants.json --config c4]"""
 import collections
 import csv
+import json
+import os
 import sys
 
-base, dst = sys.argv[1].rstrip("/") + "/", sys.argv[2]
-what = sys.argv[3] if len(sys.argv) > 3 else ("--steps 2 --warmup 1 --no-cpu-baseline\n"
-                                              "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X")
+argv = list(sys.argv[1:])
+constants = config = None
+if "--constants" in argv:
+    i = argv.index("--constants"); constants = argv[i + 1]; del argv[i:i + 2]
+if "--config" in argv:
+    i = argv.index("--config"); config = argv[i + 1]; del argv[i:i + 2]
+base, dst = argv[0].rstrip("/") + "/", argv[1]
+what = argv[2] if len(argv) > 2 else ("--steps 2 --warmup 1 --no-cpu-baseline\n"
+                                      "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X")
 
 
 def load(path):
@@ -42,3 +52,27 @@ with open(dst, "w") as out:
             out.write("   -> fabric-side bytes per launch: fetch %.2f GB (x2 corrected %.2f GB), write %.2f GB\n"
                       % (d["FETCH_SIZE"] * 1024 / 1e9, 2 * d["FETCH_SIZE"] * 1024 / 1e9, d.get("WRITE_SIZE", 0) * 1024 / 1e9))
 print(open(dst).read())
+
+if constants and config:
+    # bytes per launch at the L2 fabric side = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, in KB
+    def fabric(prefixes):
+        for k in sorted(keys):
+            if k.startswith(prefixes) and "FETCH_SIZE" in data[k]:
+                return (2.0 * data[k]["FETCH_SIZE"] + data[k].get("WRITE_SIZE", 0.0)) * 1024.0, k
+        return None, None
+    block = {"source": dst + " (rocprofv3 PMC passes of the same command, tools/pmc_run.sh; written by tools/pmc_summary.py)",
+             "note": "L2 fabric-side bytes per launch (include Infinity-Cache hits): 2 x FETCH_SIZE (gfx950 correction of "
+                     "MI355X_MICROARCH.md, HBM section) + WRITE_SIZE; bench arguments: " + what.splitlines()[0]}
+    for name, pre in (("tgemm", ("k_tgemm", "void k_tgemm")), ("syrk", ("void k_syrk<true",)), ("phi", ("void k_phi", "void k_psi32_phi")),
+                      ("moments", ("void k_moments", "void k_psi32_moments"))):
+        b, k = fabric(pre)
+        if b is not None:
+            block[name + "_bytes_per_launch"] = b
+            block[name + "_kernel"] = k
+    allc = {}
+    if os.path.exists(constants):
+        allc = json.load(open(constants))
+    allc[config] = block
+    json.dump(allc, open(constants, "w"), indent=1)
+    print("wrote", constants, config, {k: v for k, v in block.items() if k.endswith("per_launch")})
+
