@@ -1115,3 +1115,18 @@ def test_predict_over_row_blocks_equals_the_single_device_call(method, monkeypat
         many = gpz_amd.predict(XX, model, Psi=PP, n_gpus=3)
         for a, b in zip(one[:6], many[:6]):
             assert np.array_equal(a, b)
+
+
+def test_predict_branches_against_quadrature_on_the_hip_path():
+    """Every prediction branch of the HIP path (predictFull excepted: no expectation involved) against tests/quad_reference.py —
+    Gauss-Hermite quadrature of the model's definition, no formula shared with predictDiag.m / predictCov.m, the oracle or the
+    kernels (VERDICT r02 "missing 4")."""
+    import quad_reference as Q
+    from test_oracle import QUAD_CASES, _quad_case
+    for method, d, m, k, psi, miss in QUAD_CASES:
+        model, theta, Xs, Psi = _quad_case(method, d, m, k, 900 + d + m + k, psi, miss)
+        st = model.sets["best"]
+        ref = Q.predict(Xs, model, theta, st["w"], st["iSigma_w"], st["priors"], Psi)
+        got = gpz_amd.predict(Xs, model, Psi=Psi)
+        for name, a, b in zip(("mu", "sigma", "nu", "beta_i", "gamma", "PHI"), got, ref):
+            assert rel(a, b) <= 1e-9, (method, psi, miss, name, rel(a, b))
