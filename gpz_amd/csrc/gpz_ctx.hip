@@ -1614,7 +1614,7 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
 }
 
 // GC/VC branch of gpz_predict_missing (predictCov.m:134-337); see k_pmiss_cov.hip.
-static int predict_missing_cov(const gpz_desc *desc, unsigned obs, const double *theta, const double *w, const double *iSigma_w,
+static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, const double *theta, const double *w, const double *iSigma_w,
                                const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                                double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
     if (Psi && psi_kind != 2 && psi_kind != 3) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38) or n x d variances (psi_kind 3)");
@@ -1706,17 +1706,19 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     if (!desc || !theta || !w || !iSigma_w || !priors || !Xs || ns < 1 || !mu || !nu || !beta_i || !gamma)
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
     const int d = desc->d;
-    if (d > 20 || desc->k > 8)
-        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 20 and k <= 8 (d = %d, k = %d)", d, desc->k);
-    unsigned obs = 0;
-    for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1u << c; }
+    const bool covk = method_id_of(desc->method) >= 4;
+    if (d > 64 || (covk && d > 20))
+        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (GL/VL/GD/VD) and d <= 20 (GC/VC, "
+                                         "whose per-(row, pair, component) d x d factorisations are O(n m^3 d^3)); d = %d", d);
+    unsigned long long obs = 0;
+    for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1ull << c; }
     for (int c = 0; c < d; ++c)
         for (int64_t i = 0; i < ns; ++i) {
             const double xv = Xs[(size_t)c * ns + i];
-            if ((xv == xv) != (((obs >> c) & 1u) != 0))
+            if ((xv == xv) != (((obs >> c) & 1ull) != 0))
                 return fail(GPZ_ERR_ARG, "gpz_predict_missing: the rows of a group must share one NaN pattern (predict.m:45-57)");
         }
-    if (obs == (d >= 32 ? ~0u : ((1u << d) - 1u)))
+    if (obs == (d >= 64 ? ~0ull : ((1ull << d) - 1ull)))
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
     if (method_id_of(desc->method) >= 4)
         return predict_missing_cov(desc, obs, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);

@@ -289,24 +289,24 @@ void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, co
 
 // prediction with missing dimensions, diagonal kinds (predictDiag.m:127-297; k_pmiss.hip).  obs: bit c set = dimension c observed.
 void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
-                  unsigned obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
+                  unsigned long long obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
 void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio);
 // covariance kinds (predictCov.m:134-337; k_pmiss_cov.hip): see launch_pmc for the work buffers
-int pmc_rec_len(int d, unsigned obs);
-void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
+int pmc_rec_len(int d, unsigned long long obs);
+void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
                 double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
                 double *work2 = nullptr /* m * (d(d+1)/2 + d*d + d + 1) doubles: enables the register-resident route */);
 bool pmc_fast(int d, int k);   // 2 <= d <= 10, k <= 8: the register-resident kernels (needs rows_blk <= 64)
-void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned obs, const double *P, const double *G, double *B);
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned long long obs, const double *P, const double *G, double *B);
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
                    const double *G, double *Phi);
-void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned obs,
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned long long obs,
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec);
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
-                     unsigned obs, int npq, const double *T2, const double *rec, int nrec, double *sums);
+                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec, double *sums);
 
 // N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
 struct NormArgs {

@@ -273,30 +273,33 @@ __global__ __launch_bounds__(64) void k_pmc_accum(PmcPat pt, int row0, int nrows
                                                   double *__restrict__ part) {
     const int rr = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
     const int d = pt.d;
-    double acc[24], S[GDM * GDM], dl[GDM];
-#pragma unroll
-    for (int e = 0; e < 24; ++e) acc[e] = 0.0;
+    double S[GDM * GDM], dl[GDM];
     const long q0 = (long)chunk * pairs_per_chunk, q1 = min(npairs, q0 + pairs_per_chunk);
-    for (long q = q0; q < q1; ++q) {
-        const double *t = tab + (size_t)q * ntab;
-        double ec = 0.0;
-        for (int l = lane; l < m; l += 64) {
-            pmc_add_phat(S, t, pt, Phat ? Phat + ((size_t)rr * m + l) * d * d : nullptr, rec + (size_t)l * nrec);
-            const double *xh = Xhat + ((size_t)rr * m + l) * d;
-            for (int a = 0; a < d; ++a) dl[a] = xh[a] - t[d * d + a];
-            ec += exp(pmc_lognorm(S, dl, d)) * Pio[(size_t)rr * ld + l];
+    for (int e0 = 0; e0 < 3 * k; e0 += 24) {   // the 3k sums in blocks of 24 (k <= 8: one pass)
+        double acc[24];
+#pragma unroll
+        for (int e = 0; e < 24; ++e) acc[e] = 0.0;
+        for (long q = q0; q < q1; ++q) {
+            const double *t = tab + (size_t)q * ntab;
+            double ec = 0.0;
+            for (int l = lane; l < m; l += 64) {
+                pmc_add_phat(S, t, pt, Phat ? Phat + ((size_t)rr * m + l) * d * d : nullptr, rec + (size_t)l * nrec);
+                const double *xh = Xhat + ((size_t)rr * m + l) * d;
+                for (int a = 0; a < d; ++a) dl[a] = xh[a] - t[d * d + a];
+                ec += exp(pmc_lognorm(S, dl, d)) * Pio[(size_t)rr * ld + l];
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) ec += __shfl_xor(ec, off, 64);
+            const double Z = exp(t[d * d + d]) * ec;
+#pragma unroll
+            for (int e = 0; e < 24; ++e)
+                if (e0 + e < 3 * k) acc[e] = fma(Z, t[d * d + d + 1 + e0 + e], acc[e]);
         }
+        if (lane == 0) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ec += __shfl_xor(ec, off, 64);
-        const double Z = exp(t[d * d + d]) * ec;
-#pragma unroll
-        for (int e = 0; e < 24; ++e)
-            if (e < 3 * k) acc[e] = fma(Z, t[d * d + d + 1 + e], acc[e]);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int e = 0; e < 24; ++e)
-            if (e < 3 * k) part[((size_t)chunk * 3 * k + e) * ldx + row0 + rr] = acc[e];
+            for (int e = 0; e < 24; ++e)
+                if (e0 + e < 3 * k) part[((size_t)chunk * 3 * k + e0 + e) * ldx + row0 + rr] = acc[e];
+        }
     }
 }
 
@@ -497,15 +500,15 @@ static bool pmc_sum(hipStream_t st, int d, bool noisy, int nrows, int row0, int 
 // One NaN-pattern group.  obs: bit c set = dimension c observed.  Sig/iSig: m x d*d (k_gen_prep).  Work buffers are
 // allocated by the caller: rec (m*nrec), tab (npairs*ntab), Ex/Pio (rows_blk*ld each), Xhat (rows_blk*m*d),
 // Phat (rows_blk*m*d*d, only with Psi3), part (nchunk*3k*ldx).  Writes PHI rows [0,n) and part; the caller sums part.
-int pmc_rec_len(int d, unsigned obs) {
+int pmc_rec_len(int d, unsigned long long obs) {
     int no = 0;
-    for (int c = 0; c < d; ++c) no += (obs >> c) & 1u;
+    for (int c = 0; c < d; ++c) no += (obs >> c) & 1ull;
     const int nu = d - no;
     return 2 + no * no + no * nu + nu * nu;
 }
-bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // register-resident kernels (rows_blk <= 64 then)
+bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // (more outputs: the scratch kernels, 24 sums per pass)   // register-resident kernels (rows_blk <= 64 then)
 // work2: m * (d(d+1)/2 + d*d + d + 1) doubles, used by the register-resident route
-void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
+void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
                 double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
@@ -513,7 +516,7 @@ void launch_pmc(hipStream_t st, unsigned obs, int n, long ldx, int m, int ld, in
     PmcPat pt;
     pt.d = d; pt.no = 0; pt.nu = 0;
     for (int c = 0; c < d; ++c) {
-        if ((obs >> c) & 1u) pt.o[pt.no++] = c;
+        if ((obs >> c) & 1ull) pt.o[pt.no++] = c;
         else pt.u[pt.nu++] = c;
     }
     int perm[GDM];

@@ -27,8 +27,8 @@
  * register-resident kernels; wider inputs / more outputs take runtime-d kernels with the row data in LDS (k_wide.hip) and, for
  * GC/VC with input noise or missing values, a workspace-backed form of the general path (DESIGN.md section 7 gives the cost;
  * a row tile must fit the 160 KB of LDS: d <= ~100 for the diagonal kinds with input noise and missing values, ~300 without).
- * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 20 or k > 8, dtype = f32 pair kernels with d > 20 (the
- * fp64 general path is taken instead).
+ * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 64, or d > 20 for GC/VC.  dtype = f32 with d > 20 takes the
+ * fp64 general path (the fp32 pair kernels hold a d <= 20 triangle in registers).
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):
  *   - all matrices are column-major double; masks are 1 byte per row (MATLAB logical);
