@@ -18,10 +18,13 @@ SLICES = [
     ("fuzz_f32.py", ["50", "20303"]),
     ("fuzz_mgpu.py", ["50", "20304"]),
     ("fuzz_sharded.py", ["24", "20305", "2"]),
+    # d > 20 / k > 8 draws: the runtime-d kernels, the workspace-backed general path, the any-k PHI build (round 3)
+    ("fuzz_parity.py", ["40", "20311", "wide"]),
+    ("fuzz_predict.py", ["40", "20312", "wide"]),
 ]
 
 
-@pytest.mark.parametrize("tool,args", SLICES, ids=[s[0][:-3] for s in SLICES])
+@pytest.mark.parametrize("tool,args", SLICES, ids=[s[0][:-3] + ("_wide" if "wide" in s[1] else "") for s in SLICES])
 def test_seeded_fuzz_slice(tool, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), *args], capture_output=True, text=True, timeout=900,
                        cwd=ROOT)

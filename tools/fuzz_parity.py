@@ -1,5 +1,7 @@
 """Developer tool: randomised parity sweep of gpz_eval / gpz_solve against the oracle over shapes, methods, outputs, input
-noise, missing values, weights and masks.  usage: fuzz_parity.py [cases] [seed]"""
+noise, missing values, weights and masks.  usage: fuzz_parity.py [cases] [seed] [wide]
+wide: a third of the cases draw d in 21..34 (GC/VC: 11..24) and / or k in 9..11 — the runtime-d kernels of k_wide.hip, the
+workspace-backed general path and the any-k PHI build."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +12,7 @@ from helpers import make_problem, grad_tol, rel
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 bad = 0
 t0 = time.time()
 for c in range(cases):
@@ -19,11 +22,19 @@ for c in range(cases):
     k = int(rng.choice([1, 1, 1, 2, 3]))
     n = int(rng.choice([m + 3, 37, 64, 100, 257, 513, 1000, 1025, 2049]))
     n = max(n, 8)
+    if WIDE and rng.random() < 0.5:
+        which = rng.integers(0, 3)
+        if which != 1:
+            d = int(rng.integers(21, 35)) if method[1] != "C" else int(rng.integers(11, 25))
+            m = min(m, 33)
+        if which != 0:
+            k = int(rng.integers(9, 12))
+        n = min(n, 600)
     hetero = bool(rng.random() < 0.7)
     psi = bool(rng.random() < 0.35)
     nanfrac = float(rng.choice([0.0, 0.0, 0.2, 0.4])) if d > 1 else 0.0
     if method[1] == "C" and (psi or nanfrac > 0) and n * m > 60000:
-        n = max(8, 60000 // m)                      # oracle loops over pairs
+        n = max(8, (60000 if d <= 10 else 6000) // m)                      # oracle loops over pairs
     seed = int(rng.integers(1 << 30))
     model, theta, X, Y, Psi, r2 = make_problem(n, d, m, k, method, hetero, seed=seed, psi=psi, nanfrac=nanfrac)
     if model.method != method:                      # d == 1 rewrites *D/*C to *L (init.m:12-14)

@@ -1,5 +1,6 @@
 """Developer tool: randomised parity sweep of predict (all four branches of predictDiag.m / predictCov.m), getPHI (all
-outputs) and getPrior against the oracle.  usage: fuzz_predict.py [cases] [seed]"""
+outputs) and getPrior against the oracle.  usage: fuzz_predict.py [cases] [seed] [wide]
+wide: GC/VC draw d up to 12 (beyond the register-resident kernels' d <= 10), the diagonal kinds d up to 30, k up to 10."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +11,7 @@ from helpers import make_problem, rel
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 bad = 0
 t0 = time.time()
 for c in range(cases):
@@ -18,6 +20,11 @@ for c in range(cases):
     d = int(rng.integers(2, 6)) if cov else int(rng.integers(1, 8))
     m = int(rng.choice([1, 2, 3, 5, 8])) if cov else int(rng.choice([1, 2, 5, 16, 17, 40]))
     k = int(rng.choice([1, 1, 2]))
+    if WIDE and rng.random() < 0.5:
+        d = int(rng.integers(6, 13)) if cov else int(rng.integers(8, 31))
+        m = min(m, 5) if cov else m
+        if rng.random() < 0.4:
+            k = int(rng.integers(9, 11))
     hetero = bool(rng.random() < 0.7)
     seed = int(rng.integers(1 << 30))
     model, theta, X, Y, _, r2 = make_problem(120, d, m, k, method, hetero, seed=seed)
