@@ -181,7 +181,8 @@ struct gpz_ctx {
     double *mom_slab = nullptr;
     int nchunk = 1, rows_per_chunk = 1;
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
-    double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused single-output path
+    double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused path
+    bool fused = true;   // dPHI formed on the fly, output by output (no dPHI / dL matrices): k == 1, or k > 1 on the tuned kernels
     double *phipart = nullptr;   // PHI-build column-group partial sums (small row counts)
     int phipart_groups = 0;
     int nslots = 0;
@@ -653,7 +654,8 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
     if ((rc = c->ar.alloc(&c->Phi, np * mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->T, np * mp))) return bail(rc);
-    if (k > 1 && (rc = c->ar.alloc(&c->dL, np * mp))) return bail(rc);
+    c->fused = (k == 1) || !c->gen;   // the general GC/VC path chains r1 / r2 through its records: single output only
+    if (!c->fused && (rc = c->ar.alloc(&c->dL, np * mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->lnbeta, np * k))) return bail(rc);
     if ((rc = c->ar.alloc(&c->wbeta, np * k))) return bail(rc);
     if ((rc = c->ar.alloc(&c->phiw, np * k))) return bail(rc);
@@ -703,7 +705,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     c->comm2_count = m * c->nm + k * 2 * mp + k * 4 + gpz_ns(c->k);
     if ((rc = c->ar.alloc(&c->comm2, c->comm2_count))) return bail(rc);
     c->nwg_rows = c->tr.n < 2048 ? (c->tr.n > 0 ? c->tr.n : 1) : 2048;
-    if (k > 1) {
+    if (!c->fused) {
         if ((rc = c->ar.alloc(&c->colslab, (size_t)c->nwg_rows * 2 * mp))) return bail(rc);
         if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
     } else {
@@ -1060,7 +1062,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
     double *cols = mom + m * c->nm;
     double *scal = cols + k * 2 * mp;
     double *vsums = scal + k * 4;
-    const bool fused = (c->k == 1);
+    const bool fused = c->fused;
     for (int o = 0; o < c->k; ++o) {
         if (pinv) { if (int e = stage_b_pinv(c, o)) return e; }
         else stage_b(c, o);
@@ -1068,15 +1070,17 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             Stage s(c, "tgemm");
             // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip)
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
-                         c->phiw, c->m, c->m + o, c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
+                         fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o,
+                         c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
         }
         if (fused) {
             {
                 Stage s(c, "row_scalars");
-                launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->wbeta,
-                                   c->tr.n_pad, c->tr.n, c->rowscal, c->partial);
+                const size_t oo = (size_t)o * c->tr.n_pad;   // this output's columns of the k x n_pad row arrays
+                launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw + oo, c->tr.Y + oo, c->tr.om, c->lnbeta + oo,
+                                   c->wbeta + oo, c->tr.n_pad, c->tr.n, c->rowscal, c->partial);
                 launch_slab_sum(c->st, c->partial, row_scalars_nwg(c->tr.n), GPZ_NS, c->rstats);
-                HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+                HIPCHK(hipMemcpyAsync(scal + (size_t)o * 4, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
             Stage s(c, "moments");
             if (c->gen && !c->has_psi) {
@@ -1131,13 +1135,15 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             }
             FusedMomentArgs a{};
             a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr; a.rowscal = c->rowscal; a.n = c->tr.n; a.m = c->m;
-            a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w; a.v = c->hetero ? c->pr.v : nullptr;
+            a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w + (size_t)o * m;
+            a.v = c->hetero ? c->pr.v + (size_t)o * m : nullptr;
             a.nchunk = c->nchunk; a.rows_per_chunk = c->rows_per_chunk; a.slab = c->mom_slab; a.nm = c->nm;
             a.Psir = c->tr.Psir; a.Mr = c->tr.Mr; a.G2 = c->pr.G2;
             if (launch_moments_fused(c->st, a))
                 return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
             launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * (c->nm + 2), c->frec);
-            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols);
+            // dPHI is a sum over the outputs (GPz.m:113): the moments accumulate, the column sums are per output
+            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols + (size_t)o * 2 * mp, o > 0 ? 1 : 0);
             continue;
         }
         {
@@ -1152,7 +1158,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                                   scal + (size_t)o * 4);
         }
     }
-    if (c->k > 1) {
+    if (!fused) {
         {
             Stage s(c, "mul_phi");
             launch_mul_phi(c->st, c->dL, c->Phi, c->T, (size_t)c->tr.n_pad * mp);

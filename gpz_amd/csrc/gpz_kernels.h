@@ -161,7 +161,8 @@ int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a);
 int launch_moments_wide(hipStream_t st, const MomentArgs &a);
 int launch_moments_fused_wide(hipStream_t st, const FusedMomentArgs &a);   // overwrites a.T with dPHI
 // split the reduced [m][nm+2] records into mom [m][nm] and cols [2][mp]
-void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols);
+void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols,
+                        int accumulate = 0 /* add to mom instead of assigning (outputs after the first) */);
 void launch_slab_sum(hipStream_t st, const double *slab, int nslab, size_t count, double *out);
 // out[g][count] = sum of slabs seg[g] .. seg[g+1]-1, g < nseg (seg: nseg+1 device ints)
 void launch_slab_sum_seg(hipStream_t st, const double *slab, const int *seg, int nseg, size_t count, double *out);

@@ -36,18 +36,28 @@
 size_t gen_ws_per_thread(int d) { return (size_t)9 * d * d + (size_t)8 * d + 16; }
 
 // Cholesky of the leading no x no block of M (row-major, leading dimension ld), lower factor in place.
+// 1/sqrt(p) without the library's sqrt and divide (v_rsq_f64 seed + two Newton steps); NaN for p < 0 as sqrt() gives
+__device__ __forceinline__ double gen_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
 __device__ __forceinline__ bool chol_small(double *M, int no, int ld) {
     bool ok = true;
     for (int c = 0; c < no; ++c) {
         double p = M[c * ld + c];
         for (int q = 0; q < c; ++q) p = fma(-M[c * ld + q], M[c * ld + q], p);
         if (!(p > 0.0)) ok = false;
-        const double dd = sqrt(p);
-        M[c * ld + c] = dd;
+        const double inv = gen_rsqrt(p);
+        M[c * ld + c] = p * inv;
         for (int r = c + 1; r < no; ++r) {
             double s = M[r * ld + c];
             for (int q = 0; q < c; ++q) s = fma(-M[r * ld + q], M[c * ld + q], s);
-            M[r * ld + c] = s / dd;
+            M[r * ld + c] = s * inv;
         }
     }
     return ok;
@@ -55,12 +65,12 @@ __device__ __forceinline__ bool chol_small(double *M, int no, int ld) {
 
 // W = inv(L) (lower), then Minv = W' W; L in M (lower), result symmetric full in Minv.
 __device__ __forceinline__ void inv_from_chol(const double *L, int no, double *W, double *Minv, int ld) {
+    for (int c = 0; c < no; ++c) W[c * ld + c] = 1.0 / L[c * ld + c];     // the d reciprocals first: the substitution multiplies
     for (int c = 0; c < no; ++c) {
-        W[c * ld + c] = 1.0 / L[c * ld + c];
         for (int r = c + 1; r < no; ++r) {
             double s = 0.0;
             for (int q = c; q < r; ++q) s = fma(L[r * ld + q], W[q * ld + c], s);
-            W[r * ld + c] = -s / L[r * ld + r];
+            W[r * ld + c] = -s * W[r * ld + r];
         }
     }
     for (int a = 0; a < no; ++a)

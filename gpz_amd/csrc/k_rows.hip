@@ -591,19 +591,20 @@ int launch_moments_fused(hipStream_t st, const FusedMomentArgs &a) {
     return 0;
 }
 
+// accumulate: the moments of this output are added to those of the outputs before it (dPHI is a sum over outputs, GPz.m:113)
 __global__ void k_split_fused(const double *__restrict__ rec, int m, int nm, int mp, double *__restrict__ mom,
-                              double *__restrict__ cols) {
+                              double *__restrict__ cols, int accumulate) {
     const int gs = blockDim.x * gridDim.x;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * (nm + 2); e += gs) {
         const int j = e / (nm + 2), q = e % (nm + 2);
         const double v = rec[e];
-        if (q < nm) mom[(size_t)j * nm + q] = v;
+        if (q < nm) mom[(size_t)j * nm + q] = accumulate ? mom[(size_t)j * nm + q] + v : v;
         else cols[(size_t)(q - nm) * mp + j] = v;
     }
 }
 
-void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols) {
-    hipLaunchKernelGGL(k_split_fused, dim3(256), dim3(256), 0, st, rec, m, nm, mp, mom, cols);
+void launch_split_fused(hipStream_t st, const double *rec, int m, int nm, int mp, double *mom, double *cols, int accumulate) {
+    hipLaunchKernelGGL(k_split_fused, dim3(256), dim3(256), 0, st, rec, m, nm, mp, mom, cols, accumulate);
 }
 
 // ---------------------------------------------------------------------------------------------
