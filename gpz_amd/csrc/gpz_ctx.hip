@@ -576,7 +576,7 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
             return rc;
     }
     if (c->d > 20 && (c->gen || c->has_psi) &&
-        (rc = c->ar.alloc(&c->gen_ws, (size_t)GPZ_GEN_RT_THREADS * gen_ws_per_thread(c->d))))
+        (rc = c->ar.alloc(&c->gen_ws, (size_t)gen_rt_threads(c->d) * gen_ws_per_thread(c->d))))
         return rc;
     return alloc_params(c);
 }

@@ -215,10 +215,10 @@ struct GenRows {
     const int *rows_by_group;  // row indices sorted by pattern id
     int n, n_pad;
 };
-// ws: runtime-d workspace of GPZ_GEN_RT_THREADS * gen_ws_per_thread(d) doubles, needed (non-null) when d > 20; the small
+// ws: runtime-d workspace of gen_rt_threads(d) * gen_ws_per_thread(d) doubles, needed (non-null) when d > 20; the small
 // matrices of the general path live there instead of per-thread scratch and the kernels run as grid-stride loops
-#define GPZ_GEN_RT_THREADS 8192
 size_t gen_ws_per_thread(int d);
+int gen_rt_threads(int d);   // size of the grid-stride thread pool of the runtime-d kernels (workspace = threads x per-thread doubles)
 void launch_gen_prep(hipStream_t st, const double *G, int m, int d, int de, double *Sig, double *iSig,
                      const unsigned char *pat, int ngroups, double *lnS, double *ws = nullptr);
 // missing dimensions without input noise: per-pattern parameter block for the tuned PHI kernel ([R~ | c~], layout of

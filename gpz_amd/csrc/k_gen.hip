@@ -17,23 +17,34 @@
 // Small-matrix storage of the general path.  CAP > 0: compile-time capacity, the matrices live in per-thread scratch with
 // leading dimension CAP (d <= 20, the layout the path was measured with).  CAP == 0: runtime d of any size — leading
 // dimension d, the matrices live in a global workspace of gen_ws_per_thread(d) doubles per thread and the kernels run as
-// grid-stride loops over GPZ_GEN_RT_THREADS threads, so the workspace does not grow with the problem.
+// grid-stride loops over gen_rt_threads(d) threads, so the workspace does not grow with the problem.
 #define GCAP 20
+// CAP == 0: element e of a thread's array sits at ws[(offset + e) * nthreads + thread] — the lanes of a wave touch consecutive
+// doubles (per-thread contiguous blocks made every access 64 separate cache lines: 25 x slower at d = 24).  ES is the element
+// stride (1 for the scratch arrays of CAP > 0); every workspace array is indexed as name[(i) * ES].
 #define GEN_ARR(name, cap_count, rt_count)                       \
     double name##_loc[CAP ? (cap_count) : 1];                    \
     double *name = name##_loc;                                   \
-    if (!CAP) { name = wsp; wsp += (rt_count); }
+    if (!CAP) { name = wsp; wsp += (size_t)(rt_count) * nth_; }
 #define GEN_IARR(name, cap_count, rt_count)                      \
     int name##_loc[CAP ? (cap_count) : 1];                       \
     int *name = name##_loc;                                      \
-    if (!CAP) { name = (int *)wsp; wsp += ((rt_count) + 1) / 2; }
+    if (!CAP) { name = (int *)wsp; wsp += (size_t)(rt_count) * nth_; }   /* one 8-byte slot per int: the same stride */
 #define GEN_SETUP()                                                                                   \
     const long gt_ = (long)blockIdx.x * blockDim.x + threadIdx.x, nth_ = (long)gridDim.x * blockDim.x; \
     const int GDM = CAP ? CAP : d;                                                                    \
-    double *wsp = ws ? ws + (size_t)gt_ * ws_stride : nullptr;                                        \
-    (void)wsp
+    const long ES = CAP ? 1 : nth_;                                                                   \
+    const long ESI = CAP ? 1 : 2 * nth_;   /* int arrays: stride in ints */                           \
+    double *wsp = ws ? ws + gt_ : nullptr;                                                            \
+    (void)wsp; (void)ES; (void)ESI; (void)ws_stride
 
-size_t gen_ws_per_thread(int d) { return (size_t)9 * d * d + (size_t)8 * d + 16; }
+size_t gen_ws_per_thread(int d) { return (size_t)9 * d * d + (size_t)10 * d + 16; }
+// threads of the runtime-d pool: as many as 2 GiB of workspace hold, 4096 .. 65536 (whole waves)
+int gen_rt_threads(int d) {
+    long t = (long)((2048UL << 20) / (gen_ws_per_thread(d) * sizeof(double)));
+    t = t < 4096 ? 4096 : (t > 65536 ? 65536 : t);
+    return (int)(t / 64 * 64);
+}
 
 // Cholesky of the leading no x no block of M (row-major, leading dimension ld), lower factor in place.
 // 1/sqrt(p) without the library's sqrt and divide (v_rsq_f64 seed + two Newton steps); NaN for p < 0 as sqrt() gives
@@ -46,39 +57,39 @@ __device__ __forceinline__ double gen_rsqrt(double p) {
     y = fma(y, e, y);
     return y;
 }
-__device__ __forceinline__ bool chol_small(double *M, int no, int ld) {
+__device__ __forceinline__ bool chol_small(double *M, int no, int ld, long es) {
     bool ok = true;
     for (int c = 0; c < no; ++c) {
-        double p = M[c * ld + c];
-        for (int q = 0; q < c; ++q) p = fma(-M[c * ld + q], M[c * ld + q], p);
+        double p = M[(c * ld + c) * es];
+        for (int q = 0; q < c; ++q) p = fma(-M[(c * ld + q) * es], M[(c * ld + q) * es], p);
         if (!(p > 0.0)) ok = false;
         const double inv = gen_rsqrt(p);
-        M[c * ld + c] = p * inv;
+        M[(c * ld + c) * es] = p * inv;
         for (int r = c + 1; r < no; ++r) {
-            double s = M[r * ld + c];
-            for (int q = 0; q < c; ++q) s = fma(-M[r * ld + q], M[c * ld + q], s);
-            M[r * ld + c] = s * inv;
+            double s = M[(r * ld + c) * es];
+            for (int q = 0; q < c; ++q) s = fma(-M[(r * ld + q) * es], M[(c * ld + q) * es], s);
+            M[(r * ld + c) * es] = s * inv;
         }
     }
     return ok;
 }
 
 // W = inv(L) (lower), then Minv = W' W; L in M (lower), result symmetric full in Minv.
-__device__ __forceinline__ void inv_from_chol(const double *L, int no, double *W, double *Minv, int ld) {
-    for (int c = 0; c < no; ++c) W[c * ld + c] = 1.0 / L[c * ld + c];     // the d reciprocals first: the substitution multiplies
+__device__ __forceinline__ void inv_from_chol(const double *L, int no, double *W, double *Minv, int ld, long es) {
+    for (int c = 0; c < no; ++c) W[(c * ld + c) * es] = 1.0 / L[(c * ld + c) * es];     // the d reciprocals first: the substitution multiplies
     for (int c = 0; c < no; ++c) {
         for (int r = c + 1; r < no; ++r) {
             double s = 0.0;
-            for (int q = c; q < r; ++q) s = fma(L[r * ld + q], W[q * ld + c], s);
-            W[r * ld + c] = -s * W[r * ld + r];
+            for (int q = c; q < r; ++q) s = fma(L[(r * ld + q) * es], W[(q * ld + c) * es], s);
+            W[(r * ld + c) * es] = -s * W[(r * ld + r) * es];
         }
     }
     for (int a = 0; a < no; ++a)
         for (int b = 0; b <= a; ++b) {
             double s = 0.0;
-            for (int q = a; q < no; ++q) s = fma(W[q * ld + a], W[q * ld + b], s);
-            Minv[a * ld + b] = s;
-            Minv[b * ld + a] = s;
+            for (int q = a; q < no; ++q) s = fma(W[(q * ld + a) * es], W[(q * ld + b) * es], s);
+            Minv[(a * ld + b) * es] = s;
+            Minv[(b * ld + a) * es] = s;
         }
 }
 
@@ -94,13 +105,13 @@ __global__ void k_gen_prep(const double *__restrict__ G, int m, int d, int de, d
             for (int b = 0; b < d; ++b) {
                 double s = 0.0;
                 for (int q = 0; q < d; ++q) s = fma(Gj[q * de + a], Gj[q * de + b], s);
-                A[a * GDM + b] = s;
+                A[(a * GDM + b) * ES] = s;
                 iSig[(size_t)j * d * d + a * d + b] = s;
             }
-        chol_small(A, d, GDM);
-        inv_from_chol(A, d, W, Ai, GDM);
+        chol_small(A, d, GDM, ES);
+        inv_from_chol(A, d, W, Ai, GDM, ES);
         for (int a = 0; a < d; ++a)
-            for (int b = 0; b < d; ++b) Sig[(size_t)j * d * d + a * d + b] = Ai[a * GDM + b];
+            for (int b = 0; b < d; ++b) Sig[(size_t)j * d * d + a * d + b] = Ai[(a * GDM + b) * ES];
     }
 }
 
@@ -114,12 +125,12 @@ __global__ void k_gen_lndet(const double *__restrict__ Sig, const unsigned char 
         const int g = (int)(e / m), j = (int)(e % m);
         int no = 0;
         for (int c = 0; c < d; ++c)
-            if (pat[g * d + c]) o[no++] = c;
+            if (pat[g * d + c]) o[(no++) * ESI] = c;
         for (int a = 0; a < no; ++a)
-            for (int b = 0; b < no; ++b) M[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
-        chol_small(M, no, GDM);
+            for (int b = 0; b < no; ++b) M[(a * GDM + b) * ES] = Sig[(size_t)j * d * d + o[(a) * ESI] * d + o[(b) * ESI]];
+        chol_small(M, no, GDM, ES);
         double s = 0.0;
-        for (int a = 0; a < no; ++a) s += log(M[a * GDM + a]);
+        for (int a = 0; a < no; ++a) s += log(M[(a * GDM + a) * ES]);
         lnS[e] = 2.0 * s;
     }
 }
@@ -138,25 +149,25 @@ __global__ __launch_bounds__(64) void k_gen_phi(const double *__restrict__ Xr, i
         const int g = gid[i];
         int no = 0;
         for (int c = 0; c < d; ++c)
-            if (pat[g * d + c]) o[no++] = c;
+            if (pat[g * d + c]) o[(no++) * ESI] = c;
         const double cmiss = -0.5 * (double)(d - no) * GPZ_LOG2;               // -1/2 |u| ln 2
-        for (int a = 0; a < no; ++a) x[a] = Xr[(size_t)i * de + o[a]];
+        for (int a = 0; a < no; ++a) x[(a) * ES] = Xr[(size_t)i * de + o[(a) * ESI]];
         for (int j = 0; j < m; ++j) {
             const double *Sj = Sig + (size_t)j * d * d;
             for (int a = 0; a < no; ++a)
                 for (int b = 0; b <= a; ++b) {
-                    double v = Sj[o[a] * d + o[b]];
-                    if (Psi3) v += Psi3[(size_t)i * d * d + o[a] + d * o[b]];   // Psi(o,o,i)   getPHI.m:84
-                    M[a * GDM + b] = v;
+                    double v = Sj[o[(a) * ESI] * d + o[(b) * ESI]];
+                    if (Psi3) v += Psi3[(size_t)i * d * d + o[(a) * ESI] + d * o[(b) * ESI]];   // Psi(o,o,i)   getPHI.m:84
+                    M[(a * GDM + b) * ES] = v;
                 }
-            chol_small(M, no, GDM);
+            chol_small(M, no, GDM, ES);
             double quad = 0.0, ldM = 0.0;
             for (int a = 0; a < no; ++a) {                                      // y = L^-1 Delta_o
-                double s = x[a] - P[(size_t)j * de + o[a]];
-                for (int q = 0; q < a; ++q) s = fma(-M[a * GDM + q], y[q], s);
-                y[a] = s / M[a * GDM + a];
-                quad = fma(y[a], y[a], quad);
-                ldM += log(M[a * GDM + a]);
+                double s = x[(a) * ES] - P[(size_t)j * de + o[(a) * ESI]];
+                for (int q = 0; q < a; ++q) s = fma(-M[(a * GDM + q) * ES], y[(q) * ES], s);
+                y[(a) * ES] = s / M[(a * GDM + a) * ES];
+                quad = fma(y[(a) * ES], y[(a) * ES], quad);
+                ldM += log(M[(a * GDM + a) * ES]);
             }
             double lp = -0.5 * quad + cmiss;                                    // getPHI.m:76
             if (Psi3) lp += 0.5 * lnS[(size_t)g * m + j] - ldM;                 // getPHI.m:86  (+1/2 ln|S_oo| - 1/2 ln|M|)
@@ -231,18 +242,18 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
         if (j >= m) continue;
         int no = 0;
         for (int c = 0; c < d; ++c)
-            if (pat[g * d + c]) o[no++] = c;
+            if (pat[g * d + c]) o[(no++) * ESI] = c;
         double a0 = 0.0, r1 = 0.0, r2 = 0.0;
-        for (int a = 0; a < no; ++a) acc1[a] = 0.0;
-        for (int a = 0; a < no * GDM; ++a) cacc[a] = 0.0;
+        for (int a = 0; a < no; ++a) acc1[(a) * ES] = 0.0;
+        for (int a = 0; a < no * GDM; ++a) cacc[(a) * ES] = 0.0;
         const double wj = w ? w[j] : 0.0, vj = v ? v[j] : 0.0;
         const double *Sj = Sig + (size_t)j * d * d;
         const int r0 = chunk * rows_per_chunk, rend = min(nrows, r0 + rows_per_chunk);
         if (!Psi3) {   // without input noise M = Sigma_j,oo is the same for every row of the pattern: invert once
             for (int a = 0; a < no; ++a)
-                for (int b = 0; b <= a; ++b) M[a * GDM + b] = Sj[o[a] * d + o[b]];
-            chol_small(M, no, GDM);
-            inv_from_chol(M, no, W, Mi, GDM);
+                for (int b = 0; b <= a; ++b) M[(a * GDM + b) * ES] = Sj[o[(a) * ESI] * d + o[(b) * ESI]];
+            chol_small(M, no, GDM, ES);
+            inv_from_chol(M, no, W, Mi, GDM, ES);
         }
         for (int rr = r0; rr < rend; ++rr) {
             const int i = rows[rr];
@@ -256,31 +267,31 @@ __global__ __launch_bounds__(64) void k_gen_moments(const double *__restrict__ P
             } else {
                 dp = T[(size_t)i * ld + j];                                     // dPHI already formed (k > 1)
             }
-            for (int a = 0; a < no; ++a) dl[a] = Xr[(size_t)i * de + o[a]] - P[(size_t)j * de + o[a]];
+            for (int a = 0; a < no; ++a) dl[(a) * ES] = Xr[(size_t)i * de + o[(a) * ESI]] - P[(size_t)j * de + o[(a) * ESI]];
             if (Psi3) {
                 for (int a = 0; a < no; ++a)
                     for (int b = 0; b <= a; ++b)
-                        M[a * GDM + b] = Sj[o[a] * d + o[b]] + Psi3[(size_t)i * d * d + o[a] + d * o[b]];
-                chol_small(M, no, GDM);
-                inv_from_chol(M, no, W, Mi, GDM);                               // iPSoo   GPz.m:170
+                        M[(a * GDM + b) * ES] = Sj[o[(a) * ESI] * d + o[(b) * ESI]] + Psi3[(size_t)i * d * d + o[(a) * ESI] + d * o[(b) * ESI]];
+                chol_small(M, no, GDM, ES);
+                inv_from_chol(M, no, W, Mi, GDM, ES);                               // iPSoo   GPz.m:170
             }
             for (int a = 0; a < no; ++a) {
                 double s = 0.0;
-                for (int b = 0; b < no; ++b) s = fma(Mi[a * GDM + b], dl[b], s);
-                u[a] = s;
+                for (int b = 0; b < no; ++b) s = fma(Mi[(a * GDM + b) * ES], dl[(b) * ES], s);
+                u[(a) * ES] = s;
             }
             a0 += dp;
             for (int a = 0; a < no; ++a) {
-                acc1[a] = fma(dp, u[a], acc1[a]);                               // GPz.m:152,172
-                for (int b = 0; b < no; ++b) cacc[a * GDM + b] = fma(dp, u[a] * u[b] - Mi[a * GDM + b], cacc[a * GDM + b]);
+                acc1[(a) * ES] = fma(dp, u[(a) * ES], acc1[(a) * ES]);                               // GPz.m:152,172
+                for (int b = 0; b < no; ++b) cacc[(a * GDM + b) * ES] = fma(dp, u[(a) * ES] * u[(b) * ES] - Mi[(a * GDM + b) * ES], cacc[(a * GDM + b) * ES]);
             }
         }
         double *rec = slab + ((size_t)chunk * m + j) * nrec;
         for (int q = 0; q < nrec; ++q) rec[q] = 0.0;
         rec[0] = a0;
         for (int a = 0; a < no; ++a) {
-            rec[1 + o[a]] = acc1[a];
-            for (int b = 0; b < no; ++b) rec[1 + d + o[a] * d + o[b]] = cacc[a * GDM + b];
+            rec[1 + o[(a) * ESI]] = acc1[(a) * ES];
+            for (int b = 0; b < no; ++b) rec[1 + d + o[(a) * ESI] * d + o[(b) * ESI]] = cacc[(a * GDM + b) * ES];
         }
         rec[1 + d + d * d] = r1;
         rec[2 + d + d * d] = r2;
@@ -307,8 +318,8 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
     for (long it = gt_; it < (long)G * mj; it += nth_) {
     const int g = (int)(it / mj), j = (int)(it % mj);
     if (j >= m) continue;
-    for (int c = 0; c < d; ++c) dP[c] = 0.0;
-    for (int e = 0; e < d * GDM; ++e) dG[e] = 0.0;
+    for (int c = 0; c < d; ++c) dP[(c) * ES] = 0.0;
+    for (int e = 0; e < d * GDM; ++e) dG[(e) * ES] = 0.0;
     double r1 = 0.0, r2 = 0.0;
     const double *Sj = Sig + (size_t)j * d * d, *iSj = iSig + (size_t)j * d * d;
     const double *Gj = Gam + (size_t)j * de * de;
@@ -316,91 +327,91 @@ __global__ __launch_bounds__(64) void k_gen_finish(const double *__restrict__ re
         const double *rec = recs + ((size_t)g * m + j) * nrec;
         int no = 0, nu = 0;
         for (int c = 0; c < d; ++c) {
-            if (pat[g * d + c]) o[no++] = c; else uix[nu++] = c;
+            if (pat[g * d + c]) o[(no++) * ESI] = c; else uix[(nu++) * ESI] = c;
         }
         r1 += rec[1 + d + d * d];
         r2 += rec[2 + d + d * d];
         for (int a = 0; a < no; ++a)
-            for (int b = 0; b < no; ++b) Soo[a * GDM + b] = Sj[o[a] * d + o[b]];
-        for (int e = 0; e < no * GDM; ++e) tmp[e] = Soo[e];
-        chol_small(tmp, no, GDM);
+            for (int b = 0; b < no; ++b) Soo[(a * GDM + b) * ES] = Sj[o[(a) * ESI] * d + o[(b) * ESI]];
+        for (int e = 0; e < no * GDM; ++e) tmp[(e) * ES] = Soo[(e) * ES];
+        chol_small(tmp, no, GDM, ES);
         if (raw) {
             // No input noise: the records are the plain sums M1 = sum dPHI Delta_o and S = sum dPHI Delta_o Delta_o'.
             // dP_o = Sigma_oo^-1 M1 (GPz.m:153) by two triangular solves, and since dSoo = 1/2 Sigma_oo^-1 S Sigma_oo^-1
             // (GPz.m:154, the A0 terms of :174 cancel), diSoo = -Soo dSoo Soo = -1/2 S: no inverse, no products.
             for (int a = 0; a < no; ++a) {
-                double t = rec[1 + o[a]];
-                for (int q = 0; q < a; ++q) t = fma(-tmp[a * GDM + q], y[q], t);
-                y[a] = t / tmp[a * GDM + a];
+                double t = rec[1 + o[(a) * ESI]];
+                for (int q = 0; q < a; ++q) t = fma(-tmp[(a * GDM + q) * ES], y[(q) * ES], t);
+                y[(a) * ES] = t / tmp[(a * GDM + a) * ES];
             }
             for (int a = no - 1; a >= 0; --a) {
-                double t = y[a];
-                for (int q = a + 1; q < no; ++q) t = fma(-tmp[q * GDM + a], y[q], t);
-                y[a] = t / tmp[a * GDM + a];
-                dP[o[a]] += y[a];
+                double t = y[(a) * ES];
+                for (int q = a + 1; q < no; ++q) t = fma(-tmp[(q * GDM + a) * ES], y[(q) * ES], t);
+                y[(a) * ES] = t / tmp[(a * GDM + a) * ES];
+                dP[(o[(a) * ESI]) * ES] += y[(a) * ES];
             }
             for (int a = 0; a < no; ++a)
-                for (int b = 0; b < no; ++b) dS[a * GDM + b] = -0.5 * rec[1 + d + o[a] * d + o[b]];
+                for (int b = 0; b < no; ++b) dS[(a * GDM + b) * ES] = -0.5 * rec[1 + d + o[(a) * ESI] * d + o[(b) * ESI]];
         } else {
-        for (int a = 0; a < no; ++a) dP[o[a]] += rec[1 + o[a]];
+        for (int a = 0; a < no; ++a) dP[(o[(a) * ESI]) * ES] += rec[1 + o[(a) * ESI]];
         // Sigma_oo^-1
-        inv_from_chol(tmp, no, W, Sinv, GDM);
+        inv_from_chol(tmp, no, W, Sinv, GDM, ES);
         // dSoo = 1/2 (A0 Sigma_oo^-1 + Cacc)       GPz.m:174
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b)
-                dS[a * GDM + b] = 0.5 * (rec[0] * Sinv[a * GDM + b] + rec[1 + d + o[a] * d + o[b]]);
+                dS[(a * GDM + b) * ES] = 0.5 * (rec[0] * Sinv[(a * GDM + b) * ES] + rec[1 + d + o[(a) * ESI] * d + o[(b) * ESI]]);
         // diSoo = -Soo dSoo Soo                    GPz.m:176
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b) {
                 double s = 0.0;
-                for (int q = 0; q < no; ++q) s = fma(Soo[a * GDM + q], dS[q * GDM + b], s);
-                tmp[a * GDM + b] = s;
+                for (int q = 0; q < no; ++q) s = fma(Soo[(a * GDM + q) * ES], dS[(q * GDM + b) * ES], s);
+                tmp[(a * GDM + b) * ES] = s;
             }
         for (int a = 0; a < no; ++a)
             for (int b = 0; b < no; ++b) {
                 double s = 0.0;
-                for (int q = 0; q < no; ++q) s = fma(tmp[a * GDM + q], Soo[q * GDM + b], s);
-                dS[a * GDM + b] = -s;                                       // now diSoo
+                for (int q = 0; q < no; ++q) s = fma(tmp[(a * GDM + q) * ES], Soo[(q * GDM + b) * ES], s);
+                dS[(a * GDM + b) * ES] = -s;                                       // now diSoo
             }
         }
         // GuuGuo = iSigma_uu^-1 iSigma_uo  (nu x no)   GPz.m:156,178
         if (nu > 0) {
             for (int a = 0; a < nu; ++a)
-                for (int b = 0; b < nu; ++b) tmp[a * GDM + b] = iSj[uix[a] * d + uix[b]];
-            chol_small(tmp, nu, GDM);
-            inv_from_chol(tmp, nu, W, Sinv, GDM);                           // Sinv = iSigma_uu^-1
+                for (int b = 0; b < nu; ++b) tmp[(a * GDM + b) * ES] = iSj[uix[(a) * ESI] * d + uix[(b) * ESI]];
+            chol_small(tmp, nu, GDM, ES);
+            inv_from_chol(tmp, nu, W, Sinv, GDM, ES);                           // Sinv = iSigma_uu^-1
             for (int a = 0; a < nu; ++a)
                 for (int b = 0; b < no; ++b) {
                     double s = 0.0;
-                    for (int q = 0; q < nu; ++q) s = fma(Sinv[a * GDM + q], iSj[uix[q] * d + o[b]], s);
-                    Kuo[a * GDM + b] = s;
+                    for (int q = 0; q < nu; ++q) s = fma(Sinv[(a * GDM + q) * ES], iSj[uix[(q) * ESI] * d + o[(b) * ESI]], s);
+                    Kuo[(a * GDM + b) * ES] = s;
                 }
         }
         // Aeff = Gamma(:,o) - Gamma(:,u) GuuGuo  (d x no);  dGo = 2 Aeff diSoo     GPz.m:157,179
         for (int r = 0; r < d; ++r)
             for (int b = 0; b < no; ++b) {
-                double s = Gj[r * de + o[b]];
-                for (int q = 0; q < nu; ++q) s = fma(-Gj[r * de + uix[q]], Kuo[q * GDM + b], s);
-                Aeff[r * GDM + b] = s;
+                double s = Gj[r * de + o[(b) * ESI]];
+                for (int q = 0; q < nu; ++q) s = fma(-Gj[r * de + uix[(q) * ESI]], Kuo[(q * GDM + b) * ES], s);
+                Aeff[(r * GDM + b) * ES] = s;
             }
         for (int r = 0; r < d; ++r) {
             for (int b = 0; b < no; ++b) {
                 double s = 0.0;
-                for (int q = 0; q < no; ++q) s = fma(Aeff[r * GDM + q], dS[q * GDM + b], s);
-                dgo[b] = 2.0 * s;
-                dG[r * GDM + o[b]] += dgo[b];                               // dGamma(:,o,j) += dGo     GPz.m:158,180
+                for (int q = 0; q < no; ++q) s = fma(Aeff[(r * GDM + q) * ES], dS[(q * GDM + b) * ES], s);
+                dgo[(b) * ES] = 2.0 * s;
+                dG[(r * GDM + o[(b) * ESI]) * ES] += dgo[(b) * ES];                               // dGamma(:,o,j) += dGo     GPz.m:158,180
             }
             for (int a = 0; a < nu; ++a) {
                 double s = 0.0;
-                for (int b = 0; b < no; ++b) s = fma(dgo[b], Kuo[a * GDM + b], s);
-                dG[r * GDM + uix[a]] -= s;                                  // dGamma(:,u,j) -= dGo GuuGuo'   GPz.m:159,181
+                for (int b = 0; b < no; ++b) s = fma(dgo[(b) * ES], Kuo[(a * GDM + b) * ES], s);
+                dG[(r * GDM + uix[(a) * ESI]) * ES] -= s;                                  // dGamma(:,u,j) -= dGo GuuGuo'   GPz.m:159,181
             }
         }
     }
     double *op = part + ((size_t)g * m + j) * (d + d * d + 2);
-    for (int c = 0; c < d; ++c) op[c] = dP[c];
+    for (int c = 0; c < d; ++c) op[c] = dP[(c) * ES];
     for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) op[d + a * d + b] = dG[a * GDM + b];
+        for (int b = 0; b < d; ++b) op[d + a * d + b] = dG[(a * GDM + b) * ES];
     op[d + d * d] = r1;
     op[d + d * d + 1] = r2;
     }
@@ -447,7 +458,7 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
     while (a * (a + 1) / 2 > e) --a;
     while ((a + 1) * (a + 2) / 2 <= e) ++a;
     const long b = e - a * (a + 1) / 2;
-    double *o = tab + (size_t)e * rec;
+    double *ot = tab + (size_t)e * rec;
     if (kind == GPZ_KIND_DIAG) {
         double lnz = 0.0;
         for (int c = 0; c < d; ++c) {
@@ -456,11 +467,11 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
             const double sa = 1.0 / isa, sb = 1.0 / isb;          // Sigma = Gamma.^-2
             const double icij = isa + isb;
             const double pa = P[a * de + c], pb = P[b * de + c];
-            o[1 + c] = (pa * isa + pb * isb) / icij;              // cij                    :98
-            o[1 + d + c] = 1.0 / icij;                            // Cij                    :97
+            ot[1 + c] = (pa * isa + pb * isb) / icij;              // cij                    :98
+            ot[1 + d + c] = 1.0 / icij;                            // Cij                    :97
             lnz += -0.5 * log(isa) - 0.5 * log(isb) - 0.5 * (pa - pb) * (pa - pb) / (sa + sb) - 0.5 * log(sa + sb);   // :101
         }
-        o[0] = lnz;
+        ot[0] = lnz;
     } else {
         const double *iSa = iSig + (size_t)a * d * d, *iSb = iSig + (size_t)b * d * d;
         const double *Sa = Sig + (size_t)a * d * d, *Sb = Sig + (size_t)b * d * d;
@@ -469,36 +480,36 @@ __global__ void k_pair_table(int kind, int m, int d, int de, const double *__res
         for (int pass = 0; pass < 2; ++pass) {
             const double *S = pass ? Sb : Sa;
             for (int r = 0; r < d; ++r)
-                for (int c = 0; c <= r; ++c) A[r * GDM + c] = S[r * d + c];
-            chol_small(A, d, GDM);
-            for (int r = 0; r < d; ++r) lnz += log(A[r * GDM + r]);          // 1/2 ln|Sigma| = sum ln L_rr
+                for (int c = 0; c <= r; ++c) A[(r * GDM + c) * ES] = S[r * d + c];
+            chol_small(A, d, GDM, ES);
+            for (int r = 0; r < d; ++r) lnz += log(A[(r * GDM + r) * ES]);          // 1/2 ln|Sigma| = sum ln L_rr
         }
         for (int r = 0; r < d; ++r)
-            for (int c = 0; c <= r; ++c) A[r * GDM + c] = iSa[r * d + c] + iSb[r * d + c];    // iCij          :100
-        chol_small(A, d, GDM);
-        inv_from_chol(A, d, W, Ci, GDM);                                                       // Cij = inv(iCij)
+            for (int c = 0; c <= r; ++c) A[(r * GDM + c) * ES] = iSa[r * d + c] + iSb[r * d + c];    // iCij          :100
+        chol_small(A, d, GDM, ES);
+        inv_from_chol(A, d, W, Ci, GDM, ES);                                                       // Cij = inv(iCij)
         for (int c = 0; c < d; ++c) {
             double s = 0.0;
             for (int r = 0; r < d; ++r) s += P[a * de + r] * iSa[r * d + c] + P[b * de + r] * iSb[r * d + c];
-            rhs[c] = s;
+            rhs[(c) * ES] = s;
         }
         for (int c = 0; c < d; ++c) {                                                          // cij = rhs * Cij   :102
             double s = 0.0;
-            for (int r = 0; r < d; ++r) s = fma(rhs[r], Ci[r * GDM + c], s);
-            o[1 + c] = s;
+            for (int r = 0; r < d; ++r) s = fma(rhs[(r) * ES], Ci[(r * GDM + c) * ES], s);
+            ot[1 + c] = s;
         }
         for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) o[1 + d + r * d + c] = Ci[r * GDM + c];
+            for (int c = 0; c < d; ++c) ot[1 + d + r * d + c] = Ci[(r * GDM + c) * ES];
         for (int r = 0; r < d; ++r)
-            for (int c = 0; c <= r; ++c) S2[r * GDM + c] = Sa[r * d + c] + Sb[r * d + c];
-        chol_small(S2, d, GDM);
+            for (int c = 0; c <= r; ++c) S2[(r * GDM + c) * ES] = Sa[r * d + c] + Sb[r * d + c];
+        chol_small(S2, d, GDM, ES);
         double ld = 0.0;
-        for (int r = 0; r < d; ++r) ld += log(S2[r * GDM + r]);
-        inv_from_chol(S2, d, W, S2i, GDM);
+        for (int r = 0; r < d; ++r) ld += log(S2[(r * GDM + r) * ES]);
+        inv_from_chol(S2, d, W, S2i, GDM, ES);
         double q = 0.0;
         for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) q += (P[a * de + r] - P[b * de + r]) * S2i[r * GDM + c] * (P[a * de + c] - P[b * de + c]);
-        o[0] = lnz - 0.5 * q - ld;                                                             // :105  (-1/2 ln|Sa+Sb| = -ld)
+            for (int c = 0; c < d; ++c) q += (P[a * de + r] - P[b * de + r]) * S2i[(r * GDM + c) * ES] * (P[a * de + c] - P[b * de + c]);
+        ot[0] = lnz - 0.5 * q - ld;                                                             // :105  (-1/2 ln|Sa+Sb| = -ld)
     }
     }
 }
@@ -523,8 +534,8 @@ __global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx,
     const long p0 = (long)chunk * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
     for (int o = 0; o < k; ++o) { ga[o * 64] = 0.0; vl[o * 64] = 0.0; nu[o * 64] = 0.0; }
     for (int c = 0; c < d; ++c) {
-        x[c] = Xr[(size_t)i * de + c];
-        if (kind == GPZ_KIND_DIAG) ps[c] = Psir[(size_t)i * de + c];
+        x[(c) * ES] = Xr[(size_t)i * de + c];
+        if (kind == GPZ_KIND_DIAG) ps[(c) * ES] = Psir[(size_t)i * de + c];
     }
     // recover (a, b) of the first pair, then walk
     long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);
@@ -537,23 +548,23 @@ __global__ __launch_bounds__(64) void k_predict_noisy(int kind, int n, long ldx,
         if (kind == GPZ_KIND_DIAG) {
             double q = 0.0, pr = 1.0;
             for (int c = 0; c < d; ++c) {
-                const double cp = t[1 + d + c] + ps[c];                     // Cij + Psi          :105
-                const double dl = x[c] - t[1 + c];
+                const double cp = t[1 + d + c] + ps[(c) * ES];                     // Cij + Psi          :105
+                const double dl = x[(c) * ES] - t[1 + c];
                 q = fma(dl * dl, 1.0 / cp, q);
                 pr *= cp;
             }
             ln = -0.5 * q - 0.5 * log(pr);                                  // :107
         } else {
             for (int r = 0; r < d; ++r)
-                for (int c = 0; c <= r; ++c) M[r * GDM + c] = t[1 + d + r * d + c] + Psi3[(size_t)i * d * d + r + d * c];
-            chol_small(M, d, GDM);
+                for (int c = 0; c <= r; ++c) M[(r * GDM + c) * ES] = t[1 + d + r * d + c] + Psi3[(size_t)i * d * d + r + d * c];
+            chol_small(M, d, GDM, ES);
             double q = 0.0, ld = 0.0;
             for (int r = 0; r < d; ++r) {
-                double s = x[r] - t[1 + r];
-                for (int c = 0; c < r; ++c) s = fma(-M[r * GDM + c], y[c], s);
-                y[r] = s / M[r * GDM + r];
-                q = fma(y[r], y[r], q);
-                ld += log(M[r * GDM + r]);
+                double s = x[(r) * ES] - t[1 + r];
+                for (int c = 0; c < r; ++c) s = fma(-M[(r * GDM + c) * ES], y[(c) * ES], s);
+                y[(r) * ES] = s / M[(r * GDM + r) * ES];
+                q = fma(y[(r) * ES], y[(r) * ES], q);
+                ld += log(M[(r * GDM + r) * ES]);
             }
             ln = -0.5 * q - ld;                                             // predictCov.m:111
         }
@@ -642,7 +653,7 @@ void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, co
             hipLaunchKernelGGL((KERNEL<GCAP>), dim3((unsigned)(((items) + 63) / 64)), dim3(64), lds, st, __VA_ARGS__,   \
                                (double *)nullptr, (size_t)0);                                                          \
         else                                                                                                           \
-            hipLaunchKernelGGL((KERNEL<0>), dim3(GPZ_GEN_RT_THREADS / 64), dim3(64), lds, st, __VA_ARGS__, ws,          \
+            hipLaunchKernelGGL((KERNEL<0>), dim3(gen_rt_threads(d) / 64), dim3(64), lds, st, __VA_ARGS__, ws,          \
                                gen_ws_per_thread(d));                                                                  \
     } while (0)
 
@@ -730,25 +741,25 @@ __global__ void k_gen_pattern_params(const double *__restrict__ Sig, const doubl
     double *Rc = RcAll + (size_t)g * m * (de * (de + 1) / 2 + de);
     int no = 0, u0 = -1;
     for (int c = 0; c < d; ++c) {
-        if (pat[g * d + c]) o[no++] = c;
+        if (pat[g * d + c]) o[(no++) * ESI] = c;
         else if (u0 < 0) u0 = c;
     }
     for (int a = 0; a < no; ++a)
-        for (int b = 0; b < no; ++b) A[a * GDM + b] = Sig[(size_t)j * d * d + o[a] * d + o[b]];
-    chol_small(A, no, GDM);
-    inv_from_chol(A, no, W, Ki, GDM);                  // Ki = Sigma_oo^-1
-    chol_small(Ki, no, GDM);                           // Ki = L L'  ->  R~ = L' (upper)
+        for (int b = 0; b < no; ++b) A[(a * GDM + b) * ES] = Sig[(size_t)j * d * d + o[(a) * ESI] * d + o[(b) * ESI]];
+    chol_small(A, no, GDM, ES);
+    inv_from_chol(A, no, W, Ki, GDM, ES);                  // Ki = Sigma_oo^-1
+    chol_small(Ki, no, GDM, ES);                           // Ki = L L'  ->  R~ = L' (upper)
     const int nt = de * (de + 1) / 2;
     double *out = Rc + (size_t)j * (nt + de);
     for (int e = 0; e < nt + de; ++e) out[e] = 0.0;
     for (int a = 0; a < no; ++a) {
         double cs = 0.0;
         for (int b = a; b < no; ++b) {
-            const double r = Ki[b * GDM + a];          // R~[o_a][o_b] = L[b][a]
-            out[o[a] * de - o[a] * (o[a] - 1) / 2 + (o[b] - o[a])] = r;
-            cs = fma(r, P[(size_t)j * de + o[b]], cs);
+            const double r = Ki[(b * GDM + a) * ES];          // R~[o_a][o_b] = L[b][a]
+            out[o[(a) * ESI] * de - o[(a) * ESI] * (o[(a) * ESI] - 1) / 2 + (o[(b) * ESI] - o[(a) * ESI])] = r;
+            cs = fma(r, P[(size_t)j * de + o[(b) * ESI]], cs);
         }
-        out[nt + o[a]] = cs;
+        out[nt + o[(a) * ESI]] = cs;
     }
     if (u0 >= 0) out[nt + u0] = sqrt((double)(d - no) * GPZ_LOG2);
     }
