@@ -1765,7 +1765,10 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
         launch_pm_no(c->st, c->tr.Xr, Psir, de, n, (long)np, c->m, (int)mp, d, obs, c->pr.P, c->pr.G, prd, No, Pio);
         // PHI = No .* (Pio * Nij') .* exp(lnz)                                              predictDiag.m:158-161
         launch_pm_nij(c->st, c->m, (int)mp, d, de, obs, c->pr.P, c->pr.G, B);
-        launch_tgemm(c->st, Pio, (int)mp, B, (int)mp, T, (int)np, (int)mp, nullptr, nullptr, c->m, -1);
+        // the GEMMs run over the group's rows rounded up to the kernel's 128-row tile, not over the 1024-row padding of the row
+        // set: a NaN-pattern group is often a few dozen rows (7 of 8 row tiles were zeros)
+        const int npg = rup(n, 128);
+        launch_tgemm(c->st, Pio, (int)mp, B, (int)mp, T, npg, (int)mp, nullptr, nullptr, c->m, -1);
         launch_pm_phi(c->st, No, T, (int)mp, n, (long)np, c->m, d, de, c->pr.G, c->Phi);
         // mu = PHI*w, ElnS = PHI*v (+ b)                                                    predictDiag.m:163-164,203
         launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
@@ -1776,7 +1779,7 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
             const int npq = (int)((npairs - q0 < (long)width) ? npairs - q0 : (long)width);
             launch_pm_pairtab(c->st, q0, npairs, c->m, (int)mp, (int)width, d, de, c->k, obs, c->has_psi ? 1 : 0, c->pr.P,
                               c->pr.G, wd, c->hetero ? c->pr.v : nullptr, iSd, B, rec, nrec);
-            launch_tgemm(c->st, Pio, (int)mp, B, (int)width, T, (int)np, (int)width, nullptr, nullptr, c->m, -1, false, (int)mp,
+            launch_tgemm(c->st, Pio, (int)mp, B, (int)width, T, npg, (int)width, nullptr, nullptr, c->m, -1, false, (int)mp,
                          (int)width);
             launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)width, d, c->k, obs, npq, T, rec, nrec, sums);
         }
