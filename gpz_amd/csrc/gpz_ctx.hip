@@ -1740,9 +1740,9 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     const int nrec = 2 * d + 1 + 3 * (int)k;
     // pair chunks of cw * mp pairs: a NaN-pattern group is often a few dozen rows, and then the launches per chunk are what it
     // costs - wider chunks, fewer of them, as far as the chunk's T (np x width) stays under 2 GB
-    int cw = 8;
+    int cw = 32;   // (8 until round 3: the 128-row GEMM of a small group ran 32 workgroups per launch)
     while (cw > 1 && (double)np * (double)(cw * mp) * 8.0 > 2e9) cw >>= 1;
-    const size_t width = (size_t)cw * mp;
+    const size_t width = (size_t)rup((long)cw * (long)mp, 64);   // whole 64-pair blocks of the pair-table kernel
     if (!rc) rc = c->ar.alloc(&No, np * mp);
     if (!rc) rc = c->ar.alloc(&Pio, np * mp);
     if (!rc) rc = c->ar.alloc(&B, mp * width);
@@ -1751,6 +1751,9 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
     if (!rc) rc = c->ar.alloc(&prd, m);
     if (!rc) rc = c->ar.alloc(&rec, width * nrec);
+    const int nsp = pm_accum_splits(n);   // pair splits of the accumulation kernel: one slab of sums each
+    double *sums_s = nullptr;
+    if (!rc) rc = c->ar.alloc(&sums_s, (size_t)nsp * 3 * k * np);
     if (!rc) rc = c->ar.alloc(&sums, 3 * k * np);
     if (!rc) rc = c->ar.alloc(&phiw, np * k);
     if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
@@ -1773,7 +1776,7 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
         // mu = PHI*w, ElnS = PHI*v (+ b)                                                    predictDiag.m:163-164,203
         launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
                           c->lnbeta, nullptr, phiw);
-        launch_zero(c->st, sums, 3 * k * np);
+        launch_zero(c->st, sums_s, (size_t)nsp * 3 * k * np);
         const long npairs = (long)m * (m + 1) / 2;
         for (long q0 = 0; q0 < npairs; q0 += (long)width) {                                  // predictDiag.m:170-200
             const int npq = (int)((npairs - q0 < (long)width) ? npairs - q0 : (long)width);
@@ -1781,8 +1784,9 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
                               c->pr.G, wd, c->hetero ? c->pr.v : nullptr, iSd, B, rec, nrec);
             launch_tgemm(c->st, Pio, (int)mp, B, (int)width, T, npg, (int)width, nullptr, nullptr, c->m, -1, false, (int)mp,
                          (int)width);
-            launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)width, d, c->k, obs, npq, T, rec, nrec, sums);
+            launch_pm_accum(c->st, c->tr.Xr, Psir, de, n, (long)np, (int)width, d, c->k, obs, npq, T, rec, nrec, sums_s, nsp);
         }
+        launch_slab_sum(c->st, sums_s, nsp, 3 * k * np, sums);
         launch_predict_noisy_final(c->st, sums, (long)np, n, c->k, phiw, c->lnbeta, c->pr.b, outb, outb + k * np,
                                    outb + 2 * k * np);
         auto down = [&](double *dst, const double *src) {

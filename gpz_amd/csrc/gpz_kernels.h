@@ -307,7 +307,9 @@ void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int 
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec);
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
-                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec, double *sums);
+                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec,
+                     double *sums /* [nsplit][3k][n_pad] */, int nsplit = 1);
+int pm_accum_splits(int n);
 
 // N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
 struct NormArgs {

@@ -104,35 +104,35 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
                                                     const double *__restrict__ G, const double *__restrict__ w,
                                                     const double *__restrict__ v, const double *__restrict__ iS,
                                                     double *__restrict__ B, double *__restrict__ rec, int nrec) {
-    const int qq = blockIdx.x;                      // pair within the chunk: gridDim.x = chunk width = ldb (row stride of B)
+    // 64 pairs per workgroup, lanes along the pairs: a wave writes 512 contiguous bytes of a row of B (one pair per workgroup
+    // wrote a column of B, 8 bytes every ldb doubles).  cij / Cij of the 64 pairs sit in LDS as [dimension][pair].
+    extern __shared__ double sh[];
+    double *cij = sh, *Cij = sh + (size_t)d * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qq = blockIdx.x * 64 + lane;              // pair within the chunk (gridDim.x * 64 = chunk width = ldb)
     const long q = q0 + qq;
-    double *r = rec + (size_t)qq * nrec;
-    if (q >= npairs) {
-        for (int l = threadIdx.x; l < ld; l += 256) B[(size_t)l * ldb + qq] = 0.0;
-        for (int e = threadIdx.x; e < nrec; e += 256) r[e] = (e >= d && e < 2 * d) ? 1.0 : 0.0;
-        return;
-    }
-    int i, j;
-    pair_of(q, &i, &j);
-    __shared__ double cij[64], Cij[64];
-    if (threadIdx.x < d) {
-        const int c = threadIdx.x;
+    const bool live = q < npairs;
+    int i = 0, j = 0;
+    if (live) pair_of(q, &i, &j);
+    for (int c = wave; c < d; c += 4) {
         const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
         const double isi = gi * gi, isj = gj * gj;
         const double C = 1.0 / (isi + isj);                                      // :173 / :257
-        Cij[c] = C;
-        cij[c] = (P[(size_t)i * de + c] * isi + P[(size_t)j * de + c] * isj) * C;  // :174 / :258
+        Cij[c * 64 + lane] = live ? C : 1.0;
+        cij[c * 64 + lane] = live ? (P[(size_t)i * de + c] * isi + P[(size_t)j * de + c] * isj) * C : 0.0;   // :174 / :258
     }
     __syncthreads();
-    for (int l = threadIdx.x; l < ld; l += 256) {
+    // blockIdx.y splits the rows of B (64 pairs per workgroup alone would leave the chip to 64 workgroups per chunk)
+    const int lper = (ld + gridDim.y - 1) / gridDim.y, l0 = blockIdx.y * lper, l1 = min(ld, l0 + lper);
+    for (int l = l0 + wave; l < l1; l += 4) {
         double val = 0.0;
-        if (l < m) {
+        if (l < m && live) {
             double qd = 0.0, ls = 0.0;
             for (int c = 0; c < d; ++c) {
                 if ((obs >> c) & 1ull) continue;
                 const double gl = G[(size_t)l * de + c];
-                const double s = 1.0 / (gl * gl) + Cij[c];
-                const double dl = P[(size_t)l * de + c] - cij[c];
+                const double s = 1.0 / (gl * gl) + Cij[c * 64 + lane];
+                const double dl = P[(size_t)l * de + c] - cij[c * 64 + lane];
                 qd += dl * dl / s;
                 ls += log(s);
             }
@@ -140,7 +140,12 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
         }
         B[(size_t)l * ldb + qq] = val;
     }
-    if (threadIdx.x == 0) {
+    if (wave == 0 && blockIdx.y == 0) {
+        double *r = rec + (size_t)qq * nrec;
+        if (!live) {
+            for (int e = 0; e < nrec; ++e) r[e] = (e >= d && e < 2 * d) ? 1.0 : 0.0;
+            return;
+        }
         double lz = 0.0, qd = 0.0, ls = 0.0, lo = 0.0;
         for (int c = 0; c < d; ++c) {
             const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
@@ -149,9 +154,9 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
             const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
             qd += dl * dl / s;
             ls += log(s);
-            if (((obs >> c) & 1ull) && !has_psi) lo += log(Cij[c]);
-            r[c] = cij[c];
-            r[d + c] = Cij[c];
+            if (((obs >> c) & 1ull) && !has_psi) lo += log(Cij[c * 64 + lane]);
+            r[c] = cij[c * 64 + lane];
+            r[d + c] = Cij[c * 64 + lane];
         }
         r[2 * d] = -0.5 * lz - 0.5 * qd - 0.5 * ls - 0.5 * lo;
         const double c2 = (j < i) ? 2.0 : 1.0;
@@ -168,10 +173,15 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
 // One WAVE per row, lanes along the pairs of the chunk (T2 is read coalesced, the 3k sums are reduced over the wave at
 // the end): a NaN-pattern group is often a few dozen rows, and with one THREAD per row the chunk's 512 pairs were a
 // serial chain of 512 exp / divide iterations per launch (1 ms per launch whatever the group's size).
+// gridDim.y = S splits of the chunk's pairs, each accumulating into its own slab sums[s][3k][n_pad] (summed in fixed order at
+// the end): with a few dozen rows per group one wave per row left the chip empty.
 __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr, const double *__restrict__ Psir, int de,
                                                    int n, long n_pad, int ld, int d, int k, unsigned long long obs, int npq,
                                                    const double *__restrict__ T2, const double *__restrict__ rec, int nrec,
-                                                   double *__restrict__ sums) {
+                                                   double *__restrict__ sums_all) {
+    double *sums = sums_all + (size_t)blockIdx.y * 3 * k * n_pad;
+    const int per = (npq + gridDim.y - 1) / gridDim.y;
+    const int qlo = blockIdx.y * per, qhi = min(npq, qlo + per);
     __shared__ double sx[4][64], sps[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long i = (long)blockIdx.x * 4 + wave;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr,
         double acc[24];
 #pragma unroll
         for (int e = 0; e < 24; ++e) acc[e] = 0.0;
-        for (int qq = lane; qq < npq; qq += 64) {
+        for (int qq = qlo + lane; qq < qhi; qq += 64) {
             const double *r = rec + (size_t)qq * nrec;
             double qd = 0.0, ls = 0.0;
             for (int c = 0; c < d; ++c) {
@@ -234,11 +244,14 @@ void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, i
 void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned long long obs,
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec) {
-    hipLaunchKernelGGL(k_pm_pairtab, dim3(width), dim3(256), 0, st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
+    hipLaunchKernelGGL(k_pm_pairtab, dim3(width / 64, 16), dim3(256), (size_t)2 * d * 64 * sizeof(double), st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
                        iS, B, rec, nrec);
 }
+// Pair splits of the accumulation kernel.  A constant: the order in which a row's sums are formed must not depend on how many
+// rows the call holds (gpz_mgpu_predict cuts a group into row blocks and promises the single-device bits).
+int pm_accum_splits(int n) { (void)n; return 16; }
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
-                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec, double *sums) {
-    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
+                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit) {
+    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 3) / 4), nsplit), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
                        npq, T2, rec, nrec, sums);
 }

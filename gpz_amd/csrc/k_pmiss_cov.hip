@@ -12,6 +12,7 @@
 // Kept quirk (predictCov.m:266-268): with input noise the block T*Psi_oo*T' (in [o u] order) is ASSIGNED through
 // `unshuffle`, the inverse of the permutation [find(o) find(~o)] — the intended placement only when that permutation
 // is its own inverse.
+#include <stdlib.h>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -525,7 +526,8 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
     for (int a = 0; a < d; ++a) pt.inv[perm[a]] = a;                        // [~,unshuffle] = sort([find(o) find(~o)])
     const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * k;
     const long npairs = (long)m * (m + 1) / 2;
-    const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64;
+    // GPZ_PMC_SCRATCH=1 (developer switch): keep the scratch-resident kernels, to compare the two routes on one input
+    const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !getenv("GPZ_PMC_SCRATCH");
     hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec);
     hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
                        (const double *)rec, nrec, w, v, iS, tab, ntab);

