@@ -42,6 +42,7 @@ CONFIGS = {
 }
 F64_MFMA_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (datasheet f64 matrix = f64 vector rate)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+F32_MFMA_UBENCH_TFLOPS = 155.0  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 microbenchmark ceiling
 F64_MFMA_UBENCH_TFLOPS = 77.7  # tools/mfma_f64_bench.hip on this pool's MI355X: back-to-back v_mfma_f64_16x16x4_f64, >=3 waves/SIMD
 
 
@@ -362,8 +363,9 @@ def main():
                          "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not multi and not args.n else None,
                          "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
-                         "avg_ms": tg_avg, "ubench_ceiling": F64_MFMA_UBENCH_TFLOPS,
-                         "frac_of_ubench": ach / F64_MFMA_UBENCH_TFLOPS},
+                         "avg_ms": tg_avg,
+                         "ubench_ceiling": F32_MFMA_UBENCH_TFLOPS if cfg.get("psi") else F64_MFMA_UBENCH_TFLOPS,
+                         "frac_of_ubench": ach / (F32_MFMA_UBENCH_TFLOPS if cfg.get("psi") else F64_MFMA_UBENCH_TFLOPS)},
             "kernels": {"syrk_tflops_algorithmic": ach_sy, "syrk_avg_ms": sy_avg,
                         "phi_build_GBs_algorithmic": phi_gbs, "phi_build_avg_ms": ph_avg,
                         "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
