@@ -1489,7 +1489,7 @@ extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const
         return fail(GPZ_ERR_ARG, "gpz_predict_full: null argument");
     gpz_ctx *c = nullptr;
     if (has_nan(Xs, ns * (int64_t)desc->d))
-        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values (predictMissing, predictDiag.m:127) is not built");
+        return fail(GPZ_ERR_UNSUPPORTED, "gpz_predict_full: the rows have missing values (NaN): group them by pattern and call gpz_predict_missing (predict.m:45-69)");
     if (int e = make_eval_ctx(desc, Xs, ns, nullptr, 0, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
     int rc = 0;
@@ -1554,7 +1554,7 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
     if (!desc || !theta || !w || !iSigma_w || !Xs || !Psi || ns < 1 || !mu || !nu || !beta_i || !gamma)
         return fail(GPZ_ERR_ARG, "gpz_predict_noisy: null argument");
     if (has_nan(Xs, ns * (int64_t)desc->d))
-        return fail(GPZ_ERR_UNSUPPORTED, "predict with missing values (predictNoisyMissing, predictDiag.m:211) is not built");
+        return fail(GPZ_ERR_UNSUPPORTED, "gpz_predict_noisy: the rows have missing values (NaN): group them by pattern and call gpz_predict_missing (predict.m:45-69)");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     const size_t m = c->m, np = c->tr.n_pad, k = c->k;

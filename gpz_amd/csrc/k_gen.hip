@@ -8,7 +8,7 @@
 //   With Psi = 0 this reduces to the no-noise branch GPz.m:151-159 (M^-1 Delta = Sigma_oo^-1 Delta, diSoo = -1/2 Delta Delta').
 //
 // These are per-(sample, basis) d x d factorisations (SURVEY.md §8a rows a7, a22 and the missing-value branches of
-// a5, a21): not MFMA-shaped.  This first version is a straightforward correctness path — runtime d <= 20, the small
+// a5, a21): not MFMA-shaped.  A straightforward correctness path — runtime d (any: see GEN_ARR below), the small
 // matrices live in per-thread scratch — used only when Psi is given or X has NaNs with GC/VC; everything around it
 // (SYRK, factorisation, T-GEMM, row scalars) is the regular pipeline.
 #include "gpz_dev.h"

@@ -5,9 +5,9 @@
 //
 // The reference conditions every basis function on the observed dimensions (X_hat, Psi_hat) and then, for every
 // basis pair (i,j), sums a d-dimensional Gaussian over all m conditioned components: O(n m^3 d^3) interpreted work
-// (a d x d factorisation per (row, pair, component) once there is input noise).  This is a correctness path:
-// runtime d <= 20, the small matrices live in per-thread scratch, one thread per (row, basis) or per (row, pair chunk);
-// sums over pairs are ordered (chunk slabs + fixed-order sum).
+// (a d x d factorisation per (row, pair, component) once there is input noise).  Two routes: for d <= 10 the
+// register-resident record sums further down (k_pmc_sum_*); else the first, scratch-resident kernels (runtime d <= 20, one
+// thread per (row, basis) or one wave per (row, pair chunk)).  Sums over pairs are ordered (chunk slabs + fixed-order sum).
 //
 // Kept quirk (predictCov.m:266-268): with input noise the block T*Psi_oo*T' (in [o u] order) is ASSIGNED through
 // `unshuffle`, the inverse of the permutation [find(o) find(~o)] — the intended placement only when that permutation
@@ -507,7 +507,7 @@ int pmc_rec_len(int d, unsigned long long obs) {
     const int nu = d - no;
     return 2 + no * no + no * nu + nu * nu;
 }
-bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // (more outputs: the scratch kernels, 24 sums per pass)   // register-resident kernels (rows_blk <= 64 then)
+bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // register-resident kernels (rows_blk <= 64 then); more outputs: the scratch kernels, 24 sums per pass
 // work2: m * (d(d+1)/2 + d*d + d + 1) doubles, used by the register-resident route
 void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
