@@ -173,3 +173,25 @@ def test_what_is_still_refused_says_so():
     with pytest.raises(_lib.GpzError) as ei:
         gpz_amd.predict(Xs, model)
     assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("method,psi,nanfrac,k", [("VD", True, 0.2, 9), ("VC", False, 0.0, 1), ("GC", False, 0.3, 2)])
+def test_wide_inputs_through_the_multi_gpu_driver(method, psi, nanfrac, k):
+    """d = 23 through gpz_mgpu_* (three loopback shards on this box's GPU): the row-sharded form of the runtime-d kernels, the
+    pattern table of the whole data set handed to every shard, the per-output slots beyond 8 in both all-reduce buffers."""
+    n, d, m = 900, 23, 9
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=6000 + k, psi=psi, nanfrac=nanfrac)
+    tr = rng.random(n) < 0.85
+    ref = O.GPz(theta, model, X, Y, Psi, None, tr, ~tr)
+    mg = gpz_amd.GPzMulti(model, X, Y, Psi, None, tr, ~tr, n_gpus=3, reducer="loopback")
+    try:
+        f, g = mg.eval(theta)
+        stats = dict(mg.stats)
+    finally:
+        mg.close()
+    pt = phi_tol(model, theta)
+    tol = 2.0 * max(grad_tol(ref.cond), pt)
+    assert abs(f - ref.nlogML) <= max(FTOL, pt) * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= max(1e-10, pt) * max(1.0, abs(val)), key
