@@ -94,6 +94,7 @@ SYMBOLS = {
     "gpz_rccl_origin": (C.c_char_p, []),
     "gpz_last_error": (C.c_char_p, []),
     "gpz_version": (C.c_int, []),
+    "gpz_release_cached_memory": (None, []),
 }
 
 _lib = None

@@ -399,6 +399,7 @@ def reset():
     for ctx, _ in _cache.values():
         ctx.close()
     _cache.clear()
+    _lib.load().gpz_release_cached_memory()          # and the device buffers the library keeps for its next call
 
 
 def GPz(theta, model, X, Y, Psi=None, omega=None, training=None, validation=None, nargout=2):

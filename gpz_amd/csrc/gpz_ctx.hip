@@ -78,23 +78,90 @@ static int pad_dim(int d) {
 }
 static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
 
-// device allocation bookkeeping
+// device allocation bookkeeping.  Released blocks go to a per-device cache keyed by their exact size instead of back to the
+// runtime: the stand-alone entry points (getPHI, predict*, prior ...) build and drop ~30 buffers per call, predict.m calls them
+// once per NaN-pattern group, and hipFree (a device synchronisation + unmap, 38 us on average here) was 30 % of a 79-group
+// predict() (profiles/README.md, round 3).  At most GPZ_CACHE_CAP bytes per device stay cached (blocks above a quarter of
+// it are freed directly); gpz_release_cached_memory() gives everything back.
+#include <map>
+#include <mutex>
+#define GPZ_CACHE_CAP (1024UL << 20)
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> blocks;   // (device, bytes) -> pointer
+    std::map<int, size_t> held;                              // bytes cached per device
+};
+static DevCache &dev_cache() {
+    static DevCache *c = new DevCache();   // never destroyed: the HIP runtime may be gone before static destructors run
+    return *c;
+}
+static void *cache_take(int dev, size_t bytes) {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.blocks.find({dev, bytes});
+    if (it == c.blocks.end()) return nullptr;
+    void *p = it->second;
+    c.blocks.erase(it);
+    c.held[dev] -= bytes;
+    return p;
+}
+static bool cache_give(int dev, size_t bytes, void *p) {
+    if (bytes > GPZ_CACHE_CAP / 4) return false;
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.held[dev] + bytes > GPZ_CACHE_CAP) return false;
+    c.blocks.insert({{dev, bytes}, p});
+    c.held[dev] += bytes;
+    return true;
+}
+extern "C" void gpz_release_cached_memory(void) {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : c.blocks) {
+        (void)hipSetDevice(kv.first.first);
+        (void)hipFree(kv.second);
+    }
+    (void)hipSetDevice(cur);
+    c.blocks.clear();
+    c.held.clear();
+}
+
 struct Arena {
-    std::vector<void *> ptrs;
+    struct Blk { void *p; size_t bytes; int dev; };
+    std::vector<Blk> blks;
     size_t bytes = 0;
     template <typename T>
     int alloc(T **p, size_t count) {
         *p = nullptr;
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-        if (e != hipSuccess) return fail(GPZ_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-        ptrs.push_back(*p);
-        bytes += count * sizeof(T);
+        const size_t nb = count * sizeof(T);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        void *q = cache_take(dev, nb);
+        if (!q) {
+            hipError_t e = hipMalloc(&q, nb);
+            if (e != hipSuccess) {   // the cache may be what is in the way: give it back and try once more
+                gpz_release_cached_memory();
+                e = hipMalloc(&q, nb);
+            }
+            if (e != hipSuccess) return fail(GPZ_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", nb, hipGetErrorString(e));
+        }
+        *p = (T *)q;
+        blks.push_back({q, nb, dev});
+        bytes += nb;
         return 0;
     }
     void release() {
-        for (void *p : ptrs) (void)hipFree(p);
-        ptrs.clear();
+        // one device synchronisation per release (hipFree did one per block): nothing may still be running on a block that
+        // the next caller - possibly on another stream - takes from the cache
+        if (!blks.empty()) (void)hipDeviceSynchronize();
+        for (const Blk &b : blks)
+            if (!cache_give(b.dev, b.bytes, b.p)) {
+                (void)hipFree(b.p);
+            }
+        blks.clear();
     }
 };
 

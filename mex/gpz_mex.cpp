@@ -226,7 +226,7 @@ static void need_rows(const gpz_desc *d, const mxArray *X, const mxArray *Psi) {
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     char cmd[16];
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gpz:usage", "first argument: command");
-    if (!strcmp(cmd, "reset")) { cleanup(); return; }
+    if (!strcmp(cmd, "reset")) { cleanup(); gpz_release_cached_memory(); return; }   /* also the buffers the library keeps between calls */
     if (!strcmp(cmd, "builds")) { plhs[0] = mxCreateDoubleScalar((double)g_builds); return; }
     if (!strcmp(cmd, "gpus")) { plhs[0] = mxCreateDoubleScalar(g_mg ? (double)gpz_mgpu_size(g_mg) : 0.0); return; }
     /* ---- stand-alone entries (no context) ---- */
