@@ -23,7 +23,9 @@
 // [inv(SIGMA)|w] to fp32 moves f by 2.4e-10 and g by 3.6e-7 of max|g| on a 250 000-row shard of config 5).
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
+#ifndef GPZ_F32_FLUSH
 #define GPZ_F32_FLUSH 8
+#endif
 template <typename OT> struct MfmaOf;
 template <> struct MfmaOf<double> {
     typedef d4_t acc_t;
