@@ -1130,3 +1130,28 @@ def test_predict_branches_against_quadrature_on_the_hip_path():
         got = gpz_amd.predict(Xs, model, Psi=Psi)
         for name, a, b in zip(("mu", "sigma", "nu", "beta_i", "gamma", "PHI"), got, ref):
             assert rel(a, b) <= 1e-9, (method, psi, miss, name, rel(a, b))
+
+
+def test_released_buffers_are_cached_and_can_be_handed_back():
+    """Device buffers released by contexts / stand-alone calls stay cached for the next call (hipFree was a third of a many-group
+    predict()); gpz_release_cached_memory() returns them.  Results do not depend on whether a buffer is fresh or recycled."""
+    import torch
+    model, theta, X, Y, _, rng = make_problem(120000, 4, 20, 1, "VC", True, seed=91)
+    lib = _lib.load()
+    ctx = gpz_amd.GPzContext(model, X, Y)             # warm-up: code objects, runtime pools
+    first = ctx.eval(theta)
+    ctx.close()
+    lib.gpz_release_cached_memory()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    res = []
+    for _ in range(3):
+        ctx = gpz_amd.GPzContext(model, X, Y)
+        res.append(ctx.eval(theta))
+        ctx.close()
+    assert all(r[0] == first[0] and np.array_equal(r[1], first[1]) for r in res)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > 50e6                                # PHI and T of the closed contexts (2 x 31 MB) are still with the library
+    lib.gpz_release_cached_memory()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < held // 4
