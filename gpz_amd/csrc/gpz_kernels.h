@@ -279,6 +279,9 @@ int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int 
                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
                              long pairs_per_chunk, double *part,
                              int flags = 0 /* bit 0: every Psi_i diagonal, bit 1: one covariance for all basis functions (GC) */);   // k_psi.hip: 2 <= d <= 10, else -1
+int launch_predict_noisy_diag(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psir,
+                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                              long pairs_per_chunk, double *part);   // k_psi.hip: d <= 20, k <= 8, else -1
 void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int d, int de, int k, const double *Xr,
                           const double *Psir, const double *Psi3, const double *tab, int rec, const double *w,
                           const double *v, const double *iS, int nchunk, long pairs_per_chunk, double *part,

@@ -671,6 +671,9 @@ void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int 
     if (kind != GPZ_KIND_DIAG && k <= 8 &&
         launch_predict_noisy_cov(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part, flags) == 0)
         return;
+    if (kind == GPZ_KIND_DIAG &&
+        launch_predict_noisy_diag(st, n, ldx, m, d, de, k, Xr, Psir, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part) == 0)
+        return;
     const long items = (((long)n + 63) / 64 * 64) * nchunk;
     const size_t lds = (size_t)3 * k * 64 * sizeof(double);
     GEN_LAUNCH(k_predict_noisy, items, lds, kind, n, ldx, m, d, de, k, Xr, Psir, Psi3, tab, rec, w, v, iS, pairs_per_chunk,

@@ -430,4 +430,86 @@ int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int 
     return 0;
 }
 
+// predictNoisy, diagonal kinds (predictDiag.m:75-125): one thread per sample, the pairs [p0, p1) of this chunk.  tab record:
+// [lnZ | cij (d) | Cij (d)].  Per dimension one reciprocal square root r = (Cij + psi)^-1/2 serves both the quadratic form
+// (Delta^2 r^2) and the normalisation (prod r): no divide and no logarithm per pair (the scratch-resident branch of
+// k_predict_noisy spent two thirds of its instructions in d divides and a log per pair).
+template <int D, int KM>
+__global__ __launch_bounds__(64) void k_predict_noisy_diag(int n, long ldx, int m, int d, int de, int k,
+                                                            const double *__restrict__ Xr, const double *__restrict__ Psir,
+                                                            const double *__restrict__ tab, int rec,
+                                                            const double *__restrict__ w, const double *__restrict__ v,
+                                                            const double *__restrict__ iS, long pairs_per_chunk,
+                                                            double *__restrict__ part) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < n;
+    const int ic = act ? i : n - 1;
+    const long npair = (long)m * (m + 1) / 2;
+    const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
+    double x[D], ps[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        x[c] = (c < d) ? Xr[(size_t)ic * de + c] : 0.0;
+        ps[c] = (c < d) ? Psir[(size_t)ic * de + c] : 0.0;
+    }
+    double ga[KM], vl[KM], nu[KM];
+#pragma unroll
+    for (int o = 0; o < KM; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > p0) --a;
+    while ((a + 1) * (a + 2) / 2 <= p0) ++a;
+    long b = p0 - a * (a + 1) / 2;
+#pragma unroll 1
+    for (long e = p0; e < p1; ++e) {
+        const double *t = tab + (size_t)e * rec;
+        double q = 0.0, pr = 1.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < d) {
+                const double r = rsqrt_nr(t[1 + d + c] + ps[c]);               // (Cij + Psi)^-1/2          predictDiag.m:105
+                const double dl = (x[c] - t[1 + c]) * r;
+                q = fma(dl, dl, q);
+                pr *= r;
+            }
+        const double z = ((a == b) ? 1.0 : 2.0) * exp(t[0] - 0.5 * q) * pr;    // :107, 2x in the loop (:113-119)
+#pragma unroll
+        for (int o = 0; o < KM; ++o)
+            if (o < k) {
+                ga[o] = fma(z, w[a + (size_t)m * o] * w[b + (size_t)m * o], ga[o]);
+                vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[b + (size_t)m * o] : 0.0, vl[o]);
+                nu[o] = fma(z, iS[a + (size_t)m * b + (size_t)m * m * o], nu[o]);
+            }
+        if (++b > a) { ++a; b = 0; }
+    }
+    if (act) {
+#pragma unroll
+        for (int o = 0; o < KM; ++o)
+            if (o < k) {
+                part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
+                part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
+                part[(((size_t)blockIdx.y * 3 + 2) * k + o) * ldx + i] = nu[o];
+            }
+    }
+}
+
+// d <= 20, k <= 8: register-resident; else -1 (the caller keeps the runtime-d kernel)
+int launch_predict_noisy_diag(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psir,
+                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                              long pairs_per_chunk, double *part) {
+    if (d > 20 || k > 8) return -1;
+    if (n <= 0) return 0;
+#define PND(DD)                                                                                                              \
+    do {                                                                                                                     \
+        if (k == 1)                                                                                                          \
+            hipLaunchKernelGGL((k_predict_noisy_diag<DD, 1>), dim3((n + 63) / 64, nchunk), dim3(64), 0, st, n, ldx, m, d, de, k, Xr, \
+                               Psir, tab, rec, w, v, iS, pairs_per_chunk, part);                                             \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_predict_noisy_diag<DD, 8>), dim3((n + 63) / 64, nchunk), dim3(64), 0, st, n, ldx, m, d, de, k, Xr, \
+                               Psir, tab, rec, w, v, iS, pairs_per_chunk, part);                                             \
+    } while (0)
+    if (d <= 4) PND(4); else if (d <= 8) PND(8); else if (d <= 12) PND(12); else if (d <= 16) PND(16); else PND(20);
+#undef PND
+    return 0;
+}
+
 bool psi_fast_path_available(int d) { return d >= 2 && d <= 10; }
