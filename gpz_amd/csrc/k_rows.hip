@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
             const double dl = (xi[c] - p[c]) * mk;
             if (PSI) {
                 const double psi = Psir[(size_t)i * D + c];
-                const double iu = 1.0 / fma(psi, g2[c], 1.0);
+                const double iu = gpz_rcp(fma(psi, g2[c], 1.0));
                 const double dr = dl * iu;
                 A1v[c] = fma(dp * dl, g2[c] * iu, A1v[c]);
                 A2v[c] = fma(dp * dr, dr, A2v[c]);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                 const double dl = (sc[3 + c] - p[c]) * mk;
                 if (PSI) {
                     const double psi = Psir[(size_t)i * D + c];
-                    const double iu = 1.0 / fma(psi, g2[c], 1.0);
+                    const double iu = gpz_rcp(fma(psi, g2[c], 1.0));
                     const double dr = dl * iu;
                     M1[c] = fma(dp * dl, g2[c] * iu, M1[c]);
                     S[c] = fma(dp * dr, dr, S[c]);

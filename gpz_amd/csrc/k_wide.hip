@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
                         const double dl = (x - pc) * mk;
                         if (PSI) {
                             const double u = fma(ps, gc, 1.0);                 // 1 + psi/sigma   (getPHI.m:104)
-                            q[jj] = fma(dl * dl, gc / u, q[jj]);
+                            q[jj] = fma(dl * dl, gc * gpz_rcp(u), q[jj]);
                             pr[jj] *= u;
                         } else {
                             q[jj] = fma(dl * dl, gc, q[jj]);                   // getPHI.m:97
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_moments_wide(const double *__restrict__
                 const double dl = (Xr[(size_t)i * d + cc[e]] - p[e]) * mk;
                 if (PSI) {
                     const double psi = Psir[(size_t)i * d + cc[e]];
-                    const double iu = 1.0 / fma(psi, g2[e], 1.0);
+                    const double iu = gpz_rcp(fma(psi, g2[e], 1.0));
                     const double dr = dl * iu;
                     A1[e] = fma(dp * dl, g2[e] * iu, A1[e]);                   // GPz.m:202
                     A2[e] = fma(dp * dr, dr, A2[e]);                           // GPz.m:204
