@@ -529,17 +529,23 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0, n_gpu
         psin = np.asfortranarray(fixPsi(psi, ns, model.sdX, model.method))   # predict.m:43
     cube = psin is not None and psin.ndim == 3
     ds = _desc(model, device)
-    mu = np.zeros((ns, k)); nu = np.zeros((ns, k)); beta_i = np.zeros((ns, k)); gamma = np.zeros((ns, k))
-    PHI = np.zeros((ns, m))
-    # predict.m:45-57: groups of identical NaN patterns (any order gives the same outputs)
-    missing = np.isnan(Xn)
-    _, gid = np.unique(missing, axis=0, return_inverse=True)
-    gid = np.asarray(gid).ravel()
-    for g in range(int(gid.max()) + 1 if ns else 0):
-        idx = np.flatnonzero(gid == g)
-        ng = idx.size
-        Xg = _f64(Xn[idx], 2)
-        Pg = None if psin is None else np.asfortranarray(psin[:, :, idx] if cube else psin[idx])
+    mu = nu = beta_i = gamma = PHI = None            # allocated below unless the data is one group (then the outputs ARE the results)
+    # predict.m:45-57: groups of identical NaN patterns.  The grouping itself is the library's (gpz_nan_groups, ids in first-
+    # occurrence order as the reference's loop forms them; np.unique over the rows took a third of a 1e5-row predictFull); complete
+    # data is one group and is passed through without gathering.
+    if ns and np.isnan(Xn).any():
+        gid, n_groups = nan_groups(Xn, device)
+        order = np.argsort(gid, kind="stable")
+        bounds = np.concatenate(([0], np.cumsum(np.bincount(gid, minlength=n_groups))))
+        groups = [order[bounds[g]:bounds[g + 1]] for g in range(n_groups)]
+    else:
+        groups = [slice(None)] if ns else []
+    for idx in groups:
+        whole = isinstance(idx, slice)
+        Xg = Xn if whole else _f64(Xn[idx], 2)
+        ng = Xg.shape[0]
+        first_missing = bool(np.isnan(Xg[0]).any())
+        Pg = None if psin is None else (psin if whole else np.asfortranarray(psin[:, :, idx] if cube else psin[idx]))
         o_mu = np.empty((ng, k), order="F"); o_nu = np.empty((ng, k), order="F"); o_be = np.empty((ng, k), order="F")
         o_ga = np.zeros((ng, k), order="F"); o_ph = np.empty((ng, m), order="F")
         if n_gpus is not None:
@@ -549,7 +555,7 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0, n_gpu
                                             _lib.dptr(pri), _lib.dptr(Xg), ng, _lib.dptr(Pg),
                                             0 if Pg is None else (2 if cube else 1), _lib.dptr(o_mu), _lib.dptr(o_nu),
                                             _lib.dptr(o_be), _lib.dptr(o_ga), _lib.dptr(o_ph)))
-        elif not missing[idx[0]].any():
+        elif not first_missing:
             if Pg is None:                                           # predictFull, gamma = 0 (predictDiag.m:74)
                 _lib.check(lib.gpz_predict_full(C.byref(ds), _lib.dptr(theta), _lib.dptr(w), _lib.dptr(iS), _lib.dptr(Xg), ng,
                                                 _lib.dptr(o_mu), _lib.dptr(o_nu), _lib.dptr(o_be), _lib.dptr(o_ph)))
@@ -564,7 +570,15 @@ def predict(X, model, whichSet="best", Psi=None, selection=None, device=0, n_gpu
                                                _lib.dptr(Xg), ng, _lib.dptr(Pg), 0 if Pg is None else (2 if cube else 1),
                                                _lib.dptr(o_mu), _lib.dptr(o_nu), _lib.dptr(o_be), _lib.dptr(o_ga),
                                                _lib.dptr(o_ph)))
-        mu[idx] = o_mu; nu[idx] = o_nu; beta_i[idx] = o_be; gamma[idx] = o_ga; PHI[idx] = o_ph
+        if whole:
+            mu, nu, beta_i, gamma, PHI = o_mu, o_nu, o_be, o_ga, o_ph
+        else:
+            if mu is None:
+                mu = np.zeros((ns, k)); nu = np.zeros((ns, k)); beta_i = np.zeros((ns, k)); gamma = np.zeros((ns, k))
+                PHI = np.zeros((ns, m))
+            mu[idx] = o_mu; nu[idx] = o_nu; beta_i[idx] = o_be; gamma[idx] = o_ga; PHI[idx] = o_ph
+    if mu is None:                                                   # no rows
+        mu = np.zeros((ns, k)); nu = np.zeros((ns, k)); beta_i = np.zeros((ns, k)); gamma = np.zeros((ns, k)); PHI = np.zeros((ns, m))
     sigma = nu + beta_i + gamma                                      # predict.m:72
     mu = mu + model.muY                                              # predict.m:73
     return mu, sigma, nu, beta_i, gamma, PHI, w, iS
