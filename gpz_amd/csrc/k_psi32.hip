@@ -159,17 +159,6 @@ template <int D, bool DIAG>
 __device__ __forceinline__ void pair_matrix2(const f2 *__restrict__ S, const float (&pd)[DIAG ? D : 1],
                                              const float *__restrict__ PsiT, long ldp, unsigned ic, f2 (&M)[NP2_OF(D)]) {
     constexpr int H = D / 2;
-#ifdef GPZ_EXP_NOBUILD
-    // experiment (tools only, wrong results): the pair matrix as ONE LDS read per row pair - what a builder wave handing the
-    // matrix over through LDS would leave on the factorising wave
-    if (DIAG) {
-#pragma unroll
-        for (int e = 0; e < NP2_OF(D); ++e) M[e] = S[e % (D * H)] + sp(pd[e % D]);
-#pragma unroll
-        for (int c = 0; c < D; ++c) M[P2(c / 2, c)][c & 1] = 40.0f;
-        return;
-    }
-#endif
     if (DIAG) {
 #pragma unroll
         for (int e = 0; e < NP2_OF(D); ++e) M[e] = sp(0.f);
