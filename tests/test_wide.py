@@ -195,3 +195,25 @@ def test_wide_inputs_through_the_multi_gpu_driver(method, psi, nanfrac, k):
     assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
     for key, val in ref.stats.items():
         assert abs(stats[key] - val) <= max(1e-10, pt) * max(1.0, abs(val)), key
+
+
+@pytest.mark.parametrize("method,d,psi,nanfrac", [("VD", 60, True, 0.1), ("GC", 100, False, 0.0), ("VL", 140, False, 0.0)])
+def test_very_wide_inputs_use_more_than_64kb_of_lds(method, d, psi, nanfrac):
+    """Row tiles beyond 64 KB of LDS (the dynamic-LDS attribute path): VD d = 60 with input noise and missing values (93 KB), GC
+    d = 100 (Householder QR of a 100 x 100 Gamma in 81 KB), VL d = 140 (72 KB)."""
+    n, m, k = 300, 6, 1
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=7000 + d, psi=psi, nanfrac=nanfrac)
+    _gate(model, theta, X, Y, Psi, loose=4.0)
+
+
+def test_row_tile_beyond_the_lds_is_refused():
+    """VD with input noise and missing values at d = 120 needs 185 KB for its three row tiles: GPZ_ERR_UNSUPPORTED from the
+    evaluation, not a launch failure."""
+    model, theta, X, Y, Psi, rng = make_problem(200, 120, 4, 1, "VD", True, seed=7300, psi=True, nanfrac=0.1)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    try:
+        with pytest.raises(_lib.GpzError) as ei:
+            ctx.eval(theta)
+        assert ei.value.code == -5
+    finally:
+        ctx.close()
