@@ -60,7 +60,7 @@ extern "C" {
 #define GPZ_ERR_COMM        -4   /* the all-reduce hook failed */
 #define GPZ_ERR_UNSUPPORTED -5   /* valid in the reference, not built yet (see DESIGN.md scope table) */
 
-#define GPZ_VERSION 2
+#define GPZ_VERSION 3   /* 3: no limits on d, k, NaN patterns; gpz_release_cached_memory; psi_kind 3 */
 
 typedef struct gpz_ctx gpz_ctx;
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gpz_hip.h but not exported"
     assert set(declared) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.gpz_version() == 2
+    assert lib.gpz_version() == 3
 
 
 def _no_gpu():
