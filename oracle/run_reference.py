@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE — executes the reference's OWN MATLAB files with oracle/mlite.py and writes what they return to
+tests/golden/ref_*.npz (inputs + outputs; data only — no reference text is stored).
+
+    python oracle/run_reference.py            # regenerate every fixture from /root/reference/GPz/*.m (this container only)
+
+Fixtures:
+  ref_gpz_<case>.npz      [nlogML,grad,w,iSigma_w,PHI] = GPz(theta,model,X,Y,Psi,omega,training,validation) (GPz.m:1, which calls
+                          getPHI.m and inv_logdet.m) + the four globals GPz.m:3-7 leaves behind; six methods x {plain, Psi, NaN,
+                          Psi + NaN} x heteroscedastic on/off x k, with weights and a training / validation split
+  ref_predict_<case>.npz  [mu,sigma,nu,beta_i,gamma,PHI] = predict(X,model,'Psi',Psi) (predict.m:1 -> fixPsi.m, predictDiag.m /
+                          predictCov.m: predictFull, predictNoisy, predictMissing, predictNoisyMissing)
+  ref_misc.npz            getPHI with all four outputs, inv_logdet (regular and rank-deficient), Dxy, getPrior
+
+The inputs are drawn here with NumPy (seeded); the oracle is NOT involved in producing a fixture — tests/test_reference_run.py
+compares it (CPU) and the HIP path (GPU) with these files, and re-executes the .m files when /root/reference exists."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mlite as ML  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+E = ML.EMPTY
+
+
+def g_dim_of(method, m, d):
+    return {"GL": 1, "VL": m, "GD": d, "VD": m * d, "GC": d * d, "VC": d * d * m}[method]
+
+
+def draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac):
+    """seeded inputs of one GPz() call (no oracle code involved: plain NumPy)"""
+    X = rng.standard_normal((n, d))
+    A = rng.standard_normal((d, k)) / np.sqrt(d)
+    Y = np.sin(X @ A) + 0.1 * rng.standard_normal((n, k))
+    Y = Y - Y.mean(0)
+    P = X[rng.choice(n, m, replace=False)] + 0.1 * rng.standard_normal((m, d))
+    gd = g_dim_of(method, m, d)
+    if method[1] == "C":
+        blocks = [np.eye(d) * (0.8 + 0.4 * rng.random()) + 0.15 * rng.standard_normal((d, d)) for _ in range(1 if method == "GC" else m)]
+        G = np.concatenate([b.reshape(-1, order="F") for b in blocks])
+    else:
+        G = 0.6 + 0.6 * rng.random(gd)
+    lnAlpha = 0.3 * rng.standard_normal(m * k)
+    b = np.log(0.05) + 0.1 * rng.standard_normal(k)
+    parts = [P.reshape(-1, order="F"), G, lnAlpha, b]
+    if hetero:
+        parts += [0.05 * rng.standard_normal(m * k), 0.2 * rng.standard_normal(m * k)]
+    theta = np.concatenate(parts)
+    Psi = None
+    if psi:
+        if method[1] == "C":
+            Psi = np.zeros((d, d, n))
+            for i in range(n):
+                B = 0.3 * rng.standard_normal((d, d))
+                Psi[:, :, i] = B @ B.T
+        else:
+            Psi = rng.gamma(1.0, 0.2, (n, d))
+    if nanfrac > 0 and d > 1:
+        miss = rng.random((n, d)) < nanfrac
+        miss[miss.all(axis=1), 0] = False
+        X = X.copy()
+        X[miss] = np.nan
+    omega = rng.random((n, 1)) + 0.5
+    training = rng.random(n) < 0.75
+    return dict(theta=theta, X=X, Y=Y, Psi=Psi, omega=omega, training=training, validation=~training)
+
+
+def run_gpz(ip, method, m, d, k, hetero, pr, nargout=5):
+    ms = ML.model_struct(m, d, k, method, hetero, g_dim_of(method, m, d))
+    args = [ML.col(pr["theta"]), ms, pr["X"], pr["Y"], E if pr["Psi"] is None else pr["Psi"], pr["omega"],
+            pr["training"].reshape(-1, 1), pr["validation"].reshape(-1, 1)]
+    ip.globals.clear()
+    f, g = ip.call("GPz", args, nargout=2)
+    stats = {key: float(np.asarray(ip.globals[key]).reshape(-1)[0]) for key in ("trainRMSE", "trainLL", "validRMSE", "validLL")}
+    out5 = ip.call("GPz", args, nargout=5)             # nargout > 2: the solve-only mode of GPz.m:84-87
+    return dict(nlogML=float(np.asarray(f).reshape(-1)[0]), grad=np.asarray(g).reshape(-1), nlogML_solve=np.asarray(out5[0]).reshape(-1),
+                w=np.asarray(out5[2]), iSigma_w=np.asarray(out5[3]).reshape(m, m, k, order="F"), PHI=np.asarray(out5[4]), **stats)
+
+
+GPZ_CASES = []
+for _method in ("GL", "VL", "GD", "VD", "GC", "VC"):
+    for _psi, _nan in ((False, 0.0), (True, 0.0), (False, 0.3), (True, 0.3)):
+        GPZ_CASES.append((_method, 1, True, _psi, _nan))
+GPZ_CASES += [("VD", 2, True, False, 0.0), ("VC", 2, True, True, 0.0), ("GL", 2, False, False, 0.3), ("VL", 1, False, True, 0.0),
+              ("GC", 2, False, False, 0.0), ("GD", 3, True, True, 0.3)]
+
+
+def gpz_case_name(c):
+    return "ref_gpz_%s_k%d_h%d_p%d_n%d" % (c[0], c[1], int(c[2]), int(c[3]), int(c[4] > 0))
+
+
+def make_gpz(case, seed):
+    method, k, hetero, psi, nanfrac = case
+    n, d, m = 70, 3, 5
+    rng = np.random.default_rng(seed)
+    pr = draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac)
+    out = run_gpz(ML.Interp(), method, m, d, k, hetero, pr)
+    return dict(method=method, m=m, d=d, k=k, heteroscedastic=int(hetero), has_psi=int(psi),
+                Psi=(pr["Psi"] if psi else np.zeros(0)), **{key: pr[key] for key in ("theta", "X", "Y", "omega", "training", "validation")},
+                **out)
+
+
+PREDICT_CASES = [(mth, noisy, nanfrac) for mth in ("GL", "VL", "GD", "VD", "GC", "VC") for noisy in (False, True) for nanfrac in (0.0, 0.35)]
+
+
+def predict_case_name(c):
+    return "ref_predict_%s_p%d_n%d" % (c[0], int(c[1]), int(c[2] > 0))
+
+
+def make_predict(case, seed):
+    method, noisy, nanfrac = case
+    n, d, m, k, ns = 70, 3, 4, 2, 11
+    rng = np.random.default_rng(seed)
+    pr = draw_problem(rng, n, d, m, k, method, True, False, 0.0)
+    ip = ML.Interp()
+    ms0 = ML.model_struct(m, d, k, method, True, g_dim_of(method, m, d))
+    # w, iSigma_w as train.m:53 obtains them: the reference's own solve-only call
+    args = [ML.col(pr["theta"]), ms0, pr["X"], pr["Y"], E, E, E, E]
+    out4 = ip.call("GPz", args, nargout=4)
+    w, iS = np.asarray(out4[2]), np.asarray(out4[3]).reshape(m, m, k, order="F")
+    muX = 0.1 * rng.standard_normal(d); sdX = 1.0 + 0.5 * rng.random(d); muY = rng.standard_normal(k)
+    pri = rng.random(m) + 0.2
+    pri = pri / pri.sum()
+    theta = pr["theta"]
+    md, gd = m * d, g_dim_of(method, m, d)
+    P = theta[:md].reshape((m, d), order="F")
+    v = theta[md + gd + m * k + k: md + gd + 2 * m * k + k].reshape((m, k), order="F")
+    st = ML.Struct(theta=ML.col(theta), w=w, iSigma_w=iS, priors=pri.reshape(1, -1), P=P, v=v)
+    ms = ML.model_struct(m, d, k, method, True, gd, muX=muX.reshape(1, -1), sdX=sdX.reshape(1, -1), muY=muY.reshape(1, -1), best=st, last=st)
+    Xs = rng.standard_normal((ns, d)) * sdX + muX
+    if nanfrac > 0:
+        miss = rng.random((ns, d)) < nanfrac
+        miss[miss.all(axis=1), 0] = False
+        Xs[miss] = np.nan
+    Psi = None
+    if noisy:
+        if method[1] == "C":
+            Psi = np.zeros((d, d, ns))
+            for i in range(ns):
+                B = 0.3 * rng.standard_normal((d, d))
+                Psi[:, :, i] = B @ B.T
+        else:
+            Psi = rng.gamma(1.0, 0.1, (ns, d))
+    res = ip.call("predict", [Xs, ms] + (["Psi", Psi] if noisy else []), nargout=6)
+    names = ("mu", "sigma", "nu", "beta_i", "gamma", "PHIs")
+    return dict(method=method, m=m, d=d, k=k, has_psi=int(noisy), theta=theta, w=w, iSigma_w=iS, priors=pri, muX=muX, sdX=sdX, muY=muY,
+                Xs=Xs, Psi=(Psi if noisy else np.zeros(0)), **{nm: np.asarray(r) for nm, r in zip(names, res)})
+
+
+def make_misc(seed):
+    rng = np.random.default_rng(seed)
+    ip = ML.Interp()
+    out = {}
+    # Dxy.m
+    A, B = rng.standard_normal((17, 4)), rng.standard_normal((6, 4))
+    out.update(dxy_X=A, dxy_Y=B, dxy_D=np.asarray(ip.call("Dxy", [A, B], 1)[0]))
+    # inv_logdet.m: regular, and rank-deficient (singular values below max(size)*eps(norm(s,inf)) are dropped)
+    M = rng.standard_normal((9, 9)); S1 = M @ M.T + 0.5 * np.eye(9)
+    Xi, ld = ip.call("inv_logdet", [S1], 2)
+    out.update(il_A=S1, il_Xi=np.asarray(Xi), il_logdet=float(np.asarray(ld).reshape(-1)[0]))
+    L = rng.standard_normal((9, 5)); S2 = L @ L.T
+    Xi, ld = ip.call("inv_logdet", [S2], 2)
+    out.update(il2_A=S2, il2_Xi=np.asarray(Xi), il2_logdet=float(np.asarray(ld).reshape(-1)[0]))
+    # getPHI.m with all four outputs, and getPrior.m, for a diagonal and a covariance kind with input noise and missing values
+    for tag, method in (("vd", "VD"), ("vc", "VC")):
+        n, d, m, k = 40, 3, 4, 1
+        pr = draw_problem(rng, n, d, m, k, method, True, True, 0.25)
+        ms = ML.model_struct(m, d, k, method, True, g_dim_of(method, m, d))
+        sel = rng.random(n) < 0.8
+        PHI, Gam, lnb, N = ip.call("getPHI", [pr["X"], pr["Psi"], ML.col(pr["theta"]), ms, sel.reshape(-1, 1)], 4)
+        prior = ip.call("getPrior", [pr["X"], pr["Psi"], ML.col(pr["theta"]), ms, sel.reshape(-1, 1)], 1)[0]
+        out.update({tag + "_theta": pr["theta"], tag + "_X": pr["X"], tag + "_Psi": pr["Psi"], tag + "_sel": sel, tag + "_PHI": np.asarray(PHI),
+                    tag + "_Gamma": np.asarray(Gam), tag + "_lnBeta_i": np.asarray(lnb), tag + "_N": np.asarray(N),
+                    tag + "_prior": np.asarray(prior).reshape(-1)})
+    return out
+
+
+def all_fixtures():
+    """name -> maker()"""
+    fx = {}
+    for q, c in enumerate(GPZ_CASES):
+        fx[gpz_case_name(c)] = (lambda c=c, q=q: make_gpz(c, 500 + q))
+    for q, c in enumerate(PREDICT_CASES):
+        fx[predict_case_name(c)] = (lambda c=c, q=q: make_predict(c, 800 + q))
+    fx["ref_misc"] = lambda: make_misc(77)
+    return fx
+
+
+def main():
+    if not ML.available():
+        raise SystemExit("the reference tree is not present: fixtures can only be generated where /root/reference exists")
+    os.makedirs(GOLD, exist_ok=True)
+    for name, make in all_fixtures().items():
+        data = make()
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
+        print("wrote", name, flush=True)
+
+
+if __name__ == "__main__":
+    main()
