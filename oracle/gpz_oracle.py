@@ -7,7 +7,7 @@ leg of ``bench.py`` as the checker, never as the product path.
 What this is
 ------------
 A NumPy fp64 restatement of the reference's MATLAB code, written from reading
-(not executing) the sources under ``/root/reference``:
+the sources under ``/root/reference``:
 
     GPz/GPz.m:1-263        -> :func:`GPz`
     GPz/getPHI.m:1-128     -> :func:`getPHI`
@@ -26,16 +26,27 @@ Operation order follows the reference statement by statement (per-basis ``for
 j=1:m`` loops, three n*m^2 products, SVD pseudo-inverse), so it doubles as the
 "reference path (NumPy restatement, as-written)" CPU baseline of BASELINE.md §5.
 
-PARITY UNPINNED BY THE REFERENCE: neither MATLAB nor Octave exists in the build
-image, and the reference ships no tests, golden vectors or recorded outputs
-(SURVEY.md §4, §8c).  The restatement is therefore pinned by properties derived
-from the reference's own code (tests/test_oracle.py): the minFunc
+PARITY: neither MATLAB nor Octave exists in the build image, and the reference ships no
+tests, golden vectors or recorded outputs.  Since round 3 the
+restatement is pinned by OUTPUTS OF THE REFERENCE'S OWN FILES RUN HERE: ``oracle/mlite.py``
+is an interpreter for the subset of MATLAB those files use, ``oracle/run_reference.py``
+executes ``GPz.m`` (with ``getPHI.m``, ``inv_logdet.m``), ``predict.m`` (with ``fixPsi.m``,
+``predictDiag.m``, ``predictCov.m``), ``getPrior.m`` and ``Dxy.m`` where they lie under
+``/root/reference`` and stores inputs + outputs as ``tests/golden/ref_*.npz`` (55 files);
+``tests/test_reference_run.py`` compares this module with them (objective to 1e-12, every
+output, all six methods, +/- input noise, +/- missing values, k > 1, both heteroscedastic
+modes) and re-executes the files whenever the reference tree is present.  The interpreter
+is NOT MATLAB: a reader who does not accept it as a run of the reference should read
+"parity unpinned" here, as in rounds 1-2.  The pins below do not depend on it
+(tests/test_oracle.py): the minFunc
 derivative-check protocol (autoDif/autoGrad.m:34-45, derivativeCheck.m:29-40),
 the method-nesting identities of getPHI.m:26-40 / GPz.m:215-225, Psi=0 == no
 Psi, omega=1 == no omega, mask=all == no mask, an independent dense n x n
 Gaussian log-density (Woodbury) check of GPz.m:65-82,110, a hand-computed
-m=1,d=1 case, and the agreement of the separately written predictDiag.m /
-predictCov.m missing-value branches on a diagonal covariance.
+m=1,d=1 case, the agreement of the separately written predictDiag.m /
+predictCov.m missing-value branches on a diagonal covariance, 50-digit arithmetic and
+autograd (tests/mp_reference.py) and Gauss-Hermite quadrature of the prediction
+branches (tests/quad_reference.py).
 
 Known numerical limit of the reference, reproduced here: with input noise the
 dGamma chain of GPz.m:174-180 goes through Sigma = inv(Gamma'Gamma) twice and
