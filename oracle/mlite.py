@@ -1179,6 +1179,16 @@ def _mean(ip, args, nargout):
     return trim(np.mean(a, axis=ax, keepdims=True))
 
 
+def _hist(ip, args, nargout):
+    """n = hist(y, centers): counts per bin, bin edges midway between the centres, outer bins open-ended; row vector for vector y"""
+    y = num(mat(args[0])).reshape(-1, order="F")
+    c = num(mat(args[1])).reshape(-1, order="F")
+    edges = np.concatenate(([-np.inf], 0.5 * (c[1:] + c[:-1]), [np.inf]))
+    counts = np.histogram(y, bins=edges)[0].astype(np.float64)
+    # MATLAB puts a value that sits exactly on an edge into the upper bin, as np.histogram does (right-open bins)
+    return counts.reshape(1, -1)
+
+
 def _sparse(a):
     """sparse(A), sparse(m,n) or sparse(i,j,v,m,n) (duplicates add up) - held dense"""
     if len(a) == 1:
@@ -1208,6 +1218,10 @@ BUILTINS = {
     "eye": lambda ip, a, n: np.eye(*_dims(a)),
     "logical": lambda ip, a, n: mat(a[0]) != 0 if mat(a[0]).dtype != bool else mat(a[0]),
     "double": lambda ip, a, n: num(mat(a[0])),
+    "int32": lambda ip, a, n: np.round(num(mat(a[0]))),
+    "isinf": lambda ip, a, n: np.isinf(num(mat(a[0]))),
+    "imag": lambda ip, a, n: np.zeros_like(num(mat(a[0]))),      # real arithmetic only: imag(x) == 0
+    "real": lambda ip, a, n: num(mat(a[0])),
     "sum": _reduce(np.sum),
     "prod": _reduce(np.prod),
     "mean": _mean,
@@ -1242,6 +1256,8 @@ BUILTINS = {
     "any": lambda ip, a, n: mat(bool(np.any(mat(a[0]) != 0))) if min(mat(a[0]).shape) == 1 else trim(np.any(mat(a[0]) != 0, axis=0, keepdims=True)),
     "all": lambda ip, a, n: mat(bool(np.all(mat(a[0]) != 0))) if min(mat(a[0]).shape) == 1 else trim(np.all(mat(a[0]) != 0, axis=0, keepdims=True)),
     "sparse": lambda ip, a, n: _sparse(a),
+    "hist": _hist,
+    "linspace": lambda ip, a, n: np.linspace(scalar(a[0]), scalar(a[1]), int(scalar(a[2])) if len(a) > 2 else 100).reshape(1, -1),
     "full": lambda ip, a, n: mat(a[0]),
 }
 

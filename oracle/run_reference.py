@@ -9,7 +9,8 @@ Fixtures:
                           Psi + NaN} x heteroscedastic on/off x k, with weights and a training / validation split
   ref_predict_<case>.npz  [mu,sigma,nu,beta_i,gamma,PHI] = predict(X,model,'Psi',Psi) (predict.m:1 -> fixPsi.m, predictDiag.m /
                           predictCov.m: predictFull, predictNoisy, predictMissing, predictNoisyMissing)
-  ref_misc.npz            getPHI with all four outputs, inv_logdet (regular and rank-deficient), Dxy, getPrior
+  ref_misc.npz            getPHI with all four outputs, inv_logdet (regular and rank-deficient), Dxy, getPrior, getOmega, fixPsi
+  ref_lbfgs_mem.npz       minFunc's L-BFGS memory: lbfgsAdd.m / lbfgsProd.m over a wrapping ring with rejected pairs
 
 The inputs are drawn here with NumPy (seeded); the oracle is NOT involved in producing a fixture — tests/test_reference_run.py
 compares it (CPU) and the HIP path (GPU) with these files, and re-executes the .m files when /root/reference exists."""
@@ -164,6 +165,23 @@ def make_misc(seed):
     L = rng.standard_normal((9, 5)); S2 = L @ L.T
     Xi, ld = ip.call("inv_logdet", [S2], 2)
     out.update(il2_A=S2, il2_Xi=np.asarray(Xi), il2_logdet=float(np.asarray(ld).reshape(-1)[0]))
+    # getOmega.m (with hist and Dxy.m) and fixPsi.m
+    Yo = rng.gamma(2.0, 0.4, (150, 1))
+    out.update(om_Y=Yo, om_balanced=np.asarray(ip.call("getOmega", [Yo, "balanced"], 1)[0]),
+               om_balanced_w=np.asarray(ip.call("getOmega", [Yo, "balanced", ML.mat(0.05)], 1)[0]),
+               om_normalized=np.asarray(ip.call("getOmega", [Yo, "normalized"], 1)[0]))
+    sd = 1.0 + rng.random(3)
+    fp_in = {"nd": rng.gamma(1.0, 0.1, (6, 3)), "n1": rng.gamma(1.0, 0.1, (6, 1))}
+    cube = np.zeros((3, 3, 6))
+    for i in range(6):
+        Bq = 0.3 * rng.standard_normal((3, 3))
+        cube[:, :, i] = Bq @ Bq.T
+    fp_in["cube"] = cube
+    out["fp_sdX"] = sd
+    for key, val in fp_in.items():
+        out["fp_in_" + key] = val
+        for method in ("VD", "VC"):
+            out["fp_%s_%s" % (key, method)] = np.asarray(ip.call("fixPsi", [val, ML.mat(6.0), sd.reshape(1, -1), method], 1)[0])
     # getPHI.m with all four outputs, and getPrior.m, for a diagonal and a covariance kind with input noise and missing values
     for tag, method in (("vd", "VD"), ("vc", "VC")):
         n, d, m, k = 40, 3, 4, 1
@@ -178,6 +196,38 @@ def make_misc(seed):
     return out
 
 
+MINFUNC_DIR = "/root/reference/minFunc_2012/minFunc"
+
+
+def make_lbfgs(seed, p=200, corr=5, steps=14):
+    """lbfgsAdd.m / lbfgsProd.m (minFunc's L-BFGS memory: a wrapping ring with rejected pairs) in the layout of the mf_mem_* fixtures:
+    gradients G, directions D, step lengths T -> added flags, ring state and the lbfgsProd direction after every call"""
+    ip = ML.Interp(ref_dir=MINFUNC_DIR)
+    rng = np.random.default_rng(seed)
+    S = np.zeros((p, corr)); Y = np.zeros((p, corr)); YS = np.zeros((corr, 1))
+    start, end, hd = 1.0, 0.0, 1.0
+    G = np.zeros((steps + 1, p)); D = np.zeros((steps, p)); T = np.zeros(steps)
+    added = np.zeros(steps, dtype=np.int32); dirs = np.zeros((steps, p))
+    starts = np.zeros(steps, dtype=np.int32); ends = np.zeros(steps, dtype=np.int32); hds = np.zeros(steps)
+    G[0] = rng.standard_normal(p)
+    Hm = np.diag(0.5 + rng.random(p))
+    for it in range(steps):
+        D[it] = rng.standard_normal(p)
+        T[it] = 10.0 ** rng.uniform(-2, 0.5)
+        s = T[it] * D[it]
+        y = Hm @ s if it not in (4, 9) else -0.3 * s            # two pairs with y's <= 1e-10: rejected (lbfgsAdd.m:5,30)
+        G[it + 1] = G[it] + y
+        out = ip.call("lbfgsAdd", [ML.col(y), ML.col(s), S, Y, YS, ML.mat(start), ML.mat(end), ML.mat(hd), ML.mat(0.0)], 7)
+        S, Y, YS = (np.asarray(o) for o in out[:3])
+        start, end, hd, skipped = (float(np.asarray(o).reshape(-1)[0]) for o in out[3:])
+        added[it] = 0 if skipped else 1
+        starts[it], ends[it], hds[it] = int(start), int(end), hd
+        if end > 0:
+            dirs[it] = np.asarray(ip.call("lbfgsProd", [ML.col(G[it + 1]), S, Y, YS, ML.mat(start), ML.mat(end), ML.mat(hd)], 1)[0]).reshape(-1)
+    return dict(p=p, corrections=corr, G=G, D=D, T=T, added=added, directions=dirs, starts=starts, ends=ends, Hdiag=hds, S=S, Y=Y,
+                YS=YS.reshape(-1))
+
+
 def all_fixtures():
     """name -> maker()"""
     fx = {}
@@ -186,6 +236,7 @@ def all_fixtures():
     for q, c in enumerate(PREDICT_CASES):
         fx[predict_case_name(c)] = (lambda c=c, q=q: make_predict(c, 800 + q))
     fx["ref_misc"] = lambda: make_misc(77)
+    fx["ref_lbfgs_mem"] = lambda: make_lbfgs(91)
     return fx
 
 

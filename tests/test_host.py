@@ -151,7 +151,8 @@ def test_device_lbfgs_direction_matches_two_loop(p, corr, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mf_mem_p64_c3", "mf_mem_p513_c7", "mf_mem_p900_c100"])
+@pytest.mark.parametrize("name", ["mf_mem_p64_c3", "mf_mem_p513_c7", "mf_mem_p900_c100",
+                                  "ref_lbfgs_mem"])   # the last one: lbfgsAdd.m / lbfgsProd.m themselves, executed (oracle/run_reference.py)
 def test_device_lbfgs_memory_matches_the_restated_reference(name):
     """gpz_lbfgs_add / gpz_lbfgs_direction (k_lbfgs.hip) replay the fixtures of oracle/minfunc_oracle.py — lbfgsAdd.m's ring
     (wrapping, rejected pairs) and lbfgsProd.m / mex/lbfgsProdC.c:46-88's product — not the package's own host two-loop."""

@@ -49,7 +49,7 @@ def predict_inputs(g):
 
 def test_fixture_inventory():
     assert len(GPZ) == len(RR.GPZ_CASES) == 30 and len(PRED) == len(RR.PREDICT_CASES) == 24
-    assert os.path.exists(os.path.join(GOLDEN, "ref_misc.npz"))
+    assert os.path.exists(os.path.join(GOLDEN, "ref_misc.npz")) and os.path.exists(os.path.join(GOLDEN, "ref_lbfgs_mem.npz"))
 
 
 # ---- CPU: oracle against the executed reference ------------------------------------------------------------------------
@@ -85,6 +85,14 @@ def test_oracle_against_the_executed_reference_misc():
     assert rel(Xi, g["il_Xi"]) <= 1e-12 and abs(ld - float(g["il_logdet"])) <= 1e-12 * abs(float(g["il_logdet"]))
     Xi, ld = O.inv_logdet(g["il2_A"])                       # rank 5 of 9: the truncating branch of inv_logdet.m:7-12
     assert rel(Xi, g["il2_Xi"]) <= 1e-9 and abs(ld - float(g["il2_logdet"])) <= 1e-10 * abs(float(g["il2_logdet"]))
+    for key, args in (("om_balanced", ("balanced",)), ("om_balanced_w", ("balanced", 0.05)), ("om_normalized", ("normalized",))):
+        assert rel(O.getOmega(g["om_Y"], *args), g[key]) <= 1e-14, key
+    from gpz_amd import host as H                                   # host.fixPsi is NumPy: checked here as well
+    for key in ("nd", "n1", "cube"):
+        for method in ("VD", "VC"):
+            want = g["fp_%s_%s" % (key, method)]
+            assert rel(O.fixPsi(g["fp_in_" + key], 6, g["fp_sdX"], method), want) <= 1e-15, (key, method)
+            assert rel(H.fixPsi(g["fp_in_" + key], 6, g["fp_sdX"], method), want) <= 1e-15, (key, method)
     for tag, method in (("vd", "VD"), ("vc", "VC")):
         model = O.Model(m=4, d=3, k=1, method=method, heteroscedastic=True)
         sel = g[tag + "_sel"].astype(bool)
@@ -93,6 +101,25 @@ def test_oracle_against_the_executed_reference_misc():
         assert rel(PHI, g[tag + "_PHI"]) <= tol and rel(lnb, g[tag + "_lnBeta_i"]) <= tol and rel(N, g[tag + "_N"]) <= tol
         assert rel(Gam, g[tag + "_Gamma"]) == 0.0
         assert rel(O.getPrior(g[tag + "_X"], g[tag + "_Psi"], g[tag + "_theta"], model, sel), g[tag + "_prior"]) <= 1e-9
+
+
+def test_minfunc_restatement_against_the_executed_lbfgs_files():
+    """oracle/minfunc_oracle.py's lbfgsAdd / lbfgsProd against what lbfgsAdd.m / lbfgsProd.m returned: ring indices, rejected pairs,
+    Hdiag and the direction after every call."""
+    from oracle import minfunc_oracle as MF
+    z = load("ref_lbfgs_mem")
+    p, corr = int(z["p"]), int(z["corrections"])
+    S = np.zeros((p, corr)); Y = np.zeros((p, corr)); YS = np.zeros(corr)
+    start, end, hd = 1, 0, 1.0
+    for it in range(z["T"].size):
+        s = z["T"][it] * z["D"][it]
+        y = z["G"][it + 1] - z["G"][it]
+        start, end, hd, skipped = MF.lbfgsAdd(y, s, S, Y, YS, start, end, hd)
+        assert (not skipped) == bool(z["added"][it]) and start == int(z["starts"][it]) and end == int(z["ends"][it])
+        assert abs(hd - float(z["Hdiag"][it])) <= 1e-14 * abs(hd)
+        if end > 0:
+            assert rel(MF.lbfgsProd(z["G"][it + 1], S, Y, YS, start, end, hd), z["directions"][it]) <= 1e-12
+    assert rel(S, z["S"]) <= 1e-15 and rel(Y, z["Y"]) <= 1e-13 and rel(YS, z["YS"]) <= 1e-13
 
 
 @pytest.mark.skipif(not ML.available(), reason="the reference tree exists only in the build container")
@@ -190,6 +217,9 @@ def test_hip_path_against_the_executed_reference_misc():
     assert rel(Xi, g["il_Xi"]) <= 1e-10 and abs(ld - float(g["il_logdet"])) <= 1e-11 * abs(float(g["il_logdet"]))
     Xi, ld = gpz_amd.inv_logdet(g["il2_A"])
     assert rel(Xi, g["il2_Xi"]) <= 1e-8 and abs(ld - float(g["il2_logdet"])) <= 1e-9 * abs(float(g["il2_logdet"]))
+    from gpz_amd import host as H
+    for key, args in (("om_balanced", ("balanced",)), ("om_balanced_w", ("balanced", 0.05)), ("om_normalized", ("normalized",))):
+        assert rel(H.getOmega(g["om_Y"], *args), g[key]) <= 1e-13, key                 # getOmega.m:16 goes through the device Dxy
     for tag, method in (("vd", "VD"), ("vc", "VC")):
         model = gpz_amd.Model(m=4, d=3, k=1, method=method, heteroscedastic=True)
         sel = g[tag + "_sel"].astype(bool)
