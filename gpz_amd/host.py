@@ -603,7 +603,7 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
     PsiN = fixPsi(Psi, n, model.sdX, model.method) if Psi is not None else None    # train.m:36-38
     training_only = validation is None or not np.asarray(validation).any()
     state = {"best_theta": model.sets["best"]["theta"].copy(), "best_valid": model.sets["best"].get("LL", -np.inf),
-             "attempts": 0, "tic": time.time()}
+             "attempts": 0, "tic": time.time(), "log": []}
     if n_gpus is not None:
         if device_resident:
             raise ValueError("device_resident optimiser vectors live on one GPU: use it without n_gpus")
@@ -626,6 +626,7 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
                 print("\tIter\tlogML/n\t\tTrain RMSE\tTrain MLL" + ("" if training_only else "\tValid RMSE\tValid MLL") + "\tTime")
         elif kind == "iter":
             dt = time.time() - state["tic"]
+            state["log"].append((i, -f, st["trainRMSE"], st["trainLL"], st.get("validRMSE", np.nan), st.get("validLL", np.nan)))
             if training_only:
                 if verbose:
                     print(f"\t{i}\t{-f:1.5e}\t{st['trainRMSE']:1.5e}\t {st['trainLL']:1.5e}\t{dt:f}")
@@ -663,7 +664,8 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
             if name == "best":
                 st["LL"] = model.sets["best"].get("LL", -np.inf)                  # never updated by the reference either
             model.sets[name] = st
-        model.train_info = {"exitflag": flag, "funEvals": evals, "message": msg, "f": f}
+        model.train_info = {"exitflag": flag, "funEvals": evals, "message": msg, "f": f,
+                            "log": np.array(state["log"], dtype=np.float64).reshape(-1, 6)}    # the numbers of callBack.m's lines
     finally:
         ctx.close()
     return model

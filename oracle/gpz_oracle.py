@@ -31,8 +31,9 @@ tests, golden vectors or recorded outputs.  Since round 3 
 restatement is pinned by OUTPUTS OF THE REFERENCE'S OWN FILES RUN HERE: ``oracle/mlite.py``
 is an interpreter for the subset of MATLAB those files use, ``oracle/run_reference.py``
 executes ``GPz.m`` (with ``getPHI.m``, ``inv_logdet.m``), ``predict.m`` (with ``fixPsi.m``,
-``predictDiag.m``, ``predictCov.m``), ``getPrior.m`` and ``Dxy.m`` where they lie under
-``/root/reference`` and stores inputs + outputs as ``tests/golden/ref_*.npz`` (55 files);
+``predictDiag.m``, ``predictCov.m``), ``getPrior.m``, ``getOmega.m``, ``Dxy.m`` and whole ``init.m`` ->
+``train.m`` runs (``minFunc.m`` calling ``GPz.m``, ``callBack.m``) where they lie under
+``/root/reference`` and stores inputs + outputs as ``tests/golden/ref_*.npz`` (62 files);
 ``tests/test_reference_run.py`` compares this module with them (objective to 1e-12, every
 output, all six methods, +/- input noise, +/- missing values, k > 1, both heteroscedastic
 modes) and re-executes the files whenever the reference tree is present.  The interpreter

@@ -19,11 +19,14 @@ What is restated, statement by statement, from the reference tree (paths relativ
 Conventions kept from MATLAB: S and Y are p x corrections with one pair per COLUMN; lbfgs_start / lbfgs_end are
 1-based; an unknown function value or derivative handed to polyinterp is sqrt(-1) (here: the Python complex 1j).
 
-Parity unpinned by the reference: MATLAB/Octave are absent from the image, the four MEX C files need mex.h (absent;
-writing a stand-in header for a reference build is not allowed), and the reference ships no recorded optimiser
-traces.  Pins that do not share code with this file live in tests/test_minfunc_oracle.py: the dense BFGS inverse-Hessian
-recursion for the two-loop product, lbfgsProd vs lbfgsProdC, polyinterp's closed-form cubic vs its general branch,
-analytic minimisers, and the Wolfe conditions at every accepted step.
+PARITY: pinned by the reference's own files run here.  MATLAB/Octave are absent from the image and the four MEX C files need mex.h
+(absent; writing a stand-in header for a reference build is not allowed), but oracle/mlite.py executes minFunc.m,
+minFunc_processInputOptions.m, WolfeLineSearch.m, ArmijoBacktrack.m, polyinterp.m, isLegal.m, lbfgsAdd.m and lbfgsProd.m where they lie
+(oracle/run_reference.py: make_lbfgs, make_minfunc, make_train; the compiled lbfgsAddC / lbfgsProdC are stood in for by their MATLAB
+twins, as minFunc itself does with useMex = 0) and tests/test_reference_run.py holds this file to their outputs: the ring memory call
+by call, 13 line searches to 1e-13, 6 whole runs and 5 init.m -> train.m runs with GPz.m as the objective.  Pins that share no code
+with either live in tests/test_minfunc_oracle.py: the dense BFGS inverse-Hessian recursion for the two-loop product, lbfgsProd vs
+lbfgsProdC, polyinterp's closed-form cubic vs its general branch, analytic minimisers, and the Wolfe conditions at every accepted step.
 """
 from __future__ import annotations
 

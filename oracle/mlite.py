@@ -242,6 +242,9 @@ class Parser:
                 self.next()
                 return (kw,)
             raise MError("unexpected keyword " + kw)
+        if tok[0] == "id" and tok[1] == "clear" and self.peek(1)[1] == "global":    # command form `clear global` (train.m:3)
+            self.next(); self.next()
+            return ("clearglobal",)
         # multi-assignment  [a,b,~] = f(...)
         if tok[1] == "[":
             save = self.i
@@ -446,6 +449,19 @@ class Parser:
             self.in_index = saved_i
             return ("cell", items)
         if tok[1] == "@":
+            if self.peek()[1] == "(":                                # anonymous function: @(a,b,varargin) expression
+                self.next()
+                names = []
+                while self.peek()[1] != ")":
+                    t = self.next()
+                    if t[1] != ",":
+                        names.append(t[1])
+                self.next()
+                saved_m, saved_i = self.in_matrix, self.in_index
+                self.in_matrix = self.in_index = 0
+                body = self.parse_expr()
+                self.in_matrix, self.in_index = saved_m, saved_i
+                return ("lambda", names, body)
             return ("handle", self.next()[1])
         raise MError("unexpected token %r" % (tok[1],))
 
@@ -456,10 +472,14 @@ class Struct:
         self.__dict__.update(kw)
 
 
+def is_callable(v):
+    return callable(v) or (isinstance(v, tuple) and len(v) > 0 and v[0] in ("handle", "closure"))
+
+
 def mat(x):
     """every numeric value is an ndarray with at least two dimensions"""
     a = np.asarray(x)
-    if a.dtype != bool:
+    if a.dtype != bool and a.dtype.kind != "c":
         a = a.astype(np.float64)
     if a.ndim == 0:
         a = a.reshape(1, 1)
@@ -477,6 +497,39 @@ def trim(a):
 
 def num(a):
     return a.astype(np.float64) if a.dtype == bool else a
+
+
+def _sqrt(x):
+    """sqrt of a negative real is complex, as in MATLAB (polyinterp.m:49-51 tests the result with isreal)"""
+    if np.iscomplexobj(x) or np.any(x < 0):
+        return np.sqrt(x.astype(np.complex128))
+    return np.sqrt(x)
+
+
+def _struct(ip, a, n):
+    return Struct(**{a[i]: a[i + 1] for i in range(0, len(a), 2)})
+
+
+def _linsolve(ip, a, n):
+    """linsolve(A,b): LU with partial pivoting (square; a singular matrix gives a warning and Inf, not an error), QR otherwise"""
+    A, b = num(mat(a[0])), num(mat(a[1]))
+    if A.shape[0] == A.shape[1]:
+        try:
+            x = np.linalg.solve(A, b)
+        except np.linalg.LinAlgError:
+            x = np.full((A.shape[1], b.shape[1]), np.inf)
+    else:
+        x = np.linalg.lstsq(A, b, rcond=None)[0]
+    return [x, mat(0.0)]
+
+
+def _roots(ip, a, n):
+    c = num(mat(a[0])).reshape(-1)
+    c = c[np.argmax(c != 0):] if np.any(c != 0) else c[:0]
+    r = np.roots(c) if c.size > 1 else np.zeros(0)
+    if np.all(np.imag(r) == 0):
+        r = np.real(r)
+    return r.reshape(-1, 1)
 
 
 def scalar(v):
@@ -514,17 +567,19 @@ class Colon:
 # ------------------------------------------------------------------------------------------------ interpreter
 class Interp:
     def __init__(self, ref_dir=REF_DIR):
-        self.ref_dir = ref_dir
+        self.ref_dir = ref_dir                                       # one directory, or a list searched in order (the MATLAB path)
         self.funcs = {}
         self.globals = {}
         self.calls = 0
+        self.extern = {}
 
     # ---- functions from the reference tree
     def load(self, name):
         if name in self.funcs:
             return self.funcs[name]
-        path = os.path.join(self.ref_dir, name + ".m")
-        if not os.path.exists(path):
+        dirs = [self.ref_dir] if isinstance(self.ref_dir, str) else list(self.ref_dir)
+        path = next((q for q in (os.path.join(dd, name + ".m") for dd in dirs) if os.path.exists(q)), None)
+        if path is None:
             return None
         with open(path) as fh:
             src = fh.read()
@@ -583,6 +638,10 @@ class Interp:
             node = st[1]
             if node[0] == "name" and not self.has(scope, node[1]):     # command-form call of a user function
                 self.call_any(node[1], [], 0, scope)
+            elif node[0] == "index" and node[1][0] == "name" and not self.has(scope, node[1][1]):
+                self.call_any(node[1][1], self.ev_args(node[2], scope), 0, scope)
+            elif node[0] == "index" and node[1][0] == "name" and is_callable(self.get(scope, node[1][1])):
+                self.call_handle(self.get(scope, node[1][1]), self.ev_args(node[2], scope), 0, scope)
             else:
                 self.ev(node, scope)
         elif kind == "assign":
@@ -594,6 +653,8 @@ class Interp:
                 vals = self.call_any(rhs[1][1], args, len(lhs), scope)
             elif rhs[0] == "name" and not self.has(scope, rhs[1]):
                 vals = self.call_any(rhs[1], [], len(lhs), scope)
+            elif rhs[0] == "index" and rhs[1][0] == "name" and is_callable(self.get(scope, rhs[1][1])):
+                vals = self.call_handle(self.get(scope, rhs[1][1]), self.ev_args(rhs[2], scope), len(lhs), scope)
             elif rhs[0] == "index" and self.dotted(rhs[1]) == "internal.stats.parseArgs":
                 vals = parse_args_builtin(self.ev_args(rhs[2], scope))
             else:
@@ -644,6 +705,8 @@ class Interp:
             for n in st[1]:
                 scope["__globals__"].add(n)
                 scope.pop(n, None)
+        elif kind == "clearglobal":
+            self.globals.clear()
         elif kind == "return":
             raise Return()
         elif kind == "break":
@@ -659,19 +722,47 @@ class Interp:
             self.put(scope, target[1], val)
             return
         if target[0] == "field":
-            base = target[1]
-            if base[0] != "name":
-                raise MError("nested field assignment")
-            obj = self.get(scope, base[1]) if self.has(scope, base[1]) else Struct()
+            base = target[1]                                          # structs are values: the holder gets a modified copy
+            if base[0] == "name":
+                obj = self.get(scope, base[1]) if self.has(scope, base[1]) else Struct()
+            elif base[0] == "field":
+                try:
+                    obj = self.ev(base, scope)
+                except (AttributeError, KeyError):
+                    obj = Struct()
+            else:
+                raise MError("field assignment on an indexed struct")
+            obj = Struct(**obj.__dict__) if isinstance(obj, Struct) else Struct()
             setattr(obj, target[2], val)
-            self.put(scope, base[1], obj)
+            self.assign(base, obj, scope, None)
             return
         if target[0] == "index" and target[1][0] == "name":
             name = target[1][1]
+            if self.has(scope, name) and isinstance(self.get(scope, name), str) and isinstance(val, str) and len(val) == 1:   # method(2) = 'L'
+                chars = list(self.get(scope, name))
+                for q in self.to_index(self.subscripts(target[2], np.zeros((1, len(chars))), scope)[-1], len(chars)):
+                    chars[int(q)] = val
+                self.put(scope, name, "".join(chars))
+                return
             cur = mat(self.get(scope, name)) if self.has(scope, name) else np.zeros((0, 0))
             subs = self.subscripts(target[2], cur, scope)
             is_delete = rhs_node is not None and rhs_node == ("matrix", [])
             self.put(scope, name, self.delete(cur, subs) if is_delete else self.store(cur, subs, val))
+            return
+        if target[0] == "index" and target[1][0] == "field" and target[1][1][0] == "name":      # s.f(subs) = v
+            fld = target[1]
+            obj = self.get(scope, fld[1][1]) if self.has(scope, fld[1][1]) else Struct()
+            cur = mat(getattr(obj, fld[2])) if hasattr(obj, fld[2]) else np.zeros((0, 0))
+            self.assign(fld, self.store(cur, self.subscripts(target[2], cur, scope), val), scope, None)
+            return
+        if target[0] == "cellindex" and target[1][0] == "name":                                # c{i} = v
+            name = target[1][1]
+            cell = list(self.get(scope, name)) if self.has(scope, name) else []
+            idx = int(scalar(self.ev(target[2][0], scope))) - 1
+            while len(cell) <= idx:
+                cell.append(np.zeros((0, 0)))
+            cell[idx] = val
+            self.put(scope, name, cell)
             return
         raise MError("cannot assign to %r" % (target[0],))
 
@@ -712,6 +803,12 @@ class Interp:
         return idx.astype(np.int64) - 1
 
     def load_index(self, arr, subs):
+        out = self.load_index_raw(arr, subs)
+        if np.iscomplexobj(out) and not np.any(np.imag(out)):          # a subscripted reference with no imaginary part is real
+            out = np.real(out).astype(np.float64)
+        return out
+
+    def load_index_raw(self, arr, subs):
         arr = mat(arr)
         if len(subs) == 1:
             s = subs[0]
@@ -821,7 +918,29 @@ class Interp:
                 out.append(self.ev_arg(nd, scope))
         return out
 
+    def call_handle(self, h, args, nargout, scope):
+        """@name, @(args) expression, or a Python callable handed in by the driver (called as f(args, nargout) -> list)"""
+        if callable(h):
+            return list(h(args, nargout))
+        if h[0] == "handle":
+            return self.call_any(h[1], args, nargout, scope)
+        _, names, body, captured = h
+        inner = dict(captured)
+        inner["__globals__"] = set()
+        if names and names[-1] == "varargin":
+            inner["varargin"] = list(args[len(names) - 1:])
+            names = names[:-1]
+        for a, v in zip(names, args):
+            inner[a] = v
+        if body[0] == "index" and body[1][0] == "name" and not self.has(inner, body[1][1]):
+            return self.call_any(body[1][1], self.ev_args(body[2], inner), nargout, inner)
+        if body[0] == "index" and body[1][0] == "name" and is_callable(self.get(inner, body[1][1])):
+            return self.call_handle(self.get(inner, body[1][1]), self.ev_args(body[2], inner), nargout, inner)
+        return [self.ev(body, inner)]
+
     def call_any(self, name, args, nargout, scope):
+        if name in self.extern:                                      # functions the driver stands in for (compiled MEX files)
+            return list(self.extern[name](args, nargout))
         if name in BUILTINS:
             out = BUILTINS[name](self, args, nargout)
             return out if isinstance(out, list) else [out]
@@ -844,6 +963,8 @@ class Interp:
             return mat(float(scope["__end__"][-1]))
         if kind == "handle":
             return ("handle", node[1])
+        if kind == "lambda":                                         # the workspace is captured by value when the handle is made
+            return ("closure", node[1], node[2], {k: v for k, v in scope.items() if k not in ("__end__",)})
         if kind == "field":
             return getattr(self.ev(node[1], scope), node[2])
         if kind == "range":
@@ -871,6 +992,11 @@ class Interp:
                 return num(a)
             return ~(a != 0) if a.dtype != bool else ~a
         if kind == "bin":
+            if node[1] in ("||", "&&"):                              # short-circuit: the right side may name variables that do not exist yet
+                left = truth(self.ev(node[2], scope))
+                if left == (node[1] == "||"):
+                    return mat(left)
+                return mat(truth(self.ev(node[3], scope)))
             return self.binop(node[1], self.ev(node[2], scope), self.ev(node[3], scope))
         if kind == "cell":
             return [self.ev(e, scope) for e in node[1]]
@@ -891,9 +1017,8 @@ class Interp:
                 subs = self.subscripts(node[2], mat(np.zeros((1, len(target)))), scope)
                 idx = self.to_index(subs[-1], len(target))
                 return "".join(target[q] for q in idx)
-            if isinstance(target, tuple) and target[0] == "handle":
-                args = [self.ev_arg(a, scope) for a in node[2]]
-                return self.call_any(target[1], args, 1, scope)[0]
+            if is_callable(target):
+                return self.call_handle(target, self.ev_args(node[2], scope), 1, scope)[0]
             arr = mat(target)
             return self.load_index(arr, self.subscripts(node[2], arr, scope))
         raise MError("expression " + kind)
@@ -1179,6 +1304,21 @@ def _mean(ip, args, nargout):
     return trim(np.mean(a, axis=ax, keepdims=True))
 
 
+def _var(ip, args, nargout):
+    a = num(mat(args[0]))
+    ax = _first_dim(a)
+    return trim(np.var(a, axis=ax, ddof=1 if a.shape[ax] > 1 else 0, keepdims=True))
+
+
+def _eig(ip, args, nargout):
+    """eig of a real symmetric matrix (pca.m:19): ascending eigenvalues; [V,D] = eig(A) with nargout 2"""
+    A = num(mat(args[0]))
+    if not np.allclose(A, A.T, rtol=1e-12, atol=1e-300):
+        raise MError("eig: only symmetric input is implemented")
+    w, V = np.linalg.eigh(0.5 * (A + A.T))
+    return [V, np.diag(w)] if nargout >= 2 else [w.reshape(-1, 1)]
+
+
 def _hist(ip, args, nargout):
     """n = hist(y, centers): counts per bin, bin edges midway between the centres, outer bins open-ended; row vector for vector y"""
     y = num(mat(args[0])).reshape(-1, order="F")
@@ -1206,11 +1346,36 @@ def _sparse(a):
     return out
 
 
+def _setfield(ip, a, n):
+    o = Struct(**a[0].__dict__) if isinstance(a[0], Struct) else Struct()
+    setattr(o, a[1], a[2])
+    return o
+
+
+def _length(v):
+    if isinstance(v, (str, list)):
+        return len(v)
+    a = mat(v)
+    return 0 if a.size == 0 else max(a.shape)
+
+
 BUILTINS = {
+    "fieldnames": lambda ip, a, n: [list(a[0].__dict__.keys())],
+    "getfield": lambda ip, a, n: getattr(a[0], a[1]),
+    "setfield": _setfield,
+    "isfield": lambda ip, a, n: mat(isinstance(a[0], Struct) and isinstance(a[1], str) and hasattr(a[0], a[1])),
+    "upper": lambda ip, a, n: a[0].upper() if isinstance(a[0], str) else a[0],
+    "lower": lambda ip, a, n: a[0].lower() if isinstance(a[0], str) else a[0],
+    "fprintf": lambda ip, a, n: [],
+    "disp": lambda ip, a, n: [],
+    "tic": lambda ip, a, n: [],
+    "toc": lambda ip, a, n: mat(0.0),
+    "drawnow": lambda ip, a, n: [],
     "size": _size,
     "numel": lambda ip, a, n: mat(float(len(a[0]) if isinstance(a[0], str) else mat(a[0]).size)),
-    "length": lambda ip, a, n: mat(float(len(a[0]) if isinstance(a[0], str) else (max(mat(a[0]).shape) if mat(a[0]).size else 0))),
-    "isempty": lambda ip, a, n: mat(len(a[0]) == 0 if isinstance(a[0], str) else mat(a[0]).size == 0),
+    "length": lambda ip, a, n: mat(float(_length(a[0]))),
+    "isempty": lambda ip, a, n: mat(len(a[0]) == 0 if isinstance(a[0], (str, list)) else False if isinstance(a[0], Struct) or is_callable(a[0])
+                                    else mat(a[0]).size == 0),
     "zeros": lambda ip, a, n: np.zeros(_dims(a)) if a else mat(0.0),
     "ones": lambda ip, a, n: np.ones(_dims(a)) if a else mat(1.0),
     "true": lambda ip, a, n: np.ones(_dims(a), dtype=bool) if a else mat(True),
@@ -1220,13 +1385,21 @@ BUILTINS = {
     "double": lambda ip, a, n: num(mat(a[0])),
     "int32": lambda ip, a, n: np.round(num(mat(a[0]))),
     "isinf": lambda ip, a, n: np.isinf(num(mat(a[0]))),
-    "imag": lambda ip, a, n: np.zeros_like(num(mat(a[0]))),      # real arithmetic only: imag(x) == 0
-    "real": lambda ip, a, n: num(mat(a[0])),
+    "imag": lambda ip, a, n: np.imag(num(mat(a[0]))).astype(np.float64),
+    "real": lambda ip, a, n: np.real(num(mat(a[0]))).astype(np.float64),
+    "isreal": lambda ip, a, n: mat(not np.iscomplexobj(mat(a[0]))),
+    "struct": _struct,
+    "roots": _roots,
+    "linsolve": _linsolve,
+    "polyval": lambda ip, a, n: np.polyval(num(mat(a[0])).reshape(-1), num(mat(a[1]))),
     "sum": _reduce(np.sum),
     "prod": _reduce(np.prod),
     "mean": _mean,
+    "var": _var,
+    "eig": _eig,
+    "nthroot": lambda ip, a, n: np.power(num(mat(a[0])), 1.0 / num(mat(a[1]))),
     "cumsum": _cumsum,
-    "exp": _elementwise(np.exp), "log": _elementwise(np.log), "sqrt": _elementwise(np.sqrt), "abs": _elementwise(np.abs),
+    "exp": _elementwise(np.exp), "log": _elementwise(np.log), "sqrt": _elementwise(_sqrt), "abs": _elementwise(np.abs),
     "floor": _elementwise(np.floor), "ceil": _elementwise(np.ceil), "round": _elementwise(np.round),
     "isnan": lambda ip, a, n: np.isnan(num(mat(a[0]))),
     "power": lambda ip, a, n: ip.binop(".^", a[0], a[1]),

@@ -11,6 +11,9 @@ Fixtures:
                           predictCov.m: predictFull, predictNoisy, predictMissing, predictNoisyMissing)
   ref_misc.npz            getPHI with all four outputs, inv_logdet (regular and rank-deficient), Dxy, getPrior, getOmega, fixPsi
   ref_lbfgs_mem.npz       minFunc's L-BFGS memory: lbfgsAdd.m / lbfgsProd.m over a wrapping ring with rejected pairs
+  ref_minfunc.npz         WolfeLineSearch.m / ArmijoBacktrack.m / polyinterp.m and whole minFunc.m runs on the inputs of the mf_* fixtures
+  ref_train_<case>.npz    init.m -> train.m end to end (minFunc.m, callBack.m, GPz.m, getPrior.m, pca.m, fillLinear.m ...): the model after
+                          init, callBack's numbers per iteration, the model after train
 
 The inputs are drawn here with NumPy (seeded); the oracle is NOT involved in producing a fixture — tests/test_reference_run.py
 compares it (CPU) and the HIP path (GPU) with these files, and re-executes the .m files when /root/reference exists."""
@@ -228,6 +231,146 @@ def make_lbfgs(seed, p=200, corr=5, steps=14):
                 YS=YS.reshape(-1))
 
 
+def full_interp(U=None, log=None):
+    """GPz/ and minFunc/ on one path, as startup.m / demo_*.m set it up (addpath).  The two compiled MEX files minFunc calls by
+    default (useMex = 1, train.m sets no option) are stood in for by what minFunc ships as their MATLAB twins: lbfgsAddC(y,s,Y,S,ys,end)
+    stores the two columns in place (lbfgsAdd.m:22-23 is the same statement pair), lbfgsProdC is lbfgsProd.m executed.
+    rand() returns the recorded uniform matrix U (init.m:58); fprintf records its arguments (callBack.m's per-iteration line)."""
+    ip = ML.Interp(ref_dir=[ML.REF_DIR, MINFUNC_DIR])
+
+    def add_c(a, nargout):
+        y, s, Y, S, _, end = a
+        e = int(np.asarray(end).reshape(-1)[0]) - 1
+        S[:, e] = np.asarray(s).reshape(-1)
+        Y[:, e] = np.asarray(y).reshape(-1)
+        return []
+    ip.extern["lbfgsAddC"] = add_c
+    ip.extern["lbfgsProdC"] = lambda a, nargout: ip.call("lbfgsProd", a, 1)
+    if U is not None:
+        ip.extern["rand"] = lambda a, nargout: [np.array(U)]
+    if log is not None:
+        ip.extern["fprintf"] = lambda a, nargout: (log.append([a[0]] + [float(np.asarray(v).reshape(-1)[0]) for v in a[1:]]), [])[1]
+    return ip
+
+
+def py_handle(fun):
+    """a Python objective fun(x) -> (f, g) as the function handle minFunc.m calls as [f,g] = funObj(x)"""
+    def h(args, nargout):
+        f, g = fun(np.asarray(args[0]).reshape(-1).copy())
+        return [ML.mat(f), np.asarray(g, dtype=np.float64).reshape(-1, 1)]
+    return h
+
+
+def make_minfunc():
+    """WolfeLineSearch.m / ArmijoBacktrack.m (with polyinterp.m, isLegal.m) and whole minFunc.m runs, executed on the INPUTS of the
+    optimiser fixtures tests/golden/mf_ls_*.npz and mf_run_*.npz (analytic objectives of tests/minfunc_objectives.py; for
+    mf_run_gpz_* the objective is GPz.m itself, executed).  One file, keys <fixture>__<quantity>: what the reference returns for
+    the inputs those fixtures record - the restated optimiser that produced the mf_* files is checked against it."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import minfunc_objectives as F
+    m = ML.mat
+    out = {}
+    for path in sorted(glob.glob(os.path.join(GOLD, "mf_ls_*.npz"))):
+        z, name = np.load(path), os.path.splitext(os.path.basename(path))[0]
+        fun = F.OBJECTIVES[str(z["objective"])]
+        x, d = z["x"], z["d"]
+        f, g = fun(x)
+        common = [m(float(z["c1"]))] + ([m(float(z["c2"]))] if str(z["kind"]) == "wolfe" else []) + [m(float(z["ls_interp"])), m(0.0)]
+        ip = full_interp()
+        if str(z["kind"]) == "wolfe":       # WolfeLineSearch(x,t,d,f,g,gtd,c1,c2,LS_interp,LS_multi,maxLS,progTol,debug,doPlot,saveHessianComp,funObj)
+            t, fn, gn, ev = ip.call("WolfeLineSearch", [ML.col(x), m(float(z["t0"])), ML.col(d), m(f), ML.col(g), m(float(g @ d))] + common
+                                    + [m(25.0), m(1e-9), m(0.0), m(0.0), m(0.0), py_handle(fun)], 4)
+        else:                               # ArmijoBacktrack(x,t,d,f,fr,g,gtd,c1,LS_interp,LS_multi,progTol,debug,doPlot,saveHessianComp,funObj)
+            t, _, fn, gn, ev = ip.call("ArmijoBacktrack", [ML.col(x), m(float(z["t0"])), ML.col(d), m(f), m(f), ML.col(g), m(float(g @ d))]
+                                       + common + [m(1e-9), m(0.0), m(0.0), m(0.0), py_handle(fun)], 5)
+        out.update({name + "__t": float(np.asarray(t).reshape(-1)[0]), name + "__f_new": float(np.asarray(fn).reshape(-1)[0]),
+                    name + "__g_new": np.asarray(gn).reshape(-1), name + "__funEvals": int(np.asarray(ev).reshape(-1)[0])})
+    for path in sorted(glob.glob(os.path.join(GOLD, "mf_run_*.npz"))):
+        z, name = np.load(path), os.path.splitext(os.path.basename(path))[0]
+        ip = full_interp()
+        if str(z["objective"]) == "gpz":
+            mm, d = int(z["m"]), int(z["d"])
+            ms = ML.model_struct(mm, d, 1, str(z["method"]), True, g_dim_of(str(z["method"]), mm, d))
+            X, Y = z["X"], z["Y"]
+            handle = lambda a, nargout: ip.call("GPz", [a[0], ms, X, Y, E, E, E, E], 2)
+        else:
+            handle = py_handle(F.OBJECTIVES[str(z["objective"])])
+        steps = []
+        opt = ML.Struct(Method="lbfgs", Display="off", MaxIter=m(float(z["max_iter"])),
+                        outputFcn=lambda a, nargout: (steps.append(float(np.asarray(a[5]).reshape(-1)[0])) if a[1] == "iter" else None,
+                                                      [m(False)])[1])
+        if name.endswith("_c5"):
+            opt.Corr = m(5.0)
+        x, f, flag, o = ip.call("minFunc", [handle, ML.col(z["x0"]), opt], 4)
+        out.update({name + "__x": np.asarray(x).reshape(-1), name + "__f": float(np.asarray(f).reshape(-1)[0]),
+                    name + "__exitflag": int(np.asarray(flag).reshape(-1)[0]), name + "__message": str(o.message),
+                    name + "__iterations": int(np.asarray(o.iterations).reshape(-1)[0]),
+                    name + "__funcCount": int(np.asarray(o.funcCount).reshape(-1)[0]),
+                    name + "__fval": np.asarray(o.trace.fval).reshape(-1), name + "__funcCounts": np.asarray(o.trace.funcCount).reshape(-1),
+                    name + "__optCond": np.asarray(o.trace.optCond).reshape(-1), name + "__steps": np.array(steps)})
+    return out
+
+
+# (name, method, n, d, m, k, heteroscedastic, validation, nan fraction, Psi, omega, maxIter, maxAttempts)
+TRAIN_CASES = [("VD_valid", "VD", 150, 3, 6, 1, True, True, 0.0, False, None, 20, np.inf),
+               ("GC_nan_omega", "GC", 160, 3, 5, 1, True, True, 0.15, False, "normalized", 15, np.inf),
+               ("VC_psi_trainonly", "VC", 40, 2, 3, 1, True, False, 0.0, True, None, 6, np.inf),
+               ("GL_k2_attempts", "GL", 140, 3, 5, 2, True, True, 0.0, False, None, 40, 2),
+               ("VL_d1_homo", "VL", 130, 1, 7, 1, False, True, 0.0, False, "balanced", 15, np.inf)]
+
+
+def make_train(case, seed):
+    """init.m -> train.m (minFunc.m, WolfeLineSearch.m, polyinterp.m, lbfgsAdd.m, lbfgsProd.m, callBack.m, GPz.m, getPHI.m, getPrior.m,
+    pca.m, fillLinear.m, Dxy.m, fixPsi.m, getOmega.m): the model after init, callBack's line per iteration, the model after train"""
+    name, method, n, d, m, k, hetero, valid, nanfrac, psi, omega_kind, max_iter, max_att = case
+    rng = np.random.default_rng(seed)
+    scale, shift = 0.5 + 2.0 * rng.random(d), rng.standard_normal(d)
+    X = rng.standard_normal((n, d)) * scale + shift
+    Y = np.sin((X - shift) / scale @ rng.standard_normal((d, k))) + 0.1 * rng.standard_normal((n, k)) + 0.7
+    if omega_kind:
+        Y = np.abs(Y) + 0.05
+    U = rng.random((m, d))
+    training = rng.random(n) < 0.7
+    validation = ~training
+    Psi = rng.gamma(1.0, 0.05, (n, d)) * scale ** 2 if psi else None
+    if nanfrac > 0:
+        miss = rng.random((n, d)) < nanfrac
+        miss[miss.all(axis=1), 0] = False
+        X[miss] = np.nan
+    log = []
+    ip = full_interp(U, log)
+    opts = ["heteroscedastic", ML.mat(bool(hetero)), "training", training.reshape(-1, 1)]
+    topts = ["maxIter", ML.mat(float(max_iter)), "maxAttempts", ML.mat(float(max_att)), "training", training.reshape(-1, 1)]
+    omega = None
+    if omega_kind:
+        omega = np.asarray(ip.call("getOmega", [Y[:, :1], omega_kind], 1)[0])
+        opts += ["omega", omega]
+        topts += ["omega", omega]
+    if psi:
+        opts += ["Psi", Psi]
+        topts += ["Psi", Psi]
+    if valid:
+        topts += ["validation", validation.reshape(-1, 1)]
+    model = ip.call("init", [X, Y, method, ML.mat(float(m))] + opts, 1)[0]
+    out = dict(method=method, method_after_init=model.method, m=m, d=d, k=k, heteroscedastic=int(hetero), X=X, Y=Y, U=U, training=training,
+               validation=(validation if valid else np.zeros(0, dtype=bool)), omega=(omega if omega is not None else np.zeros(0)),
+               Psi=(Psi if psi else np.zeros(0)), maxIter=max_iter, maxAttempts=max_att, muX=np.asarray(model.muX), sdX=np.asarray(model.sdX),
+               muY=np.asarray(model.muY), g_dim=int(np.asarray(model.g_dim).reshape(-1)[0]), theta0=np.asarray(model.last.theta).reshape(-1),
+               w0=np.asarray(model.last.w), iSigma_w0=np.asarray(model.last.iSigma_w).reshape(m, m, k, order="F"))
+    del log[:]
+    model = ip.call("train", [model, X, Y] + topts, 1)[0]
+    rows = [r[1:6] + [r[6] if len(r) > 7 else np.nan] for r in log if r[0].startswith("\\t%d")]
+    rows = [[r[0], r[1], r[2], r[3], r[4] if valid else np.nan, r[5] if valid else np.nan] for r in rows]
+    out.update(log=np.array(rows), message=[r[0] for r in log][-1])
+    for which in ("last", "best"):
+        st = getattr(model, which)
+        out.update({which + "_theta": np.asarray(st.theta).reshape(-1), which + "_w": np.asarray(st.w),
+                    which + "_iSigma_w": np.asarray(st.iSigma_w).reshape(m, m, k, order="F"),
+                    which + "_priors": np.asarray(st.priors).reshape(-1)})
+    return out
+
+
 def all_fixtures():
     """name -> maker()"""
     fx = {}
@@ -237,6 +380,9 @@ def all_fixtures():
         fx[predict_case_name(c)] = (lambda c=c, q=q: make_predict(c, 800 + q))
     fx["ref_misc"] = lambda: make_misc(77)
     fx["ref_lbfgs_mem"] = lambda: make_lbfgs(91)
+    fx["ref_minfunc"] = make_minfunc
+    for i, c in enumerate(TRAIN_CASES):
+        fx["ref_train_" + c[0]] = (lambda c=c, i=i: make_train(c, 400 + i))
     return fx
 
 

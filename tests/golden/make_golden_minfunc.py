@@ -2,8 +2,9 @@
 
     python tests/golden/make_golden_minfunc.py
 
-The reference's minFunc is MATLAB + MEX and cannot run in the build image, and it ships no recorded traces, so these
-vectors are outputs of the restatement (itself pinned by tests/test_minfunc_oracle.py), frozen at generation time:
+These vectors are outputs of the restatement, frozen at generation time (they carry per-trial traces and phases the reference does
+not return).  What the reference's own minFunc files return on the same inputs is in ref_minfunc.npz (oracle/run_reference.py executes
+them; tests/test_reference_run.py compares the two):
 
     mf_mem_*    a sequence of lbfgsAdd(g - g_old, t*d, ...) calls through a wrapping ring with rejected pairs, and the
                 lbfgsProd direction after every call (inputs: G, D, T; outputs: added flags, ring state, directions)

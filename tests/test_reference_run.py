@@ -21,6 +21,9 @@ GPZ = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path
 PRED = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "ref_predict_*.npz")))
 
 
+TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES]
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}
@@ -49,7 +52,8 @@ def predict_inputs(g):
 
 def test_fixture_inventory():
     assert len(GPZ) == len(RR.GPZ_CASES) == 30 and len(PRED) == len(RR.PREDICT_CASES) == 24
-    assert os.path.exists(os.path.join(GOLDEN, "ref_misc.npz")) and os.path.exists(os.path.join(GOLDEN, "ref_lbfgs_mem.npz"))
+    assert all(os.path.exists(os.path.join(GOLDEN, f + ".npz")) for f in ["ref_misc", "ref_lbfgs_mem", "ref_minfunc"] + TRAIN)
+    assert len(MF_LS) == 13 and len(MF_RUN) == 6
 
 
 # ---- CPU: oracle against the executed reference ------------------------------------------------------------------------
@@ -120,6 +124,111 @@ def test_minfunc_restatement_against_the_executed_lbfgs_files():
         if end > 0:
             assert rel(MF.lbfgsProd(z["G"][it + 1], S, Y, YS, start, end, hd), z["directions"][it]) <= 1e-12
     assert rel(S, z["S"]) <= 1e-15 and rel(Y, z["Y"]) <= 1e-13 and rel(YS, z["YS"]) <= 1e-13
+
+
+MF_LS = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "mf_ls_*.npz")))
+MF_RUN = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "mf_run_*.npz")))
+
+
+@pytest.mark.parametrize("name", MF_LS)
+def test_line_search_fixtures_are_what_the_executed_line_searches_return(name):
+    """tests/golden/mf_ls_*.npz were produced by the restated optimiser (oracle/minfunc_oracle.py); ref_minfunc.npz holds what
+    WolfeLineSearch.m / ArmijoBacktrack.m (polyinterp.m, isLegal.m) returned on the same inputs."""
+    z, r = load(name), load("ref_minfunc")
+    assert int(z["funEvals"]) == int(r[name + "__funEvals"])
+    assert float(z["t"]) == pytest.approx(float(r[name + "__t"]), rel=1e-13, abs=0)
+    assert float(z["f_new"]) == pytest.approx(float(r[name + "__f_new"]), rel=1e-13, abs=1e-300)
+    assert rel(z["g_new"], r[name + "__g_new"]) <= 1e-13
+
+
+@pytest.mark.parametrize("name", MF_RUN)
+def test_minfunc_run_fixtures_are_what_the_executed_minfunc_returns(name):
+    """whole runs: evaluation counts, exit, message per run; steps and function values per iteration (a prefix tightly - later
+    iterations drift with the summation order of the two-loop product, as between any two BLAS builds)"""
+    z, r = load(name), load("ref_minfunc")
+    for key in ("exitflag", "iterations", "funcCount"):
+        assert int(z[key]) == int(r[name + "__" + key]), key
+    assert str(z["message"]) == str(r[name + "__message"])
+    assert list(z["funcCounts"]) == list(r[name + "__funcCounts"].astype(int))
+    q = min(10, z["steps"].size)
+    assert np.allclose(z["steps"][:q], r[name + "__steps"][:q], rtol=1e-9) and np.allclose(z["fval"][:q + 1], r[name + "__fval"][:q + 1], rtol=1e-11)
+    assert np.allclose(z["steps"], r[name + "__steps"], rtol=1e-3) and np.allclose(z["fval"], r[name + "__fval"], rtol=1e-5, atol=1e-9)
+    assert rel(z["x"], r[name + "__x"]) <= 1e-5 and rel(z["optCond"], r[name + "__optCond"]) <= 1e-3
+
+
+TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES]
+
+
+class RecordedRand:
+    """init.m:58 draws rand(m,d); the fixture holds the matrix the executed init.m was given"""
+    def __init__(self, U):
+        self.U = U
+
+    def random(self, shape):
+        assert tuple(shape) == self.U.shape
+        return self.U.copy()
+
+
+def check_training_log(log, want, valid):
+    """callBack.m's numbers per iteration.  L-BFGS amplifies rounding differences along the trajectory (the executed reference and
+    a re-run of it with another BLAS differ the same way), so the first iterations are compared tightly and the rest loosely."""
+    assert log.shape == want.shape
+    cols = slice(0, 6) if valid else slice(0, 4)
+    head = min(4, len(want))
+    assert np.allclose(log[:head, cols], want[:head, cols], rtol=1e-8, atol=1e-10)
+    assert np.allclose(log[:, cols], want[:, cols], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", TRAIN)
+def test_oracle_training_against_the_executed_reference(name):
+    """init.m + train.m + minFunc.m + callBack.m executed end to end (oracle/run_reference.py:make_train) against the restatements:
+    oracle.init_theta (theta after init), oracle.GPz (w, iSigma_w after init), minfunc_oracle.minFunc on oracle.GPz with
+    callBack.m's bookkeeping (the per-iteration line, best-on-validation, the early stop), oracle.getPrior."""
+    from oracle import minfunc_oracle as MF
+    z = load(name)
+    m, d, k, method = int(z["m"]), int(z["d"]), int(z["k"]), str(z["method_after_init"])
+    model = O.Model(m=m, d=d, k=k, method=method, heteroscedastic=bool(int(z["heteroscedastic"])))
+    assert int(z["g_dim"]) == O.g_dim_of(method, m, d)
+    tr = z["training"].astype(bool)
+    valid = z["validation"].size > 0
+    va = z["validation"].astype(bool) if valid else None
+    Xn, Yc = (z["X"] - z["muX"]) / z["sdX"], z["Y"] - z["muY"]
+    om = z["omega"] if z["omega"].size else None
+    Psi = O.fixPsi(z["Psi"], Xn.shape[0], z["sdX"].reshape(-1), method) if z["Psi"].size else None
+    if not np.isnan(z["X"]).any():                                       # init_theta covers the case without missing values
+        _, th0 = O.init_theta(Xn, Yc, str(z["method"]), m, model.heteroscedastic, RecordedRand(z["U"]), tr)
+        assert rel(th0, z["theta0"]) <= 1e-10
+    r0 = O.GPz(z["theta0"], model, Xn, Yc, Psi, om, tr, None, nargout=5)
+    assert rel(r0.w, z["w0"]) <= 1e-9 and rel(r0.iSigma_w, z["iSigma_w0"]) <= 1e-9
+
+    state = {"best_valid": -np.inf, "best_theta": z["theta0"].copy(), "attempts": None, "stats": None, "log": []}
+
+    def fun(th):
+        r = O.GPz(th, model, Xn, Yc, Psi, om, tr, va)
+        state["stats"] = r.stats
+        return r.nlogML, r.grad
+
+    def call_back(x, kind, i, evals, f, t, gtd, g, dd, opt):             # callBack.m:16-47; `attempts` stays [] until the first improvement
+        st = state["stats"]
+        if kind == "iter":
+            state["log"].append([i, -f, st["trainRMSE"], st["trainLL"], st.get("validRMSE", np.nan), st.get("validLL", np.nan)])
+            if not valid:
+                state["best_valid"], state["best_theta"] = st["trainLL"], x.copy()
+            elif st["validLL"] >= state["best_valid"]:
+                state["best_valid"], state["best_theta"], state["attempts"] = st["validLL"], x.copy(), 0
+            elif state["attempts"] is not None:
+                state["attempts"] += 1
+        return state["attempts"] is not None and state["attempts"] == float(z["maxAttempts"])
+
+    x, f, flag, out = MF.minFunc(fun, z["theta0"], maxIter=int(z["maxIter"]), maxFunEvals=np.inf, outputFcn=call_back)
+    check_training_log(np.array(state["log"]), z["log"], valid)
+    assert ("No improvment" in str(z["message"])) == (flag == -1)
+    assert rel(x, z["last_theta"]) <= 2e-3 and rel(state["best_theta"], z["best_theta"]) <= 2e-3
+    for which in ("last", "best"):                                       # train.m:53-80 on the reference's own theta: w, inv(SIGMA), priors
+        th = z[which + "_theta"]
+        r = O.GPz(th, model, Xn, Yc, Psi, om, tr, va, nargout=5)
+        assert rel(r.w, z[which + "_w"]) <= 1e-8 and rel(r.iSigma_w, z[which + "_iSigma_w"]) <= 1e-8
+        assert rel(O.getPrior(Xn, Psi, th, model, tr), z[which + "_priors"]) <= 1e-8
 
 
 @pytest.mark.skipif(not ML.available(), reason="the reference tree exists only in the build container")
@@ -227,3 +336,47 @@ def test_hip_path_against_the_executed_reference_misc():
         tol = max(1e-11, 2000.0 * cov_cond(O.Model(m=4, d=3, k=1, method=method, heteroscedastic=True), g[tag + "_theta"]) * 2.2e-16)
         assert rel(PHI, g[tag + "_PHI"]) <= tol and rel(lnb, g[tag + "_lnBeta_i"]) <= tol and rel(N, g[tag + "_N"]) <= tol
         assert rel(gpz_amd.getPrior(g[tag + "_X"], g[tag + "_Psi"], g[tag + "_theta"], model, sel), g[tag + "_prior"]) <= 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_resident", [False, True])
+@pytest.mark.parametrize("name", TRAIN)
+def test_hip_init_and_train_against_the_executed_reference(name, device_resident):
+    """gpz_amd.init -> gpz_amd.train (the package's minFunc driver on the HIP objective, host- or device-resident optimiser
+    vectors) against init.m -> train.m executed end to end: normalisation, theta after init, the first solve, callBack.m's
+    numbers per iteration, the stop, and last / best theta, w, inv(SIGMA), priors."""
+    import gpz_amd
+    z = load(name)
+    m, k = int(z["m"]), int(z["k"])
+    tr = z["training"].astype(bool)
+    valid = z["validation"].size > 0
+    va = z["validation"].astype(bool) if valid else None
+    om = z["omega"] if z["omega"].size else None
+    Psi = z["Psi"] if z["Psi"].size else None
+    model = gpz_amd.init(z["X"], z["Y"], str(z["method"]), m, heteroscedastic=bool(int(z["heteroscedastic"])), omega=om, training=tr,
+                         Psi=Psi, rng=RecordedRand(z["U"]))
+    assert model.method == str(z["method_after_init"]) and model.g_dim == int(z["g_dim"])
+    assert rel(model.muX, z["muX"].reshape(-1)) <= 1e-13 and rel(model.sdX, z["sdX"].reshape(-1)) <= 1e-13
+    assert rel(model.muY, z["muY"].reshape(-1)) <= 1e-13
+    last = model.sets["last"]
+    assert rel(last["theta"], z["theta0"]) <= 1e-10
+    assert rel(last["w"], z["w0"]) <= 1e-8 and rel(last["iSigma_w"], z["iSigma_w0"]) <= 1e-8
+    model = gpz_amd.train(model, z["X"], z["Y"], maxIter=int(z["maxIter"]), maxAttempts=float(z["maxAttempts"]), omega=om, training=tr,
+                          validation=va, Psi=Psi, verbose=False, device_resident=device_resident)
+    check_training_log(model.train_info["log"], z["log"], valid)
+    assert ("No improvment" in str(z["message"])) == (model.train_info["exitflag"] == -1)
+    for which in ("last", "best"):
+        st = model.sets[which]
+        assert rel(st["theta"], z[which + "_theta"]) <= 2e-3, which
+        assert rel(st["w"], z[which + "_w"]) <= 2e-2 and rel(st["priors"], z[which + "_priors"]) <= 2e-3, which
+    # the closing statements of train.m on the reference's own theta (no trajectory in between): w, inv(SIGMA), priors
+    Xn, Yc = (z["X"] - model.muX) / model.sdX, z["Y"] - model.muY
+    PsiN = gpz_amd.fixPsi(Psi, Xn.shape[0], model.sdX, model.method) if Psi is not None else None
+    ctx = gpz_amd.GPzContext(model, Xn, Yc, PsiN, om, tr, va)
+    try:
+        for which in ("last", "best"):
+            w, iS, _ = ctx.solve(z[which + "_theta"])
+            assert rel(w, z[which + "_w"]) <= 1e-7 and rel(iS, z[which + "_iSigma_w"]) <= 1e-7
+            assert rel(gpz_amd.getPrior(Xn, PsiN, z[which + "_theta"], model, tr), z[which + "_priors"]) <= 1e-8
+    finally:
+        ctx.close()
