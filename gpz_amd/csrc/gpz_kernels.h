@@ -233,6 +233,14 @@ void launch_gen_phi(hipStream_t st, const GenRows &r, int m, int mp, int d, int 
                     double *ws = nullptr);
 void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int m, int mp, int k, const double *Y);
 // register-resident variants for Psi without missing dimensions, 2 <= d <= 10 (k_psi.hip); return -1 outside that range
+// fp64 GC/VC + Psi for 10 < d <= 64 (k_cpsi.hip): same arguments and records as launch_psi_phi / launch_psi_moments
+bool cpsi_available(int d);
+int launch_cpsi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                    const double *lnS, double *Phi, int ld, const unsigned char *pat);
+int launch_cpsi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                        int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
+                        const int *chunktab);
 bool psi_fast_path_available(int d);
 // pat (observed flags [G][d]) non-null: rows carry missing dimensions (r.gid = pattern per row, lnS = [G][m]);
 // chunktab (optional): {first row, end row} per moment chunk
