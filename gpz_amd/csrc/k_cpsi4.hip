@@ -1,0 +1,392 @@
+// GC/VC with input noise in fp64 for 10 < d <= 32: FOUR (sample, basis) pairs per wave on v_mfma_f64_4x4x4_4b_f64.
+//
+//   getPHI.m:78-89   ln PHI_ij = -1/2 Delta' M^-1 Delta + 1/2 ln|Sigma_j| - 1/2 ln|M|,   M = Psi_i + Sigma_j
+//   GPz.m:164-185    sum_i dPHI_ij * [1, M^-1 Delta, (M^-1 Delta)(M^-1 Delta)' - M^-1]
+//
+// Same elimination as k_cpsi.hip (symmetric sweep in panels of four pivots, the pivot block through its Cholesky factor), but the
+// pair matrix is cut into 4 x 4 TILES, one f64 per lane and tile: the instruction multiplies four independent 4 x 4 x 4 blocks,
+// lane = 16 hi + 4 b + lo with b the block (here: the pair), and (measured, tools/mfma_f64_4x4_probe.hip)
+//       A operand: lane (hi = k, lo = i) supplies A[i][k]      B operand: lane (hi = k, lo = j) supplies B[k][j]
+//       result:    lane (hi = i, lo = j) receives D[i][j]
+// so a tile held in the RESULT layout is a B operand as it stands and, used as the A operand, its own transpose:
+// mfma(X, Z, C) = C + X'Z on result-layout registers.  Every product of the sweep has that shape - nothing moves between lanes
+// except the pivot block (16 doubles per pair through LDS, so that every lane can factorise it) and one transpose per
+// pivot-column tile (the lower triangle only is stored):
+//       W = inv(L), A11 = L L'                       per lane, 4 pairs per wave (k_cpsi.hip: 1 pair per wave for the same work)
+//       Y_J' = W A_1J              = mfma(W', A_1J)          A_1J = tile (p, J), or the transposed tile (J, p) for J > p
+//       B_IJ = A_IJ - Y_I Y_J'     = mfma(-Y_I', Y_J', A_IJ)
+//       B_1J = W' Y_J'  (J < p)    = mfma(W, Y_J')       B_J1 = Y_J W  (J > p) = mfma(Y_J', W)       B_11 = -W'W = mfma(-W, W)
+// Delta rides along as row 0 of an extra tile row (index ND): after the sweep that row is (M^-1 Delta)', its corner -Delta' M^-1 Delta,
+// and u u' for the moment sums is one more mfma of two tiles of that row (rows 1..3 are zero).  20 cycles per instruction measured:
+// 0.4 of the 16x16x4 rate, but the per-panel scalar work (4 x 4 Cholesky, inverse, logarithm) is shared by four pairs.
+// d is padded to 4 ND with identity; missing dimensions are marginalised as in k_psi.hip (identity block in M, zero Delta).
+#include <stdlib.h>
+#include "gpz_dev.h"
+#include "gpz_kernels.h"
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ double c4_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
+__device__ __forceinline__ void c4_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// W = inv(L) for A = L L' (4 x 4, lower triangle read), entries above the diagonal not written; returns det A.
+__device__ __forceinline__ double c4_inv4(const double (&a)[4][4], double (&w)[4][4]) {
+    const double p0 = a[0][0];
+    const double r0 = c4_rsqrt(p0);
+    const double l10 = a[1][0] * r0, l20 = a[2][0] * r0, l30 = a[3][0] * r0;
+    const double p1 = fma(-l10, l10, a[1][1]);
+    const double r1 = c4_rsqrt(p1);
+    const double l21 = fma(-l20, l10, a[2][1]) * r1, l31 = fma(-l30, l10, a[3][1]) * r1;
+    const double p2 = fma(-l21, l21, fma(-l20, l20, a[2][2]));
+    const double r2 = c4_rsqrt(p2);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, a[3][2])) * r2;
+    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a[3][3])));
+    const double r3 = c4_rsqrt(p3);
+    w[0][0] = r0; w[1][1] = r1; w[2][2] = r2; w[3][3] = r3;
+    w[1][0] = -l10 * r0 * r1;
+    w[2][1] = -l21 * r1 * r2;
+    w[3][2] = -l32 * r2 * r3;
+    w[2][0] = -fma(l21, w[1][0], l20 * r0) * r2;
+    w[3][1] = -fma(l32, w[2][1], l31 * r1) * r3;
+    w[3][0] = -fma(l32, w[2][0], fma(l31, w[1][0], l30 * r0)) * r3;
+    return (p0 * p1) * (p2 * p3);
+}
+
+constexpr int c4_lt(int I, int J) { return I * (I + 1) / 2 + J; }   // tile (I, J), J <= I, of the lower triangle (tile row ND = Delta)
+#define C4_NT(ND) (((ND) + 1) * ((ND) + 2) / 2)
+// workgroups per CU the register allocation aims at: two waves per SIMD hide the latency of the pivot-block chain (measured at
+// n = 1e5, m = 256, d = 24: moments 62 -> 35 ms); the moment kernel of d > 28 needs more than 256 registers for its tiles and sums
+#define C4_MINB_PHI(ND) ((ND) <= 7 ? 2 : 1)
+#define C4_MINB_MOM(ND) ((ND) <= 7 ? 2 : 1)
+
+struct C4Lane {
+    int lane, hi, b, lo, tl;          // tl: the lane that holds the transposed element of a tile
+    bool h1, h2, h3, l1, l2, l3;      // hi == 1, 2, 3;  lo == 1, 2, 3
+};
+__device__ __forceinline__ C4Lane c4_lane() {
+    C4Lane L;
+    L.lane = threadIdx.x & 63;
+    L.hi = L.lane >> 4; L.b = (L.lane >> 2) & 3; L.lo = L.lane & 3;
+    L.tl = 16 * L.lo + 4 * L.b + L.hi;
+    L.h1 = L.hi == 1; L.h2 = L.hi == 2; L.h3 = L.hi == 3;
+    L.l1 = L.lo == 1; L.l2 = L.lo == 2; L.l3 = L.lo == 3;
+    return L;
+}
+__device__ __forceinline__ double c4_pick(bool s1, bool s2, bool s3, double v0, double v1, double v2, double v3) {
+    return s3 ? v3 : (s2 ? v2 : (s1 ? v1 : v0));
+}
+
+// pivot tile -> every lane of the pair (through LDS) -> W = inv(chol), and the determinant into a running mantissa / exponent pair
+__device__ __forceinline__ void c4_factor(double tile, double *__restrict__ ex, const C4Lane &L, double (&W)[4][4], double *mant,
+                                          int *expo) {
+    c4_sync();
+    ex[L.lane] = tile;                               // slot 16 hi + 4 b + lo
+    c4_sync();
+    double A[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y <= x; ++y) A[x][y] = ex[16 * x + 4 * L.b + y];
+    const double det = c4_inv4(A, W);
+    *mant *= __builtin_amdgcn_frexp_mant(det);       // ln|M| = ln(prod mant) + (sum exp) ln 2: one logarithm per pair instead of one per panel
+    *expo += __builtin_amdgcn_frexp_exp(det);
+}
+
+// Sweep of the ND pivot tiles of T (lower tiles, result layout).  INV: the whole matrix (T(0..ND-1, .) becomes -M^-1, row 0 of tile
+// row ND (M^-1 Delta)', the corner -Delta' M^-1 Delta); else only the tiles below / right of the pivot are updated (the corner still
+// ends as -Delta' M^-1 Delta).  *logdet = ln|M|.  ex: 64 doubles of LDS private to the wave.
+template <int ND, bool INV>
+__device__ __forceinline__ void c4_sweep(double (&T)[C4_NT(ND)], double *__restrict__ ex, const C4Lane &L, double *logdet) {
+    double mant = 1.0;
+    int expo = 0;
+    double W[4][4];
+    c4_factor(T[c4_lt(0, 0)], ex, L, W, &mant, &expo);
+#pragma unroll
+    for (int p = 0; p < ND; ++p) {
+        // result-layout registers of W and W' (zero above / below the diagonal)
+        const double rh0 = c4_pick(L.h1, L.h2, L.h3, W[0][0], W[1][0], W[2][0], W[3][0]);
+        const double rh1 = c4_pick(L.h1, L.h2, L.h3, 0.0, W[1][1], W[2][1], W[3][1]);
+        const double rh2 = c4_pick(L.h1, L.h2, L.h3, 0.0, 0.0, W[2][2], W[3][2]);
+        const double rh3 = c4_pick(L.h1, L.h2, L.h3, 0.0, 0.0, 0.0, W[3][3]);
+        const double Wd = c4_pick(L.l1, L.l2, L.l3, rh0, rh1, rh2, rh3);              // W[hi][lo]
+        const double rl0 = c4_pick(L.l1, L.l2, L.l3, W[0][0], W[1][0], W[2][0], W[3][0]);
+        const double rl1 = c4_pick(L.l1, L.l2, L.l3, 0.0, W[1][1], W[2][1], W[3][1]);
+        const double rl2 = c4_pick(L.l1, L.l2, L.l3, 0.0, 0.0, W[2][2], W[3][2]);
+        const double rl3 = c4_pick(L.l1, L.l2, L.l3, 0.0, 0.0, 0.0, W[3][3]);
+        const double Wt = c4_pick(L.h1, L.h2, L.h3, rl0, rl1, rl2, rl3);              // W[lo][hi] = W'[hi][lo]
+        double Yt[ND + 1];
+        // the next pivot tile first: its factorisation (a chain of dependent scalar work) then runs beside the other updates
+        if (p + 1 < ND) {
+            Yt[p + 1] = MFMA4(Wt, __shfl(T[c4_lt(p + 1, p)], L.tl, 64), 0.0);
+            T[c4_lt(p + 1, p + 1)] = MFMA4(-Yt[p + 1], Yt[p + 1], T[c4_lt(p + 1, p + 1)]);
+            c4_factor(T[c4_lt(p + 1, p + 1)], ex, L, W, &mant, &expo);
+        }
+#pragma unroll
+        for (int J = 0; J <= ND; ++J) {
+            if (J == p || (J == p + 1 && p + 1 < ND) || (!INV && J < p)) continue;
+            const double a1 = J < p ? T[c4_lt(p, J)] : __shfl(T[c4_lt(J, p)], L.tl, 64);
+            Yt[J] = MFMA4(Wt, a1, 0.0);                                               // Y_J' = W A_1J
+        }
+#pragma unroll
+        for (int I = 0; I <= ND; ++I) {
+            if (I == p || (!INV && I < p)) continue;
+            const double ny = -Yt[I];
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                if (J == p || (!INV && J < p) || (I == p + 1 && J == p + 1 && p + 1 < ND)) continue;
+                T[c4_lt(I, J)] = MFMA4(ny, Yt[J], T[c4_lt(I, J)]);                    // A_IJ - Y_I Y_J'
+            }
+        }
+        if (INV) {
+#pragma unroll
+            for (int J = 0; J <= ND; ++J) {
+                if (J < p) T[c4_lt(p, J)] = MFMA4(Wd, Yt[J], 0.0);                    // W' Y_J'
+                else if (J > p) T[c4_lt(J, p)] = MFMA4(Yt[J], Wd, 0.0);               // Y_J W
+            }
+            T[c4_lt(p, p)] = MFMA4(-Wd, Wd, 0.0);                                     // -W'W
+        }
+    }
+    *logdet = log(mant) + GPZ_LOG2 * (double)expo;
+}
+
+// PHI: block b of a wave = one sample, loop over the basis functions.  Arguments as k_psi_phi (k_psi.hip).
+template <int ND, bool MISS>
+__global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double *__restrict__ Xr, int de, const double *__restrict__ Psi3, int n,
+                                                    int m, int d, const double *__restrict__ P, const double *__restrict__ Sig,
+                                                    const double *__restrict__ lnS, double *__restrict__ Phi, int ld,
+                                                    const int *__restrict__ gid, const unsigned char *__restrict__ pat) {
+    constexpr int NTD = ND * (ND + 1) / 2;
+    __shared__ double ex_all[4][64];
+    const C4Lane L = c4_lane();
+    const int wave = threadIdx.x >> 6;
+    double *ex = ex_all[wave];
+    const int i = (blockIdx.x * 4 + wave) * 4 + L.b;
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const int g = MISS ? gid[ic] : 0;
+    const unsigned char *ob = MISS ? pat + (size_t)g * d : nullptr;
+    const double *ps = Psi3 + (size_t)ic * d * d;
+    // which elements of the lower tiles are Psi + Sigma (the rest is the identity padding / a marginalised dimension): one bit per tile
+    unsigned long long kpm = 0ull;
+#pragma unroll
+    for (int I = 0; I < ND; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+            bool k = row < d && col < d;
+            if (MISS && k) k = ob[row] && ob[col];
+            if (k) kpm |= 1ull << c4_lt(I, J);
+        }
+    const int eoff = L.hi * d + L.lo;                 // element (4I + hi, 4J + lo) of a row-major d x d matrix: eoff + 4 (I d + J)
+    double xv[ND];
+    bool obx[ND];
+#pragma unroll
+    for (int J = 0; J < ND; ++J) {
+        const int col = 4 * J + L.lo;
+        bool k = L.hi == 0 && col < d;
+        if (MISS && k) k = ob[col];
+        obx[J] = k;
+        xv[J] = k ? Xr[(size_t)ic * de + col] : 0.0;
+    }
+    double cmiss = 0.0;
+    if (MISS) {
+        int nmiss = 0;
+        for (int c = 0; c < d; ++c) nmiss += ob[c] ? 0 : 1;
+        cmiss = -0.5 * GPZ_LOG2 * nmiss;                                               // -1/2 |u| ln 2   (getPHI.m:87)
+    }
+    const int slot = 4 * L.hi + L.lo;
+    double held = 0.0;
+    for (int j = 0; j < m; ++j) {
+        double T[C4_NT(ND)];
+        const double *sg = Sig + (size_t)j * d * d;
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const int e = eoff + 4 * (I * d + J);
+                const bool k = (kpm >> c4_lt(I, J)) & 1ull;
+                T[c4_lt(I, J)] = k ? ps[e] + sg[e] : ((I == J && L.hi == L.lo) ? 1.0 : 0.0);   // Psi(o,o,i) + Sigma(o,o)   getPHI.m:84 (both symmetric)
+            }
+#pragma unroll
+        for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = obx[J] ? xv[J] - P[(size_t)j * de + 4 * J + L.lo] : 0.0;
+        T[c4_lt(ND, ND)] = 0.0;
+        double logdet;
+        c4_sweep<ND, false>(T, ex, L, &logdet);
+        const double quad = -__shfl(T[c4_lt(ND, ND)], 4 * L.b, 64);
+        const double lns = MISS ? lnS[(size_t)g * m + j] : lnS[j];
+        const double lp = -0.5 * quad + 0.5 * lns - 0.5 * logdet + cmiss;               // getPHI.m:86
+        if ((j & 15) == slot) held = lp;
+        if ((j & 15) == 15 || j == m - 1) {
+            const int jb = j & ~15;
+            if (valid && jb + slot <= j) Phi[(size_t)i * ld + jb + slot] = exp(held);
+        }
+    }
+}
+
+// Moment records for k_gen_finish: block b of a wave = one basis function, rows of a chunk.  rec = [A0 | Acc1 (d) | Cacc (d*d) | r1 | r2].
+template <int ND, bool MISS>
+__global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const double *__restrict__ Phi, const double *__restrict__ Tm, int ld,
+                                                        const double *__restrict__ rowscal, const double *__restrict__ w,
+                                                        const double *__restrict__ v, const double *__restrict__ Xr, int de,
+                                                        const double *__restrict__ Psi3, int n, int m, int d,
+                                                        const double *__restrict__ P, const double *__restrict__ Sig,
+                                                        int rows_per_chunk, double *__restrict__ slab, int nrec,
+                                                        const int *__restrict__ gid, const unsigned char *__restrict__ pat,
+                                                        const int *__restrict__ chunktab) {
+    constexpr int NTD = ND * (ND + 1) / 2;
+    __shared__ double ex_all[4][64];
+    const C4Lane L = c4_lane();
+    const int wave = threadIdx.x >> 6;
+    double *ex = ex_all[wave];
+    const int j = (blockIdx.y * 4 + wave) * 4 + L.b;
+    const bool valid = j < m;
+    const int jc = valid ? j : m - 1;
+    const int chunk = blockIdx.x;
+    double cacc[NTD], acc1[ND], pv[ND];
+#pragma unroll
+    for (int e = 0; e < NTD; ++e) cacc[e] = 0.0;
+    const int eoff = L.hi * d + L.lo;                 // element (4I + hi, 4J + lo) of a row-major d x d matrix: eoff + 4 (I d + J)
+    const double *sg = Sig + (size_t)jc * d * d;
+#pragma unroll
+    for (int J = 0; J < ND; ++J) {
+        const int col = 4 * J + L.lo;
+        pv[J] = (L.hi == 0 && col < d) ? P[(size_t)jc * de + col] : 0.0;
+        acc1[J] = 0.0;
+    }
+    const double wj = w ? w[jc] : 0.0, vj = v ? v[jc] : 0.0;
+    double a0 = 0.0, r1 = 0.0, r2 = 0.0;
+    int r0 = chunk * rows_per_chunk, rend = min(n, r0 + rows_per_chunk);
+    if (chunktab) { r0 = chunktab[2 * chunk]; rend = chunktab[2 * chunk + 1]; }   // chunks that end at pattern boundaries
+    for (int i = r0; i < rend; ++i) {
+        const double ph = Phi[(size_t)i * ld + jc];
+        double dp;
+        if (rowscal) {
+            const double *rs = rowscal + (size_t)i * 4;
+            dp = (-rs[0] * Tm[(size_t)i * ld + jc] - rs[1] * wj + rs[2] * vj) * ph;    // GPz.m:72,90,106,113
+            r1 = fma(ph, rs[1], r1);
+            r2 = fma(ph, rs[2], r2);
+        } else {
+            dp = Tm[(size_t)i * ld + jc];
+        }
+        const unsigned char *ob = MISS ? pat + (size_t)gid[i] * d : nullptr;
+        const double *ps = Psi3 + (size_t)i * d * d;
+        double T[C4_NT(ND)];
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+                bool k = row < d && col < d;
+                if (MISS && k) k = ob[row] && ob[col];
+                const int e = eoff + 4 * (I * d + J);
+                T[c4_lt(I, J)] = k ? sg[e] + ps[e] : ((row == col) ? 1.0 : 0.0);      // Sigma + Psi_i   GPz.m:170 (both symmetric)
+            }
+#pragma unroll
+        for (int J = 0; J < ND; ++J) {
+            const int col = 4 * J + L.lo;
+            bool k = L.hi == 0 && col < d;
+            if (MISS && k) k = ob[col];
+            T[c4_lt(ND, J)] = k ? Xr[(size_t)i * de + col] - pv[J] : 0.0;
+        }
+        T[c4_lt(ND, ND)] = 0.0;
+        double logdet;
+        c4_sweep<ND, true>(T, ex, L, &logdet);                                         // tiles: -M^-1; tile row ND, row 0: (M^-1 Delta)'
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const double t = MFMA4(T[c4_lt(ND, I)], T[c4_lt(ND, J)], T[c4_lt(I, J)]);   // u_I u_J' - (M^-1)_IJ
+                cacc[c4_lt(I, J)] = fma(dp, t, cacc[c4_lt(I, J)]);                     // GPz.m:174
+            }
+#pragma unroll
+        for (int J = 0; J < ND; ++J) acc1[J] = fma(dp, T[c4_lt(ND, J)], acc1[J]);      // GPz.m:172
+        a0 += dp;
+    }
+    if (!valid) return;
+    double *rec = slab + ((size_t)chunk * m + j) * nrec;
+    if (L.hi == 0 && L.lo == 0) {
+        rec[0] = a0;
+        rec[1 + d + d * d] = r1;
+        rec[2 + d + d * d] = r2;
+    }
+#pragma unroll
+    for (int J = 0; J < ND; ++J)
+        if (L.hi == 0 && 4 * J + L.lo < d) rec[1 + 4 * J + L.lo] = acc1[J];
+#pragma unroll
+    for (int I = 0; I < ND; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+            if (row < d && col < d) {
+                rec[1 + d + row * d + col] = cacc[c4_lt(I, J)];
+                if (I > J) rec[1 + d + col * d + row] = cacc[c4_lt(I, J)];
+            }
+        }
+}
+
+bool cpsi4_available(int d) {
+    static const bool off = getenv("GPZ_CPSI4_OFF") != nullptr;   // debugging switch: the 16 x 16 tile kernels of k_cpsi.hip instead
+    return !off && d > 10 && d <= 32;
+}
+
+#define CPSI4_CASES(MACRO)          \
+    switch ((d + 3) / 4) {          \
+        case 3: MACRO(3); break;    \
+        case 4: MACRO(4); break;    \
+        case 5: MACRO(5); break;    \
+        case 6: MACRO(6); break;    \
+        case 7: MACRO(7); break;    \
+        case 8: MACRO(8); break;    \
+        default: return -1;         \
+    }
+
+int launch_cpsi4_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                     const double *lnS, double *Phi, int ld, const unsigned char *pat) {
+    if (!cpsi4_available(d)) return -1;
+    if (r.n <= 0) return 0;
+#define PHI_CASE(ND)                                                                                                          \
+    do {                                                                                                                      \
+        if (pat)                                                                                                              \
+            hipLaunchKernelGGL((k_cpsi4_phi<ND, true>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, d, P, \
+                               Sig, lnS, Phi, ld, r.gid, pat);                                                               \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cpsi4_phi<ND, false>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, d, \
+                               P, Sig, lnS, Phi, ld, nullptr, nullptr);                                                      \
+    } while (0)
+    CPSI4_CASES(PHI_CASE)
+#undef PHI_CASE
+    return 0;
+}
+
+int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                         const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
+                         int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
+                         const int *chunktab) {
+    if (!cpsi4_available(d)) return -1;
+    if (nchunk <= 0) return 0;
+#define MOM_CASE(ND)                                                                                                          \
+    do {                                                                                                                      \
+        if (pat)                                                                                                              \
+            hipLaunchKernelGGL((k_cpsi4_moments<ND, true>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld, rowscal, \
+                               w, v, r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, r.gid, pat, chunktab);   \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cpsi4_moments<ND, false>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld,         \
+                               rowscal, w, v, r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, nullptr,       \
+                               nullptr, chunktab);                                                                            \
+    } while (0)
+    CPSI4_CASES(MOM_CASE)
+#undef MOM_CASE
+    return 0;
+}

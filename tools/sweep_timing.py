@@ -23,7 +23,7 @@ for method in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["VD", "VC"]):
         Xn[rng.random((n, d)) < 0.02] = np.nan
         Xn[:, 0] = X[:, 0]
         for name, kw, XX in [("plain", {}, X), ("psi", {"Psi": Psi}, X), ("nan", {}, Xn)]:
-            if cov and d > 10 and name == "psi": kw = dict(kw, dtype="f32")
+            if cov and d > 10 and name == "psi" and not os.environ.get("GPZ_SWEEP_F64"): kw = dict(kw, dtype="f32")   # GPZ_SWEEP_F64=1: the fp64 pair kernels instead
             try:
                 ctx = gpz_amd.GPzContext(model, XX, y, **kw)
                 ctx.eval(theta)
