@@ -1,0 +1,97 @@
+"""GC/VC with input noise in fp64 beyond the register kernels (10 < d <= 64): the MFMA-accumulator kernels of k_cpsi4.hip (four
+pairs per wave, d <= 32) and k_cpsi.hip (one pair per wave, d <= 64) - getPHI.m:78-89, GPz.m:164-185 - against the oracle:
+objective, gradient, statistics, solve, PHI; missing values (identity block + zero Delta), weights, training / validation masks,
+every tile count, d not a multiple of 4, m not a multiple of the 4 / 16 pairs a wave / workgroup takes, row shards."""
+import numpy as np
+import pytest
+
+import gpz_amd
+from oracle import gpz_oracle as O
+from helpers import make_problem, rel
+from test_gpu_parity import phi_tol
+from test_wide import _gate
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, d, m, k, method, hetero, seed, nanfrac=0.0):
+    """make_problem with the Gamma blocks redrawn as gamma_j (I + 0.3 G / sqrt(d)): its 0.05 N(0,1) perturbation of gamma_j I is larger
+    than gamma_j itself at d ~ 20 (cond(Gamma'Gamma) ~ 1e8: both sides of the comparison are rounding noise there)"""
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, hetero, seed=seed, psi=True, nanfrac=nanfrac)
+    md = m * d
+    nb = 1 if method == "GC" else m
+    for q in range(nb):
+        blk = theta[md + q * d * d: md + (q + 1) * d * d].reshape((d, d), order="F")
+        gam = float(np.mean(np.diag(blk)))
+        theta[md + q * d * d: md + (q + 1) * d * d] = (gam * (np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d))).reshape(-1, order="F")
+    return model, theta, X, Y, Psi, rng
+
+
+def _loose(model, theta):
+    # the reference's chain dS -> diS = -Sigma dS Sigma -> dGamma goes through inv(Gamma'Gamma) twice and loses cond^1.5 * eps
+    # (DESIGN.md section 4); oracle and HIP path run the same formula and differ by that rounding noise
+    c = phi_tol(model, theta) / (200.0 * 2.2e-16)
+    return max(2.0, 10.0 * c ** 1.5 * 2.2e-16 / phi_tol(model, theta))
+
+
+@pytest.mark.parametrize("method", ["VC", "GC"])
+@pytest.mark.parametrize("d", [11, 12, 13, 16, 19, 20, 21, 24, 27, 28, 32, 33, 41, 48, 49, 64])
+@pytest.mark.parametrize("nanfrac", [0.0, 0.3])
+def test_pair_kernels_every_tile_count(method, d, nanfrac):
+    if d > 32 and nanfrac and method == "GC":
+        pytest.skip("covered by VC")
+    n, m = (230, 7) if d <= 32 else (90, 5)
+    model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, method, True, 500 + d, nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    _gate(model, theta, X, Y, Psi, om, tr, ~tr, loose=_loose(model, theta))
+
+
+@pytest.mark.parametrize("d,m,n", [(14, 1, 37), (20, 17, 130), (24, 33, 64), (30, 4, 3)])
+def test_pair_kernels_ragged_sizes(d, m, n):
+    """fewer pairs than a wave holds, m / n not multiples of 4 or 16, fewer rows than chunks"""
+    model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, "VC", True, 700 + d)
+    _gate(model, theta, X, Y, Psi, loose=_loose(model, theta))
+
+
+def test_pair_kernels_two_outputs_and_homoscedastic():
+    for hetero, k in ((True, 2), (False, 1)):
+        model, theta, X, Y, Psi, rng = _problem(150, 18, 6, k, "VC", hetero, 810 + k)
+        _gate(model, theta, X, Y, Psi, loose=_loose(model, theta))
+
+
+@pytest.mark.parametrize("d", [20, 36])
+def test_pair_kernels_over_row_shards(d):
+    """three loopback shards (rows split, records summed by the reducer) against the single context"""
+    n, m = 300, 6
+    model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, "VC", True, 900 + d)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    try:
+        f1, g1 = ctx.eval(theta)
+    finally:
+        ctx.close()
+    multi = gpz_amd.GPzMulti(model, X, Y, Psi, n_gpus=3, reducer="loopback")
+    try:
+        f3, g3 = multi.eval(theta)
+    finally:
+        multi.close()
+    assert abs(f3 - f1) <= 1e-12 * abs(f1) and rel(g3, g1) <= 1e-9
+
+
+def test_fp64_and_fp32_pair_kernels_agree_at_d20():
+    """config 5's shape in the reference's own precision (k_cpsi4) against the fp32 pair kernels (k_psi32) on diagonal Psi"""
+    n, d, m = 400, 20, 16
+    model, theta, X, Y, _, rng = _problem(n, d, m, 1, "VC", True, 77)
+    var = rng.gamma(1.0, 0.2, (n, d))
+    Psi = np.zeros((d, d, n))
+    Psi[np.arange(d), np.arange(d), :] = var.T
+    out = {}
+    for dtype in ("f64", "f32"):
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, dtype=dtype)
+        try:
+            out[dtype] = ctx.eval(theta)
+        finally:
+            ctx.close()
+    ref = O.GPz(theta, model, X, Y, Psi)
+    assert abs(out["f64"][0] - ref.nlogML) <= 1e-9 * abs(ref.nlogML)
+    assert abs(out["f32"][0] - out["f64"][0]) <= 1e-4 * abs(out["f64"][0]) and rel(out["f32"][1], out["f64"][1]) <= 1e-3
