@@ -249,6 +249,9 @@ int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int
                          const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                          int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
                          const int *chunktab);
+int launch_cpsi4_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
+                               const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                               long pairs_per_chunk, double *part, bool shared /* GC: one covariance for every pair */);
 bool psi_fast_path_available(int d);
 // pat (observed flags [G][d]) non-null: rows carry missing dimensions (r.gid = pattern per row, lnS = [G][m]);
 // chunktab (optional): {first row, end row} per moment chunk

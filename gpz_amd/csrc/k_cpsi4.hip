@@ -336,6 +336,122 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
         }
 }
 
+// predictNoisy, covariance kinds (predictCov.m:70-132) for 10 < d <= 32: block b of a wave = one sample, the pairs [p0, p1) of this
+// chunk; partial sums part[chunk][3][k][ldx] as k_predict_noisy_cov (k_psi.hip).  tab record: [lnz | cij (d) | Cij (d x d)].
+// N(x; cij, Cij + Psi_i) = exp(-1/2 Delta' M^-1 Delta - 1/2 ln|M|): one sweep without the inverse per (sample, pair).
+//   SHARED   GC: every basis function has the same covariance, so Cij = Sigma/2 for every pair: M = Sigma/2 + Psi_i is swept ONCE per
+//            sample WITH the inverse, and a pair costs Delta' M^-1 Delta = sum_J (sum_{I>J} 2 Delta_I' S_IJ + Delta_J' S_JJ) Delta_J on the
+//            tiles S of M^-1 (ND(ND+1)/2 instructions instead of a sweep)
+template <int ND, int KM, bool SHARED>
+__global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_predict_noisy(int n, long ldx, int m, int d, int de, int k,
+                                                                               const double *__restrict__ Xr,
+                                                                               const double *__restrict__ Psi3,
+                                                                               const double *__restrict__ tab, int rec,
+                                                                               const double *__restrict__ w,
+                                                                               const double *__restrict__ v,
+                                                                               const double *__restrict__ iS, long pairs_per_chunk,
+                                                                               double *__restrict__ part) {
+    __shared__ double ex_all[4][64];
+    const C4Lane L = c4_lane();
+    const int wave = threadIdx.x >> 6;
+    double *ex = ex_all[wave];
+    const int i = (blockIdx.x * 4 + wave) * 4 + L.b;
+    const bool act = i < n;
+    const int ic = act ? i : n - 1;
+    const long npair = (long)m * (m + 1) / 2;
+    const long p0 = (long)blockIdx.y * pairs_per_chunk, p1 = min(npair, p0 + pairs_per_chunk);
+    const double *ps = Psi3 + (size_t)ic * d * d;
+    const int eoff = L.hi * d + L.lo;
+    double xv[ND];
+#pragma unroll
+    for (int J = 0; J < ND; ++J) xv[J] = (L.hi == 0 && 4 * J + L.lo < d) ? Xr[(size_t)ic * de + 4 * J + L.lo] : 0.0;
+    double ga[KM], vl[KM], nu[KM];
+#pragma unroll
+    for (int o = 0; o < KM; ++o) { ga[o] = 0.0; vl[o] = 0.0; nu[o] = 0.0; }
+    long a = (long)((sqrt(8.0 * (double)p0 + 1.0) - 1.0) * 0.5);   // (a, b) of the first pair, then walk
+    while (a * (a + 1) / 2 > p0) --a;
+    while ((a + 1) * (a + 2) / 2 <= p0) ++a;
+    long bb = p0 - a * (a + 1) / 2;
+    double S[C4_NT(ND)];
+    double logdet = 0.0;
+    auto build = [&](double (&T)[C4_NT(ND)], const double *t) {
+        const double *cc = t + 1 + d;
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+                const int q = eoff + 4 * (I * d + J);
+                T[c4_lt(I, J)] = (row < d && col < d) ? cc[q] + ps[q] : ((row == col) ? 1.0 : 0.0);   // Cij + Psi   predictCov.m:109 (both symmetric)
+            }
+    };
+    if (SHARED && p0 < p1) {
+        build(S, tab + (size_t)p0 * rec);
+#pragma unroll
+        for (int J = 0; J <= ND; ++J) S[c4_lt(ND, J)] = 0.0;
+        c4_sweep<ND, true>(S, ex, L, &logdet);                       // S = -M^-1
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) S[c4_lt(I, J)] *= (I == J) ? -1.0 : -2.0;
+    }
+    double xc[SHARED ? ND : 1];                                      // x as columns: lane (hi, lo = 0) holds x[4I + hi]
+    if (SHARED) {
+#pragma unroll
+        for (int I = 0; I < ND; ++I) xc[I] = (L.lo == 0 && 4 * I + L.hi < d) ? Xr[(size_t)ic * de + 4 * I + L.hi] : 0.0;
+    }
+#pragma unroll 1
+    for (long e = p0; e < p1; ++e) {
+        const double *t = tab + (size_t)e * rec;
+        double quad;
+        if (SHARED) {
+            double dr[ND], dc[ND];                                   // Delta_J' as row 0 of a tile, Delta_I as column 0
+#pragma unroll
+            for (int J = 0; J < ND; ++J) {
+                dr[J] = (L.hi == 0 && 4 * J + L.lo < d) ? xv[J] - t[1 + 4 * J + L.lo] : 0.0;
+                dc[J] = (L.lo == 0 && 4 * J + L.hi < d) ? xc[J] - t[1 + 4 * J + L.hi] : 0.0;
+            }
+            double qq = 0.0;
+#pragma unroll
+            for (int J = 0; J < ND; ++J) {
+                double h = 0.0;
+#pragma unroll
+                for (int I = J; I < ND; ++I) h = MFMA4(dc[I], S[c4_lt(I, J)], h);      // row 0: sum_I Delta_I' S_IJ
+                qq = fma(h, dr[J], qq);                                                // lanes (0, lo): h_J[lo] Delta_J[lo]
+            }
+            qq += __shfl_xor(qq, 1, 64);
+            qq += __shfl_xor(qq, 2, 64);
+            quad = __shfl(qq, 4 * L.b, 64);
+        } else {
+            double T[C4_NT(ND)];
+            build(T, t);
+#pragma unroll
+            for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = (L.hi == 0 && 4 * J + L.lo < d) ? xv[J] - t[1 + 4 * J + L.lo] : 0.0;
+            T[c4_lt(ND, ND)] = 0.0;
+            c4_sweep<ND, false>(T, ex, L, &logdet);
+            quad = -__shfl(T[c4_lt(ND, ND)], 4 * L.b, 64);
+        }
+        const double z = ((a == bb) ? 1.0 : 2.0) * exp(t[0] - 0.5 * quad - 0.5 * logdet);      // :111, 2x in the loop (:113-119)
+#pragma unroll
+        for (int o = 0; o < KM; ++o)
+            if (o < k) {
+                ga[o] = fma(z, w[a + (size_t)m * o] * w[bb + (size_t)m * o], ga[o]);
+                vl[o] = fma(z, v ? v[a + (size_t)m * o] * v[bb + (size_t)m * o] : 0.0, vl[o]);
+                nu[o] = fma(z, iS[a + (size_t)m * bb + (size_t)m * m * o], nu[o]);
+            }
+        if (++bb > a) { ++a; bb = 0; }
+    }
+    if (act && L.hi == 0 && L.lo == 0) {
+#pragma unroll
+        for (int o = 0; o < KM; ++o)
+            if (o < k) {
+                part[(((size_t)blockIdx.y * 3 + 0) * k + o) * ldx + i] = ga[o];
+                part[(((size_t)blockIdx.y * 3 + 1) * k + o) * ldx + i] = vl[o];
+                part[(((size_t)blockIdx.y * 3 + 2) * k + o) * ldx + i] = nu[o];
+            }
+    }
+}
+
 bool cpsi4_available(int d) {
     static const bool off = getenv("GPZ_CPSI4_OFF") != nullptr;   // debugging switch: the 16 x 16 tile kernels of k_cpsi.hip instead
     return !off && d > 10 && d <= 32;
@@ -388,5 +504,30 @@ int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int
     } while (0)
     CPSI4_CASES(MOM_CASE)
 #undef MOM_CASE
+    return 0;
+}
+
+int launch_cpsi4_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
+                               const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                               long pairs_per_chunk, double *part, bool shared) {
+    if (!cpsi4_available(d) || k > 8) return -1;
+    if (n <= 0) return 0;
+#define PN_CASE(ND)                                                                                                           \
+    do {                                                                                                                      \
+        if (k == 1 && shared)                                                                                                 \
+            hipLaunchKernelGGL((k_cpsi4_predict_noisy<ND, 1, true>), dim3((n + 15) / 16, nchunk), dim3(256), 0, st, n, ldx, m, d, \
+                               de, k, Xr, Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);                                   \
+        else if (k == 1)                                                                                                      \
+            hipLaunchKernelGGL((k_cpsi4_predict_noisy<ND, 1, false>), dim3((n + 15) / 16, nchunk), dim3(256), 0, st, n, ldx, m, d, \
+                               de, k, Xr, Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);                                   \
+        else if (shared)                                                                                                      \
+            hipLaunchKernelGGL((k_cpsi4_predict_noisy<ND, 8, true>), dim3((n + 15) / 16, nchunk), dim3(256), 0, st, n, ldx, m, d, \
+                               de, k, Xr, Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);                                   \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cpsi4_predict_noisy<ND, 8, false>), dim3((n + 15) / 16, nchunk), dim3(256), 0, st, n, ldx, m, d, \
+                               de, k, Xr, Psi3, tab, rec, w, v, iS, pairs_per_chunk, part);                                   \
+    } while (0)
+    CPSI4_CASES(PN_CASE)
+#undef PN_CASE
     return 0;
 }

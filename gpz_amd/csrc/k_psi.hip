@@ -417,6 +417,9 @@ __global__ __launch_bounds__(64) void k_predict_noisy_cov(int n, long ldx, int m
 int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                              const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
                              long pairs_per_chunk, double *part, int flags) {
+    if (cpsi4_available(d) && k <= 8)   // 10 < d <= 32: four (sample, pair) units per wave on 4 x 4 MFMA tiles (k_cpsi4.hip)
+        return launch_cpsi4_predict_noisy(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part,
+                                          (flags & 2) != 0);
     if (n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;
     const bool dg = flags & 1, sh = flags & 2;
 #define PN_LAUNCH(DD, DG, SH, KM)                                                                                          \

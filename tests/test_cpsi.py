@@ -95,3 +95,27 @@ def test_fp64_and_fp32_pair_kernels_agree_at_d20():
     ref = O.GPz(theta, model, X, Y, Psi)
     assert abs(out["f64"][0] - ref.nlogML) <= 1e-9 * abs(ref.nlogML)
     assert abs(out["f32"][0] - out["f64"][0]) <= 1e-4 * abs(out["f64"][0]) and rel(out["f32"][1], out["f64"][1]) <= 1e-3
+
+
+@pytest.mark.parametrize("method", ["VC", "GC"])
+@pytest.mark.parametrize("d,k,cube", [(12, 1, False), (17, 2, True), (20, 1, True), (29, 1, False), (32, 2, False)])
+def test_predict_with_input_noise_on_the_pair_kernels(method, d, k, cube):
+    """predictNoisy for GC/VC at 10 < d <= 32 (predictCov.m:70-132): one sweep per (sample, pair) on 4 x 4 tiles; GC shares the
+    factorisation over the pairs (Cij = Sigma/2).  Psi as n x d variances or as full d x d x n cubes; ns not a multiple of 16."""
+    m, ns = 6, 37
+    model, theta, X, Y, _, rng = _problem(260, d, m, k, method, True, 4200 + d)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w}
+    Xs = rng.standard_normal((ns, d))
+    if cube:
+        Psi = np.zeros((d, d, ns))
+        for i in range(ns):
+            B = 0.2 * rng.standard_normal((d, d))
+            Psi[:, :, i] = B @ B.T
+    else:
+        Psi = rng.gamma(1.0, 0.1, (ns, d))
+    ref = O.predict_noisy(Xs, Psi, model)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    tol = max(1e-9, phi_tol(model, theta))
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= tol, name
