@@ -13,7 +13,8 @@ Fixtures:
   ref_lbfgs_mem.npz       minFunc's L-BFGS memory: lbfgsAdd.m / lbfgsProd.m over a wrapping ring with rejected pairs
   ref_minfunc.npz         WolfeLineSearch.m / ArmijoBacktrack.m / polyinterp.m and whole minFunc.m runs on the inputs of the mf_* fixtures
   ref_train_<case>.npz    init.m -> train.m end to end (minFunc.m, callBack.m, GPz.m, getPrior.m, pca.m, fillLinear.m ...): the model after
-                          init, callBack's numbers per iteration, the model after train
+                          init, callBack's numbers per iteration, the model after train; ref_train_demo_sinc: demo_sinc.m's own
+                          configuration (BASELINE config 1) with its predictions and test metrics
 
 The inputs are drawn here with NumPy (seeded); the oracle is NOT involved in producing a fixture — tests/test_reference_run.py
 compares it (CPU) and the HIP path (GPU) with these files, and re-executes the .m files when /root/reference exists."""
@@ -371,6 +372,58 @@ def make_train(case, seed):
     return out
 
 
+def make_demo_sinc(seed=1, max_iter=40):
+    """demo_sinc.m as shipped (the reference's own CPU-runnable case, BASELINE config 1): n = 10000 points on [-10, 10] minus the gap
+    (-7, -2), y = sinc(x) + heteroscedastic noise, Gamma-distributed input-noise variances, x observed through that noise,
+    sample(n, 0.7, 0.15, 0.15), init(X, Y, 'VL', 100, ...), train(..., 'maxAttempts', 50, ...), predict on a grid and on the test
+    rows, RMSE and mean log-likelihood as the demo prints them (demo_sinc.m:7-32,36-66,71,104-122).  The draws come from NumPy
+    (randn / gamrnd / randperm / rand are handed the recorded arrays); maxIter is 40 instead of the demo's 500 to keep the
+    comparison on the part of the trajectory where two implementations still walk together."""
+    rng = np.random.default_rng(seed)
+    m, method = 100, "VL"
+    x = np.linspace(-10.0, 10.0, 10000)
+    x = x[(x < -7.0) | (x > -2.0)]
+    n = x.size
+    sx = 0.05 + (1.0 / (1.0 + np.exp(-0.2 * x))) * (1.0 + np.sin(2.0 * x)) * 0.2
+    Y = (np.sinc(x / np.pi) + rng.standard_normal(n) * sx).reshape(-1, 1)
+    E_, V_ = 0.5, 0.25
+    Psi = rng.gamma(E_ ** 2 / V_, V_ / E_, n).reshape(-1, 1)
+    X = (x + rng.standard_normal(n) * np.sqrt(Psi[:, 0])).reshape(-1, 1)
+    perm = rng.permutation(n) + 1.0
+    U = rng.random((m, 1))
+    log = []
+    ip = full_interp(U, log)
+    ip.extern["randperm"] = lambda a, nargout: [perm.reshape(1, -1).copy()]
+    tr, va, te = (np.asarray(q).astype(bool).reshape(-1) for q in
+                  ip.call("sample", [ML.mat(float(n)), ML.mat(0.7), ML.mat(0.15), ML.mat(0.15)], 3))
+    model = ip.call("init", [X, Y, method, ML.mat(float(m)), "normalize", ML.mat(True), "heteroscedastic", ML.mat(True),
+                             "training", tr.reshape(-1, 1), "Psi", Psi], 1)[0]
+    k = 1
+    out = dict(method=method, method_after_init=model.method, m=m, d=1, k=k, heteroscedastic=1, X=X, Y=Y, U=U, perm=perm, training=tr,
+               validation=va, testing=te, omega=np.zeros(0), Psi=Psi, maxIter=max_iter, maxAttempts=50.0, muX=np.asarray(model.muX),
+               sdX=np.asarray(model.sdX), muY=np.asarray(model.muY), g_dim=int(np.asarray(model.g_dim).reshape(-1)[0]),
+               theta0=np.asarray(model.last.theta).reshape(-1), w0=np.asarray(model.last.w),
+               iSigma_w0=np.asarray(model.last.iSigma_w).reshape(m, m, k, order="F"))
+    del log[:]
+    model = ip.call("train", [model, X, Y, "maxIter", ML.mat(float(max_iter)), "maxAttempts", ML.mat(50.0), "training", tr.reshape(-1, 1),
+                              "validation", va.reshape(-1, 1), "Psi", Psi], 1)[0]
+    rows = [r[1:7] for r in log if r[0].startswith("\\t%d")]
+    out.update(log=np.array(rows), message=[r[0] for r in log][-1])
+    for which in ("last", "best"):
+        st = getattr(model, which)
+        out.update({which + "_theta": np.asarray(st.theta).reshape(-1), which + "_w": np.asarray(st.w),
+                    which + "_iSigma_w": np.asarray(st.iSigma_w).reshape(m, m, k, order="F"),
+                    which + "_priors": np.asarray(st.priors).reshape(-1)})
+    Xs = np.linspace(-15.0, 15.0, 200).reshape(-1, 1)
+    grid = ip.call("predict", [Xs, model], 5)                                                    # demo_sinc.m:71
+    out.update(Xs=Xs, **{"grid_" + nm: np.asarray(v) for nm, v in zip(("mu", "sigma", "nu", "beta_i", "gamma"), grid)})
+    mu, sigma = (np.asarray(v) for v in ip.call("predict", [X, model, "Psi", Psi, "selection", te.reshape(-1, 1)], 2))   # :104
+    err = Y[te] - mu
+    out.update(test_mu=mu, test_sigma=sigma, rmse=float(np.sqrt(np.mean(err ** 2))),
+               mll=float(np.mean(-0.5 * err ** 2 / sigma - 0.5 * np.log(sigma)) - 0.5 * np.log(2 * np.pi)))      # :117-122
+    return out
+
+
 def all_fixtures():
     """name -> maker()"""
     fx = {}
@@ -383,6 +436,7 @@ def all_fixtures():
     fx["ref_minfunc"] = make_minfunc
     for i, c in enumerate(TRAIN_CASES):
         fx["ref_train_" + c[0]] = (lambda c=c, i=i: make_train(c, 400 + i))
+    fx["ref_train_demo_sinc"] = make_demo_sinc
     return fx
 
 

@@ -21,7 +21,7 @@ GPZ = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path
 PRED = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "ref_predict_*.npz")))
 
 
-TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES]
+TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES] + ["ref_train_demo_sinc"]
 
 
 def load(name):
@@ -156,8 +156,6 @@ def test_minfunc_run_fixtures_are_what_the_executed_minfunc_returns(name):
     assert rel(z["x"], r[name + "__x"]) <= 1e-5 and rel(z["optCond"], r[name + "__optCond"]) <= 1e-3
 
 
-TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES]
-
 
 class RecordedRand:
     """init.m:58 draws rand(m,d); the fixture holds the matrix the executed init.m was given"""
@@ -231,13 +229,39 @@ def test_oracle_training_against_the_executed_reference(name):
         assert rel(O.getPrior(Xn, Psi, th, model, tr), z[which + "_priors"]) <= 1e-8
 
 
+def demo_model(z, cls):
+    m = int(z["m"])
+    model = cls(m=m, d=1, k=1, method=str(z["method_after_init"]), heteroscedastic=True)
+    model.muX, model.sdX, model.muY = z["muX"].reshape(-1), z["sdX"].reshape(-1), z["muY"].reshape(-1)
+    model.sets["best"] = {"theta": z["best_theta"], "w": z["best_w"], "iSigma_w": z["best_iSigma_w"], "priors": z["best_priors"]}
+    return model
+
+
+def test_oracle_predictions_of_the_executed_demo():
+    """demo_sinc.m:71,104-122 on the model the executed train.m returned: the grid prediction, the test-row prediction with
+    input noise and the two numbers the demo prints"""
+    z = load("ref_train_demo_sinc")
+    model = demo_model(z, O.Model)
+    out = O.predict_any(z["Xs"], model)
+    for key, val in zip(("mu", "sigma", "nu", "beta_i", "gamma"), out):
+        assert rel(val, z["grid_" + key]) <= 1e-9, key
+    te = z["testing"].astype(bool)
+    mu, sigma = O.predict_any(z["X"], model, Psi=z["Psi"], selection=te)[:2]
+    assert rel(mu, z["test_mu"]) <= 1e-9 and rel(sigma, z["test_sigma"]) <= 1e-9
+    err = z["Y"][te] - mu
+    assert abs(np.sqrt(np.mean(err ** 2)) - float(z["rmse"])) <= 1e-10
+    assert abs(np.mean(-0.5 * err ** 2 / sigma - 0.5 * np.log(sigma)) - 0.5 * np.log(2 * np.pi) - float(z["mll"])) <= 1e-9
+
+
 @pytest.mark.skipif(not ML.available(), reason="the reference tree exists only in the build container")
 def test_committed_vectors_are_what_the_reference_files_return():
     """Re-executes the reference's .m files and compares with every committed ref_*.npz: the vectors are the reference's own
     outputs on the recorded inputs (bit for bit up to BLAS summation order), not data that could drift from it."""
     for name, make in RR.all_fixtures().items():
         if name.startswith("ref_gpz_") and not name.endswith(("_p0_n0", "_p1_n1")):
-            continue                                    # a third of the GPz cases keeps the CPU suite short; all predict / misc cases
+            continue
+        if name == "ref_train_demo_sinc":
+            continue                                    # two minutes of interpreted loops (7500 rows, m = 100): regenerated by run_reference.py only                                    # a third of the GPz cases keeps the CPU suite short; all predict / misc cases
         fresh, old = make(), load(name)
         assert set(fresh) == set(old), name
         for key, val in fresh.items():
@@ -380,3 +404,21 @@ def test_hip_init_and_train_against_the_executed_reference(name, device_resident
             assert rel(gpz_amd.getPrior(Xn, PsiN, z[which + "_theta"], model, tr), z[which + "_priors"]) <= 1e-8
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_predictions_of_the_executed_demo():
+    """demo_sinc.m's predictions and printed scores (BASELINE config 1, the reference's own CPU-runnable case) from the HIP path, on
+    the model the executed train.m returned"""
+    import gpz_amd
+    z = load("ref_train_demo_sinc")
+    model = demo_model(z, gpz_amd.Model)
+    out = gpz_amd.predict(z["Xs"], model)
+    for key, val in zip(("mu", "sigma", "nu", "beta_i", "gamma"), out):
+        assert rel(val, z["grid_" + key]) <= 1e-8, key
+    te = z["testing"].astype(bool)
+    mu, sigma = gpz_amd.predict(z["X"], model, Psi=z["Psi"], selection=te)[:2]
+    assert rel(mu, z["test_mu"]) <= 1e-8 and rel(sigma, z["test_sigma"]) <= 1e-8
+    err = z["Y"][te] - mu
+    assert abs(np.sqrt(np.mean(err ** 2)) - float(z["rmse"])) <= 1e-9
+    assert abs(np.mean(-0.5 * err ** 2 / sigma - 0.5 * np.log(sigma)) - 0.5 * np.log(2 * np.pi) - float(z["mll"])) <= 1e-8
