@@ -66,26 +66,36 @@ __device__ __forceinline__ double c4_inv4(const double (&a)[4][4], double (&w)[4
 
 constexpr int c4_lt(int I, int J) { return I * (I + 1) / 2 + J; }   // tile (I, J), J <= I, of the lower triangle (tile row ND = Delta)
 #define C4_NT(ND) (((ND) + 1) * ((ND) + 2) / 2)
-// workgroups per CU the register allocation aims at: two waves per SIMD hide the latency of the pivot-block chain (measured at
-// n = 1e5, m = 256, d = 24: moments 62 -> 35 ms); the moment kernel of d > 28 needs more than 256 registers for its tiles and sums
-#define C4_MINB_PHI(ND) ((ND) <= 7 ? 2 : 1)
-#define C4_MINB_MOM(ND) ((ND) <= 7 ? 2 : 1)
+// Register budget.  Tile loads are issued without a branch (clamped index, then a select) so that a pair's loads go out back to
+// back: n = 1e5, m = 256, d = 20: 56 -> 39 ms per evaluation, d = 32: 188 -> 134 ms; that keeps up to two registers per tile in
+// flight.  Two waves per SIMD (256 registers) hide the latency of the pivot-block chain where tiles, sums and loads fit without
+// spilling (ND <= 5, d <= 20); beyond that one wave per SIMD with everything in flight wins (d = 28: 106 ms against 166 ms with
+// two waves and 484 bytes of scratch).  -D overrides for experiments.
+#ifndef C4_MINB_PHI
+#define C4_MINB_PHI(ND) ((ND) <= 5 ? 2 : 1)
+#endif
+#ifndef C4_MINB_MOM
+#define C4_MINB_MOM(ND) ((ND) <= 5 ? 2 : 1)
+#endif
+#ifndef C4_UNCOND
+#define C4_UNCOND(ND) 1
+#endif
 
 struct C4Lane {
     int lane, hi, b, lo, tl;          // tl: the lane that holds the transposed element of a tile
-    bool h1, h2, h3, l1, l2, l3;      // hi == 1, 2, 3;  lo == 1, 2, 3
+    double mh[4], ml[4];              // 1.0 where hi == x / lo == x, else 0.0: W[lo][hi] is picked out of the lane-uniform W by multiply-adds
 };
 __device__ __forceinline__ C4Lane c4_lane() {
     C4Lane L;
     L.lane = threadIdx.x & 63;
     L.hi = L.lane >> 4; L.b = (L.lane >> 2) & 3; L.lo = L.lane & 3;
     L.tl = 16 * L.lo + 4 * L.b + L.hi;
-    L.h1 = L.hi == 1; L.h2 = L.hi == 2; L.h3 = L.hi == 3;
-    L.l1 = L.lo == 1; L.l2 = L.lo == 2; L.l3 = L.lo == 3;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        L.mh[x] = L.hi == x ? 1.0 : 0.0;
+        L.ml[x] = L.lo == x ? 1.0 : 0.0;
+    }
     return L;
-}
-__device__ __forceinline__ double c4_pick(bool s1, bool s2, bool s3, double v0, double v1, double v2, double v3) {
-    return s3 ? v3 : (s2 ? v2 : (s1 ? v1 : v0));
 }
 
 // pivot tile -> every lane of the pair (through LDS) -> W = inv(chol), and the determinant into a running mantissa / exponent pair
@@ -115,17 +125,14 @@ __device__ __forceinline__ void c4_sweep(double (&T)[C4_NT(ND)], double *__restr
     c4_factor(T[c4_lt(0, 0)], ex, L, W, &mant, &expo);
 #pragma unroll
     for (int p = 0; p < ND; ++p) {
-        // result-layout registers of W and W' (zero above / below the diagonal)
-        const double rh0 = c4_pick(L.h1, L.h2, L.h3, W[0][0], W[1][0], W[2][0], W[3][0]);
-        const double rh1 = c4_pick(L.h1, L.h2, L.h3, 0.0, W[1][1], W[2][1], W[3][1]);
-        const double rh2 = c4_pick(L.h1, L.h2, L.h3, 0.0, 0.0, W[2][2], W[3][2]);
-        const double rh3 = c4_pick(L.h1, L.h2, L.h3, 0.0, 0.0, 0.0, W[3][3]);
-        const double Wd = c4_pick(L.l1, L.l2, L.l3, rh0, rh1, rh2, rh3);              // W[hi][lo]
-        const double rl0 = c4_pick(L.l1, L.l2, L.l3, W[0][0], W[1][0], W[2][0], W[3][0]);
-        const double rl1 = c4_pick(L.l1, L.l2, L.l3, 0.0, W[1][1], W[2][1], W[3][1]);
-        const double rl2 = c4_pick(L.l1, L.l2, L.l3, 0.0, 0.0, W[2][2], W[3][2]);
-        const double rl3 = c4_pick(L.l1, L.l2, L.l3, 0.0, 0.0, 0.0, W[3][3]);
-        const double Wt = c4_pick(L.h1, L.h2, L.h3, rl0, rl1, rl2, rl3);              // W[lo][hi] = W'[hi][lo]
+        // result-layout register of W' (lane (hi, lo) holds W[lo][hi], zero below the diagonal): 14 multiply-adds with the lane masks
+        // (a select chain costs 60 v_cndmask); W itself is the lane transpose of that
+        const double rl0 = fma(L.ml[3], W[3][0], fma(L.ml[2], W[2][0], fma(L.ml[1], W[1][0], L.ml[0] * W[0][0])));
+        const double rl1 = fma(L.ml[3], W[3][1], fma(L.ml[2], W[2][1], L.ml[1] * W[1][1]));
+        const double rl2 = fma(L.ml[3], W[3][2], L.ml[2] * W[2][2]);
+        const double rl3 = L.ml[3] * W[3][3];
+        const double Wt = fma(L.mh[3], rl3, fma(L.mh[2], rl2, fma(L.mh[1], rl1, L.mh[0] * rl0)));
+        const double Wd = INV ? __shfl(Wt, L.tl, 64) : 0.0;                           // W[hi][lo]
         double Yt[ND + 1];
         // the next pivot tile first: its factorisation (a chain of dependent scalar work) then runs beside the other updates
         if (p + 1 < ND) {
@@ -215,12 +222,22 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double
         for (int I = 0; I < ND; ++I)
 #pragma unroll
             for (int J = 0; J <= I; ++J) {
-                const int e = eoff + 4 * (I * d + J);
                 const bool k = (kpm >> c4_lt(I, J)) & 1ull;
-                T[c4_lt(I, J)] = k ? ps[e] + sg[e] : ((I == J && L.hi == L.lo) ? 1.0 : 0.0);   // Psi(o,o,i) + Sigma(o,o)   getPHI.m:84 (both symmetric)
+                const double idn = (I == J && L.hi == L.lo) ? 1.0 : 0.0;
+                if (C4_UNCOND(ND)) {
+                    const int e = min(eoff + 4 * (I * d + J), d * d - 1);
+                    const double sv = ps[e] + sg[e];
+                    T[c4_lt(I, J)] = k ? sv : idn;                                     // Psi(o,o,i) + Sigma(o,o)   getPHI.m:84 (both symmetric)
+                } else {
+                    const int e = eoff + 4 * (I * d + J);
+                    T[c4_lt(I, J)] = k ? ps[e] + sg[e] : idn;
+                }
             }
 #pragma unroll
-        for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = obx[J] ? xv[J] - P[(size_t)j * de + 4 * J + L.lo] : 0.0;
+        for (int J = 0; J < ND; ++J) {
+            const double pj = P[(size_t)j * de + min(4 * J + L.lo, de - 1)];
+            T[c4_lt(ND, J)] = obx[J] ? xv[J] - pj : 0.0;
+        }
         T[c4_lt(ND, ND)] = 0.0;
         double logdet;
         c4_sweep<ND, false>(T, ex, L, &logdet);
@@ -290,15 +307,23 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
                 const int row = 4 * I + L.hi, col = 4 * J + L.lo;
                 bool k = row < d && col < d;
                 if (MISS && k) k = ob[row] && ob[col];
-                const int e = eoff + 4 * (I * d + J);
-                T[c4_lt(I, J)] = k ? sg[e] + ps[e] : ((row == col) ? 1.0 : 0.0);      // Sigma + Psi_i   GPz.m:170 (both symmetric)
+                const double idn = (row == col) ? 1.0 : 0.0;
+                if (C4_UNCOND(ND)) {
+                    const int e = min(eoff + 4 * (I * d + J), d * d - 1);
+                    const double sv = sg[e] + ps[e];
+                    T[c4_lt(I, J)] = k ? sv : idn;                                     // Sigma + Psi_i   GPz.m:170 (both symmetric)
+                } else {
+                    const int e = eoff + 4 * (I * d + J);
+                    T[c4_lt(I, J)] = k ? sg[e] + ps[e] : idn;
+                }
             }
 #pragma unroll
         for (int J = 0; J < ND; ++J) {
             const int col = 4 * J + L.lo;
             bool k = L.hi == 0 && col < d;
             if (MISS && k) k = ob[col];
-            T[c4_lt(ND, J)] = k ? Xr[(size_t)i * de + col] - pv[J] : 0.0;
+            const double xi = Xr[(size_t)i * de + min(col, de - 1)];
+            T[c4_lt(ND, J)] = k ? xi - pv[J] : 0.0;
         }
         T[c4_lt(ND, ND)] = 0.0;
         double logdet;
@@ -381,8 +406,9 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_predict_noisy(in
 #pragma unroll
             for (int J = 0; J <= I; ++J) {
                 const int row = 4 * I + L.hi, col = 4 * J + L.lo;
-                const int q = eoff + 4 * (I * d + J);
-                T[c4_lt(I, J)] = (row < d && col < d) ? cc[q] + ps[q] : ((row == col) ? 1.0 : 0.0);   // Cij + Psi   predictCov.m:109 (both symmetric)
+                const int q = min(eoff + 4 * (I * d + J), d * d - 1);   // unconditional loads: clamp, then select
+                const double sv = cc[q] + ps[q];
+                T[c4_lt(I, J)] = (row < d && col < d) ? sv : ((row == col) ? 1.0 : 0.0);   // Cij + Psi   predictCov.m:109 (both symmetric)
             }
     };
     if (SHARED && p0 < p1) {
