@@ -69,6 +69,21 @@ def make_problem(n, d, m, k, method, hetero, seed, psi=False, nanfrac=0.0):
     return model, theta, X, Y, Psi, rng
 
 
+def recondition_gamma(model, theta, rng, amp=0.3):
+    """Redraw the Gamma blocks of a GC/VC theta as gamma_j (I + amp G / sqrt(d)).  make_problem's 0.05 N(0,1) perturbation of
+    gamma_j I is larger than gamma_j itself once d ~ 20 (cond(Gamma'Gamma) ~ 1e8 ... 1e9): with input noise the reference's own
+    dGamma chain loses cond^1.5 eps there and both sides of a comparison are rounding noise."""
+    if model.method[1] != "C":
+        return theta
+    m, d = model.m, model.d
+    md = m * d
+    for q in range(1 if model.method == "GC" else m):
+        blk = theta[md + q * d * d: md + (q + 1) * d * d].reshape((d, d), order="F")
+        gam = float(np.mean(np.diag(blk)))
+        theta[md + q * d * d: md + (q + 1) * d * d] = (gam * (np.eye(d) + amp * rng.standard_normal((d, d)) / np.sqrt(d))).reshape(-1, order="F")
+    return theta
+
+
 def grad_tol(cond):
     """Parity gate of BASELINE.md §6."""
     return max(1e-8, 50.0 * cond * 2.2e-16)

@@ -7,7 +7,7 @@ import pytest
 
 import gpz_amd
 from oracle import gpz_oracle as O
-from helpers import make_problem, rel
+from helpers import make_problem, recondition_gamma, rel
 from test_gpu_parity import phi_tol
 from test_wide import _gate
 
@@ -18,12 +18,7 @@ def _problem(n, d, m, k, method, hetero, seed, nanfrac=0.0):
     """make_problem with the Gamma blocks redrawn as gamma_j (I + 0.3 G / sqrt(d)): its 0.05 N(0,1) perturbation of gamma_j I is larger
     than gamma_j itself at d ~ 20 (cond(Gamma'Gamma) ~ 1e8: both sides of the comparison are rounding noise there)"""
     model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, hetero, seed=seed, psi=True, nanfrac=nanfrac)
-    md = m * d
-    nb = 1 if method == "GC" else m
-    for q in range(nb):
-        blk = theta[md + q * d * d: md + (q + 1) * d * d].reshape((d, d), order="F")
-        gam = float(np.mean(np.diag(blk)))
-        theta[md + q * d * d: md + (q + 1) * d * d] = (gam * (np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d))).reshape(-1, order="F")
+    recondition_gamma(model, theta, rng)
     return model, theta, X, Y, Psi, rng
 
 

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gpz_amd
 from oracle import gpz_oracle as O
-from helpers import make_problem, grad_tol, rel
+from helpers import make_problem, grad_tol, recondition_gamma, rel
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -37,6 +37,8 @@ for c in range(cases):
         n = max(8, (60000 if d <= 10 else 6000) // m)                      # oracle loops over pairs
     seed = int(rng.integers(1 << 30))
     model, theta, X, Y, Psi, r2 = make_problem(n, d, m, k, method, hetero, seed=seed, psi=psi, nanfrac=nanfrac)
+    if model.method[1] == "C" and d > 10:           # keep cond(Gamma'Gamma) moderate: beyond ~1e6 the reference formula is rounding noise
+        recondition_gamma(model, theta, r2)
     if model.method != method:                      # d == 1 rewrites *D/*C to *L (init.m:12-14)
         method = model.method
     multi = bool(nanfrac > 0 and d > 2 and rng.random() < 0.5)
