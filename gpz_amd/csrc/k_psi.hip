@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                    const double *lnS, double *Phi, int ld, const unsigned char *pat) {
     if (cpsi4_available(d)) return launch_cpsi4_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld, pat);   // four pairs per wave on 4 x 4 tiles (k_cpsi4.hip)
+    if (!pat && cpsi4w_available(d)) return launch_cpsi4w_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld);   // the same up to d = 48 (k_cpsi4w.hip)
     if (d > 10) return launch_cpsi_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld, pat);   // wave-per-pair MFMA elimination (k_cpsi.hip)
     if (r.n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;   // a rank of a sharded run may hold no row of this set
 #define PHI_CASE(DD)                                                                                                       \
@@ -307,6 +308,8 @@ int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int l
     if (cpsi4_available(d))
         return launch_cpsi4_moments(st, Phi, T, ld, rowscal, w, v, r, m, d, de, P, Sig, nchunk, rows_per_chunk, slab, nrec, pat,
                                     chunktab);
+    if (!pat && cpsi4w_available(d))
+        return launch_cpsi4w_moments(st, Phi, T, ld, rowscal, w, v, r, m, d, de, P, Sig, nchunk, rows_per_chunk, slab, nrec, chunktab);
     if (d > 10)
         return launch_cpsi_moments(st, Phi, T, ld, rowscal, w, v, r, m, d, de, P, Sig, nchunk, rows_per_chunk, slab, nrec, pat,
                                    chunktab);

@@ -10,8 +10,8 @@ cd $R
 {
 echo "# sweep_timing.py 100000 256 VD,VC 10,20,24,32   (d > 20: runtime-d kernels of k_wide.hip; VC psi at d > 10 takes dtype f32 up to d = 20)"
 python tools/sweep_timing.py 100000 256 VD,VC 10,20,24,32 2>&1 | grep -v amdgpu.ids
-echo "# GPZ_SWEEP_F64=1 sweep_timing.py 100000 256 VC 12,16,20,24,28,32,40,48,64   (VC psi in fp64: k_cpsi4.hip up to d = 32, k_cpsi.hip up to 64)"
-GPZ_SWEEP_F64=1 python tools/sweep_timing.py 100000 256 VC 12,16,20,24,28,32,40,48,64 2>&1 | grep " psi "
+echo "# GPZ_SWEEP_F64=1 sweep_timing.py 100000 256 VC 12,16,20,24,28,32,36,40,48,64   (VC psi in fp64: k_cpsi4.hip up to d = 32, k_cpsi4w.hip up to 48, k_cpsi.hip up to 64)"
+GPZ_SWEEP_F64=1 python tools/sweep_timing.py 100000 256 VC 12,16,20,24,28,32,36,40,48,64 2>&1 | grep " psi "
 echo "# the same at d = 16, 20, 24 on the 16 x 16 tile kernels (GPZ_CPSI4_OFF=1) and on the general kernels of k_gen.hip (GPZ_CPSI_OFF=1)"
 GPZ_CPSI4_OFF=1 GPZ_SWEEP_F64=1 python tools/sweep_timing.py 100000 256 VC 16,20,24 2>&1 | grep " psi "
 GPZ_CPSI_OFF=1 GPZ_SWEEP_F64=1 python tools/sweep_timing.py 100000 256 VC 16,20,24 2>&1 | grep " psi "
