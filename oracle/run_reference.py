@@ -44,7 +44,8 @@ def draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac):
     P = X[rng.choice(n, m, replace=False)] + 0.1 * rng.standard_normal((m, d))
     gd = g_dim_of(method, m, d)
     if method[1] == "C":
-        blocks = [np.eye(d) * (0.8 + 0.4 * rng.random()) + 0.15 * rng.standard_normal((d, d)) for _ in range(1 if method == "GC" else m)]
+        blocks = [np.eye(d) * (0.8 + 0.4 * rng.random()) + 0.15 * rng.standard_normal((d, d)) / max(1.0, np.sqrt(d / 3.0))
+                  for _ in range(1 if method == "GC" else m)]
         G = np.concatenate([b.reshape(-1, order="F") for b in blocks])
     else:
         G = 0.6 + 0.6 * rng.random(gd)
@@ -93,13 +94,18 @@ GPZ_CASES += [("VD", 2, True, False, 0.0), ("VC", 2, True, True, 0.0), ("GL", 2,
               ("GC", 2, False, False, 0.0), ("GD", 3, True, True, 0.3)]
 
 
+# inputs wider than the register-resident kernels of the HIP path (its MFMA pair kernels, its runtime-d kernels): (.., n, d, m)
+GPZ_CASES += [("VC", 1, True, True, 0.0, 40, 13, 4), ("GC", 1, True, True, 0.3, 30, 22, 3), ("VD", 2, True, True, 0.0, 50, 24, 4),
+              ("VC", 1, True, False, 0.3, 30, 21, 3), ("VC", 1, True, True, 0.0, 24, 34, 3)]
+
+
 def gpz_case_name(c):
-    return "ref_gpz_%s_k%d_h%d_p%d_n%d" % (c[0], c[1], int(c[2]), int(c[3]), int(c[4] > 0))
+    return "ref_gpz_%s_k%d_h%d_p%d_n%d" % (c[0], c[1], int(c[2]), int(c[3]), int(c[4] > 0)) + ("_d%d" % c[6] if len(c) > 5 else "")
 
 
 def make_gpz(case, seed):
-    method, k, hetero, psi, nanfrac = case
-    n, d, m = 70, 3, 5
+    method, k, hetero, psi, nanfrac = case[:5]
+    n, d, m = case[5:] if len(case) > 5 else (70, 3, 5)
     rng = np.random.default_rng(seed)
     pr = draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac)
     out = run_gpz(ML.Interp(), method, m, d, k, hetero, pr)
