@@ -33,7 +33,7 @@ is an interpreter for the subset of MATLAB those files use, ``oracle/run_referen
 executes ``GPz.m`` (with ``getPHI.m``, ``inv_logdet.m``), ``predict.m`` (with ``fixPsi.m``,
 ``predictDiag.m``, ``predictCov.m``), ``getPrior.m``, ``getOmega.m``, ``Dxy.m`` and whole ``init.m`` ->
 ``train.m`` runs (``minFunc.m`` calling ``GPz.m``, ``callBack.m``) where they lie under
-``/root/reference`` and stores inputs + outputs as ``tests/golden/ref_*.npz`` (68 files, one of them demo_sinc.m's own configuration, five at d = 13 ... 34);
+``/root/reference`` and stores inputs + outputs as ``tests/golden/ref_*.npz`` (71 files, one of them demo_sinc.m's own configuration, eight at d = 13 ... 34);
 ``tests/test_reference_run.py`` compares this module with them (objective to 1e-12, every
 output, all six methods, +/- input noise, +/- missing values, k > 1, both heteroscedastic
 modes) and re-executes the files whenever the reference tree is present.  The interpreter

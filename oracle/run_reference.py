@@ -117,13 +117,16 @@ def make_gpz(case, seed):
 PREDICT_CASES = [(mth, noisy, nanfrac) for mth in ("GL", "VL", "GD", "VD", "GC", "VC") for noisy in (False, True) for nanfrac in (0.0, 0.35)]
 
 
+PREDICT_CASES += [("VC", True, 0.0, 13), ("GC", True, 0.0, 22), ("VD", True, 0.35, 23)]   # (.., d): beyond the register kernels of the HIP path
+
+
 def predict_case_name(c):
-    return "ref_predict_%s_p%d_n%d" % (c[0], int(c[1]), int(c[2] > 0))
+    return "ref_predict_%s_p%d_n%d" % (c[0], int(c[1]), int(c[2] > 0)) + ("_d%d" % c[3] if len(c) > 3 else "")
 
 
 def make_predict(case, seed):
-    method, noisy, nanfrac = case
-    n, d, m, k, ns = 70, 3, 4, 2, 11
+    method, noisy, nanfrac = case[:3]
+    n, d, m, k, ns = 70, (case[3] if len(case) > 3 else 3), 4, 2, 11
     rng = np.random.default_rng(seed)
     pr = draw_problem(rng, n, d, m, k, method, True, False, 0.0)
     ip = ML.Interp()
