@@ -256,6 +256,9 @@ int launch_cpsi4w_phi(hipStream_t st, const GenRows &r, int m, int d, int de, co
 int launch_cpsi4w_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                           const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                           int nchunk, int rows_per_chunk, double *slab, int nrec, const int *chunktab);
+int launch_cpsi4w_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
+                                const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
+                                long pairs_per_chunk, double *part, bool shared);
 int launch_cpsi4_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                                const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
                                long pairs_per_chunk, double *part, bool shared /* GC: one covariance for every pair */);

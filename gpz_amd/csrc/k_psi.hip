@@ -423,6 +423,9 @@ int launch_predict_noisy_cov(hipStream_t st, int n, long ldx, int m, int d, int 
     if (cpsi4_available(d) && k <= 8)   // 10 < d <= 32: four (sample, pair) units per wave on 4 x 4 MFMA tiles (k_cpsi4.hip)
         return launch_cpsi4_predict_noisy(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part,
                                           (flags & 2) != 0);
+    if (cpsi4w_available(d) && k == 1)   // 32 < d <= 48, one output (k_cpsi4wp.hip)
+        return launch_cpsi4w_predict_noisy(st, n, ldx, m, d, de, k, Xr, Psi3, tab, rec, w, v, iS, nchunk, pairs_per_chunk, part,
+                                           (flags & 2) != 0);
     if (n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;
     const bool dg = flags & 1, sh = flags & 2;
 #define PN_LAUNCH(DD, DG, SH, KM)                                                                                          \

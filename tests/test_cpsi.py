@@ -93,9 +93,10 @@ def test_fp64_and_fp32_pair_kernels_agree_at_d20():
 
 
 @pytest.mark.parametrize("method", ["VC", "GC"])
-@pytest.mark.parametrize("d,k,cube", [(12, 1, False), (17, 2, True), (20, 1, True), (29, 1, False), (32, 2, False)])
+@pytest.mark.parametrize("d,k,cube", [(12, 1, False), (17, 2, True), (20, 1, True), (29, 1, False), (32, 2, False), (37, 1, False),
+                                      (44, 1, True), (48, 1, False)])
 def test_predict_with_input_noise_on_the_pair_kernels(method, d, k, cube):
-    """predictNoisy for GC/VC at 10 < d <= 32 (predictCov.m:70-132): one sweep per (sample, pair) on 4 x 4 tiles; GC shares the
+    """predictNoisy for GC/VC at 10 < d <= 48 (predictCov.m:70-132): one sweep per (sample, pair) on 4 x 4 tiles; GC shares the
     factorisation over the pairs (Cij = Sigma/2).  Psi as n x d variances or as full d x d x n cubes; ns not a multiple of 16."""
     m, ns = 6, 37
     model, theta, X, Y, _, rng = _problem(260, d, m, k, method, True, 4200 + d)
