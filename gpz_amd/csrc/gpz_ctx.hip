@@ -1780,8 +1780,8 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
     const int d = desc->d;
     const bool covk = method_id_of(desc->method) >= 4;
-    if (d > 64 || (covk && d > 20))
-        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (GL/VL/GD/VD) and d <= 20 (GC/VC, "
+    if (d > 64 || (covk && d > 32))
+        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (GL/VL/GD/VD) and d <= 32 (GC/VC, "
                                          "whose per-(row, pair, component) d x d factorisations are O(n m^3 d^3)); d = %d", d);
     unsigned long long obs = 0;
     for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1ull << c; }

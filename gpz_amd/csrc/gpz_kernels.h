@@ -262,6 +262,11 @@ int launch_cpsi4w_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, i
 int launch_cpsi4_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,
                                const double *tab, int rec, const double *w, const double *v, const double *iS, int nchunk,
                                long pairs_per_chunk, double *part, bool shared /* GC: one covariance for every pair */);
+// prediction with missing values, GC/VC, 10 < d <= 32: the record sums on 4 x 4 MFMA tiles (k_pmc4.hip); arguments as pmc_sum (k_pmiss_cov.hip)
+bool pmc4_available(int d);
+bool launch_pmc4_sum(hipStream_t st, int d, bool noisy, int nrows, int row0, int m, int ld, long R, int nchunk, const double *tab,
+                     int ntab, int nw, const double *Pio, const double *XhT, const double *PsT, double *Phi, long ldx,
+                     double *part);
 bool psi_fast_path_available(int d);
 // pat (observed flags [G][d]) non-null: rows carry missing dimensions (r.gid = pattern per row, lnS = [G][m]);
 // chunktab (optional): {first row, end row} per moment chunk

@@ -5,9 +5,10 @@
 //
 // The reference conditions every basis function on the observed dimensions (X_hat, Psi_hat) and then, for every
 // basis pair (i,j), sums a d-dimensional Gaussian over all m conditioned components: O(n m^3 d^3) interpreted work
-// (a d x d factorisation per (row, pair, component) once there is input noise).  Two routes: for d <= 10 the
-// register-resident record sums further down (k_pmc_sum_*); else the first, scratch-resident kernels (runtime d <= 20, one
-// thread per (row, basis) or one wave per (row, pair chunk)).  Sums over pairs are ordered (chunk slabs + fixed-order sum).
+// (a d x d factorisation per (row, pair, component) once there is input noise).  Three routes for the sums: for d <= 10 the
+// register-resident record sums further down (k_pmc_sum_*); for 10 < d <= 32 the same sums as MFMA sweeps (k_pmc4.hip); else
+// (more than 8 outputs) the first, scratch-resident kernels (runtime d <= 32, one thread per (row, basis) or one wave per
+// (row, pair chunk)).  Sums over pairs are ordered (chunk slabs + fixed-order sum).
 //
 // Kept quirk (predictCov.m:266-268): with input noise the block T*Psi_oo*T' (in [o u] order) is ASSIGNED through
 // `unshuffle`, the inverse of the permutation [find(o) find(~o)] — the intended placement only when that permutation
@@ -16,7 +17,7 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
-#define GDM 20
+#define GDM 32   // widest input of this file's scratch-resident kernels
 
 __device__ inline void pmc_chol(double *M, int n) {        // lower Cholesky in place, leading dimension GDM
     for (int c = 0; c < n; ++c) {
@@ -492,7 +493,8 @@ static bool pmc_sum(hipStream_t st, int d, bool noisy, int nrows, int row0, int 
         return true;
     switch (d) {
         PMC_CASE(2) PMC_CASE(3) PMC_CASE(4) PMC_CASE(5) PMC_CASE(6) PMC_CASE(7) PMC_CASE(8) PMC_CASE(9) PMC_CASE(10)
-        default: return false;
+        default:   // 10 < d <= 32: four components per wave on 4 x 4 MFMA tiles (k_pmc4.hip)
+            return launch_pmc4_sum(st, d, noisy, nrows, row0, m, ld, R, nchunk, tab, ntab, nw, Pio, XhT, PsT, Phi, ldx, part);
     }
 #undef PMC_CASE
 }
@@ -507,7 +509,7 @@ int pmc_rec_len(int d, unsigned long long obs) {
     const int nu = d - no;
     return 2 + no * no + no * nu + nu * nu;
 }
-bool pmc_fast(int d, int k) { return d >= 2 && d <= 10 && k <= 8; }   // register-resident kernels (rows_blk <= 64 then); more outputs: the scratch kernels, 24 sums per pass
+bool pmc_fast(int d, int k) { return d >= 2 && (d <= 10 || pmc4_available(d)) && k <= 8; }   // register-resident kernels (rows_blk <= 64 then); more outputs: the scratch kernels, 24 sums per pass
 // work2: m * (d(d+1)/2 + d*d + d + 1) doubles, used by the register-resident route
 void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,

@@ -29,7 +29,7 @@
  * fit the 160 KB of LDS: d <= ~100 for the diagonal kinds with input noise and missing values, ~300 without).  GC/VC with
  * input noise in fp64 runs register-resident up to d = 10 and as a block elimination in f64 MFMA accumulators for
  * 10 < d <= 64 (four pairs per wave up to d = 48), the workspace form beyond.
- * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 64, or d > 20 for GC/VC.  dtype = f32 with d > 20 takes the
+ * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 64, or d > 32 for GC/VC.  dtype = f32 with d > 20 takes the
  * fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers).
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):

@@ -115,3 +115,31 @@ def test_predict_with_input_noise_on_the_pair_kernels(method, d, k, cube):
     tol = max(1e-9, phi_tol(model, theta))
     for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
         assert rel(out[i], ref[i]) <= tol, name
+
+
+@pytest.mark.parametrize("method", ["GC", "VC"])
+@pytest.mark.parametrize("d,noisy,k", [(12, False, 1), (13, True, 2), (22, False, 1), (22, True, 1), (30, True, 1), (32, False, 2)])
+def test_predict_with_missing_values_on_the_pair_kernels(method, d, noisy, k):
+    """predictMissing / predictNoisyMissing for GC/VC at 10 < d <= 32 (predictCov.m:134-337): the record sums
+    sum_l N(X_hat_l - c; C + Psi_hat_l) Pio_l as sweeps on 4 x 4 tiles, four components per wave; without input noise the
+    factorisation is shared by the rows of the group.  Several NaN patterns, rows not a multiple of anything."""
+    m, ns = 5, 11
+    model, theta, X, Y, _, rng = _problem(200, d, m, k, method, True, 6100 + d)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = rng.random(m) + 0.2
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri / pri.sum()}
+    Xs = rng.standard_normal((ns, d))
+    Xs[:4, 1] = np.nan
+    Xs[4:9, [0, d - 1, d // 2]] = np.nan
+    Xs[9:, 2:d - 3] = np.nan                                  # most dimensions missing
+    Psi = None
+    if noisy:
+        Psi = np.zeros((d, d, ns))
+        for i in range(ns):
+            B = 0.2 * rng.standard_normal((d, d))
+            Psi[:, :, i] = B @ B.T
+    ref = O.predict_any(Xs, model, Psi=Psi)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    tol = max(1e-8, 10.0 * phi_tol(model, theta))
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))

@@ -163,8 +163,8 @@ def test_predict_missing_cov_kind_with_many_outputs():
 
 
 def test_what_is_still_refused_says_so():
-    """Prediction with missing values for GC/VC keeps d <= 20 (O(n m^3 d^3) per-triple factorisations in per-thread scratch)."""
-    d = 22
+    """Prediction with missing values for GC/VC keeps d <= 32 (O(n m^3 d^3) per-triple factorisations)."""
+    d = 34
     model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "GC", True, seed=5)
     r4 = O.GPz(theta, model, X, Y, nargout=4)
     pri = np.full(5, 0.2)
