@@ -18,8 +18,8 @@
 //       B_IJ = A_IJ - Y_I Y_J'     = mfma(-Y_I', Y_J', A_IJ)
 //       B_1J = W' Y_J'  (J < p)    = mfma(W, Y_J')       B_J1 = Y_J W  (J > p) = mfma(Y_J', W)       B_11 = -W'W = mfma(-W, W)
 // Delta rides along as row 0 of an extra tile row (index ND): after the sweep that row is (M^-1 Delta)', its corner -Delta' M^-1 Delta,
-// and u u' for the moment sums is one more mfma of two tiles of that row (rows 1..3 are zero).  20 cycles per instruction measured:
-// 0.4 of the 16x16x4 rate, but the per-panel scalar work (4 x 4 Cholesky, inverse, logarithm) is shared by four pairs.
+// and u u' for the moment sums is one more mfma of two tiles of that row (rows 1..3 are zero).  16 cycles per instruction
+// (PMC: the same 32 flop / clock / SIMD as the 16x16x4 form), and the per-panel scalar work (4 x 4 Cholesky, inverse) is shared by four pairs.
 // d is padded to 4 ND with identity; missing dimensions are marginalised as in k_psi.hip (identity block in M, zero Delta).
 #include "k_cpsi4_impl.h"
 
