@@ -81,11 +81,13 @@ static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
 // device allocation bookkeeping.  Released blocks go to a per-device cache keyed by their exact size instead of back to the
 // runtime: the stand-alone entry points (getPHI, predict*, prior ...) build and drop ~30 buffers per call, predict.m calls them
 // once per NaN-pattern group, and hipFree (a device synchronisation + unmap, 38 us on average here) was 30 % of a 79-group
-// predict() (profiles/README.md, round 3).  At most GPZ_CACHE_CAP bytes per device stay cached (blocks above a quarter of
-// it are freed directly); gpz_release_cached_memory() gives everything back.
+// predict() (profiles/README.md, round 3).  At most GPZ_CACHE_CAP bytes per device stay cached (blocks above GPZ_CACHE_BLOCK_MAX
+// are freed directly: the limit sits just above the 2 GiB runtime-d workspace of d > 20, which a many-group predict() with
+// missing values would otherwise allocate and free once per group); gpz_release_cached_memory() gives everything back.
 #include <map>
 #include <mutex>
-#define GPZ_CACHE_CAP (1024UL << 20)
+#define GPZ_CACHE_CAP (4096UL << 20)
+#define GPZ_CACHE_BLOCK_MAX (2304UL << 20)
 struct DevCache {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> blocks;   // (device, bytes) -> pointer
@@ -106,7 +108,7 @@ static void *cache_take(int dev, size_t bytes) {
     return p;
 }
 static bool cache_give(int dev, size_t bytes, void *p) {
-    if (bytes > GPZ_CACHE_CAP / 4) return false;
+    if (bytes > GPZ_CACHE_BLOCK_MAX) return false;
     DevCache &c = dev_cache();
     std::lock_guard<std::mutex> g(c.mu);
     if (c.held[dev] + bytes > GPZ_CACHE_CAP) return false;

@@ -272,7 +272,7 @@ const char *gpz_rccl_origin(void);
 const char *gpz_last_error(void);
 int gpz_version(void);
 
-/* Device buffers released by contexts and stand-alone calls are kept (up to 1 GiB per device) for the next call instead of
+/* Device buffers released by contexts and stand-alone calls are kept (up to 4 GiB per device) for the next call instead of
  * being returned to the runtime one hipFree at a time; this hands all of them back.  No reference counterpart. */
 void gpz_release_cached_memory(void);
 
