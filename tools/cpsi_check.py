@@ -1,4 +1,5 @@
-"""Developer tool: fp64 GC/VC + Psi (k_cpsi.hip, 10 < d <= 64) against the oracle, +- missing values.  usage: cpsi_check.py [n] [m]"""
+"""Developer tool: fp64 GC/VC + Psi beyond the register kernels (k_cpsi4.hip / k_cpsi4w.hip / k_cpsi.hip, 10 < d <= 64) against the oracle,
++- missing values; CPSI_D=11,20,... picks the widths, GPZ_CPSI4_OFF / GPZ_CPSI_OFF the route.  usage: cpsi_check.py [n] [m]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -21,7 +22,6 @@ for method in ("VC", "GC"):
                 t0 = time.perf_counter()
                 f, g = ctx.eval(theta)
                 dt = time.perf_counter() - t0
-                ephi = rel(ctx.phi(), ref_phi) if False else float("nan")
             finally:
                 ctx.close()
             ef, eg = abs(f - ref.nlogML) / abs(ref.nlogML), rel(g, ref.grad)
