@@ -143,3 +143,20 @@ def test_predict_with_missing_values_on_the_pair_kernels(method, d, noisy, k):
     tol = max(1e-8, 10.0 * phi_tol(model, theta))
     for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
         assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))
+
+
+def test_predict_with_missing_values_wide_and_many_outputs_takes_the_scratch_kernels():
+    """k = 9 > 8 at d = 22: the 3k sums do not fit the record kernels' 24 slots per pass, the scratch-resident kernels (runtime d <= 32)
+    take the group"""
+    d, m, k, ns = 22, 4, 9, 7
+    model, theta, X, Y, _, rng = _problem(160, d, m, k, "GC", True, 6400)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = rng.random(m) + 0.2
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri / pri.sum()}
+    Xs = rng.standard_normal((ns, d))
+    Xs[:, [1, 7, 20]] = np.nan
+    ref = O.predict_any(Xs, model)
+    out = gpz_amd.predict(Xs, model)
+    tol = max(1e-8, 10.0 * phi_tol(model, theta))
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))
