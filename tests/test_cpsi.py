@@ -160,3 +160,32 @@ def test_predict_with_missing_values_wide_and_many_outputs_takes_the_scratch_ker
     tol = max(1e-8, 10.0 * phi_tol(model, theta))
     for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
         assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))
+
+
+@pytest.mark.parametrize("d,switch", [(20, "GPZ_CPSI4_OFF"), (20, "GPZ_CPSI_OFF"), (40, "GPZ_CPSI4_OFF")])
+def test_the_pair_kernel_routes_agree_with_each_other(d, switch, tmp_path):
+    """the same evaluation through the route a developer switch selects in a fresh process (4 x 4 tiles -> 16 x 16 tiles -> general
+    kernels) against this process's default route: three independent implementations of getPHI.m:78-89 / GPz.m:164-185"""
+    import os
+    import subprocess
+    import sys
+    n, m = 120, 5
+    model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, "VC", True, 7300 + d)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    try:
+        f, g = ctx.eval(theta)
+    finally:
+        ctx.close()
+    np.savez(tmp_path / "in.npz", theta=theta, X=X, Y=Y, Psi=Psi, m=m, d=d)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import gpz_amd\n"
+            "z = np.load(%r)\n"
+            "model = gpz_amd.Model(m=int(z['m']), d=int(z['d']), k=1, method='VC', heteroscedastic=True)\n"
+            "ctx = gpz_amd.GPzContext(model, z['X'], z['Y'], z['Psi'])\n"
+            "f, g = ctx.eval(z['theta']); ctx.close()\n"
+            "np.savez(%r, f=f, g=g)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"),
+                                          str(tmp_path / "out.npz"))
+    env = dict(os.environ, **{switch: "1"})
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    o = np.load(tmp_path / "out.npz")
+    assert abs(float(o["f"]) - f) <= 1e-11 * abs(f)
+    assert rel(o["g"], g) <= max(1e-9, _loose(model, theta) * phi_tol(model, theta))
