@@ -189,3 +189,20 @@ def test_the_pair_kernel_routes_agree_with_each_other(d, switch, tmp_path):
     o = np.load(tmp_path / "out.npz")
     assert abs(float(o["f"]) - f) <= 1e-11 * abs(f)
     assert rel(o["g"], g) <= max(1e-9, _loose(model, theta) * phi_tol(model, theta))
+
+
+@pytest.mark.parametrize("method", ["VC", "GC"])
+@pytest.mark.parametrize("d", [25, 30, 36, 50])
+def test_missing_values_without_input_noise_wide(method, d):
+    """GC/VC with missing values and no Psi at d = 25 ... 50: the per-pattern route on the runtime-d kernels (routing these through
+    the pair kernels with Psi = 0 was measured and dropped: the per-(pattern, basis) finish dominates either way - d = 32,
+    ~2000 patterns: 540 ms per pattern route, 890 ms through the pair kernels); several missing dimensions per row, validation split"""
+    n, m = 260, 6
+    model, theta, X, Y, _, rng = _problem(n, d, m, 1, method, True, 8100 + d)
+    miss = rng.random((n, d)) < 0.08
+    miss[:, 0] = False
+    X = X.copy()
+    X[miss] = np.nan
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    _gate(model, theta, X, Y, None, om, tr, ~tr, loose=_loose(model, theta))
