@@ -262,6 +262,13 @@ struct gpz_ctx {
     void *priv = nullptr;                 // owned by whoever attached it (the RCCL communicator of gpz_ctx_init_rccl),
     void (*priv_free)(void *) = nullptr;  // released with the context
     bool timing = false;
+    // One evaluation = ~40 launches on one stream between the upload of theta and the download of the result block, every argument
+    // fixed for the life of the context: from the third gpz_eval on it is replayed as a hipGraph (single rank, host theta, stage
+    // timing off).  graph_state: 0 first call (eager), 1 capture on this call, 2 replay, -1 disabled (capture failed / GPZ_NO_GRAPH)
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_st = nullptr;   // the recording runs on a stream of its own (the null stream cannot be captured); the graph is launched on st
+    int graph_state = 0;
+    bool capturing = false;
     StageTimer tm;
     bool phi_valid = false;
     bool has_psi = false, has_missing = false;
@@ -816,6 +823,8 @@ extern "C" void gpz_ctx_destroy(gpz_ctx *c) {
     c->ar.release();
     if (c->out_h) (void)hipHostFree(c->out_h);
     if (c->theta_h) (void)hipHostFree(c->theta_h);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph_st) (void)hipStreamDestroy(c->graph_st);
     for (hipEvent_t e : c->tm.pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1351,6 +1360,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
     } else {
         HIPCHK(hipMemcpyAsync(c->out_h, c->out_d, ((size_t)c->p + 10) * sizeof(double), hipMemcpyDeviceToHost, c->st));
     }
+    if (c->capturing) return 0;   // being recorded into the evaluation graph: the caller synchronises after the replay
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
     return 0;
@@ -1376,10 +1386,66 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
                        double stats[4], double diag[2]) {
     (void)g_dev;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-    if (int e = stage_a(c, theta, theta_dev)) return e;
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
-    if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
+    static const bool no_graph = getenv("GPZ_NO_GRAPH") != nullptr;
+    const bool graphable = theta && !c->g_dev_out && c->desc.world <= 1 && !c->timing && c->pinv_mode != 1 && !no_graph &&
+                           c->graph_state >= 0;
+    bool done = false;
+    if (graphable && c->graph_state == 2) {
+        memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
+        if (hipGraphLaunch(c->graph_exec, c->st) == hipSuccess) {
+            HIPCHK(hipStreamSynchronize(c->st));
+            HIPCHK(hipGetLastError());
+            done = true;
+        } else {
+            (void)hipGetLastError();
+            c->graph_state = -1;
+        }
+    } else if (graphable && c->graph_state == 1) {
+        hipGraph_t graph = nullptr;
+        int rc = 0;
+        const char *why = "";
+        hipStream_t user_st = c->st;
+        hipError_t he = c->graph_st ? hipSuccess : hipStreamCreate(&c->graph_st);
+        if (he == hipSuccess) {
+            c->st = c->graph_st;
+            he = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
+        }
+        if (he == hipSuccess) {
+            c->capturing = true;
+            if ((he = hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st)) != hipSuccess) { rc = -1; why = "memset"; }
+            if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";
+            if (!rc && (rc = eval_tail(c, false))) why = "stage B";
+            c->capturing = false;
+            const hipError_t he2 = hipStreamEndCapture(c->st, &graph);
+            if (he2 != hipSuccess || !graph) { if (!rc) { rc = -1; why = "end capture"; he = he2; } }
+        } else {
+            rc = -1; why = "begin capture";
+        }
+        c->st = user_st;
+        if (!rc && (he = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0)) != hipSuccess) { rc = -1; why = "instantiate"; }
+        if (rc && getenv("GPZ_GRAPH_DEBUG"))
+            fprintf(stderr, "gpz: evaluation graph: %s: %s | %s\n", why, hipGetErrorString(he), gpz_last_error());
+        if (graph) (void)hipGraphDestroy(graph);
+        if (getenv("GPZ_GRAPH_DEBUG")) fprintf(stderr, "gpz: evaluation graph capture %s\n", rc ? "failed" : "ok");
+        if (!rc) {
+            c->graph_state = 2;
+            HIPCHK(hipGraphLaunch(c->graph_exec, c->st));
+            HIPCHK(hipStreamSynchronize(c->st));
+            HIPCHK(hipGetLastError());
+            done = true;
+        } else {                     // not capturable here: stay on plain launches for the life of the context
+            (void)hipGetLastError();
+            c->graph_exec = nullptr;
+            c->graph_state = -1;
+        }
+    }
+    if (!done) {
+        HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
+        if (int e = stage_a(c, theta, theta_dev)) return e;
+        if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
+        if (graphable && c->graph_state == 0) c->graph_state = 1;
+    }
     // k_cond_flag (info[1], returned in slot 7 of the statistics block): SIGMA is close enough to singular that
     // inv_logdet.m may truncate -> redo the solve and everything after it through the SVD route.  PHI and the
     // reduced partials of stage A are still in place; every rank sees the same SIGMA and takes the same branch.

@@ -1155,3 +1155,29 @@ def test_released_buffers_are_cached_and_can_be_handed_back():
     lib.gpz_release_cached_memory()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < held // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,psi,nanfrac", [("VD", False, 0.0), ("VC", False, 0.0), ("VC", True, 0.0), ("GC", False, 0.3), ("VL", True, 0.2)])
+def test_graph_replay_of_the_evaluation_is_bitwise_the_plain_launch_sequence(method, psi, nanfrac):
+    """From its third call on gpz_eval replays the evaluation as a hipGraph recorded on the second call (single rank, stage timing
+    off): first (plain launches), second (recorded, then replayed) and later calls agree to the last bit, for one theta and across
+    changing thetas; with stage timing on the plain sequence runs again and still agrees."""
+    model, theta, X, Y, Psi, rng = make_problem(700, 4, 9, 1, method, True, seed=91, psi=psi, nanfrac=nanfrac)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    try:
+        th2 = theta + 1e-2 * rng.standard_normal(theta.size)
+        f1, g1 = ctx.eval(theta)            # plain
+        f2, g2 = ctx.eval(theta)            # recorded + replayed
+        fb, gb = ctx.eval(th2)              # replayed with another theta
+        f3, g3 = ctx.eval(theta)            # replayed
+        assert f1 == f2 == f3 and np.array_equal(g1, g2) and np.array_equal(g1, g3)
+        ctx.enable_timing(True)
+        f4, g4 = ctx.eval(theta)            # stage timing: plain launches
+        fc, gc = ctx.eval(th2)
+        ctx.enable_timing(False)
+        f5, g5 = ctx.eval(theta)
+        assert f4 == f1 and np.array_equal(g4, g1) and fc == fb and np.array_equal(gc, gb) and f5 == f1 and np.array_equal(g5, g1)
+        assert fb != f1
+    finally:
+        ctx.close()
