@@ -116,18 +116,22 @@ static bool cache_give(int dev, size_t bytes, void *p) {
     c.held[dev] += bytes;
     return true;
 }
+static void pmc_model_cache_release_all();
 extern "C" void gpz_release_cached_memory(void) {
-    DevCache &c = dev_cache();
-    std::lock_guard<std::mutex> g(c.mu);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    for (auto &kv : c.blocks) {
-        (void)hipSetDevice(kv.first.first);
-        (void)hipFree(kv.second);
+    {
+        DevCache &c = dev_cache();
+        std::lock_guard<std::mutex> g(c.mu);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto &kv : c.blocks) {
+            (void)hipSetDevice(kv.first.first);
+            (void)hipFree(kv.second);
+        }
+        (void)hipSetDevice(cur);
+        c.blocks.clear();
+        c.held.clear();
     }
-    (void)hipSetDevice(cur);
-    c.blocks.clear();
-    c.held.clear();
+    pmc_model_cache_release_all();   // after the block cache's lock is gone: a running prediction holds its model entry and takes the block cache inside
 }
 
 struct Arena {
@@ -1754,6 +1758,46 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
     return rc;
 }
 
+// predict.m:60-69 calls once per NaN-pattern group with the same model, and the entry point is stateless: Sigma_j / inv(Sigma_j)
+// (k_gen_prep) and the basis-pair table (k_pmc_pairs: m (m + 1) / 2 d x d inversions) depend on theta, w and iSigma_w only and were
+// half of a many-group call (profiles/r03_predict_wide_kernel_stats.txt).  The last model's tables stay on the device, one entry
+// per device, keyed by the CONTENTS of theta, w, iSigma_w; gpz_release_cached_memory() drops them.
+struct PmcModelCache {
+    std::mutex mu;                     // held for the whole call: one group at a time per device
+    int m = 0, d = 0, k = 0, mid = -1, hetero = -1;
+    std::vector<double> theta, w, iS;
+    double *Sig = nullptr, *iSig = nullptr, *tab = nullptr;
+    void drop() {
+        if (Sig) (void)hipFree(Sig);
+        if (iSig) (void)hipFree(iSig);
+        if (tab) (void)hipFree(tab);
+        Sig = iSig = tab = nullptr;
+        m = d = k = 0; mid = hetero = -1;
+        theta.clear(); w.clear(); iS.clear();
+    }
+};
+static PmcModelCache *pmc_model_cache(int dev) {
+    static std::mutex mu;
+    static std::map<int, PmcModelCache *> *by_dev = new std::map<int, PmcModelCache *>();   // never destroyed (see dev_cache)
+    std::lock_guard<std::mutex> g(mu);
+    auto it = by_dev->find(dev);
+    if (it != by_dev->end()) return it->second;
+    return (*by_dev)[dev] = new PmcModelCache();
+}
+static void pmc_model_cache_release_all() {
+    int cur = 0, ndev = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipGetDeviceCount(&ndev);
+    for (int dev = 0; dev < ndev; ++dev) {
+        PmcModelCache *e = pmc_model_cache(dev);
+        std::lock_guard<std::mutex> g(e->mu);
+        if (!e->Sig && !e->tab) continue;
+        (void)hipSetDevice(dev);
+        e->drop();
+    }
+    (void)hipSetDevice(cur);
+}
+
 // GC/VC branch of gpz_predict_missing (predictCov.m:134-337); see k_pmiss_cov.hip.
 static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, const double *theta, const double *w, const double *iSigma_w,
                                const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
@@ -1767,9 +1811,30 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st) != hipSuccess)
         rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
-    launch_gen_prep(c->st, c->pr.G, c->m, d, de, c->Sig, c->iSig, c->pat_d, c->ngroups, c->lnS, c->gen_ws);
     const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * (int)k;
     const long npairs = (long)m * (m + 1) / 2;
+    // the model's tables of the previous group, if it was the same model (see PmcModelCache)
+    PmcModelCache *mc = pmc_model_cache(c->device);
+    std::unique_lock<std::mutex> mc_lock(mc->mu);
+    const size_t sig_n = m * (size_t)d * d, tab_n = (size_t)npairs * ntab;
+    bool cacheable = (tab_n + 2 * sig_n) * sizeof(double) <= (2048UL << 20) && !getenv("GPZ_PMC_NO_MODEL_CACHE");
+    bool hit = cacheable && mc->tab && mc->m == (int)m && mc->d == d && mc->k == (int)k && mc->mid == c->mid &&
+               mc->hetero == (int)c->hetero && mc->theta.size() == (size_t)c->p &&
+               memcmp(mc->theta.data(), theta, (size_t)c->p * sizeof(double)) == 0 &&
+               memcmp(mc->w.data(), w, m * k * sizeof(double)) == 0 &&
+               memcmp(mc->iS.data(), iSigma_w, m * m * k * sizeof(double)) == 0;
+    if (cacheable && !hit) {
+        mc->drop();
+        if (hipMalloc((void **)&mc->Sig, sig_n * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&mc->iSig, sig_n * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&mc->tab, tab_n * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            mc->drop();
+            cacheable = false;
+        }
+    }
+    double *SigU = cacheable ? mc->Sig : c->Sig, *iSigU = cacheable ? mc->iSig : c->iSig;
+    if (!hit) launch_gen_prep(c->st, c->pr.G, c->m, d, de, SigU, iSigU, c->pat_d, c->ngroups, c->lnS, c->gen_ws);
     // rows per block: X_hat / Psi_hat of a block stay below ~512 MB
     long rb = (1L << 26) / ((long)m * d * d);
     if (rb > n) rb = n;
@@ -1788,7 +1853,8 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (!rc) rc = c->ar.alloc(&iSd, m * m * k);
     if (!rc) rc = c->ar.alloc(&prd, m);
     if (!rc) rc = c->ar.alloc(&rec, m * nrec);
-    if (!rc) rc = c->ar.alloc(&tab, (size_t)npairs * ntab);
+    if (cacheable) tab = mc->tab;
+    else if (!rc) rc = c->ar.alloc(&tab, (size_t)npairs * ntab);
     if (!rc) rc = c->ar.alloc(&Ex, (size_t)rows_blk * mp);
     if (!rc) rc = c->ar.alloc(&Pio, (size_t)rows_blk * mp);
     if (!rc) rc = c->ar.alloc(&Xhat, (size_t)rows_blk * m * d);
@@ -1808,8 +1874,9 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (!rc) {
         launch_zero(c->st, c->Phi, np * mp);
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
-        launch_pmc(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, c->Sig, c->iSig, prd, wd,
-                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi, work2);
+        launch_pmc(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, SigU, iSigU, prd, wd,
+                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi, work2,
+                   hit);
         launch_slab_sum(c->st, part, nchunk, 3 * k * np, sums);
         launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
                           c->lnbeta, nullptr, phiw);
@@ -1835,6 +1902,16 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     }
     if (hipStreamSynchronize(c->st) != hipSuccess && !rc) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: sync failed");
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: kernel failed");
+    if (cacheable && !hit) {
+        if (rc) mc->drop();            // never keep tables of a call that failed
+        else {
+            mc->m = (int)m; mc->d = d; mc->k = (int)k; mc->mid = c->mid; mc->hetero = (int)c->hetero;
+            mc->theta.assign(theta, theta + c->p);
+            mc->w.assign(w, w + m * k);
+            mc->iS.assign(iSigma_w, iSigma_w + m * m * k);
+        }
+    }
+    mc_lock.unlock();
     free_eval_ctx(c);
     return rc;
 }

@@ -515,7 +515,7 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
                 double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
-                double *work2) {
+                double *work2, bool tab_ready) {
     PmcPat pt;
     pt.d = d; pt.no = 0; pt.nu = 0;
     for (int c = 0; c < d; ++c) {
@@ -531,8 +531,9 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
     // GPZ_PMC_SCRATCH=1 (developer switch): keep the scratch-resident kernels, to compare the two routes on one input
     const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !getenv("GPZ_PMC_SCRATCH");
     hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec);
-    hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
-                       (const double *)rec, nrec, w, v, iS, tab, ntab);
+    if (!tab_ready)   // the pair table depends on theta, w, iSigma_w only: predict.m calls once per NaN-pattern group with the same model
+        hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
+                           (const double *)rec, nrec, w, v, iS, tab, ntab);
     double *CUT = work2, *ptab = work2 ? work2 + (size_t)m * (d * (d + 1) / 2) : nullptr;
     if (fast) {
         if (!Psi3) hipLaunchKernelGGL(k_pmc_cut, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, (const double *)rec, nrec, CUT);

@@ -273,7 +273,8 @@ const char *gpz_last_error(void);
 int gpz_version(void);
 
 /* Device buffers released by contexts and stand-alone calls are kept (up to 4 GiB per device) for the next call instead of
- * being returned to the runtime one hipFree at a time; this hands all of them back.  No reference counterpart. */
+ * being returned to the runtime one hipFree at a time, and gpz_predict_missing (GC/VC) keeps the last model's covariance and
+ * basis-pair tables on the device for the next NaN-pattern group; this hands all of that back.  No reference counterpart. */
 void gpz_release_cached_memory(void);
 
 #ifdef __cplusplus

@@ -1181,3 +1181,34 @@ def test_graph_replay_of_the_evaluation_is_bitwise_the_plain_launch_sequence(met
         assert fb != f1
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_model_tables_kept_between_nan_pattern_groups_are_keyed_by_contents():
+    """gpz_predict_missing (GC/VC) keeps Sigma_j / inv(Sigma_j) and the basis-pair table of the last model on the device for the
+    next NaN-pattern group (predict.m:60-69 calls once per group).  The key is the CONTENT of theta, w, iSigma_w: two models that
+    share theta but not w / iSigma_w, and one with another theta, predicted alternately, each against the oracle; releasing the
+    cache in between changes nothing."""
+    d, m, k = 5, 7, 1
+    model, theta, X, Y, _, rng = make_problem(300, d, m, k, "VC", True, seed=812)
+    Y2 = Y + 0.5 * rng.standard_normal(Y.shape)
+    pri = rng.random(m) + 0.2
+    pri /= pri.sum()
+    models = []
+    for th, yy in ((theta, Y), (theta, Y2), (theta + 0.02 * rng.standard_normal(theta.size), Y)):
+        r4 = O.GPz(th, model, X, yy, nargout=4)
+        mdl = gpz_amd.Model(m=m, d=d, k=k, method="VC", heteroscedastic=True)
+        mdl.sets["best"] = {"theta": th, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
+        omdl = O.Model(m=m, d=d, k=k, method="VC", heteroscedastic=True)
+        omdl.sets["best"] = dict(mdl.sets["best"])
+        models.append((mdl, omdl))
+    Xs = rng.standard_normal((14, d))
+    Xs[:5, 1] = np.nan
+    Xs[5:, [0, 3]] = np.nan
+    refs = [O.predict_any(Xs, om) for _, om in models]
+    for order in ((0, 1, 0, 2, 1, 2, 0), (2, 2, 1)):
+        for q in order:
+            out = gpz_amd.predict(Xs, models[q][0])
+            for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+                assert rel(out[i], refs[q][i]) <= 1e-8, (q, name)
+        _lib.load().gpz_release_cached_memory()
