@@ -1018,7 +1018,7 @@ static int build_phi(gpz_ctx *c) {
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else if (c->psi_fast) {
             launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp,
-                           c->psi_miss ? c->pat_d : nullptr);
+                           c->psi_miss ? c->pat_d : nullptr, c->mid == 4);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else {
             launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
@@ -1310,7 +1310,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else if (c->psi_fast) {
             launch_psi_phi(c->st, gen_rows(c->va), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi_v, c->mp,
-                           c->psi_miss ? c->pat_d : nullptr);
+                           c->psi_miss ? c->pat_d : nullptr, c->mid == 4);
             launch_gen_fill(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->mp, c->k, nullptr);
         } else {
             launch_gen_phi(c->st, gen_rows(c->va), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,

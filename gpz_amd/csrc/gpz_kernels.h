@@ -244,7 +244,7 @@ int launch_cpsi_moments(hipStream_t st, const double *Phi, const double *T, int 
 // the same for 10 < d <= 32 with four pairs per wave (k_cpsi4.hip)
 bool cpsi4_available(int d);
 int launch_cpsi4_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                     const double *lnS, double *Phi, int ld, const unsigned char *pat);
+                     const double *lnS, double *Phi, int ld, const unsigned char *pat, bool shared = false /* GC: one covariance */);
 int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                          const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                          int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
@@ -271,7 +271,7 @@ bool psi_fast_path_available(int d);
 // pat (observed flags [G][d]) non-null: rows carry missing dimensions (r.gid = pattern per row, lnS = [G][m]);
 // chunktab (optional): {first row, end row} per moment chunk
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                   const double *lnS, double *Phi, int ld, const unsigned char *pat);
+                   const double *lnS, double *Phi, int ld, const unsigned char *pat, bool shared = false /* GC: every basis function has the same covariance */);
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                        int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,

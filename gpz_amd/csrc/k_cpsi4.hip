@@ -40,20 +40,22 @@ bool cpsi4_available(int d) {
     }
 
 int launch_cpsi4_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                     const double *lnS, double *Phi, int ld, const unsigned char *pat) {
+                     const double *lnS, double *Phi, int ld, const unsigned char *pat, bool shared) {
     if (!cpsi4_available(d)) return -1;
     if (r.n <= 0) return 0;
+#define PHI_LAUNCH(ND, MS, SH)                                                                                                \
+    hipLaunchKernelGGL((k_cpsi4_phi<ND, MS, SH>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, d, P, Sig, lnS, \
+                       Phi, ld, (MS) ? r.gid : nullptr, (MS) ? pat : nullptr)
 #define PHI_CASE(ND)                                                                                                          \
     do {                                                                                                                      \
-        if (pat)                                                                                                              \
-            hipLaunchKernelGGL((k_cpsi4_phi<ND, true>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, d, P, \
-                               Sig, lnS, Phi, ld, r.gid, pat);                                                               \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((k_cpsi4_phi<ND, false>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Xr, de, r.Psi3, r.n, m, d, \
-                               P, Sig, lnS, Phi, ld, nullptr, nullptr);                                                      \
+        if (pat && shared) PHI_LAUNCH(ND, true, true);                                                                        \
+        else if (pat) PHI_LAUNCH(ND, true, false);                                                                            \
+        else if (shared) PHI_LAUNCH(ND, false, true);                                                                         \
+        else PHI_LAUNCH(ND, false, false);                                                                                    \
     } while (0)
     CPSI4_CASES(PHI_CASE)
 #undef PHI_CASE
+#undef PHI_LAUNCH
     return 0;
 }
 

@@ -150,7 +150,9 @@ __device__ __forceinline__ void c4_sweep(double (&T)[C4_NT(ND)], double *__restr
 }
 
 // PHI: block b of a wave = one sample, loop over the basis functions.  Arguments as k_psi_phi (k_psi.hip).
-template <int ND, bool MISS>
+//   SHARED   GC: every basis function has the same covariance, so M = Sigma + Psi_i is swept ONCE per sample WITH the inverse and a basis
+//            function costs Delta' M^-1 Delta as ND(ND+1)/2 tile products (as the GC branch of k_cpsi4_predict_noisy)
+template <int ND, bool MISS, bool SHARED = false>
 __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double *__restrict__ Xr, int de, const double *__restrict__ Psi3, int n,
                                                     int m, int d, const double *__restrict__ P, const double *__restrict__ Sig,
                                                     const double *__restrict__ lnS, double *__restrict__ Phi, int ld,
@@ -197,9 +199,7 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double
     }
     const int slot = 4 * L.hi + L.lo;
     double held = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double T[C4_NT(ND)];
-        const double *sg = Sig + (size_t)j * d * d;
+    auto build = [&](double (&T)[C4_NT(ND)], const double *sg) {
 #pragma unroll
         for (int I = 0; I < ND; ++I)
 #pragma unroll
@@ -216,15 +216,58 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double
                     T[c4_lt(I, J)] = k ? ps[e] + sg[e] : idn;
                 }
             }
+    };
+    double S[SHARED ? C4_NT(ND) : 1], xc[SHARED ? ND : 1];
+    bool obc[SHARED ? ND : 1];
+    double logdet = 0.0;
+    if (SHARED) {
+        double (&Sf)[C4_NT(ND)] = reinterpret_cast<double (&)[C4_NT(ND)]>(S);
+        build(Sf, Sig);
 #pragma unroll
-        for (int J = 0; J < ND; ++J) {
-            const double pj = P[(size_t)j * de + min(4 * J + L.lo, de - 1)];
-            T[c4_lt(ND, J)] = obx[J] ? xv[J] - pj : 0.0;
+        for (int J = 0; J <= ND; ++J) Sf[c4_lt(ND, J)] = 0.0;
+        c4_sweep<ND, true>(Sf, ex, L, &logdet);                      // -M^-1, M = Sigma + Psi_i (missing dimensions: identity block)
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) Sf[c4_lt(I, J)] *= (I == J) ? -1.0 : -2.0;
+#pragma unroll
+        for (int I = 0; I < ND; ++I) {
+            const int row = 4 * I + L.hi;
+            bool k = L.lo == 0 && row < d;
+            if (MISS && k) k = ob[row];
+            obc[I] = k;
+            xc[I] = k ? Xr[(size_t)ic * de + row] : 0.0;             // x as columns: lane (hi, lo = 0) holds x[4I + hi]
         }
-        T[c4_lt(ND, ND)] = 0.0;
-        double logdet;
-        c4_sweep<ND, false>(T, ex, L, &logdet);
-        const double quad = -__shfl(T[c4_lt(ND, ND)], 4 * L.b, 64);
+    }
+    for (int j = 0; j < m; ++j) {
+        double quad;
+        if (SHARED) {
+            double qq = 0.0, dc[ND];
+#pragma unroll
+            for (int I = 0; I < ND; ++I) dc[I] = obc[SHARED ? I : 0] ? xc[SHARED ? I : 0] - P[(size_t)j * de + min(4 * I + L.hi, de - 1)] : 0.0;
+#pragma unroll
+            for (int J = 0; J < ND; ++J) {
+                const double dr = obx[J] ? xv[J] - P[(size_t)j * de + min(4 * J + L.lo, de - 1)] : 0.0;
+                double h = 0.0;
+#pragma unroll
+                for (int I = J; I < ND; ++I) h = MFMA4(dc[I], S[SHARED ? c4_lt(I, J) : 0], h);   // row 0: sum_I Delta_I' S_IJ
+                qq = fma(h, dr, qq);
+            }
+            qq += __shfl_xor(qq, 1, 64);
+            qq += __shfl_xor(qq, 2, 64);
+            quad = __shfl(qq, 4 * L.b, 64);
+        } else {
+            double T[C4_NT(ND)];
+            build(T, Sig + (size_t)j * d * d);
+#pragma unroll
+            for (int J = 0; J < ND; ++J) {
+                const double pj = P[(size_t)j * de + min(4 * J + L.lo, de - 1)];
+                T[c4_lt(ND, J)] = obx[J] ? xv[J] - pj : 0.0;
+            }
+            T[c4_lt(ND, ND)] = 0.0;
+            c4_sweep<ND, false>(T, ex, L, &logdet);
+            quad = -__shfl(T[c4_lt(ND, ND)], 4 * L.b, 64);
+        }
         const double lns = MISS ? lnS[(size_t)g * m + j] : lnS[j];
         const double lp = -0.5 * quad + 0.5 * lns - 0.5 * logdet + cmiss;               // getPHI.m:86
         if ((j & 15) == slot) held = lp;

@@ -281,8 +281,8 @@ __global__ __launch_bounds__(64) void k_psi_moments(const double *__restrict__ P
 // returns -1 when d is outside the instantiated range (caller falls back to the general kernels).
 // pat != nullptr: rows carry missing dimensions (r.gid, lnS = [G][m]); nullptr: one pattern, lnS = [m].
 int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
-                   const double *lnS, double *Phi, int ld, const unsigned char *pat) {
-    if (cpsi4_available(d)) return launch_cpsi4_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld, pat);   // four pairs per wave on 4 x 4 tiles (k_cpsi4.hip)
+                   const double *lnS, double *Phi, int ld, const unsigned char *pat, bool shared) {
+    if (cpsi4_available(d)) return launch_cpsi4_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld, pat, shared);   // four pairs per wave on 4 x 4 tiles (k_cpsi4.hip)
     if (!pat && cpsi4w_available(d)) return launch_cpsi4w_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld);   // the same up to d = 48 (k_cpsi4w.hip)
     if (d > 10) return launch_cpsi_phi(st, r, m, d, de, P, Sig, lnS, Phi, ld, pat);   // wave-per-pair MFMA elimination (k_cpsi.hip)
     if (r.n <= 0) return (d >= 2 && d <= 10) ? 0 : -1;   // a rank of a sharded run may hold no row of this set
