@@ -1172,9 +1172,14 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             if (c->gen && c->psi32) {
                 int nch, rpc;
                 psi32_chunks(c, &nch, &rpc);
-                launch_psi32_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, c->tr.Xr,
-                                     c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig,
-                                     c->pr.Rc, nch, rpc, c->gen_slab, c->nrec);
+                if (c->tr.psi_diag && psi32m_available(c->d))   // diagonal Psi: the 4 x 4-tile MFMA form (k_psi32m.hip)
+                    launch_psi32m_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, c->tr.Xr,
+                                          c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.n, c->m, c->pr.P, c->pr.Rc, nch, rpc,
+                                          c->gen_slab);
+                else
+                    launch_psi32_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr, c->tr.Xr,
+                                         c->de, c->d, c->tr.PsiT, (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig,
+                                         c->pr.Rc, nch, rpc, c->gen_slab, c->nrec);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
                 launch_psi32_records(c->st, c->psi32_raw, c->d, c->tr.psi_diag, c->m, mom, c->nrec);
                 continue;
@@ -1251,9 +1256,13 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         } else if (c->gen && c->psi32) {
             int nch, rpc;
             psi32_chunks(c, &nch, &rpc);
-            launch_psi32_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, c->tr.Xr, c->de, c->d, c->tr.PsiT,
-                                 (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig, c->pr.Rc, nch, rpc,
-                                 c->gen_slab, c->nrec);
+            if (c->tr.psi_diag && psi32m_available(c->d))
+                launch_psi32m_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, c->tr.Xr, c->de, c->d, c->tr.PsiT,
+                                      (long)c->tr.n_pad, c->tr.n, c->m, c->pr.P, c->pr.Rc, nch, rpc, c->gen_slab);
+            else
+                launch_psi32_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, c->tr.Xr, c->de, c->d, c->tr.PsiT,
+                                     (long)c->tr.n_pad, c->tr.psi_diag, c->tr.n, c->m, c->pr.P, c->Sig, c->pr.Rc, nch, rpc,
+                                     c->gen_slab, c->nrec);
             launch_slab_sum(c->st, c->gen_slab, nch, m * psi32_raw_len(c->d), c->psi32_raw);
             launch_psi32_records(c->st, c->psi32_raw, c->d, c->tr.psi_diag, c->m, mom, c->nrec);
         } else if (c->gen && c->psi_fast) {

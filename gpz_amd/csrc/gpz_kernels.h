@@ -288,6 +288,12 @@ void launch_psi32_finish(hipStream_t st, const double *recs, int m, int d, int d
                          int nrec);
 int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
                      const double *P, const double *Sig, const double *Rc, const double *lnS, double *Phi, int ld);
+// the same sums for DIAGONAL Psi on the matrix pipe (k_psi32m.hip): sixteen pairs per wave on v_mfma_f32_4x4x1_16b_f32; writes the raw
+// layout of launch_psi32_moments (rows_per_chunk any positive number)
+bool psi32m_available(int d);
+int launch_psi32m_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
+                          const double *v, const double *Xr, int de, int d, const float *PsiT, long ldp, int n, int m,
+                          const double *P, const double *Rc, int nchunk, int rows_per_chunk, double *slab);
 int launch_psi32_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                          const double *v, const double *Xr, int de, int d, const float *PsiT, long ldp, int diag, int n, int m,
                          const double *P, const double *Sig, const double *Rc, int nchunk, int rows_per_chunk, double *slab,

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
                                                        const double *__restrict__ v, const double *__restrict__ Xr, int de,
                                                        int d, const float *__restrict__ PsiT, long ldp, int n, int m,
                                                        const double *__restrict__ P, const double *__restrict__ Sig,
-                                                       const double *__restrict__ Rc, int rows_per_chunk,
+                                                       const double *__restrict__ Rc, int nchunk, int rows_per_chunk,
                                                        double *__restrict__ slab, int nrec) {
     constexpr int NP = D * (D + 1) / 2;
     constexpr int H = D / 2;
@@ -336,7 +336,14 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
     __shared__ double acc[JB][NG * 32];
     __shared__ double sPh[JB][64], sTt[JB][64];        // PHI / T of the wave's 64 rows x JB basis functions
     const int lane = threadIdx.x;
-    const int chunk = blockIdx.x, j0 = blockIdx.y * JB;
+    // Workgroup -> (row chunk, basis block), XCD-aware: consecutive workgroup ids go round the 8 XCDs (each with its own L2), so
+    // chunk c belongs to XCD c % 8 and an XCD walks the basis blocks of one chunk before it takes its next chunk.  The chunk's rows of
+    // X and Psi then come from HBM once per chunk (not once per basis block: 250 blocks at m = 2000), and the two halves of a 128-byte
+    // line of PHI / T (two basis blocks) are read by neighbours in time.  Fabric-side bytes of a launch at config 5's shard: 34 GB
+    // with blockIdx.x = chunk, blockIdx.y = block; the algorithmic 8 GB are PHI and T read once.
+    const int njb = (m + JB - 1) / JB, xcd = blockIdx.x & 7, tseq = blockIdx.x >> 3;
+    const int chunk = (tseq / njb) * 8 + xcd, j0 = (tseq % njb) * JB;
+    if (chunk >= nchunk) return;                       // (the grid is padded to a multiple of 8 chunks)
     stage_params<D, JB, DIAG>(lane, 64, j0, m, d, de, Sig, Rc, P, sS, sP);
     for (int e = lane; e < JB * NG * 32; e += 64) (&acc[0][0])[e] = 0.0;
     __syncthreads();
@@ -592,11 +599,11 @@ int launch_psi32_moments(hipStream_t st, const double *Phi, const double *T, int
 #define MOM_CASE(DD)                                                                                                    \
     do {                                                                                                                \
         if (diag)                                                                                                       \
-            hipLaunchKernelGGL((k_psi32_moments<DD, true>), dim3(nchunk, (m + 7) / 8), dim3(64), 0, st, Phi, T, ld, rowscal, w, \
-                               v, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, rows_per_chunk, slab, nrec);                  \
+            hipLaunchKernelGGL((k_psi32_moments<DD, true>), dim3((nchunk + 7) / 8 * 8 * ((m + 7) / 8)), dim3(64), 0, st, Phi, T, ld, \
+                               rowscal, w, v, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, nchunk, rows_per_chunk, slab, nrec); \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_psi32_moments<DD, false>), dim3(nchunk, (m + 7) / 8), dim3(64), 0, st, Phi, T, ld, rowscal, \
-                               w, v, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, rows_per_chunk, slab, nrec);               \
+            hipLaunchKernelGGL((k_psi32_moments<DD, false>), dim3((nchunk + 7) / 8 * 8 * ((m + 7) / 8)), dim3(64), 0, st, Phi, T, ld, \
+                               rowscal, w, v, Xr, de, d, PsiT, ldp, n, m, P, Sig, Rc, nchunk, rows_per_chunk, slab, nrec); \
     } while (0)
     PSI32_CASES(MOM_CASE)
 #undef MOM_CASE

@@ -848,6 +848,32 @@ def test_pinv_golden_through_c_abi(name):
     assert rel(Xi, z["Xi"]) <= 1e3 * (s[0] / s[r - 1]) * 2.2e-16
 
 
+@pytest.mark.parametrize("shape", [(300, 3, 8, 1), (420, 7, 37, 2), (500, 10, 70, 1), (333, 14, 20, 1), (500, 20, 17, 1), (260, 20, 130, 1)])
+def test_f32_moments_on_4x4_mfma_tiles(shape, monkeypatch):
+    """The moment sums of the fp32 diagonal-Psi route on v_mfma_f32_4x4x1_16b_f32 (k_psi32m.hip, opt-in by GPZ_PSI32_MFMA=1: sixteen
+    pairs per wave, bordered elimination without square roots) against the oracle at the fp32 tolerances and against the
+    lane-per-pair kernel; the objective does not involve the moment kernel and must not move at all.  Shapes cover every tile count
+    (d = 3 ... 20), basis counts that are not multiples of 16 or 64, k = 2 (dPHI handed over, no row scalars) and chunks that end
+    inside a flush interval."""
+    n, d, m, k = shape
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, "VC", True, seed=401 + d, psi=True)
+    theta = _well_conditioned_gamma(model, theta, rng)
+    Psi = np.zeros((d, d, n))
+    Psi[np.arange(d), np.arange(d), :] = rng.gamma(1.0, 0.2, (d, n))
+    tr = rng.random(n) < 0.85
+    ref = O.GPz(theta, model, X, Y, Psi, None, tr, ~tr)
+    out = {}
+    for route in ("0", "1"):
+        monkeypatch.setenv("GPZ_PSI32_MFMA", route)
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, None, tr, ~tr, dtype="f32")
+        out[route] = ctx.eval(theta)
+        ctx.close()
+    assert out["1"][0] == out["0"][0]
+    assert abs(out["1"][0] - ref.nlogML) <= F32_FTOL * abs(ref.nlogML)
+    assert rel(out["1"][1], ref.grad) <= F32_GTOL
+    assert rel(out["1"][1], out["0"][1]) <= F32_GTOL and not np.array_equal(out["1"][1], out["0"][1])
+
+
 def test_f32_whitened_gradient_is_stable_for_ill_conditioned_gamma():
     """dtype = f32 with diagonal Psi: dGamma_j is chained through the QR factor of Gamma_j (dGamma = -Q C~' R^-T), not through
     Sigma_j = inv(Gamma_j'Gamma_j) twice as GPz.m:174-180 does.  For a basis function with cond(Gamma_j'Gamma_j) = 1e10 the
