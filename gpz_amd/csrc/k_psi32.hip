@@ -40,6 +40,14 @@
 // diagonal; that slot is junk during the factorisation (never read as a row-c value) and is set to zero in the inverse
 // factor, where whole columns enter dot products.  D(D+2)/4 pairs instead of D(D+1)/2 scalars: 110 vs 210 at D = 20.
 typedef float f2 __attribute__((ext_vector_type(2)));
+// A scalar add the SLP vectoriser cannot see: it turns two independent adds of register halves (the horizontal sums of packed dot
+// products, the adds behind the lane swaps of reduce32) into THREE moves that build aligned pairs and one v_pk_add_f32 - four issue
+// slots instead of two (500 v_mov_b32 per pair and wave in k_psi32_moments<20>).
+__device__ __forceinline__ float addf(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f2 sp(float x) {
     f2 r;
     r.x = x;
@@ -293,12 +301,12 @@ __device__ __forceinline__ void reduce32(float (&v)[32], int lane) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 16]), false, false);
-        v[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        v[k] = addf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 8]), false, false);
-        v[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        v[k] = addf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     }
 #pragma unroll
     for (int s = 4, bit = 8; s >= 1; s >>= 1, bit >>= 1) {
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
                     f2 s2 = L[P2(a / 2, a)] * y[a / 2];
 #pragma unroll
                     for (int t = a / 2 + 1; t < H; ++t) s2 += L[P2(t, a)] * y[t];
-                    u[a] = s2.x + s2.y;
+                    u[a] = addf(s2.x, s2.y);
                 }
             }
             // Values in record order, pushed 32 at a time through the wave reduction and added to the fp64
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(64) void k_psi32_moments(const double *__restrict__
                     f2 m2 = L[P2(a / 2, a)] * L[P2(a / 2, b)];                         // Minv(a,b) = sum_q W[q][a] W[q][b]
 #pragma unroll
                     for (int t = a / 2 + 1; t < H; ++t) m2 += L[P2(t, a)] * L[P2(t, b)];
-                    push(dp * (u[a] * u[b] - (m2.x + m2.y)));                          // GPz.m:174
+                    push(dp * (u[a] * u[b] - addf(m2.x, m2.y)));                          // GPz.m:174
                 }
 #pragma unroll
             for (int e = NV; e < NG * 32; ++e) push(0.f);
