@@ -86,8 +86,17 @@ static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
 // missing values would otherwise allocate and free once per group); gpz_release_cached_memory() gives everything back.
 #include <map>
 #include <mutex>
-#define GPZ_CACHE_CAP (4096UL << 20)
+#define GPZ_CACHE_CAP_DEFAULT (4096UL << 20)
 #define GPZ_CACHE_BLOCK_MAX (2304UL << 20)
+// GPZ_CACHE_CAP_MB (environment, read once): bytes per device that may stay cached, for hosts that share the GPU with another
+// allocator (PyTorch's, a second process); 0 = no caching at all.  INTEGRATION.md, "device memory".
+static size_t cache_cap() {
+    static const size_t cap = [] {
+        const char *e = getenv("GPZ_CACHE_CAP_MB");
+        return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)GPZ_CACHE_CAP_DEFAULT;
+    }();
+    return cap;
+}
 struct DevCache {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> blocks;   // (device, bytes) -> pointer
@@ -111,27 +120,44 @@ static bool cache_give(int dev, size_t bytes, void *p) {
     if (bytes > GPZ_CACHE_BLOCK_MAX) return false;
     DevCache &c = dev_cache();
     std::lock_guard<std::mutex> g(c.mu);
-    if (c.held[dev] + bytes > GPZ_CACHE_CAP) return false;
+    if (c.held[dev] + bytes > cache_cap()) return false;
     c.blocks.insert({{dev, bytes}, p});
     c.held[dev] += bytes;
     return true;
 }
+// Frees the cached blocks only.  This is what a failed hipMalloc retries with: it takes no lock but the block cache's own, so it
+// is safe under a model-table entry's mutex (predict_missing_cov allocates while it holds one - calling the full release there
+// locked that same non-recursive mutex again, and would have freed the tables the call was using).
+static void cache_release_blocks() {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : c.blocks) {
+        (void)hipSetDevice(kv.first.first);
+        (void)hipFree(kv.second);
+    }
+    (void)hipSetDevice(cur);
+    c.blocks.clear();
+    c.held.clear();
+}
 static void pmc_model_cache_release_all();
 extern "C" void gpz_release_cached_memory(void) {
-    {
-        DevCache &c = dev_cache();
-        std::lock_guard<std::mutex> g(c.mu);
-        int cur = 0;
-        (void)hipGetDevice(&cur);
-        for (auto &kv : c.blocks) {
-            (void)hipSetDevice(kv.first.first);
-            (void)hipFree(kv.second);
-        }
-        (void)hipSetDevice(cur);
-        c.blocks.clear();
-        c.held.clear();
-    }
-    pmc_model_cache_release_all();   // after the block cache's lock is gone: a running prediction holds its model entry and takes the block cache inside
+    cache_release_blocks();
+    pmc_model_cache_release_all();   // after the block cache's lock is gone; entries a running prediction holds are skipped
+}
+// test hook (GPZ_TEST_FAIL_ALLOC=<k>, read at every allocation): the k-th hipMalloc from now on reports out-of-memory once, so the
+// retry path can be exercised without exhausting 288 GB
+static bool alloc_fault_due() {
+    static std::mutex mu;
+    static long countdown = -1;
+    static std::string seen;
+    const char *e = getenv("GPZ_TEST_FAIL_ALLOC");
+    if (!e) return false;
+    std::lock_guard<std::mutex> g(mu);
+    if (seen != e) { seen = e; countdown = atol(e); }
+    if (countdown <= 0) return false;
+    return --countdown == 0;
 }
 
 struct Arena {
@@ -145,11 +171,13 @@ struct Arena {
         const size_t nb = count * sizeof(T);
         int dev = 0;
         (void)hipGetDevice(&dev);
-        void *q = cache_take(dev, nb);
+        const bool fault = alloc_fault_due();   // (test hook: this allocation finds neither a cached block nor memory at first)
+        void *q = fault ? nullptr : cache_take(dev, nb);
         if (!q) {
-            hipError_t e = hipMalloc(&q, nb);
-            if (e != hipSuccess) {   // the cache may be what is in the way: give it back and try once more
-                gpz_release_cached_memory();
+            hipError_t e = fault ? hipErrorOutOfMemory : hipMalloc(&q, nb);
+            if (e != hipSuccess) {   // the block cache may be what is in the way: give it back and try once more
+                (void)hipGetLastError();
+                cache_release_blocks();
                 e = hipMalloc(&q, nb);
             }
             if (e != hipSuccess) return fail(GPZ_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", nb, hipGetErrorString(e));
@@ -162,7 +190,15 @@ struct Arena {
     void release() {
         // one device synchronisation per release (hipFree did one per block): nothing may still be running on a block that
         // the next caller - possibly on another stream - takes from the cache
-        if (!blks.empty()) (void)hipDeviceSynchronize();
+        int cur = 0, last = -1;
+        (void)hipGetDevice(&cur);
+        for (const Blk &b : blks)
+            if (b.dev != last) {   // (every block of an arena normally sits on one device: one synchronisation)
+                (void)hipSetDevice(b.dev);
+                (void)hipDeviceSynchronize();
+                last = b.dev;
+            }
+        if (last != -1 && last != cur) (void)hipSetDevice(cur);
         for (const Blk &b : blks)
             if (!cache_give(b.dev, b.bytes, b.p)) {
                 (void)hipFree(b.p);
@@ -1799,7 +1835,8 @@ static void pmc_model_cache_release_all() {
     (void)hipGetDeviceCount(&ndev);
     for (int dev = 0; dev < ndev; ++dev) {
         PmcModelCache *e = pmc_model_cache(dev);
-        std::lock_guard<std::mutex> g(e->mu);
+        std::unique_lock<std::mutex> g(e->mu, std::try_to_lock);
+        if (!g.owns_lock()) continue;      // a prediction is using this entry right now (possibly this very thread): leave it
         if (!e->Sig && !e->tab) continue;
         (void)hipSetDevice(dev);
         e->drop();

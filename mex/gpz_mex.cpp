@@ -169,7 +169,9 @@ static void ensure_context(const mxArray *const *args) {
     const mxArray *model = args[0];
     closure_key key;
     key_of(model, args + 1, &key);
-    if (g_mg && !memcmp(&key, &g_key, sizeof key)) return;
+    // a handle a failed rank has left dead (GPZ_ERR_COMM with the RCCL reducer) is rebuilt like a changed closure: a MATLAB caller has no
+    // other way to get rid of it than gpz_mex('reset')
+    if (g_mg && gpz_mgpu_alive(g_mg) && !memcmp(&key, &g_key, sizeof key)) return;
     cleanup();
     const mxArray *X = args[1], *Y = args[2], *Psi = args[3], *om = args[4];
     need_double(X, "X", 0); need_double(Y, "Y", 0); need_double(Psi, "Psi", 1); need_double(om, "omega", 1);

@@ -1210,6 +1210,52 @@ def test_graph_replay_of_the_evaluation_is_bitwise_the_plain_launch_sequence(met
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kth", [1, 3, 9, 17])
+def test_allocation_failure_inside_predict_missing_retries_without_deadlock(kth, monkeypatch):
+    """A hipMalloc that fails inside gpz_predict_missing (GC/VC) - while the call holds the model-table entry of its device - gives the
+    cached BLOCKS back and retries; it must not take the entry's own (non-recursive) mutex again or free the tables the call is
+    using.  The fault is injected by GPZ_TEST_FAIL_ALLOC = k: the k-th allocation from now on reports out-of-memory
+    once.  Run in a worker process under a timeout so that a regression shows up as a failure, not as a hung suite."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_alloc_fault_worker, args=(kth, q))
+    p.start()
+    p.join(180)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("gpz_predict_missing hung after an injected allocation failure")
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
+
+
+def _alloc_fault_worker(kth, q):
+    import os
+    d, m, k = 5, 7, 1
+    model, theta, X, Y, _, rng = make_problem(300, d, m, k, "VC", True, seed=812)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = np.full(m, 1.0 / m)
+    mdl = gpz_amd.Model(m=m, d=d, k=k, method="VC", heteroscedastic=True)
+    mdl.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
+    omdl = O.Model(m=m, d=d, k=k, method="VC", heteroscedastic=True)
+    omdl.sets["best"] = dict(mdl.sets["best"])
+    Xs = rng.standard_normal((14, d))
+    Xs[:5, 1] = np.nan
+    Xs[5:, [0, 3]] = np.nan
+    ref = O.predict_any(Xs, omdl)
+    gpz_amd.predict(Xs, mdl)                               # warm: the model tables and the block cache are populated
+    os.environ["GPZ_TEST_FAIL_ALLOC"] = str(kth)
+    out = gpz_amd.predict(Xs, mdl)
+    os.environ.pop("GPZ_TEST_FAIL_ALLOC")
+    for i in range(6):
+        assert rel(out[i], ref[i]) <= 1e-8, i
+    out = gpz_amd.predict(Xs, mdl)                         # and the cache still serves the next call
+    for i in range(6):
+        assert rel(out[i], ref[i]) <= 1e-8, i
+    q.put("ok")
+
+
+@pytest.mark.gpu
 def test_model_tables_kept_between_nan_pattern_groups_are_keyed_by_contents():
     """gpz_predict_missing (GC/VC) keeps Sigma_j / inv(Sigma_j) and the basis-pair table of the last model on the device for the
     next NaN-pattern group (predict.m:60-69 calls once per group).  The key is the CONTENT of theta, w, iSigma_w: two models that
