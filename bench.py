@@ -89,6 +89,16 @@ def synth(cfg, n=None):
     theta = np.concatenate([P.ravel(order="F"), G.ravel(order="F"), np.full(m, -math.log(vy)), [math.log(vy)],
                             0.01 * rng.standard_normal(m), np.zeros(m)])
     theta = theta + 0.05 * np.random.default_rng(2).standard_normal(theta.size)
+    if cfg.get("psi") and method == "VC" and cfg.get("gamma", "relative") == "relative":
+        # With input noise the precision matrices are drawn as gamma_j (I + 0.3 N(0,1)/sqrt(d)): cond(Gamma_j'Gamma_j) of a few units.
+        # The absolute 0.05 N(0,1) perturbation above is larger than gamma_j itself at d = 20 (cond up to 7e9), and there the REFERENCE's
+        # dGamma chain through inv(Gamma_j'Gamma_j) (GPz.m:174-180) is rounding noise, so no parity statement about those blocks can be
+        # made against it (cfg["gamma"] = "absolute" keeps that theta for the robustness tests).
+        r3 = np.random.default_rng(3)
+        g0 = m * d
+        for j in range(m):
+            Gj = gam[j] * (np.eye(d) + 0.3 * r3.standard_normal((d, d)) / math.sqrt(d))
+            theta[g0 + j * d * d:g0 + (j + 1) * d * d] = Gj.ravel(order="F")
     return model, theta, X, y, omega
 
 
@@ -349,7 +359,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: n={n} d={cfg['d']} m={m} method={cfg['method']} heteroscedastic k=1"
                                    + (" omega=(1+y-min y)^-2" if cfg["omega"] else "")
-                                   + (f" Psi=diag cubes dtype={dtype}" if cfg.get("psi") else "")
+                                   + (f" Psi=diag cubes (Gamma(1, 0.5) variances) dtype={dtype} Gamma_j=gamma_j(I+0.3 N(0,1)/sqrt(d))" if cfg.get("psi") else "")
                                    + (f" validation={int(va_mask.sum())} rows (training {n_local})" if va_mask is not None else ""),
                        "rows_per_gpu": n_local, "sharding": (f"rows/{world} + all-reduce of the m x m and m x (d^2+d) partials: "
                                                               + ("RCCL inside the library (gpz_ctx_init_rccl)" if comm != "torch"
@@ -429,44 +439,16 @@ def main():
                              "rel_g_max": float(np.max(np.abs(g2 - ref.grad)) / np.max(np.abs(ref.grad))),
                              "cond_sigma": ref.cond, "tol_g": max(1e-8, 50 * ref.cond * 2.2e-16)}
             if cfg.get("psi"):
-                # With input noise the reference's dGamma_j goes through Sigma_j = inv(Gamma_j'Gamma_j) twice (GPz.m:146-181)
-                # and loses cond(Gamma_j'Gamma_j)^2 * eps: for the worst-conditioned basis functions of this theta the
-                # oracle's own gradient is off (tools/c5_parity_by_cond.py, tools/c5_grad_check.py).  Report the
-                # comparison separately for the basis functions where the reference formula is trustworthy.
-                from oracle import gpz_oracle as O
+                # conditioning of the precision matrices of this theta (synth draws them with cond of a few units: the reference's
+                # dGamma chain through inv(Gamma_j'Gamma_j), GPz.m:174-180, keeps its digits and rel_g_max is gated as it stands)
                 m_, d_ = cfg["m"], cfg["d"]
                 Gm = theta0[m_ * d_:m_ * d_ + d_ * d_ * m_].reshape((d_, d_, m_), order="F")
                 cg = np.array([np.linalg.cond(Gm[:, :, j].T @ Gm[:, :, j]) for j in range(m_)])
-                err = np.abs(g2 - ref.grad) / np.max(np.abs(ref.grad))
-                eG = err[m_ * d_:m_ * d_ + d_ * d_ * m_].reshape((d_, d_, m_), order="F").max(axis=(0, 1))
-                ok = cg <= 1e6
-                rest = np.r_[0:m_ * d_, m_ * d_ + d_ * d_ * m_:theta0.size]
-                # the judge for the ill-conditioned ones: central differences of the fp64 objective along the dGamma block of
-                # the worst-conditioned basis function
-                jw = int(np.argmax(cg))
-                v = np.zeros(theta0.size)
-                blk = slice(m_ * d_ + d_ * d_ * jw, m_ * d_ + d_ * d_ * (jw + 1))
-                v[blk] = np.random.default_rng(5).standard_normal(d_ * d_)
-                v /= np.linalg.norm(v)
-                c64 = gpz_amd.GPzContext(model, X[:rows], y[:rows], synth_psi(cfg, np.arange(rows)), device=local_rank)
-                hh = 1e-5
-                fd = (c64.eval(theta0 + hh * v)[0] - c64.eval(theta0 - hh * v)[0]) / (2 * hh)
-                c64.close()
-                out["parity"]["worst_conditioned_basis"] = {
-                    "cond": float(cg[jw]), "fd_directional": float(fd), "hip_g_dot_v": float(g2 @ v),
-                    "oracle_g_dot_v": float(ref.grad @ v),
-                    "note": ("dtype=f32 with diagonal Psi chains dGamma through the QR factor of Gamma_j (stable); the "
-                             "reference chain goes through inv(Gamma_j'Gamma_j) twice") if f32_route else
-                            ("fp64 route: the reference's own chain through inv(Gamma_j'Gamma_j) twice (GPz.m:146-181), as the oracle; at this "
-                             "conditioning both are rounding noise around the central difference (DESIGN.md section 4)")}
-                # the fp64 gate does not apply to the fp32 path: its gate is tol_f32 on the well-conditioned basis functions
-                out["parity"]["tol_g"] = 1e-3 if f32_route else 1e-5   # fp64 route: 10 cond^1.5 eps at cond = 1e6
-                out["parity"]["gated_quantity"] = "rel_g_max_cond_le_1e6 (rel_g_max spans basis functions whose reference gradient is rounding noise)"
-                out["parity"].update({"dtype": dtype, **({"tol_f32": {"f": 1e-4, "g": 1e-3}} if f32_route else {}),
-                                      "rel_g_max_cond_le_1e6": float(max(eG[ok].max() if ok.any() else 0.0, err[rest].max())),
-                                      "bases_cond_gt_1e6": int((~ok).sum()), "max_cond_gamma": float(cg.max()),
-                                      "note": "rel_g_max includes dGamma_j of basis functions with cond(Gamma_j'Gamma_j) > 1e6, "
-                                              "where the reference formula itself loses cond^2*eps"})
+                out["parity"].update({"dtype": dtype, "max_cond_gamma": float(cg.max()),
+                                      "tol_f": 1e-4 if f32_route else 1e-8,
+                                      "tol_g": 1e-3 if f32_route else max(1e-8, 50 * max(ref.cond, float(cg.max()) ** 1.5) * 2.2e-16)})
+            out["parity"]["pass"] = bool(out["parity"]["rel_f"] <= out["parity"].get("tol_f", 1e-8) and
+                                         out["parity"]["rel_g_max"] <= out["parity"]["tol_g"])
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
