@@ -325,14 +325,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tim = ctx.timings()
+    route = ctx.route() if hasattr(ctx, "route") else None
     per_rank = None
     if multi:
-        per_rank = [{"rank": r, "rows": ctx.rows_per_gpu[r],
+        per_rank = [{"rank": r, "rows": ctx.rows_per_gpu[r], "rccl": rccl_origin,
                      "stage_ms_per_eval": {k: v[0] / args.steps for k, v in ctx.timings(r).items()}} for r in range(ctx.n_gpus)]
     elif use_dist:
-        mine = {"rank": rank, "rows": n_local, "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}}
+        # per rank: its rows, every stage (allreduce1 / allreduce2 are the two exchange points) and the RCCL it bound - the first
+        # real multi-GPU line can be read stage by stage against the single-GPU shard line (profiles/*_shard125k.json)
+        mine = {"rank": rank, "rows": n_local, "comm": comm, "rccl": rccl_origin, "route": route,
+                "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}}
         per_rank = [None] * world if rank == 0 else None
         dist.gather_object(mine, per_rank, dst=0)
+    # Second pass with stage timing OFF: the evaluation is then replayed as one hipGraph (~40 launches; the timed region above
+    # records HIP events around every stage, which keeps it on eager launches).  Matters for the latency-bound configurations only.
+    graph_pass = None
+    if not use_dist and not multi:
+        ctx.enable_timing(False)
+        for i in range(max(3, args.warmup)):
+            ctx.eval(thetas[i % len(thetas)])
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        for i in range(args.steps):
+            ctx.eval(thetas[args.warmup + i])
+        torch.cuda.synchronize()
+        tg1 = time.perf_counter() - tg0
+        graph_pass = {"ms_per_step": tg1 / args.steps * 1e3, "evals_per_s": args.steps / tg1, "route": ctx.route(),
+                      "note": "same K steps, stage timing off: one hipGraph launch per evaluation"}
     finite = bool(np.isfinite(fs).all() and np.isfinite(g).all())
 
     out = None
@@ -389,6 +408,10 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if route:
+            out["route"] = route
+        if graph_pass:
+            out["graph_pass"] = graph_pass
         if cfg.get("psi") and not f32_route:
             # config 5 in fp64: the per-pair sweeps of k_cpsi4.hip (four pairs per wave on v_mfma_f64_4x4x4).  Algorithmic work per
             # (sample, basis) pair at d = 20 in the M = Psi + Sigma form: PHI d^3/6 + d^2 = 1733 FMA, moments d^3/2 + 2 d^2 = 4800 FMA.

@@ -61,6 +61,7 @@ SYMBOLS = {
     "gpz_ctx_last_pinv": (C.c_int, [C.c_void_p, c_double_p]),
     "gpz_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "gpz_ctx_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_double_p, C.POINTER(C.c_int64), C.c_int]),
+    "gpz_ctx_route": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gpz_ctx_reset_timings": (C.c_int, [C.c_void_p]),
     "gpz_phi": (C.c_int, [C.POINTER(gpz_desc), c_double_p, c_double_p, C.c_int64, c_double_p, C.c_int32, c_double_p,
                           c_double_p, c_double_p]),

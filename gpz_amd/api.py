@@ -243,6 +243,12 @@ class GPzContext:
         n = self._lib.gpz_ctx_timings(self._h, names, ms, calls, cap)
         return {names[i].decode(): (ms[i], int(calls[i])) for i in range(min(n, cap))}
 
+    def route(self):
+        """Which kernels this context runs and the state of its evaluation graph (gpz_ctx_route), as one line of text."""
+        buf = C.create_string_buffer(512)
+        self._lib.gpz_ctx_route(self._h, buf, 512)
+        return buf.value.decode()
+
 
 class GPzMulti:
     """The same closure on several GPUs behind ONE synchronous call (gpz_mgpu_* of the C ABI): the library splits the

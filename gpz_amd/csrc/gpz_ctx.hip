@@ -924,6 +924,31 @@ extern "C" int gpz_ctx_timings(gpz_ctx *c, const char **names, double *ms, int64
     return n;
 }
 
+// Which kernels this context runs, in words, and where the evaluation graph stands: a caller that asked for dtype = f32 learns
+// here whether its rows actually take the fp32 pair kernels (input noise, no missing dimension, d <= 20) or the fp64 ones, and a
+// bench line can show a graph capture that failed instead of silently timing eager launches.
+extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
+    if (!c || !buf || cap <= 0) return fail(GPZ_ERR_ARG, "gpz_ctx_route: null argument");
+    const bool f32req = c->desc.dtype == GPZ_F32;
+    const char *phi, *why = "";
+    if (!c->gen) phi = c->d > 20 ? "tuned diagonal / covariance kernels, runtime-d form (k_wide)" : "tuned kernels (k_phi, k_rows)";
+    else if (!c->has_psi) phi = "covariance kinds with missing dimensions: tuned kernels per NaN pattern";
+    else if (c->psi32) phi = (c->tr.psi_diag && psi32m_available(c->d))
+                                 ? "fp32 pair kernels: k_psi32_phi + k_psi32m_moments (4x4 MFMA tiles)" : "fp32 pair kernels (k_psi32)";
+    else if (c->psi_fast) phi = c->d <= 10 ? "fp64 pair kernels in registers (k_psi)"
+                                : cpsi4_available(c->d) ? "fp64 pair kernels on 4x4 f64 MFMA tiles (k_cpsi4)" : "fp64 pair kernels on MFMA tiles (k_cpsi4w / k_cpsi)";
+    else phi = "fp64 pair kernels, workspace form (k_gen)";
+    if (f32req && !c->psi32)
+        why = !c->gen || !c->has_psi ? " [dtype f32 requested: no input noise on a covariance kind, nothing runs in fp32]"
+              : c->d > 20            ? " [dtype f32 requested: d > 20 has no fp32 pair kernel, fp64 route]"
+                                     : " [dtype f32 requested: rows with missing dimensions, fp64 route]";
+    const char *gs = c->graph_state == 2 ? "replayed" : c->graph_state == -1 ? "disabled (capture failed or GPZ_NO_GRAPH)"
+                     : c->timing ? "off (stage timing on)" : c->desc.world > 1 ? "off (sharded)" : "eager (not captured yet)";
+    const bool f32mm = c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF");
+    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA; evaluation graph: %s", phi, why,
+                    f32mm ? "fp32-operand (fp64 master sums)" : "fp64", gs);
+}
+
 // ---- pipeline stages -----------------------------------------------------------------------------
 static GenRows gen_rows(const RowSet &rs) {
     GenRows r{};
@@ -1436,7 +1461,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
     (void)g_dev;
     HIPCHK(hipSetDevice(c->device));
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
-    static const bool no_graph = getenv("GPZ_NO_GRAPH") != nullptr;
+    const bool no_graph = getenv("GPZ_NO_GRAPH") != nullptr;   // (read per call: one process can compare replay with eager launches)
     const bool graphable = theta && !c->g_dev_out && c->desc.world <= 1 && !c->timing && c->pinv_mode != 1 && !no_graph &&
                            c->graph_state >= 0;
     bool done = false;

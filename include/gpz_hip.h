@@ -157,6 +157,10 @@ int gpz_ctx_last_pinv(const gpz_ctx *ctx, double out[4]);
 int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);
 int gpz_ctx_timings(gpz_ctx *ctx, const char **names, double *ms, int64_t *calls, int cap);
 int gpz_ctx_reset_timings(gpz_ctx *ctx);
+/* Which kernel family this context's rows run on (e.g. dtype = GPZ_F32 with missing values or d > 20 takes the fp64 pair kernels:
+ * said here instead of silently), which MFMA operand type the contractions use, and the state of the captured evaluation graph
+ * ("replayed" / "eager" / "disabled").  Writes a NUL-terminated description of at most cap bytes; returns its full length. */
+int gpz_ctx_route(const gpz_ctx *ctx, char *buf, int cap);
 
 /* [PHI,~,lnBeta_i,N] = getPHI(X,Psi,theta,model,[]) on ns rows: PHI ns x m, lnBeta_i ns x k, N ns x m
  * (column-major, host; any output may be NULL).  Psi / psi_kind as in gpz_ctx_create; X may contain NaN. */

@@ -1280,6 +1280,49 @@ def _alloc_fault_worker(kth, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["tuned_VD", "tuned_VC_k2", "cov_missing", "psi_fp64_d5", "psi_fp64_d12", "psi32", "psi32_mfma", "validation_rows"])
+def test_graph_replay_is_bitwise_the_eager_evaluation(route, monkeypatch):
+    """From the third gpz_eval on an evaluation is one hipGraph replay; every host-side decision made during the capture is frozen
+    into it (route flags, grid sizes, the per-pattern launch loops).  Five evaluations at five thetas per route, replayed vs eager
+    (GPZ_NO_GRAPH), must agree bit for bit, and the context must say that the graph really ran."""
+    kw = {}
+    if route == "tuned_VD":
+        model, theta, X, Y, Psi, rng = make_problem(900, 6, 20, 1, "VD", True, seed=5)
+    elif route == "tuned_VC_k2":
+        model, theta, X, Y, Psi, rng = make_problem(700, 5, 12, 2, "VC", True, seed=6)
+    elif route == "cov_missing":
+        model, theta, X, Y, Psi, rng = make_problem(600, 4, 9, 1, "VC", True, seed=7, nanfrac=0.3)
+    elif route in ("psi_fp64_d5", "psi_fp64_d12"):
+        model, theta, X, Y, Psi, rng = make_problem(400, 5 if route.endswith("d5") else 12, 8, 1, "VC", True, seed=8, psi=True)
+    elif route in ("psi32", "psi32_mfma"):
+        model, theta, X, Y, _, rng = make_problem(500, 10, 20, 1, "VC", True, seed=9, psi=True)
+        theta = _well_conditioned_gamma(model, theta, rng)
+        Psi = np.zeros((10, 10, 500)); Psi[np.arange(10), np.arange(10), :] = rng.gamma(1.0, 0.2, (10, 500))
+        kw["dtype"] = "f32"
+        monkeypatch.setenv("GPZ_PSI32_MFMA", "1" if route == "psi32_mfma" else "0")
+    else:
+        model, theta, X, Y, Psi, rng = make_problem(800, 5, 15, 1, "VC", True, seed=10)
+    tr = va = None
+    if route == "validation_rows":
+        tr = rng.random(X.shape[0]) < 0.8
+        va = ~tr
+    thetas = [theta + 0.01 * rng.standard_normal(theta.size) for _ in range(5)]
+    res = {}
+    for mode in ("graph", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("GPZ_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("GPZ_NO_GRAPH", raising=False)
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, None, tr, va, **kw)
+        res[mode] = [ctx.eval(t) for t in thetas]
+        txt = ctx.route()
+        ctx.close()
+        assert ("evaluation graph: replayed" in txt) == (mode == "graph"), txt
+    for (f0, g0), (f1, g1) in zip(res["graph"], res["eager"]):
+        assert f0 == f1 and np.array_equal(g0, g1)
+
+
+@pytest.mark.gpu
 def test_model_tables_kept_between_nan_pattern_groups_are_keyed_by_contents():
     """gpz_predict_missing (GC/VC) keeps Sigma_j / inv(Sigma_j) and the basis-pair table of the last model on the device for the
     next NaN-pattern group (predict.m:60-69 calls once per group).  The key is the CONTENT of theta, w, iSigma_w: two models that
