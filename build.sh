@@ -8,7 +8,7 @@ mkdir -p $OUT build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$SRC"
 pids=()
 for f in k_phi k_gemm k_chol k_pinv k_rows k_gen k_psi k_psi32 k_psi32m k_pmiss k_pmiss_cov k_lbfgs k_wide k_cpsi k_cpsi4 k_cpsi4w k_cpsi4wp k_pmc4 gpz_ctx gpz_mgpu; do
-  if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ $SRC/gpz_kernels.h -nt build/$f.o ] || [ $SRC/gpz_dev.h -nt build/$f.o ] || [ $SRC/k_cpsi4_impl.h -nt build/$f.o ] || [ include/gpz_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ $SRC/gpz_kernels.h -nt build/$f.o ] || [ $SRC/gpz_dev.h -nt build/$f.o ] || [ $SRC/k_cpsi4_impl.h -nt build/$f.o ] || [ $SRC/gpz_mgpu_sync.h -nt build/$f.o ] || [ include/gpz_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $SRC/$f.hip -o build/$f.o &
     pids+=($!)
   fi

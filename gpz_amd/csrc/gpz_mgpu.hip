@@ -46,6 +46,7 @@
 
 #include "../../include/gpz_hip.h"
 #include "gpz_kernels.h"
+#include "gpz_mgpu_sync.h"
 
 // ---- RCCL binding ------------------------------------------------------------------------------------------------
 struct RcclApi {
@@ -144,38 +145,8 @@ extern "C" int gpz_device_count(void) {
 }
 
 // ---- single-process multi-device driver ---------------------------------------------------------------------------
-// A barrier that can be poisoned: a rank that fails before an exchange point releases the others with an error
-// instead of leaving them waiting.
-struct Barrier {
-    std::mutex mu;
-    std::condition_variable cv;
-    int n = 1, waiting = 0;
-    unsigned long gen = 0;
-    bool poisoned = false;
-    bool wait() {
-        std::unique_lock<std::mutex> lk(mu);
-        if (poisoned) return false;
-        const unsigned long g = gen;
-        if (++waiting == n) {
-            waiting = 0;
-            ++gen;
-            cv.notify_all();
-            return true;
-        }
-        cv.wait(lk, [&] { return gen != g || poisoned; });
-        return !poisoned;
-    }
-    void poison() {
-        std::lock_guard<std::mutex> lk(mu);
-        poisoned = true;
-        cv.notify_all();
-    }
-    void reset() {
-        std::lock_guard<std::mutex> lk(mu);
-        poisoned = false;
-        waiting = 0;
-    }
-};
+// Barrier, AbortGate, CmdLoop: gpz_mgpu_sync.h (host-only, also compiled under -fsanitize=thread by the tests)
+using gpz_sync::Barrier;
 
 __global__ void k_loopback_sum(double *const *bufs, int nb, size_t count) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
@@ -202,26 +173,17 @@ struct gpz_mgpu {
     std::vector<gpz_ctx *> ctx;
     std::vector<ncclComm_t> comms;
     std::vector<RankSlot> slots;
-    std::vector<std::thread> workers;
-    // command hand-off
-    std::mutex mu;
-    std::condition_variable cv_go, cv_done;
-    unsigned long gen = 0;
-    int cmd = 0, pending = 0;                      // 1 eval, 2 solve, 3 quit
-    const double *theta = nullptr;
+    gpz_sync::CmdLoop core;                        // one persistent thread per rank; commands: 1 eval, 2 solve
     // per-rank results (rank 0's are handed to the caller)
     std::vector<double> f, stats, diag;            // n, 4n, 2n
     std::vector<std::vector<double>> g, w, iS, part;
-    std::vector<int> rc;
     std::vector<std::string> err;
     double *out_w = nullptr, *out_iS = nullptr, *out_part = nullptr;
     // failure handling (RCCL reducer): a rank that fails before or at an exchange point would leave the others inside
     // ncclAllReduce for ever, so the failing rank's thread aborts every communicator of the handle (ncclCommAbort ends
     // the in-flight collectives) and the handle is dead from then on: later calls return GPZ_ERR_COMM.  Enqueues hold
-    // comm_mu shared, the abort holds it exclusively, so no thread enqueues on a communicator that is being freed.
-    std::shared_mutex comm_mu;
-    std::atomic<bool> dead{false};
-    std::string dead_why;
+    // the gate shared, the abort holds it exclusively, so no thread enqueues on a communicator that is being freed.
+    gpz_sync::AbortGate gate;
     int inject_rank = -1, inject_exchange = 0;     // gpz_mgpu_debug_fail_at (tests)
     // loopback reducer
     Barrier bar;
@@ -239,9 +201,13 @@ static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
     }
     if (h->reducer == GPZ_REDUCER_RCCL) {
         RcclApi *api = rccl_api();
-        std::shared_lock<std::shared_mutex> lk(h->comm_mu);
-        if (h->dead.load() || !h->comms[s->rank]) { s->secondary = true; return 1; }
-        return api->AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comms[s->rank], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+        int res = 1;
+        const bool alive = h->gate.enqueue([&] {
+            if (!h->comms[s->rank]) return -1;
+            return api->AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comms[s->rank], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+        }, &res);
+        if (!alive || res < 0) { s->secondary = true; return 1; }
+        return res;
     }
     // loopback: every rank's contribution complete -> rank 0 sums in rank order into all buffers -> everyone continues
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { h->bar.poison(); return 1; }
@@ -263,86 +229,49 @@ static int mgpu_hook(void *user, void *buf, size_t count, void *stream) {
 
 // RCCL reducer, after a failure on one rank: end every in-flight collective of the handle and mark it dead.
 static void abort_comms(gpz_mgpu *h, int r, const char *why) {
-    std::unique_lock<std::shared_mutex> lk(h->comm_mu);
-    if (h->dead.exchange(true)) return;
-    h->dead_why = std::string("rank ") + std::to_string(r) + ": " + (why ? why : "");
-    RcclApi *api = h->comms.empty() ? nullptr : rccl_api();
-    for (ncclComm_t &c : h->comms) {
-        if (api && c) (void)api->CommAbort(c);     // frees the communicator as well: never destroyed again
-        c = nullptr;
-    }
+    h->gate.abort(r, why, [&] {
+        RcclApi *api = h->comms.empty() ? nullptr : rccl_api();
+        for (ncclComm_t &c : h->comms) {
+            if (api && c) (void)api->CommAbort(c);     // frees the communicator as well: never destroyed again
+            c = nullptr;
+        }
+    });
 }
 
-static void worker_main(gpz_mgpu *h, int r) {
-    (void)hipSetDevice(h->dev[r]);
-    unsigned long seen = 0;
-    for (;;) {
-        int cmd;
-        const double *theta;
-        {
-            std::unique_lock<std::mutex> lk(h->mu);
-            h->cv_go.wait(lk, [&] { return h->gen != seen; });
-            seen = h->gen;
-            cmd = h->cmd;
-            theta = h->theta;
-        }
-        if (cmd == 3) return;
-        int rc = 0;
-        h->slots[r].exchange = 0;
-        h->slots[r].secondary = false;
-        if (cmd == 1)
-            rc = gpz_eval(h->ctx[r], theta, &h->f[r], h->g[r].data(), &h->stats[4 * r], &h->diag[2 * r]);
-        else if (cmd == 2)
-            rc = gpz_solve(h->ctx[r], theta, r == 0 ? h->out_w : h->w[r].data(), r == 0 ? h->out_iS : h->iS[r].data(),
-                           !h->out_part ? nullptr : (r == 0 ? h->out_part : h->part[r].data()));   // same branch on every rank
-        h->rc[r] = rc;
-        if (rc) {
-            h->err[r] = gpz_last_error();
-            h->bar.poison();                        // loopback: do not leave the other ranks at an exchange point
-            if (h->reducer == GPZ_REDUCER_RCCL && h->n > 1) abort_comms(h, r, h->err[r].c_str());   // RCCL: nor inside ncclAllReduce
-        }
-        {
-            std::lock_guard<std::mutex> lk(h->mu);
-            if (--h->pending == 0) h->cv_done.notify_all();
-        }
+// the work of rank r for one command (runs on the rank's own thread)
+static int rank_command(gpz_mgpu *h, int r, int cmd, const double *theta) {
+    int rc = 0;
+    h->slots[r].exchange = 0;
+    h->slots[r].secondary = false;
+    if (cmd == 1)
+        rc = gpz_eval(h->ctx[r], theta, &h->f[r], h->g[r].data(), &h->stats[4 * r], &h->diag[2 * r]);
+    else if (cmd == 2)
+        rc = gpz_solve(h->ctx[r], theta, r == 0 ? h->out_w : h->w[r].data(), r == 0 ? h->out_iS : h->iS[r].data(),
+                       !h->out_part ? nullptr : (r == 0 ? h->out_part : h->part[r].data()));   // same branch on every rank
+    if (rc) {
+        h->err[r] = gpz_last_error();
+        h->bar.poison();                        // loopback: do not leave the other ranks at an exchange point
+        if (h->reducer == GPZ_REDUCER_RCCL && h->n > 1) abort_comms(h, r, h->err[r].c_str());   // RCCL: nor inside ncclAllReduce
     }
+    return rc;
 }
 
 static int run_command(gpz_mgpu *h, int cmd, const double *theta) {
-    if (h->dead.load())
+    if (h->gate.is_dead())
         return gpz_fail(GPZ_ERR_COMM, "this multi-GPU handle is dead: its communicators were aborted after a failure (%s); destroy it and "
-                                      "create a new one", h->dead_why.c_str());
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        h->cmd = cmd;
-        h->theta = theta;
-        h->pending = h->n;
-        ++h->gen;
-    }
-    h->cv_go.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(h->mu);
-        h->cv_done.wait(lk, [&] { return h->pending == 0; });
-    }
+                                      "create a new one (the MEX gateway does so on its next call)", h->gate.reason().c_str());
+    h->core.submit(cmd, theta);
     h->bar.reset();
     h->inject_rank = -1;                            // an injected failure fires once
     for (int pass = 0; pass < 2; ++pass)           // the rank whose failure was not the echo of another rank's comes first
         for (int r = 0; r < h->n; ++r)
-            if (h->rc[r] && (pass == 1 || !h->slots[r].secondary))
-                return gpz_fail(h->rc[r], "rank %d (device %d): %s", r, h->dev[r], h->err[r].c_str());
+            if (h->core.rc[r] && (pass == 1 || !h->slots[r].secondary))
+                return gpz_fail(h->core.rc[r], "rank %d (device %d): %s", r, h->dev[r], h->err[r].c_str());
     return GPZ_OK;
 }
 
 static void mgpu_free(gpz_mgpu *h) {
-    if (!h->workers.empty()) {
-        {
-            std::lock_guard<std::mutex> lk(h->mu);
-            h->cmd = 3;
-            ++h->gen;
-        }
-        h->cv_go.notify_all();
-        for (auto &t : h->workers) t.join();
-    }
+    h->core.stop();
     for (int r = 0; r < (int)h->ctx.size(); ++r)
         if (h->ctx[r]) gpz_ctx_destroy(h->ctx[r]);
     RcclApi *api = h->comms.empty() ? nullptr : rccl_api();
@@ -497,7 +426,6 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
     h->stats.assign(4 * n_gpus, 0.0);
     h->diag.assign(2 * n_gpus, 0.0);
     h->g.resize(n_gpus); h->w.resize(n_gpus); h->iS.resize(n_gpus); h->part.resize(n_gpus);
-    h->rc.assign(n_gpus, 0);
     h->err.resize(n_gpus);
     for (int r = 0; r < n_gpus; ++r) {
         h->slots[r].h = h;
@@ -510,7 +438,9 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
         }
         if (n_gpus > 1) (void)gpz_ctx_set_allreduce(h->ctx[r], mgpu_hook, &h->slots[r]);
     }
-    for (int r = 0; r < n_gpus; ++r) h->workers.emplace_back(worker_main, h, r);
+    h->core.init = [h](int r) { (void)hipSetDevice(h->dev[r]); };
+    h->core.run = [h](int r, int cmd, const void *arg) { return rank_command(h, r, cmd, (const double *)arg); };
+    h->core.start(n_gpus);
     *out = h;
     return GPZ_OK;
 }
@@ -630,7 +560,7 @@ extern "C" int gpz_mgpu_debug_fail_at(gpz_mgpu *h, int32_t rank, int32_t exchang
     h->inject_exchange = exchange;
     return GPZ_OK;
 }
-extern "C" int32_t gpz_mgpu_alive(const gpz_mgpu *h) { return (h && !h->dead.load()) ? 1 : 0; }
+extern "C" int32_t gpz_mgpu_alive(const gpz_mgpu *h) { return (h && !h->gate.is_dead()) ? 1 : 0; }
 extern "C" int32_t gpz_mgpu_size(const gpz_mgpu *h) { return h ? h->n : -1; }
 extern "C" int64_t gpz_mgpu_theta_len(const gpz_mgpu *h) { return h ? h->p : -1; }
 extern "C" gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t rank) { return (h && rank >= 0 && rank < h->n) ? h->ctx[rank] : nullptr; }

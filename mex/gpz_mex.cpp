@@ -92,7 +92,12 @@ static gpz_desc desc_of(const mxArray *model, int32_t *n_gpus) {
     d.world = 1;
     const mxArray *dt = mxGetField(model, 0, "dtype");
     char buf[8] = "";
-    if (dt && !mxGetString(dt, buf, sizeof buf) && !strcmp(buf, "f32")) d.dtype = GPZ_F32;
+    if (dt && !mxIsEmpty(dt)) {
+        if (mxGetString(dt, buf, sizeof buf) || (strcmp(buf, "f32") && strcmp(buf, "f64")))
+            mexErrMsgIdAndTxt("gpz:model", "model.dtype must be 'f64' or 'f32'");
+        if (!strcmp(buf, "f32")) d.dtype = GPZ_F32;
+    }
+    if (gpz_theta_len_of(&d) < 0) mexErrMsgIdAndTxt("gpz:model", "model.d, m, k must be >= 1 and model.method one of GL VL GD VD GC VC");
     if (n_gpus) {
         const mxArray *ng = mxGetField(model, 0, "n_gpus");
         *n_gpus = (ng && !mxIsEmpty(ng)) ? (int32_t)mxGetScalar(ng) : 0;       /* 0: every GPU of the node */
@@ -165,6 +170,7 @@ static void key_of(const mxArray *model, const mxArray *const *arr, closure_key 
 
 /* (Re)build the device context when the closure's arguments differ from the live one's.  args: model, X, Y, Psi, omega,
  * training, validation  (GPz.m:1's own argument order after theta). */
+static void need_rows(const gpz_desc *d, const mxArray *X, const mxArray *Psi);
 static void ensure_context(const mxArray *const *args) {
     const mxArray *model = args[0];
     closure_key key;
@@ -177,6 +183,7 @@ static void ensure_context(const mxArray *const *args) {
     need_double(X, "X", 0); need_double(Y, "Y", 0); need_double(Psi, "Psi", 1); need_double(om, "omega", 1);
     int32_t n_gpus = 0;
     gpz_desc d = desc_of(model, &n_gpus);
+    need_rows(&d, X, Psi);   /* the library reads n*d (or d*d*n) doubles of Psi: a smaller array must not reach it */
     const mwSize n = mxGetM(X);
     if (mxGetN(X) != (mwSize)d.d || mxGetM(Y) != n || mxGetN(Y) != (mwSize)d.k)
         mexErrMsgIdAndTxt("gpz:size", "X must be n x model.d and Y n x model.k");
