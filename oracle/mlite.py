@@ -406,7 +406,7 @@ class Parser:
             return ("name", tok[1])
         if tok[1] == "(":
             saved_m, self.in_matrix = self.in_matrix, 0
-            saved_i, self.in_index = self.in_index, 0
+            saved_i = self.in_index                                  # `end` stays legal in a parenthesised part of a subscript: A((end - 1) / 2)
             e = self.parse_expr()
             self.expect(")")
             self.in_matrix, self.in_index = saved_m, saved_i
@@ -414,7 +414,7 @@ class Parser:
         if tok[1] == "[":
             rows, row = [], []
             self.in_matrix += 1
-            saved_i, self.in_index = self.in_index, 0
+            saved_i = self.in_index                                  # ... and in a bracketed one: A(2:end, [1 end])
             while True:
                 t = self.peek()
                 if t[1] == "]":
@@ -504,6 +504,35 @@ def _sqrt(x):
     if np.iscomplexobj(x) or np.any(x < 0):
         return np.sqrt(x.astype(np.complex128))
     return np.sqrt(x)
+
+
+def _log(x):
+    """log of a negative real is complex (log(-1) = 0 + 3.1416i), log(0) = -Inf"""
+    if np.iscomplexobj(x) or np.any(x < 0):
+        return np.log(x.astype(np.complex128))
+    return np.log(x)
+
+
+def _mod(a, b):
+    """mod(a, 0) = a; otherwise the result has the sign of b (floored division)"""
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.mod(a, np.where(b == 0, 1.0, b))
+    return np.where(b == 0, a, r)
+
+
+def _nthroot(x, n):
+    """real n-th root: negative x needs an odd integer n (nthroot(-27, 3) = -3)"""
+    x, n = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(n, dtype=np.float64))
+    if np.any((x < 0) & (np.mod(n, 2) != 1)):
+        raise MError("nthroot: if x is negative, n must be an odd integer")
+    with np.errstate(invalid="ignore"):
+        return np.sign(x) * np.power(np.abs(x), 1.0 / n)
+
+
+def _round_half_away(x):
+    """round / integer conversion: ties away from zero (round(2.5) = 3, round(-2.5) = -3), unlike NumPy's ties-to-even"""
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
 
 
 def _struct(ip, a, n):
@@ -942,6 +971,7 @@ class Interp:
         if name in self.extern:                                      # functions the driver stands in for (compiled MEX files)
             return list(self.extern[name](args, nargout))
         if name in BUILTINS:
+            BUILTINS_REACHED[name] = BUILTINS_REACHED.get(name, 0) + 1     # coverage list of tests/test_reference_run.py
             out = BUILTINS[name](self, args, nargout)
             return out if isinstance(out, list) else [out]
         return self.call(name, args, nargout)
@@ -1150,8 +1180,8 @@ def _first_dim(a):
 def _reduce(fn):
     def f(ip, args, nargout):
         a = num(mat(args[0]))
-        if a.size == 0 and len(args) == 1:
-            return mat(0.0)
+        if a.shape == (0, 0) and len(args) == 1:
+            return mat(0.0 if fn is np.sum else 1.0)              # sum([]) is 0, prod([]) is 1
         ax = _first_dim(a) if len(args) == 1 else int(scalar(args[1])) - 1
         if ax >= a.ndim:
             return a
@@ -1231,8 +1261,17 @@ def _svd(ip, args, nargout):
 
 
 def _reshape(ip, args, nargout):
+    """reshape(A, sz), reshape(A, m, n, ...), one dimension may be [] (computed from numel)"""
     a = mat(args[0])
-    dims = _dims(args[1:])
+    rest = args[1:]
+    if len(rest) > 1 and any(mat(r).size == 0 for r in rest):
+        known = [int(scalar(r)) for r in rest if mat(r).size]
+        prod = int(np.prod(known)) if known else 1
+        if sum(mat(r).size == 0 for r in rest) != 1 or prod == 0 or a.size % prod:
+            raise MError("reshape: one [] placeholder, and the known dimensions must divide numel")
+        dims = tuple(int(scalar(r)) if mat(r).size else a.size // prod for r in rest)
+    else:
+        dims = _dims(rest)
     return trim(a.reshape(dims, order="F"))
 
 
@@ -1260,17 +1299,23 @@ def _norm(ip, args, nargout):
 
 def _minmax(fn, argfn):
     def f(ip, args, nargout):
+        # NaNs are ignored (the default 'omitnan' of max / min); a slice that is all NaN gives NaN, with index 1
         a = num(mat(args[0]))
         if len(args) >= 2 and mat(args[1]).size > 0:
-            return fn(a, num(mat(args[1])))
+            return (np.fmax if fn is np.maximum else np.fmin)(a, num(mat(args[1])))
         if a.size == 0:
             return a
         ax = _first_dim(a) if len(args) < 3 else int(scalar(args[2])) - 1
-        red = np.max if fn is np.maximum else np.min
-        vals = trim(red(a, axis=ax, keepdims=True))
+        big = fn is np.maximum
+        nanmask = np.isnan(a)
+        filled = np.where(nanmask, -np.inf if big else np.inf, a)
+        vals = (np.max if big else np.min)(filled, axis=ax, keepdims=True)
+        allnan = nanmask.all(axis=ax, keepdims=True)
+        vals = np.where(allnan, np.nan, vals)
         if nargout >= 2:
-            return [vals, trim(argfn(a, axis=ax, keepdims=True) + 1.0)]
-        return vals
+            idx = argfn(filled, axis=ax, keepdims=True) + 1.0
+            return [trim(vals), trim(np.where(allnan, 1.0, idx))]
+        return trim(vals)
     return f
 
 
@@ -1305,9 +1350,15 @@ def _mean(ip, args, nargout):
 
 
 def _var(ip, args, nargout):
+    """var(A), var(A, w), var(A, w, dim): w = 0 (default) normalises by N - 1, w = 1 by N; vector weights are not implemented"""
     a = num(mat(args[0]))
-    ax = _first_dim(a)
-    return trim(np.var(a, axis=ax, ddof=1 if a.shape[ax] > 1 else 0, keepdims=True))
+    w = 0.0
+    if len(args) >= 2 and mat(args[1]).size > 0:
+        if mat(args[1]).size != 1:
+            raise MError("var: weight vectors are not implemented")
+        w = scalar(args[1])
+    ax = _first_dim(a) if len(args) < 3 else int(scalar(args[2])) - 1
+    return trim(np.var(a, axis=ax, ddof=1 if (w == 0.0 and a.shape[ax] > 1) else 0, keepdims=True))
 
 
 def _eig(ip, args, nargout):
@@ -1322,11 +1373,18 @@ def _eig(ip, args, nargout):
 def _hist(ip, args, nargout):
     """n = hist(y, centers): counts per bin, bin edges midway between the centres, outer bins open-ended; row vector for vector y"""
     y = num(mat(args[0])).reshape(-1, order="F")
-    c = num(mat(args[1])).reshape(-1, order="F")
+    c = num(mat(args[1])).reshape(-1, order="F") if len(args) > 1 else np.array([10.0])
+    if c.size == 1:                                                  # hist(y, nbins): equally spaced bins between min(y) and max(y)
+        nb = int(c[0])
+        lo, hi = float(np.min(y)), float(np.max(y))
+        if lo == hi:
+            lo, hi = lo - nb / 2.0, hi + nb / 2.0
+        width = (hi - lo) / nb
+        c = lo + width * (np.arange(nb) + 0.5)
     edges = np.concatenate(([-np.inf], 0.5 * (c[1:] + c[:-1]), [np.inf]))
     counts = np.histogram(y, bins=edges)[0].astype(np.float64)
     # MATLAB puts a value that sits exactly on an edge into the upper bin, as np.histogram does (right-open bins)
-    return counts.reshape(1, -1)
+    return [counts.reshape(1, -1), c.reshape(1, -1)] if nargout >= 2 else counts.reshape(1, -1)
 
 
 def _sparse(a):
@@ -1359,6 +1417,8 @@ def _length(v):
     return 0 if a.size == 0 else max(a.shape)
 
 
+BUILTINS_REACHED = {}      # name -> calls, filled while reference files execute (which builtins the pins must cover)
+
 BUILTINS = {
     "fieldnames": lambda ip, a, n: [list(a[0].__dict__.keys())],
     "getfield": lambda ip, a, n: getattr(a[0], a[1]),
@@ -1383,7 +1443,7 @@ BUILTINS = {
     "eye": lambda ip, a, n: np.eye(*_dims(a)),
     "logical": lambda ip, a, n: mat(a[0]) != 0 if mat(a[0]).dtype != bool else mat(a[0]),
     "double": lambda ip, a, n: num(mat(a[0])),
-    "int32": lambda ip, a, n: np.round(num(mat(a[0]))),
+    "int32": lambda ip, a, n: np.clip(_round_half_away(num(mat(a[0]))), -2147483648.0, 2147483647.0),
     "isinf": lambda ip, a, n: np.isinf(num(mat(a[0]))),
     "imag": lambda ip, a, n: np.imag(num(mat(a[0]))).astype(np.float64),
     "real": lambda ip, a, n: np.real(num(mat(a[0]))).astype(np.float64),
@@ -1397,14 +1457,14 @@ BUILTINS = {
     "mean": _mean,
     "var": _var,
     "eig": _eig,
-    "nthroot": lambda ip, a, n: np.power(num(mat(a[0])), 1.0 / num(mat(a[1]))),
+    "nthroot": lambda ip, a, n: _nthroot(num(mat(a[0])), num(mat(a[1]))),
     "cumsum": _cumsum,
-    "exp": _elementwise(np.exp), "log": _elementwise(np.log), "sqrt": _elementwise(_sqrt), "abs": _elementwise(np.abs),
-    "floor": _elementwise(np.floor), "ceil": _elementwise(np.ceil), "round": _elementwise(np.round),
+    "exp": _elementwise(np.exp), "log": _elementwise(_log), "sqrt": _elementwise(_sqrt), "abs": _elementwise(np.abs),
+    "floor": _elementwise(np.floor), "ceil": _elementwise(np.ceil), "round": _elementwise(_round_half_away),
     "isnan": lambda ip, a, n: np.isnan(num(mat(a[0]))),
     "power": lambda ip, a, n: ip.binop(".^", a[0], a[1]),
     "times": lambda ip, a, n: ip.binop(".*", a[0], a[1]),
-    "mod": lambda ip, a, n: np.mod(num(mat(a[0])), num(mat(a[1]))),
+    "mod": lambda ip, a, n: _mod(num(mat(a[0])), num(mat(a[1]))),
     "bsxfun": _bsxfun,
     "find": _find,
     "diag": _diag,

@@ -457,6 +457,11 @@ def main():
         data = make()
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
         print("wrote", name, flush=True)
+    # which builtins of the interpreter the executed files reached (calls each): the list tests/test_reference_run.py pins one by one
+    # against MATLAB's documentation
+    import json
+    with open(os.path.join(GOLD, "mlite_builtins_reached.json"), "w") as fh:
+        json.dump(dict(sorted(ML.BUILTINS_REACHED.items())), fh, indent=0)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@ pin of the oracle and — on the GPU — of the HIP path.
 import glob
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -301,6 +303,189 @@ def test_interpreter_basics():
     assert np.array_equal(ev("bsxfun(@minus,[1;2],[1 2])"), [[0.0, -1.0], [1.0, 0.0]])
     with pytest.raises(ML.MError):
         ev("[1 2 3]+[1 2]")                                                            # no implicit expansion in the reference's MATLAB
+
+
+def _mrun(body, **vars):
+    """Execute MATLAB statements in a fresh scope of the interpreter and return the scope."""
+    ip = ML.Interp(ref_dir="/nonexistent")
+    f = ML.Parser(ML.lex("function t()\n%s\nend\n" % body)).parse_file()["t"]
+    scope = {"__globals__": set()}
+    scope.update({k: (v if isinstance(v, (str, ML.Struct)) else ML.mat(v)) for k, v in vars.items()})
+    ip.run_block(f["body"], scope)
+    return scope
+
+
+def test_every_builtin_the_executed_reference_reaches_is_pinned_to_matlab_documentation():
+    """The parity claim rests on oracle/mlite.py executing the reference's .m files, so every builtin those files reach
+    (tests/golden/mlite_builtins_reached.json, written by oracle/run_reference.py from Interp.call_any's counters) is asserted here
+    on input / output pairs of MATLAB's documentation - the example of the function's reference page where it has one with
+    printed values, the documented rule otherwise (page named in the comment: mathworks.com/help/matlab/ref/<name>.html).
+    A builtin that the reference reaches and this table does not cover fails the test; an unknown function is a hard error."""
+    import json
+    reached = json.load(open(os.path.join(GOLDEN, "mlite_builtins_reached.json")))
+    A3 = np.array([[4.0, -7.0, 3.0], [1.0, 4.0, -2.0], [10.0, 7.0, 9.0]])
+    T = [
+        # ---- reductions
+        ("sum", "r = sum([1 3 2; 4 2 5; 6 1 4]);", [[11.0, 6.0, 11.0]]),                                   # sum: "Sum of Matrix Columns"
+        ("sum", "r = sum([1 3 2; 4 2 5; 6 1 4], 2);", [[6.0], [11.0], [11.0]]),                            # sum: "Sum of Matrix Rows"
+        ("sum", "r = sum([1 2 3 4]);", [[10.0]]),                                                          # sum: vector -> scalar whatever its orientation
+        ("sum", "r = sum(zeros(0,3));", [[0.0, 0.0, 0.0]]),                                                # sum: 0-by-n input -> 1-by-n zeros
+        ("mean", "r = mean([0 1 1; 2 3 2; 1 3 2; 4 2 2]);", [[1.75, 2.25, 1.75]]),                         # mean: "Mean of Matrix Columns"
+        ("mean", "r = mean([0 1 1; 2 3 2; 3 0 1; 1 2 3], 2);", [[2 / 3], [7 / 3], [4 / 3], [2.0]]),        # mean: "Mean of Matrix Rows"
+        ("mean", "r = mean([1 2 3 6]);", [[3.0]]),
+        ("var", "r = var(A);", [[21.0, 163.0 / 3.0, 91.0 / 3.0]]),                                         # var: "Variance of Matrix" (N-1 normalisation)
+        ("var", "r = var([2 4 4 4 5 5 7 9]);", [[32.0 / 7.0]]),                                            # var: default weight 0 = N-1
+        ("var", "r = var(A, 0, 2);", [[37.0], [9.0], [7.0 / 3.0]]),                                        # var: "Variance Along Dimension" (rows: [4 -7 3] -> 74/2)
+        ("cumsum", "r = cumsum(1:5);", [[1.0, 3.0, 6.0, 10.0, 15.0]]),                                     # cumsum: "Cumulative Sum of Vector"
+        ("cumsum", "r = cumsum([1 4 7; 2 5 8; 3 6 9]);", [[1.0, 4.0, 7.0], [3.0, 9.0, 15.0], [6.0, 15.0, 24.0]]),   # cumsum: columns
+        ("cumsum", "r = cumsum([1 3 5; 2 4 6], 2);", [[1.0, 4.0, 9.0], [2.0, 6.0, 12.0]]),                 # cumsum: "Cumulative Sum of Each Row"
+        ("max", "r = max([23 42 37 18 52]);", [[52.0]]),                                                   # max: "Largest Vector Element"
+        ("max", "r = max([2 8 4; 7 3 9]);", [[7.0, 8.0, 9.0]]),                                            # max: "Largest Element in Each Matrix Column"
+        ("max", "r = max([1.7 1.2 1.5; 1.3 1.6 1.99], [], 2);", [[1.7], [1.99]]),                          # max: "Largest Element in Each Matrix Row"
+        ("max", "[r, i] = max([1 9 -2; 8 4 -5]);", [[8.0, 9.0, -2.0]]),                                    # max: "Largest Element Indices"
+        ("max", "[m, r] = max([1 9 -2; 8 4 -5]);", [[2.0, 1.0, 1.0]]),
+        ("max", "r = max([1 7 3; 6 2 9], 5);", [[5.0, 7.0, 5.0], [6.0, 5.0, 9.0]]),                        # max: "Largest Element Comparison" (array vs scalar)
+        ("max", "r = max([1.77 -0.005 NaN -2.95; NaN 0.34 NaN 0.19]);", [[1.77, 0.34, np.nan, 0.19]]),     # max: NaNs are ignored unless a column is all NaN
+        ("min", "r = min([23 42 37 15 52]);", [[15.0]]),                                                   # min: "Smallest Vector Element"
+        ("min", "r = min([2 8 4; 7 3 9]);", [[2.0, 3.0, 4.0]]),                                            # min: "Smallest Element in Each Matrix Column"
+        ("min", "[m, r] = min([1 9 -2; 8 4 -5]);", [[1.0, 2.0, 2.0]]),                                     # min: "Smallest Element Indices"
+        ("min", "r = min([NaN 3 1]);", [[1.0]]),                                                           # min: NaN ignored
+        ("sort", "r = sort([9 0 -7 5 3 8 -10 4 2]);", [[-10.0, -7.0, 0.0, 2.0, 3.0, 4.0, 5.0, 8.0, 9.0]]),  # sort: "Sort Vector in Ascending Order"
+        ("sort", "r = sort([3 6 5; 7 -2 4; 1 0 -9]);", [[1.0, -2.0, -9.0], [3.0, 0.0, 4.0], [7.0, 6.0, 5.0]]),  # sort: columns of a matrix
+        ("sort", "[b, r] = sort([3 1 2]);", [[2.0, 3.0, 1.0]]),                                            # sort: index output, A(I) == B
+        ("sort", "r = sort([3 NaN 1]);", [[1.0, 3.0, np.nan]]),                                            # sort: NaN last in ascending order ("MissingPlacement" auto)
+        ("sort", "r = sort([10 -12 4 8], 'descend');", [[10.0, 8.0, 4.0, -12.0]]),                         # sort: "Sort Matrix Rows in Descending Order" (direction argument)
+        ("any", "r = any([0 0 3; 0 0 3; 0 0 3]);", [[False, False, True]]),                                # any: "Determine if Any Array Elements Are Nonzero" (columns)
+        ("any", "r = any([0 0 0 1]);", [[True]]),
+        ("norm", "r = norm([1 -2 3]);", [[math.sqrt(14.0)]]),                                              # norm: "Vector Magnitude" 3.7417
+        ("norm", "r = round(norm([2 0 1; -1 1 0; -3 3 0]) * 1e4) / 1e4;", [[4.7234]]),                    # norm: "2-Norm of Matrix" 4.7234
+        ("norm", "r = norm([-2 3 -1], 1);", [[6.0]]),                                                      # norm: "1-Norm of Vector"
+        ("norm", "r = norm([2 0 1; -1 1 0; -3 3 0], 'fro');", [[5.0]]),                                    # norm: "Frobenius Norm of Matrix" sqrt(25)
+        # ---- element-wise
+        ("abs", "r = abs([-5 3 -0.5]);", [[5.0, 3.0, 0.5]]),                                               # abs: "Absolute Value of Vector"
+        ("exp", "r = exp(1);", [[math.e]]),                                                                # exp: "Numeric Representation of e"
+        ("log", "r = log([1 exp(2)]);", [[0.0, 2.0]]),
+        ("log", "r = log(-1);", [[complex(0.0, math.pi)]]),                                                # log: "Natural Logarithm of Negative Number" 0 + 3.1416i
+        ("sqrt", "r = sqrt([4 9 2.25]);", [[2.0, 3.0, 1.5]]),
+        ("sqrt", "r = sqrt(-4);", [[complex(0.0, 2.0)]]),                                                  # sqrt: "Square Root of Vector Elements": negative -> complex
+        ("floor", "r = floor([-1.9 -0.2 3.4 5.6 7]);", [[-2.0, -1.0, 3.0, 5.0, 7.0]]),                     # floor: "Round Matrix Elements Toward Negative Infinity"
+        ("ceil", "r = ceil([-1.9 -0.2 3.4 5.6 7]);", [[-1.0, -0.0, 4.0, 6.0, 7.0]]),                       # ceil: "Round Matrix Elements Toward Positive Infinity"
+        ("mod", "r = mod(23, 5);", [[3.0]]),                                                               # mod: "Remainder After Division of Scalar"
+        ("mod", "r = mod(-4:-1, 3);", [[2.0, 0.0, 1.0, 2.0]]),                                             # mod: "Remainder After Division for Positive and Negative Values"
+        ("mod", "r = mod(5, 0);", [[5.0]]),                                                                # mod: mod(a, 0) is a
+        ("nthroot", "r = nthroot(-27, 3);", [[-3.0]]),                                                     # nthroot: "Calculate Real Root of Scalar"
+        ("nthroot", "r = nthroot([8 625], [3 4]);", [[2.0, 5.0]]),                                         # nthroot: element-wise roots
+        ("power", "r = power([1 2 3], 2);", [[1.0, 4.0, 9.0]]),                                            # power: "Square Each Element of Vector"
+        ("double", "r = double(int32(7));", [[7.0]]),
+        ("int32", "r = int32([2.5 -2.5 3.49]);", [[3.0, -3.0, 3.0]]),                                      # int32 / integer conversion: rounds to nearest, ties away from zero
+        ("logical", "r = logical([1 0 -3 0.5]);", [[True, False, True, True]]),                            # logical: nonzero -> true
+        ("real", "r = real(sqrt(-4) + 3);", [[3.0]]),
+        ("imag", "r = imag(sqrt(-4) + 3);", [[2.0]]),
+        ("isreal", "r = isreal(sqrt(-4));", [[False]]),                                                    # isreal: complex storage -> false
+        ("isreal", "r = isreal([1 2]);", [[True]]),
+        ("isnan", "r = isnan([1 NaN Inf]);", [[False, True, False]]),                                      # isnan: "Determine Which Array Elements Are NaN"
+        ("isinf", "r = isinf([1 NaN -Inf]);", [[False, False, True]]),
+        ("eps", "r = eps(10);", [[2.0 ** -49]]),                                                           # eps: "Accuracy in Double Precision" eps(10) = 1.7764e-15
+        ("eps", "r = eps;", [[2.0 ** -52]]),
+        ("pi", "r = pi;", [[math.pi]]),
+        ("inf", "r = -inf;", [[-math.inf]]),
+        # ---- construction / shape
+        ("zeros", "r = size(zeros(2, 3));", [[2.0, 3.0]]),                                                 # zeros: "Matrix of Zeros" sizes
+        ("zeros", "r = zeros(2);", [[0.0, 0.0], [0.0, 0.0]]),                                              # zeros(n) is n-by-n
+        ("ones", "r = ones(2, 3);", [[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]),
+        ("eye", "r = eye(2, 3);", [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),                                     # eye: "Rectangular Matrix"
+        ("true", "r = true(1, 2);", [[True, True]]),
+        ("false", "r = false(2, 1);", [[False], [False]]),
+        ("size", "r = size(zeros(3, 4, 5));", [[3.0, 4.0, 5.0]]),                                          # size: "Size of 3-D Array"
+        ("size", "r = size(zeros(3, 4, 5), 2);", [[4.0]]),                                                 # size: "Size of Dimension"
+        ("size", "[a, r] = size(ones(3, 4, 5));", [[20.0]]),                                               # size: fewer outputs than dimensions: the last one is the product of the rest
+        ("length", "r = length(zeros(3, 7));", [[7.0]]),                                                   # length: "Number of Vector Elements" = largest dimension
+        ("length", "r = length(zeros(0, 5));", [[0.0]]),                                                   # length of an empty array is 0
+        ("isempty", "r = isempty(zeros(0, 3));", [[True]]),                                                # isempty: "Determine Whether Array Is Empty"
+        ("isempty", "r = isempty(0);", [[False]]),
+        ("reshape", "r = reshape(1:10, [5 2]);", np.arange(1.0, 11.0).reshape(5, 2, order="F")),           # reshape: "Reshape Vector into Matrix"
+        ("reshape", "r = reshape([1 2 3 4 5 6], [], 2);", [[1.0, 4.0], [2.0, 5.0], [3.0, 6.0]]),           # reshape: "Reshape Matrix to Have Specified Number of Columns" ([] placeholder)
+        ("repmat", "r = repmat([1 2; 3 4], 2, 3);", np.tile(np.array([[1.0, 2.0], [3.0, 4.0]]), (2, 3))),  # repmat: "Square Block Format" / rectangular
+        ("repmat", "r = size(repmat([1 2; 3 4], [1 2 3]));", [[2.0, 4.0, 3.0]]),                           # repmat: "3-D Block Array"
+        ("squeeze", "r = size(squeeze(zeros(2, 1, 3)));", [[2.0, 3.0]]),                                   # squeeze: "Remove Dimensions of Length 1"
+        ("squeeze", "r = size(squeeze(zeros(1, 1, 3)));", [[3.0, 1.0]]),                                   # squeeze: 1x1xn -> n-by-1 column
+        ("diag", "r = diag([2 1 -1]);", [[2.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]]),             # diag: "Create Diagonal Matrices"
+        ("diag", "r = diag([1 2; 3 4]);", [[1.0], [4.0]]),                                                 # diag: "Get Diagonal Elements" (column vector)
+        ("find", "r = find([1 0 2; 0 1 1; 0 0 4]);", [[1.0], [5.0], [7.0], [8.0], [9.0]]),                 # find: "Zero and Nonzero Elements in Matrix" (linear indices, column)
+        ("find", "r = find([0 3 0 4]);", [[2.0, 4.0]]),                                                    # find: row vector in -> row vector out
+        ("find", "r = find([0 1 0 1 1], 2);", [[2.0, 4.0]]),                                               # find(X, n): the first n
+        ("linspace", "r = linspace(-5, 5, 7);", [np.linspace(-5.0, 5.0, 7)]),                              # linspace: "Vector with Specified Number of Values"
+        ("bsxfun", "r = bsxfun(@minus, [1 2 10; 3 4 20; 9 6 15], mean([1 2 10; 3 4 20; 9 6 15]));",        # bsxfun: "Deviation of Matrix Elements from Column Mean"
+         np.array([[1.0, 2.0, 10.0], [3.0, 4.0, 20.0], [9.0, 6.0, 15.0]]) - np.array([[13.0 / 3.0, 4.0, 15.0]])),
+        ("bsxfun", "r = bsxfun(@times, [1; 2], [1 2 3]);", [[1.0, 2.0, 3.0], [2.0, 4.0, 6.0]]),
+        ("sparse", "r = full(sparse([6 6 6 5 10 10 9 9]', [1 1 1 2 3 3 10 10]', [100 202 173 305 410 550 626 726]', 10, 10));",   # sparse: "Accumulate Values into Sparse Matrix"
+         None),
+        ("hist", "r = hist([1 2 2 3 3 3 4 4 4 4], 4);", [[1.0, 2.0, 3.0, 4.0]]),                           # hist: nbins equally spaced bins between min and max
+        ("hist", "[c, r] = hist([1 2 2 3 3 3 4 4 4 4], 4);", [[1.375, 2.125, 2.875, 3.625]]),              # hist: second output = bin CENTRES
+        # ---- linear algebra
+        ("inv", "r = inv([1 0 2; -1 5 0; 0 3 -9]);", np.linalg.inv([[1.0, 0.0, 2.0], [-1.0, 5.0, 0.0], [0.0, 3.0, -9.0]])),   # inv: "Inverse Matrix": 0.8824 -0.1176 0.1961; ...
+        ("inv", "r = round(inv([1 0 2; -1 5 0; 0 3 -9]) * 10000) / 10000;", [[0.8824, -0.1176, 0.1961], [0.1765, 0.1765, 0.0392], [0.0588, 0.0588, -0.0980]]),
+        ("eig", "r = eig([2 0; 0 1]);", [[1.0], [2.0]]),                                                   # eig: symmetric input -> eigenvalues in ascending order, column vector
+        ("eig", "[v, r] = eig([2 1; 1 2]);", [[1.0, 0.0], [0.0, 3.0]]),                                    # eig: "Eigenvalues and Eigenvectors of Symmetric Matrix": D diagonal, ascending
+        ("svd", "r = round(svd([1 0 1; -1 -2 0; 0 1 -1]) * 1e4) / 1e4;", [[2.4605], [1.6996], [0.2391]]),   # svd: "Singular Values of Matrix" 2.4605 1.6996 0.2391 (descending column)
+        ("svd", "[u, r, v] = svd([2 0; 0 3]);", [[3.0, 0.0], [0.0, 2.0]]),                                 # svd: S diagonal, descending
+        ("linsolve", "r = linsolve([1 2; 3 4], [5; 6]);", [[-4.0], [4.5]]),                                # linsolve: "Solve Linear System" A*x = b
+        ("roots", "r = round(roots([3 -2 -4]) * 1e4) / 1e4;", [[1.5352], [-0.8685]]),                      # roots: "Roots of Quadratic Polynomial" 1.5352 -0.8685
+        ("polyval", "r = polyval([3 2 1], [5 7 9]);", [[86.0, 162.0, 262.0]]),                             # polyval: "Evaluate Polynomial at Several Points"
+        # ---- structs, strings
+        ("struct", "s = struct('a', 5, 'b', 'text'); r = s.a;", [[5.0]]),                                  # struct: "Store Related Pieces of Data"
+        ("isfield", "s = struct('a', 5); r = [isfield(s, 'a') isfield(s, 'z')];", [[True, False]]),        # isfield: "Determine if Field Exists"
+        ("getfield", "s = struct('a', 5); r = getfield(s, 'a');", [[5.0]]),
+        ("setfield", "s = struct('a', 5); s = setfield(s, 'a', 7); r = s.a;", [[7.0]]),
+        ("fieldnames", "s = struct('a', 5, 'b', 6); f = fieldnames(s); r = length(f);", [[2.0]]),          # fieldnames: cell array of the names, in creation order
+        ("strcmp", "r = [strcmp('Yes', 'No') strcmp('Yes', 'Yes') strcmp('yes', 'Yes')];", [[False, True, False]]),   # strcmp: "Compare Two Character Vectors" (case-sensitive)
+        ("upper", "r = strcmp(upper('vc'), 'VC');", [[True]]),                                             # upper: "Convert Character Vector to Uppercase"
+        ("tic", "tic; r = toc >= 0;", [[True]]),
+        ("toc", "tic; r = toc >= 0;", [[True]]),
+    ]
+    covered, failures = set(), []
+    for name, src, want in T:
+        covered.add(name)
+        try:
+            got = _mrun(src, A=A3)["r"]
+        except Exception as e:                                                        # noqa: BLE001 - report which pin failed
+            failures.append("%s: %s raised %r" % (name, src, e))
+            continue
+        if want is None:                                                              # the sparse accumulation example: four accumulated entries
+            want = np.zeros((10, 10))
+            want[5, 0], want[4, 1], want[9, 2], want[8, 9] = 475.0, 305.0, 960.0, 1352.0
+        got, want = np.asarray(got), np.asarray(want)
+        if got.shape != want.shape:
+            failures.append("%s: %s shape %s, MATLAB %s" % (name, src, got.shape, want.shape))
+        elif want.dtype == bool:
+            if got.dtype != bool or not np.array_equal(got, want):
+                failures.append("%s: %s -> %r (%s), MATLAB %r" % (name, src, got.tolist(), got.dtype, want.tolist()))
+        elif not np.allclose(got, want, rtol=1e-12, atol=1e-300, equal_nan=True):
+            failures.append("%s: %s -> %r, MATLAB %r" % (name, src, got.tolist(), want.tolist()))
+    assert not failures, "\n".join(failures)
+    # language semantics the executed files lean on (MATLAB documentation: "Array Indexing", "for", "end", "Short-Circuit AND/OR")
+    S = _mrun("A = magic4; r1 = A(end, 1); r2 = A(2, end); r3 = A(end); B = A(2:end, [1 end]); r4 = B(end, end);\n"
+              "v = []; v(3) = 7; w = [1 2 3 4 5]; w([2 4]) = []; g = zeros(2, 2); g(3, 3) = 1;\n"
+              "c = 0; cols = zeros(2, 0); for col = [1 2 3; 4 5 6]\n c = c + 1; cols = [cols col];\n end\n"
+              "k = 0; for q = 1:0\n k = k + 1;\n end\n"
+              "t = 0; while true\n t = t + 1;\n if t >= 3\n break;\n end\n end\n"
+              "sc = false && (1/0 > error_if_evaluated); so = true || error_if_evaluated;\n"
+              "x = A(A(4, 1), A(1, end) - 10); nested = A(min(end, 9), max(1, end - 3));",
+              magic4=np.array([[16.0, 2.0, 3.0, 13.0], [5.0, 11.0, 10.0, 8.0], [9.0, 7.0, 6.0, 12.0], [4.0, 14.0, 15.0, 1.0]]))
+    assert S["r1"][0, 0] == 4.0 and S["r2"][0, 0] == 8.0 and S["r3"][0, 0] == 1.0 and S["r4"][0, 0] == 1.0      # `end` per dimension / linear
+    assert np.array_equal(S["v"], [[0.0, 0.0, 7.0]]) and np.array_equal(S["w"], [[1.0, 3.0, 5.0]])              # growth by assignment pads with zeros; deletion
+    assert S["g"].shape == (3, 3) and S["g"][2, 2] == 1.0 and S["g"][0, 2] == 0.0
+    assert S["c"][0, 0] == 3.0 and np.array_equal(S["cols"], [[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]])               # for iterates over COLUMNS
+    assert S["k"][0, 0] == 0.0 and S["t"][0, 0] == 3.0                                                          # empty range: body never runs; break
+    assert not S["sc"][0, 0] and S["so"][0, 0]                                                                  # short circuit: the right operand is not evaluated
+    assert S["x"][0, 0] == 15.0 and S["nested"][0, 0] == 4.0                                                    # A(4, 3) of magic(4); `end` inside a call inside an index refers to the indexed array's dimension
+    with pytest.raises(ML.MError):
+        _mrun("r = no_such_function(1);")                                                                       # unknown function: hard error
+    missing = sorted(set(reached) - covered)
+    print("builtins reached by the executed reference files: %d; pinned: %d; assertions: %d" % (len(reached), len(covered & set(reached)), len(T) + 14))
+    print("coverage list:", ", ".join("%s(%d)" % (k, reached[k]) for k in sorted(reached)))
+    assert not missing, "reached by the reference but not pinned: %s" % missing
+    assert len(T) + 14 >= 80
 
 
 # ---- GPU: the HIP path against the executed reference ---------------------------------------------------------------------
