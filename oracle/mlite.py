@@ -1504,6 +1504,10 @@ def parse_args_builtin(args):
     for q in range(0, len(rest), 2):
         key = rest[q]
         hits = [i for i, nm in enumerate(pnames) if nm.lower() == str(key).lower()]
+        if not hits:                                                 # a unique, case-insensitive PREFIX of a name is accepted as well
+            hits = [i for i, nm in enumerate(pnames) if nm.lower().startswith(str(key).lower())]   # (demo_2D.m:72 passes 'maxAttempt')
+            if len(hits) > 1:
+                raise MError("parseArgs: ambiguous parameter name %r" % (key,))
         if not hits:
             raise MError("parseArgs: unknown parameter %r" % (key,))
         out[hits[0]] = rest[q + 1]

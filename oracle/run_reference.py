@@ -433,6 +433,80 @@ def make_demo_sinc(seed=1, max_iter=40):
     return out
 
 
+def make_demo_2D(seed=2, max_iter=40):
+    """demo_2D.m's configuration (the reference's own end-to-end use of missing values: VD, m = 50, three Gaussian bumps in 2-D,
+    n = 3000, Gamma-distributed input-noise variances, the first variable removed from a quarter of the rows and the second from
+    another quarter, demo_2D.m:7-25,28-89): sample(n, 0.7, 0.15, 0.15), init(Xn, Y, 'VD', 50, ..., 'Psi', Psi) with NaNs in Xn,
+    train(..., 'maxAttempt', 50, ...) - the demo's own spelling, which parseArgs resolves as a unique prefix of 'maxAttempts' -
+    then predict on a grid without missing values (:96-100), predict with only ONE variable observed (:127-138) and the test-set
+    error with the other variable missing (:155-159).  The draws come from NumPy and are handed over as recorded arrays; maxIter
+    is 40 instead of 500, the grids are coarser than the demo's (30 x 30 and 200 points) to keep the interpreted run short; the
+    single-variable reference models of :161-178 are the demo's comparison baseline, not the path under test, and are not trained."""
+    rng = np.random.default_rng(seed)
+    m, method = 50, "VD"
+    means = [np.array([10.0, 0.0]), np.array([10.0, 10.0]), np.array([5.0, 5.0])]
+    covs = [np.array([[10.0, 0.0], [0.0, 1.0]]), np.array([[5.0, -3.0], [-3.0, 3.0]]), np.array([[2.0, 0.0], [0.0, 2.0]])]
+    X = np.vstack([rng.multivariate_normal(mu, S, 1000) for mu, S in zip(means, covs)])
+    n, d = X.shape
+
+    def mvnpdf(Z, mu, S):
+        dz = Z - mu
+        return np.exp(-0.5 * np.einsum("ij,jk,ik->i", dz, np.linalg.inv(S), dz)) / (2.0 * np.pi * np.sqrt(np.linalg.det(S)))
+    w_true = np.array([-9.0, 6.0, 3.0])
+    Y = (np.column_stack([mvnpdf(X, mu, S) for mu, S in zip(means, covs)]) @ w_true + 0.01 * rng.standard_normal(n)).reshape(-1, 1)
+    E_, V_ = 0.5, 0.25
+    Psi = rng.gamma(E_ ** 2 / V_, V_ / E_, (n, d))
+    Xn = X + rng.standard_normal((n, d)) * np.sqrt(Psi)
+    r = rng.permutation(n)
+    psize = int(np.ceil(0.5 * n / 2))
+    Xn[r[:psize], 0] = np.nan
+    Xn[r[psize:2 * psize], 1] = np.nan
+    perm = rng.permutation(n) + 1.0
+    U = rng.random((m, d))
+    log = []
+    ip = full_interp(U, log)
+    ip.extern["randperm"] = lambda a, nargout: [perm.reshape(1, -1).copy()]
+    tr, va, te = (np.asarray(q).astype(bool).reshape(-1) for q in
+                  ip.call("sample", [ML.mat(float(n)), ML.mat(0.7), ML.mat(0.15), ML.mat(0.15)], 3))
+    model = ip.call("init", [Xn, Y, method, ML.mat(float(m)), "heteroscedastic", ML.mat(True), "normalize", ML.mat(True),
+                             "training", tr.reshape(-1, 1), "Psi", Psi], 1)[0]
+    k = 1
+    out = dict(method=method, method_after_init=model.method, m=m, d=d, k=k, heteroscedastic=1, X=Xn, Xclean=X, Y=Y, U=U, perm=perm,
+               training=tr, validation=va, testing=te, omega=np.zeros(0), Psi=Psi, maxIter=max_iter, maxAttempts=50.0,
+               muX=np.asarray(model.muX), sdX=np.asarray(model.sdX), muY=np.asarray(model.muY),
+               g_dim=int(np.asarray(model.g_dim).reshape(-1)[0]), theta0=np.asarray(model.last.theta).reshape(-1),
+               w0=np.asarray(model.last.w), iSigma_w0=np.asarray(model.last.iSigma_w).reshape(m, m, k, order="F"))
+    del log[:]
+    model = ip.call("train", [model, Xn, Y, "maxIter", ML.mat(float(max_iter)), "maxAttempt", ML.mat(50.0), "training", tr.reshape(-1, 1),
+                              "validation", va.reshape(-1, 1), "Psi", Psi], 1)[0]
+    rows = [q[1:7] for q in log if q[0].startswith("\\t%d")]
+    out.update(log=np.array(rows), message=[q[0] for q in log][-1])
+    for which in ("last", "best"):
+        st = getattr(model, which)
+        out.update({which + "_theta": np.asarray(st.theta).reshape(-1), which + "_w": np.asarray(st.w),
+                    which + "_iSigma_w": np.asarray(st.iSigma_w).reshape(m, m, k, order="F"),
+                    which + "_priors": np.asarray(st.priors).reshape(-1)})
+    gx, gy = np.meshgrid(np.linspace(X[:, 0].min() - 1, X[:, 0].max() + 1, 30), np.linspace(X[:, 1].min() - 1, X[:, 1].max() + 1, 30))
+    Xs = np.column_stack([gx.reshape(-1, order="F"), gy.reshape(-1, order="F")])                 # demo_2D.m:96-97
+    grid = ip.call("predict", [Xs, model], 5)                                                    # :100
+    out.update(Xs=Xs, **{"grid_" + nm: np.asarray(v) for nm, v in zip(("mu", "sigma", "nu", "beta_i", "gamma"), grid)})
+    rmses = np.zeros(2)
+    for o in range(2):
+        rng_o = X[:, o].max() - X[:, o].min()
+        Xo = np.linspace(X[:, o].min() - rng_o / 10, X[:, o].max() + rng_o / 10, 200)
+        Xm = np.full((Xo.size, 2), np.nan)
+        Xm[:, o] = Xo                                                                            # :132-136
+        res = ip.call("predict", [Xm, model], 5)
+        out.update({"only%d_X" % o: Xm}, **{"only%d_%s" % (o, nm): np.asarray(v) for nm, v in zip(("mu", "sigma", "nu", "beta_i", "gamma"), res)})
+        Xt = np.full((int(te.sum()), 2), np.nan)
+        Xt[:, o] = X[te, o]                                                                      # :155-158
+        mu = np.asarray(ip.call("predict", [Xt, model], 1)[0])
+        rmses[o] = float(np.sqrt(np.mean((Y[te] - mu) ** 2)))                                    # :159
+        out.update({"test%d_X" % o: Xt, "test%d_mu" % o: mu})
+    out["rmses_predicted"] = rmses
+    return out
+
+
 def all_fixtures():
     """name -> maker()"""
     fx = {}
@@ -446,6 +520,7 @@ def all_fixtures():
     for i, c in enumerate(TRAIN_CASES):
         fx["ref_train_" + c[0]] = (lambda c=c, i=i: make_train(c, 400 + i))
     fx["ref_train_demo_sinc"] = make_demo_sinc
+    fx["ref_train_demo_2D"] = make_demo_2D
     return fx
 
 

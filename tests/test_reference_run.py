@@ -23,7 +23,7 @@ GPZ = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path
 PRED = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "ref_predict_*.npz")))
 
 
-TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES] + ["ref_train_demo_sinc"]
+TRAIN = ["ref_train_" + c[0] for c in RR.TRAIN_CASES] + ["ref_train_demo_sinc", "ref_train_demo_2D"]
 
 
 def load(name):
@@ -233,7 +233,7 @@ def test_oracle_training_against_the_executed_reference(name):
 
 def demo_model(z, cls):
     m = int(z["m"])
-    model = cls(m=m, d=1, k=1, method=str(z["method_after_init"]), heteroscedastic=True)
+    model = cls(m=m, d=int(z["d"]), k=1, method=str(z["method_after_init"]), heteroscedastic=True)
     model.muX, model.sdX, model.muY = z["muX"].reshape(-1), z["sdX"].reshape(-1), z["muY"].reshape(-1)
     model.sets["best"] = {"theta": z["best_theta"], "w": z["best_w"], "iSigma_w": z["best_iSigma_w"], "priors": z["best_priors"]}
     return model
@@ -262,7 +262,7 @@ def test_committed_vectors_are_what_the_reference_files_return():
     for name, make in RR.all_fixtures().items():
         if name.startswith("ref_gpz_") and not name.endswith(("_p0_n0", "_p1_n1", "_d13")):
             continue
-        if name == "ref_train_demo_sinc":
+        if name in ("ref_train_demo_sinc", "ref_train_demo_2D"):
             continue                                    # two minutes of interpreted loops (7500 rows, m = 100): regenerated by run_reference.py only                                    # a third of the GPz cases keeps the CPU suite short; all predict / misc cases
         fresh, old = make(), load(name)
         assert set(fresh) == set(old), name
@@ -303,6 +303,30 @@ def test_interpreter_basics():
     assert np.array_equal(ev("bsxfun(@minus,[1;2],[1 2])"), [[0.0, -1.0], [1.0, 0.0]])
     with pytest.raises(ML.MError):
         ev("[1 2 3]+[1 2]")                                                            # no implicit expansion in the reference's MATLAB
+
+
+def _demo_2d_predictions(z, predict, model, tol):
+    """demo_2D.m:100 (grid, nothing missing), :132-138 (only one variable observed), :155-159 (test rows with the other variable
+    missing and the RMSE the demo prints)"""
+    out = predict(z["Xs"], model)
+    for key, val in zip(("mu", "sigma", "nu", "beta_i", "gamma"), out):
+        assert rel(val, z["grid_" + key]) <= tol, key
+    te = z["testing"].astype(bool)
+    for o in range(2):
+        out = predict(z["only%d_X" % o], model)
+        for key, val in zip(("mu", "sigma", "nu", "beta_i", "gamma"), out):
+            assert rel(val, z["only%d_%s" % (o, key)]) <= tol, (o, key)
+        mu = predict(z["test%d_X" % o], model)[0]
+        assert rel(mu, z["test%d_mu" % o]) <= tol
+        assert abs(np.sqrt(np.mean((z["Y"][te] - mu) ** 2)) - z["rmses_predicted"][o]) <= 1e-9
+
+
+def test_oracle_predictions_of_the_executed_demo_2D():
+    """the reference's own end-to-end exercise of missing values (demo_2D.m): predictFull on the grid, predictMissing with one of
+    the two variables observed, on the model the executed train.m returned (trained on rows with NaNs and input noise)"""
+    z = load("ref_train_demo_2D")
+    assert np.isnan(z["X"]).any(axis=1).mean() == 0.5 and str(z["method"]) == "VD" and int(z["m"]) == 50
+    _demo_2d_predictions(z, O.predict_any, demo_model(z, O.Model), 1e-9)
 
 
 def _mrun(body, **vars):
@@ -589,6 +613,16 @@ def test_hip_init_and_train_against_the_executed_reference(name, device_resident
             assert rel(gpz_amd.getPrior(Xn, PsiN, z[which + "_theta"], model, tr), z[which + "_priors"]) <= 1e-8
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_predictions_of_the_executed_demo_2D():
+    """demo_2D.m's predictions (grid; one variable observed; test rows with a variable missing, the printed RMSE) from the HIP path
+    on the model the executed train.m returned: predictFull and predictMissing (gpz_predict_missing, diagonal kinds) + getPrior's
+    mixture weights, the combination the reference's own demo exercises"""
+    import gpz_amd
+    z = load("ref_train_demo_2D")
+    _demo_2d_predictions(z, gpz_amd.predict, demo_model(z, gpz_amd.Model), 1e-8)
 
 
 @pytest.mark.gpu
