@@ -1945,9 +1945,10 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (!rc) {
         launch_zero(c->st, c->Phi, np * mp);
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
-        launch_pmc(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, SigU, iSigU, prd, wd,
-                   c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi, work2,
-                   hit);
+        // 32 < d <= 64: the scratch-resident kernels with 64-wide temporaries (k_pmiss_cov64.hip); else every route of k_pmiss_cov.hip
+        (d > 32 ? launch_pmc_wide : launch_pmc)(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, SigU,
+                                               iSigU, prd, wd, c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat,
+                                               Phat, nchunk, ppc, part, c->Phi, work2, hit);
         launch_slab_sum(c->st, part, nchunk, 3 * k * np, sums);
         launch_gen_rowdot(c->st, c->Phi, c->mp, n, (long)np, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b, nullptr, wd,
                           c->lnbeta, nullptr, phiw);
@@ -1996,9 +1997,10 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
     const int d = desc->d;
     const bool covk = method_id_of(desc->method) >= 4;
-    if (d > 64 || (covk && d > 32))
-        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (GL/VL/GD/VD) and d <= 32 (GC/VC, "
-                                         "whose per-(row, pair, component) d x d factorisations are O(n m^3 d^3)); d = %d", d);
+    (void)covk;
+    if (d > 64)
+        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (the NaN pattern of a group is a 64-bit "
+                                         "mask throughout these kernels); d = %d", d);
     unsigned long long obs = 0;
     for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1ull << c; }
     for (int c = 0; c < d; ++c)

@@ -343,6 +343,12 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
                 double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
                 double *work2 = nullptr /* m * (d(d+1)/2 + d*d + d + 1) doubles: enables the register-resident route */,
                 bool tab_ready = false /* the pair table (pattern-independent) is already in `tab`: kept from the previous group */);
+// the same for 32 < d <= 64: scratch-resident kernels only (k_pmiss_cov64.hip); work2 is not used
+void launch_pmc_wide(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
+                     const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
+                     const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
+                     double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
+                     double *work2, bool tab_ready);
 bool pmc_fast(int d, int k);   // 2 <= d <= 10, k <= 8: the register-resident kernels (needs rows_blk <= 64)
 void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned long long obs, const double *P, const double *G, double *B);
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,

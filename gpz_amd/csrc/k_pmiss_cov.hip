@@ -17,7 +17,23 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
+// This file is compiled twice: as it stands (GDM = 32: every route), and from k_pmiss_cov64.hip with GDM = 64 and PMC_WIDE defined -
+// the scratch-resident kernels only, under other names, for 32 < d <= 64 (launch_pmc_wide).  There a thread's d x d temporaries are
+// 32 KB each in scratch memory: correct and slow (DESIGN.md section 7 has the cost line); the sums of the narrow routes do not apply.
+#ifndef GDM
 #define GDM 32   // widest input of this file's scratch-resident kernels
+#endif
+#ifdef PMC_WIDE
+#define k_pmc_prep k_pmc_prep_w
+#define k_pmc_rows k_pmc_rows_w
+#define k_pmc_phi k_pmc_phi_w
+#define k_pmc_pairs k_pmc_pairs_w
+#define k_pmc_accum k_pmc_accum_w
+#define PmcPat PmcPatW
+#define pmc_chol pmc_chol_w
+#define pmc_lognorm pmc_lognorm_w
+#define pmc_inv pmc_inv_w
+#endif
 
 __device__ inline void pmc_chol(double *M, int n) {        // lower Cholesky in place, leading dimension GDM
     for (int c = 0; c < n; ++c) {
@@ -305,6 +321,7 @@ __global__ __launch_bounds__(64) void k_pmc_accum(PmcPat pt, int row0, int nrows
     }
 }
 
+#ifndef PMC_WIDE
 // ---------------------------------------------------------------------------------------------------------------
 // Register-resident form of the two sums above for 2 <= d <= 10 (template D, packed triangles, division-free Cholesky):
 //     out(row, r) = exp(lnZ_r) * sum_l N(X_hat(row,l) - c_r ; C_r + Psi_hat_l(row)) * Pio(row,l)
@@ -499,10 +516,13 @@ static bool pmc_sum(hipStream_t st, int d, bool noisy, int nrows, int row0, int 
 #undef PMC_CASE
 }
 
+#endif   // !PMC_WIDE
+
 // ---- host side -------------------------------------------------------------------------------------
 // One NaN-pattern group.  obs: bit c set = dimension c observed.  Sig/iSig: m x d*d (k_gen_prep).  Work buffers are
 // allocated by the caller: rec (m*nrec), tab (npairs*ntab), Ex/Pio (rows_blk*ld each), Xhat (rows_blk*m*d),
 // Phat (rows_blk*m*d*d, only with Psi3), part (nchunk*3k*ldx).  Writes PHI rows [0,n) and part; the caller sums part.
+#ifndef PMC_WIDE
 int pmc_rec_len(int d, unsigned long long obs) {
     int no = 0;
     for (int c = 0; c < d; ++c) no += (obs >> c) & 1ull;
@@ -510,12 +530,22 @@ int pmc_rec_len(int d, unsigned long long obs) {
     return 2 + no * no + no * nu + nu * nu;
 }
 bool pmc_fast(int d, int k) { return d >= 2 && (d <= 10 || pmc4_available(d)) && k <= 8; }   // register-resident kernels (rows_blk <= 64 then); more outputs: the scratch kernels, 24 sums per pass
+#endif
 // work2: m * (d(d+1)/2 + d*d + d + 1) doubles, used by the register-resident route
+#ifdef PMC_WIDE
+void launch_pmc_wide(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
+                const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
+                const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
+                double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
+                double *work2, bool tab_ready) 
+#else
 void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, int ld, int d, int de, int k, const double *Xr,
                 const double *Psi3, const double *P, const double *Sig, const double *iSig, const double *priors,
                 const double *w, const double *v, const double *iS, int rows_blk, double *rec, double *tab, double *Ex,
                 double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
-                double *work2, bool tab_ready) {
+                double *work2, bool tab_ready) 
+#endif
+{
     PmcPat pt;
     pt.d = d; pt.no = 0; pt.nu = 0;
     for (int c = 0; c < d; ++c) {
@@ -529,21 +559,28 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
     const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * k;
     const long npairs = (long)m * (m + 1) / 2;
     // GPZ_PMC_SCRATCH=1 (developer switch): keep the scratch-resident kernels, to compare the two routes on one input
+#ifdef PMC_WIDE
+    const bool fast = false;
+#else
     const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !getenv("GPZ_PMC_SCRATCH");
+#endif
     hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec);
     if (!tab_ready)   // the pair table depends on theta, w, iSigma_w only: predict.m calls once per NaN-pattern group with the same model
         hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
                            (const double *)rec, nrec, w, v, iS, tab, ntab);
     double *CUT = work2, *ptab = work2 ? work2 + (size_t)m * (d * (d + 1) / 2) : nullptr;
+#ifndef PMC_WIDE
     if (fast) {
         if (!Psi3) hipLaunchKernelGGL(k_pmc_cut, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, (const double *)rec, nrec, CUT);
         hipLaunchKernelGGL(k_pmc_phitab, dim3((m + 63) / 64), dim3(64), 0, st, m, d, de, P, Sig, (const double *)rec, nrec, ptab);
     }
+#endif
     for (int row0 = 0; row0 < n; row0 += rows_blk) {
         const int nr = (n - row0 < rows_blk) ? n - row0 : rows_blk;
         hipLaunchKernelGGL(k_pmc_rows, dim3((m + 63) / 64, nr), dim3(64), 0, st, pt, row0, nr, m, ld, Xr, de, Psi3, P, Sig,
                            (const double *)rec, nrec, Ex, Xhat, Psi3 ? Phat : nullptr, fast ? 1 : 0);
         launch_pm_pio(st, Ex, ld, nr, m, priors, Pio);
+#ifndef PMC_WIDE
         if (fast) {
             const double *PsT = Psi3 ? Phat : CUT;
             pmc_sum(st, d, Psi3 != nullptr, nr, row0, m, ld, (long)m, m < 256 ? m : 256, ptab, d * d + d + 1, 0, Pio, Xhat, PsT,
@@ -552,6 +589,7 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
                     part);
             continue;
         }
+#endif
         hipLaunchKernelGGL(k_pmc_phi, dim3((m + 63) / 64, nr), dim3(64), 0, st, pt, nr, m, ld, de, P, Sig, (const double *)rec,
                            nrec, (const double *)Pio, (const double *)Xhat, (const double *)(Psi3 ? Phat : nullptr), Phi, row0);
         hipLaunchKernelGGL(k_pmc_accum, dim3(nr, nchunk), dim3(64), 0, st, pt, row0, nr, m, ld, k, npairs,

@@ -29,8 +29,10 @@
  * fit the 160 KB of LDS: d <= ~100 for the diagonal kinds with input noise and missing values, ~300 without).  GC/VC with
  * input noise in fp64 runs register-resident up to d = 10 and as a block elimination in f64 MFMA accumulators for
  * 10 < d <= 64 (four pairs per wave up to d = 48), the workspace form beyond.
- * Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing with d > 64, or d > 32 for GC/VC.  dtype = f32 with d > 20 takes the
- * fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers).
+ * gpz_predict_missing for GC/VC runs register / MFMA kernels up to d = 32 and scratch-resident kernels with 64-wide temporaries for
+ * 32 < d <= 64 (correct and slow: 32 KB of scratch per thread and temporary).  Still refused (GPZ_ERR_UNSUPPORTED):
+ * gpz_predict_missing with d > 64 (the NaN pattern of a group is a 64-bit mask in those kernels).  dtype = f32 with d > 20 takes
+ * the fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers); gpz_ctx_route says which route a context runs.
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):
  *   - all matrices are column-major double; masks are 1 byte per row (MATLAB logical);

@@ -118,6 +118,7 @@ PREDICT_CASES = [(mth, noisy, nanfrac) for mth in ("GL", "VL", "GD", "VD", "GC",
 
 
 PREDICT_CASES += [("VC", True, 0.0, 13), ("GC", True, 0.0, 22), ("VD", True, 0.35, 23)]   # (.., d): beyond the register kernels of the HIP path
+PREDICT_CASES += [("VC", False, 0.08, 40)]   # predictCov.m:134-229 at d = 40: the 64-wide scratch kernels of the HIP path (k_pmiss_cov64.hip)
 
 
 def predict_case_name(c):

@@ -162,10 +162,38 @@ def test_predict_missing_cov_kind_with_many_outputs():
         assert rel(out[i], ref[i]) <= 1e-8, name
 
 
+@pytest.mark.parametrize("method,d,noisy", [("GC", 34, False), ("VC", 40, True), ("VC", 64, False)])
+def test_predict_with_missing_values_cov_kinds_beyond_32_dimensions(method, d, noisy):
+    """predictMissing / predictNoisyMissing for GC/VC at 32 < d <= 64 (predictCov.m:134-337 is generic in d): the scratch-resident
+    kernels with 64-wide temporaries (k_pmiss_cov64.hip) against the oracle; several NaN patterns, complete rows mixed in."""
+    m, k = 4, 1
+    model, theta, X, Y, _, rng = make_problem(120, d, m, k, method, True, seed=5300 + d)
+    from helpers import recondition_gamma
+    theta = recondition_gamma(model, theta, rng)
+    r4 = O.GPz(theta, model, X, Y, nargout=4)
+    pri = rng.random(m) + 0.2
+    model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri / pri.sum()}
+    ns = 9
+    Xs = rng.standard_normal((ns, d))
+    Xs[:4, [1, d - 1]] = np.nan
+    Xs[4:7, 5] = np.nan
+    Psi = None
+    if noisy:
+        Psi = np.zeros((d, d, ns))
+        for i in range(ns):
+            B = 0.2 * rng.standard_normal((d, 3))
+            Psi[:, :, i] = B @ B.T + 0.05 * np.eye(d)
+    ref = O.predict_any(Xs, model, Psi=Psi)
+    out = gpz_amd.predict(Xs, model, Psi=Psi)
+    tol = max(1e-8, 2000.0 * d * 2.2e-16 * 1e3)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))
+
+
 def test_what_is_still_refused_says_so():
-    """Prediction with missing values for GC/VC keeps d <= 32 (O(n m^3 d^3) per-triple factorisations)."""
-    d = 34
-    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "GC", True, seed=5)
+    """Prediction with missing values keeps d <= 64: the NaN pattern of a group is a 64-bit mask throughout those kernels."""
+    d = 66
+    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "VD", True, seed=5)
     r4 = O.GPz(theta, model, X, Y, nargout=4)
     pri = np.full(5, 0.2)
     model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
