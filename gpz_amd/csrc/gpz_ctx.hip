@@ -272,7 +272,7 @@ struct gpz_ctx {
     double *slab = nullptr;
     size_t slab_count = 0;
     int nsplit = 1, rows_per_split = 16;       // off-diagonal tiles of PHI' W PHI
-    int nsplit_d = 1, rows_per_split_d = 16;   // diagonal tiles (3/4 of the work per row: longer row ranges)
+    int nsplit_d = 1, rows_per_split_d = 16;   // diagonal tiles (9/16 of the work per row: longer row ranges)
     int nsplit_l = 1, rows_per_split_l = 16;
     // communication buffers
     double *comm1 = nullptr;   // [k * mp*mp | GPZ_NS]
@@ -787,8 +787,9 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
         int target = (c->tr.n_pad / (1024 / npairs > 0 ? 1024 / npairs : 1) >= 16384) ? 1024 : 512;
         if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e) > 0 ? atoi(e) : target;
-        // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 6 of 8 MFMAs per K step):
-        // the pair that minimises max(1/s1, 0.75/s2) with noff*s1 + nt*s2 workgroups inside the target.
+        // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 9 MFMAs per SIMD and K step against 16:
+        // the 36 products on and above the diagonal, k_gemm.hip): the pair that minimises max(1/s1, 0.6/s2) with
+        // noff*s1 + nt*s2 workgroups inside the target.
         const int noff = npairs - nt, max_ns = c->tr.n_pad / 64 > 0 ? c->tr.n_pad / 64 : 1;
         int s1 = 1, s2 = 1;
         double best = 1e300;
@@ -797,7 +798,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             if (b > max_ns) b = max_ns;
             if (b > a) b = a;
             if (b < 1) b = 1;
-            const double cost = 1.0 / a > 0.75 / b ? 1.0 / a : 0.75 / b;
+            const double cost = 1.0 / a > 0.6 / b ? 1.0 / a : 0.6 / b;   // 0.595 measured (tools/syrk_split_sweep.py); 9/16 by MFMA count
             if (cost < best) { best = cost; s1 = a; s2 = b; }
         }
         if (const char *e = getenv("GPZ_SYRK_S1")) s1 = atoi(e) > 0 ? atoi(e) : s1;   // tuning only

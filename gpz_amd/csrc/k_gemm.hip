@@ -61,10 +61,10 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     constexpr int NI = 8 / WC;            // 16-column MFMA tiles per wave
     constexpr int Q = 1024 / NT;          // double2 per thread per operand slice (16 x 128 doubles)
     constexpr bool diag_tile = DIAGT;
-    // Off-diagonal tiles scale the A operand by the row weight once, while it is staged (Q multiplies per thread and
-    // slice); diagonal tiles stage one operand for both sides, so there the A fragment is scaled in the MFMA loop.
-    // f64 VALU multiplies run on the MFMA pipe: the fragment form costs 4 per K step and wave.
-    constexpr bool PRESCALE = WEIGHTED && !DIAGT;
+    // The A operand is scaled by the row weight once, while it is staged (Q multiplies per thread and slice; f64 VALU multiplies
+    // run on the MFMA pipe, a fragment scaled in the MFMA loop costs one per fragment and K step).  Diagonal tiles stage the one
+    // operand they load twice: scaled into sA, as it is into sB.
+    constexpr bool PRESCALE = WEIGHTED;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
 
@@ -87,7 +87,7 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     auto flush = [&]() {
         if constexpr (F32) {
 #pragma unroll
-            for (int a = 0; a < (DIAGT ? 3 : 4); ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b) {
 #pragma unroll
@@ -130,9 +130,10 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
         for (int q = 0; q < Q; ++q) {
             int idx = q * NT + tid;
             int row = idx >> 6, c = (idx & 63) * 2;
+            if (diag_tile) *reinterpret_cast<pair_t *>(&sB[buf][row][c]) = to_pair<OT>(ra[q]);
+            else *reinterpret_cast<pair_t *>(&sB[buf][row][c]) = to_pair<OT>(rb[q]);
             if (PRESCALE) { ra[q].x *= rwq[q]; ra[q].y *= rwq[q]; }
             *reinterpret_cast<pair_t *>(&sA[buf][row][c]) = to_pair<OT>(ra[q]);
-            if (!diag_tile) *reinterpret_cast<pair_t *>(&sB[buf][row][c]) = to_pair<OT>(rb[q]);
         }
         if (WEIGHTED && !PRESCALE && tid < 16) sW[buf][tid] = (OT)rw;
     };
@@ -148,23 +149,38 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     }
     __syncthreads();
     // Fragments one K step ahead of the MFMA burst, barrier in front of a slice's last burst (see tgemm_body).
-    // Diagonal tiles: only the 64x64 blocks (0,0), (0,1), (1,1) are wanted.  Each block is dealt over all eight waves
-    // as 16x32 strips (wave -> strip row dr, strip half dh), so a wave runs 6 MFMAs per K step on 2 A and 4 B fragments
-    // and every SIMD carries the same 3/4 of an off-diagonal tile's work (k_syrk splits the rows accordingly).
+    // Diagonal tiles: only the 36 16x16 products on and above the diagonal of the 8 x 8 grid are wanted (the 64x64-block deal of
+    // rounds 1-3 issued 48: both diagonal blocks in full).  They are dealt so that every SIMD carries NINE per K step: wave s
+    // (s = 0..3) takes five products of grid row s, wave s + 4 - its partner on SIMD s - the rest of row s and all of row 7 - s
+    // (rows 0 / 7, 1 / 6, 2 / 5, 3 / 4 hold 8 + 1, 7 + 2, 6 + 3, 5 + 4 products).  Per product one A and one B fragment, each a
+    // loop-invariant LDS address; the first product's A fragment serves the fifth (five-product waves stay in one row).
+    // A diagonal workgroup costs 9/16 of an off-diagonal one per row (was 12/16): k_syrk splits the rows accordingly.
     static_assert(!DIAGT || NI == 2, "diagonal-tile wave roles are written for the 2 x 4 wave grid");
-    constexpr int NA = DIAGT ? 3 : 4, NB = DIAGT ? 4 : NI;   // fragment registers (diagonal: 2 A + weight, 4 B)
-    const int dr = DIAGT ? wave >> 1 : 0, dh = DIAGT ? wave & 1 : 0;
+    constexpr int NA = 4, NB = DIAGT ? 5 : NI;   // fragment registers
+    int dra[5] = {0, 0, 0, 0, 0}, dcb[5] = {0, 0, 0, 0, 0};
+    bool has5 = false;
+    if (DIAGT) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        // grid row / column of product p of wave w, 4 bits each (product 4 of the four-product waves repeats product 3: not issued)
+        const unsigned RA[8] = {0x00000u, 0x11111u, 0x22222u, 0x33333u, 0x77000u, 0x66611u, 0x55552u, 0x44444u};
+        const unsigned CB[8] = {0x43210u, 0x54321u, 0x65432u, 0x76543u, 0x77765u, 0x77676u, 0x77657u, 0x77654u};
+        has5 = wv < 4;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            dra[p] = (RA[wv] >> (4 * p)) & 15;
+            dcb[p] = (CB[wv] >> (4 * p)) & 15;
+        }
+    }
     auto rdfrag = [&](int cur, int kk, OT (&a)[NA], OT (&b)[NB]) {
         const OT(*tA)[LDS_LD128] = sA[cur];
+        const OT(*tB)[LDS_LD128] = sB[cur];
         const int krow = kk * 4 + (lane >> 4);
         if (DIAGT) {
-            if (WEIGHTED) a[2] = sW[cur][krow];   // applied in burst(): a multiply here would wait for the LDS data at once
 #pragma unroll
-            for (int h = 0; h < 2; ++h) a[h] = tA[krow][h * 64 + dr * 16 + (lane & 15)];
+            for (int p = 0; p < 4; ++p) a[p] = tA[krow][dra[p] * 16 + (lane & 15)];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = tA[krow][(q >> 1) * 64 + dh * 32 + (q & 1) * 16 + (lane & 15)];
+            for (int p = 0; p < 5; ++p) b[p] = tB[krow][dcb[p] * 16 + (lane & 15)];
         } else {
-            const OT(*tB)[LDS_LD128] = sB[cur];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) a[mi] = tA[krow][wr * 64 + mi * 16 + (lane & 15)];
 #pragma unroll
@@ -174,13 +190,9 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     auto burst = [&](const OT (&a)[NA], const OT (&b)[NB]) {
         __builtin_amdgcn_s_setprio(1);   // see tgemm_body
         if (DIAGT) {
-            const OT a0 = WEIGHTED ? a[0] * a[2] : a[0], a1 = WEIGHTED ? a[1] * a[2] : a[1];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[0][ni] = MfmaOf<OT>::run(a0, b[ni], acc[0][ni]);        // block (0,0)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[1][ni] = MfmaOf<OT>::run(a0, b[2 + ni], acc[1][ni]);    // block (0,1)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[2][ni] = MfmaOf<OT>::run(a1, b[2 + ni], acc[2][ni]);    // block (1,1)
+            for (int p = 0; p < 4; ++p) acc[p][0] = MfmaOf<OT>::run(a[p], b[p], acc[p][0]);
+            if (has5) acc[0][1] = MfmaOf<OT>::run(a[0], b[DIAGT ? 4 : 0], acc[0][1]);
         } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -230,18 +242,30 @@ __device__ __forceinline__ void syrk_body(const double *__restrict__ Phi, int ld
     // row of accumulator register r inside a 16x16 tile: the f64 instruction deals rows (lane >> 4) + 4r, the f32 one 4(lane >> 4) + r
     auto crow = [&](int r) -> int { return F32 ? 4 * (lane >> 4) + r : (lane >> 4) + 4 * r; };
 
+    if (DIAGT) {
 #pragma unroll
-    for (int mi = 0; mi < (DIAGT ? 3 : 4); ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = DIAGT ? j0 + (mi == 0 ? 0 : 64) + dh * 32 + ni * 16 + (lane & 15)
-                                  : j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
+        for (int p = 0; p < 5; ++p) {
+            if (p == 4 && !has5) break;
+            const int col = j0 + dcb[p] * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = DIAGT ? i0 + (mi == 2 ? 64 : 0) + dr * 16 + crow(r) : i0 + wr * 64 + mi * 16 + crow(r);
-                if (row < mp && col < mp) out[(size_t)row * mp + col] = res(mi, ni, r);
+                const int row = i0 + dra[p] * 16 + crow(r);
+                if (row < mp && col < mp) out[(size_t)row * mp + col] = p < 4 ? res(p, 0, r) : res(0, 1, r);
             }
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wr * 64 + mi * 16 + crow(r);
+                    if (row < mp && col < mp) out[(size_t)row * mp + col] = res(mi, ni, r);
+                }
+            }
+    }
 }
 
 template <bool WEIGHTED, bool TRI, int WC, typename OT>
