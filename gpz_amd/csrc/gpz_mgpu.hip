@@ -145,7 +145,7 @@ extern "C" int gpz_device_count(void) {
 }
 
 // ---- single-process multi-device driver ---------------------------------------------------------------------------
-// Barrier, AbortGate, CmdLoop: gpz_mgpu_sync.h (host-only, also compiled under -fsanitize=thread by the tests)
+// Barrier, AbortGate, CmdLoop: gpz_mgpu_sync.h (host-only, also compiled under ThreadSanitizer by the tests)
 using gpz_sync::Barrier;
 
 __global__ void k_loopback_sum(double *const *bufs, int nb, size_t count) {

@@ -1,7 +1,7 @@
 // Host-side synchronisation core of the single-process multi-device driver (gpz_mgpu.hip): command hand-off to one persistent
 // thread per rank, the poisonable barrier of the loopback reducer, and the gate that keeps enqueues and the abort of the
 // communicators apart.  No HIP, no RCCL, no gpz types: the per-rank work and what "abort" does are callbacks, so this file also
-// compiles host-only with a stub rank function under -fsanitize=thread (tests/stubs/mgpu_sync_tsan.cpp, SURVEY.md section 5
+// compiles host-only with a stub rank function under ThreadSanitizer (tests/stubs/mgpu_sync_tsan.cpp, SURVEY.md section 5
 // "race detection").
 #pragma once
 #include <atomic>

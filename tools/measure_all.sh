@@ -24,4 +24,12 @@ python tools/pmc_summary.py gpurun_out/$tag/pmc_c5 gpurun_out/$tag/pmc_c5_summar
 find gpurun_out/$tag/pmc_c5/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_c5.csv \;
 # keep the merged-back payload small: the raw counter CSVs are large
 find gpurun_out/$tag/pmc -name "*.csv" -size +4M -delete
+# round 4: config 5 with the moment sums on 4 x 4 MFMA tiles (opt-in route), config 5 in fp64, the loopback-8 run of c4 with per-rank
+# stage times (the line a first real 8-GPU run is read against), and the issue-rate microbenchmarks behind DESIGN.md section 8
+GPZ_PSI32_MFMA=1 python bench.py --config c5 --rows 250000 --steps 3 --warmup 1 --no-cpu-baseline > $O/c5s_mfma_route.json 2> $O/c5s_mfma_route.err
+python bench.py --config c5_f64 --rows 250000 --steps 2 --warmup 1 --no-cpu-baseline > $O/c5s_f64.json 2> $O/c5s_f64.err
+python bench.py --native-mgpu 8 --no-cpu-baseline --steps 5 > $O/c4_native_mgpu8_loopback.json 2> $O/c4_native_mgpu8_loopback.err
+for t in mfma_f32_4x4_rate mfma_valu_overlap; do
+  hipcc --offload-arch=gfx950 -O3 tools/$t.hip -o build/$t 2> /dev/null && build/$t > $O/ubench_$t.txt 2>&1
+done
 tail -c 600 $O/c4.json; echo; tail -c 300 $O/c2.json; echo; tail -c 300 $O/c3.json; echo; tail -c 300 $O/c4_shard125k.json
