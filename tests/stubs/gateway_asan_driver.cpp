@@ -1,6 +1,6 @@
 // Sanitizer driver for mex/gpz_mex.cpp (tests/test_sanitizers.py): every command of the gateway, with good arguments and with each
 // class of bad ones, against the host-only stand-in of the library (gpz_stub.cpp) and the stand-in MEX runtime (mex_runtime.cpp),
-// built with -fsanitize=address,undefined.  TEST INFRASTRUCTURE.  Exit code 0 = every call behaved as expected; the sanitizers
+// built with AddressSanitizer + UBSan.  TEST INFRASTRUCTURE.  Exit code 0 = every call behaved as expected; the sanitizers
 // abort the process on a finding.  (MATLAB frees the mxArrays a failing MEX call leaves behind; the stand-in runtime does not, so
 // the test runs with leak detection off.)
 #include <stdio.h>

@@ -1,5 +1,5 @@
 // Host-only stand-in for libgpz_hip.so behind the MEX gateway, for the sanitizer build of mex/gpz_mex.cpp
-// (tests/test_sanitizers.py: -fsanitize=address,undefined has no GPU side).  TEST INFRASTRUCTURE: it computes nothing of GPz - every
+// (tests/test_sanitizers.py: AddressSanitizer + UBSan has no GPU side).  TEST INFRASTRUCTURE: it computes nothing of GPz - every
 // entry point checks its arguments the way the library documents them in include/gpz_hip.h and WRITES EVERY ELEMENT of every output
 // it is handed at the documented size, so a gateway that allocates an output too small, passes a wrong length or reads past an
 // input is caught by AddressSanitizer.  Inputs are read completely as well (checksummed into the outputs).

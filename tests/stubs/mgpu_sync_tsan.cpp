@@ -7,7 +7,7 @@
 // with failures injected at random (rank, exchange point).  Checked besides TSAN's own report: no hang (the caller runs this under
 // a timeout), every command returns, the failing rank is reported, sums are right when nothing failed, a loopback handle keeps
 // working after a failure, a gate handle is dead after one.
-//   g++ -std=c++17 -O1 -g -fsanitize=thread -Igpz_amd/csrc tests/stubs/mgpu_sync_tsan.cpp -o build/mgpu_sync_tsan -lpthread
+//   (build line: tests/test_sanitizers.py)
 #include <stdio.h>
 #include <stdlib.h>
 
