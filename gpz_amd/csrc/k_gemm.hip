@@ -410,12 +410,18 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         }
     };
 
-    // number of valid 16-column MFMA tiles of this wave (only the last column tile can be partial)
+    // The last column tile can be partial (m = 1000: 112 of its 128 columns exist).  Skipping the missing 16-column MFMA tiles in
+    // the 2 x WC wave grid leaves the SIMD that hosts the waves of the last wave column with half the work and the others with all
+    // of it - no time saved.  EDGE tiles are therefore dealt in ROW STRIPS: wave w takes rows 16 w .. 16 w + 15 and every valid
+    // column tile (one A fragment, nvalid <= 8 B fragments per K step), so all four SIMDs run 2 nvalid MFMAs per K step instead of 16.
     int nvalid = NI;
     if (EDGE) {
-        nvalid = (mp - (j0 + wc * (16 * NI)) + 15) / 16;
-        nvalid = nvalid < 0 ? 0 : (nvalid > NI ? NI : nvalid);
+        nvalid = (mp - j0 + 15) / 16;
+        nvalid = nvalid < 0 ? 0 : (nvalid > 8 ? 8 : nvalid);
+        nvalid = __builtin_amdgcn_readfirstlane(nvalid);
     }
+    static_assert(!EDGE || 4 * NI == 8, "the row-strip deal keeps its eight accumulators in acc[4][2]");
+    constexpr int NFA = EDGE ? 1 : 4, NFB = EDGE ? 8 : NI;
 
     // Software pipeline as in syrk_body: loads of slice s+2 issued mid-slice s, LDS writes between the MFMA halves.
     const int nstage = kdim / 16;        // K (= mp for the evaluation's T = PHI*[inv(SIGMA)|w]; the output may be wider: mp columns)
@@ -425,28 +431,39 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     __syncthreads();
     // Operand fragments are fetched from LDS one K step ahead of the MFMA burst that uses them, and the barrier of a
     // slice sits in front of its last burst, so the first fragment of the next slice is fetched under that burst.
-    auto rdfrag = [&](int cur, int kk, OT (&a)[4], OT (&b)[NI]) {
+    auto rdfrag = [&](int cur, int kk, OT (&a)[NFA], OT (&b)[NFB]) {
         const int kc = kk * 4 + (lane >> 4);
+        if (EDGE) {
+            a[0] = sA[cur][wave * 16 + (lane & 15)][kc];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
+            for (int p = 0; p < NFB; ++p) b[p] = sB[cur][kc][p * 16 + (lane & 15)];   // (columns past mp were staged from the last valid pair)
+        } else {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
+            for (int mi = 0; mi < NFA; ++mi) a[mi] = sA[cur][wr * 64 + mi * 16 + (lane & 15)][kc];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = sB[cur][kc][wc * (16 * NI) + ni * 16 + (lane & 15)];
+        }
     };
     // Raised wave priority over the MFMA burst only: the SIMD's issue arbiter then prefers a wave whose operands are
     // ready over the waves that are staging (global loads, LDS writes, address VALU), which otherwise take issue
     // slots in front of it.  k_tgemm 33.15 -> 31.95 ms at c4; raising it over the LDS operand reads as well gives
     // nothing, priority 3 the same as 1.  Fragment prefetch on top: 32.1 -> 31.6 ms.
-    auto burst = [&](const OT (&a)[4], const OT (&b)[NI]) {
+    auto burst = [&](const OT (&a)[NFA], const OT (&b)[NFB]) {
         __builtin_amdgcn_s_setprio(1);
+        if (EDGE) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-            if (!EDGE || ni < nvalid) {
+            for (int p = 0; p < NFB; ++p)
+                if (p < nvalid) acc[p >> 1][p & 1] = MfmaOf<OT>::run(a[0], b[p], acc[p >> 1][p & 1]);
+        } else {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = MfmaOf<OT>::run(a[mi], b[ni], acc[mi][ni]);
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < NFA; ++mi) acc[mi][ni] = MfmaOf<OT>::run(a[mi], b[ni], acc[mi][ni]);
             }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
-    OT fa0[4], fb0[NI], fa1[4], fb1[NI];
+    OT fa0[NFA], fb0[NFB], fa1[NFA], fb1[NFB];
     rdfrag(0, 0, fa0, fb0);
     auto stage = [&](auto curc, int s) {
         constexpr int cur = decltype(curc)::value;
@@ -482,17 +499,50 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     // row of accumulator register r inside a 16x16 tile: the f64 instruction deals rows (lane >> 4) + 4r, the f32 one 4(lane >> 4) + r
     auto crow = [&](int r) -> int { return std::is_same<OT, float>::value ? 4 * (lane >> 4) + r : (lane >> 4) + 4 * r; };
 
+    if (EDGE) {
+        // row strip of this wave: rows i0 + 16 wave + crow(r), column tile p
+#pragma unroll
+        for (int p = 0; p < NFB; ++p) {
+            const int col = j0 + p * 16 + (lane & 15);
+            if (p < nvalid && col < mp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[(size_t)(i0 + wave * 16 + crow(r)) * ldt + col] = res(p >> 1, p & 1, r);
+            }
+        }
+        if (nupart) {
+            // the consumers sum WC slots per column tile and row: this wave's sum over ALL columns of the tile goes to slot 0,
+            // zeros to the others
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wave * 16 + crow(r);
+                double pp = 0.0;
+#pragma unroll
+                for (int p = 0; p < NFB; ++p) {
+                    const int col = j0 + p * 16 + (lane & 15);
+                    if (p < nvalid && col < m) pp = fma(Phi[(size_t)row * ld + col], res(p >> 1, p & 1, r), pp);
+                    if (p < nvalid && col == mcol) phiw[row] = res(p >> 1, p & 1, r);
+                }
+                pp += __shfl_xor(pp, 1, 64);
+                pp += __shfl_xor(pp, 2, 64);
+                pp += __shfl_xor(pp, 4, 64);
+                pp += __shfl_xor(pp, 8, 64);
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int q = 0; q < WC; ++q) nupart[(size_t)(ct * WC + q) * n_pad + row] = q == 0 ? pp : 0.0;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
-            if (!EDGE || col < mp) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i0 + wr * 64 + mi * 16 + crow(r);
-                    T[(size_t)row * ldt + col] = res(mi, ni, r);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wr * 64 + mi * 16 + crow(r);
+                T[(size_t)row * ldt + col] = res(mi, ni, r);
             }
         }
     if (nupart) {
