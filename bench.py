@@ -436,8 +436,13 @@ def main():
             ach_mo = pairs * 6370 * 2 / (mo_avg * 1e-3) / 1e12 if mo_avg > 0 else 0.0
             ach_ph = pairs * 3480 * 2 / (ph_avg * 1e-3) / 1e12 if ph_avg > 0 else 0.0
             pair = {
-                "bound": "fp32 VALU (157.3 TFLOP/s spec = the fp32 MFMA rate; tools/fp32_valu_bench.hip has the issue rates per occupancy)",
+                "bound": "fp32 VALU (157.3 TFLOP/s spec = the fp32 MFMA rate)",
                 "peak": 157.3, "unit": "TFLOP/s",
+                # measured issue ceilings of fp32 instruction streams on this chip (tools/pk_fma_rate.hip, profiles/r04_ubench_pk_fma_rate.txt;
+                # DESIGN.md section 8): the kernels' 2:1 mix of v_pk_fma_f32 and v_fma_f32 at four waves per SIMD, and at the ONE wave per
+                # SIMD a 220-register triangle per lane allows
+                "measured_issue_ceiling": {"mix_4_waves_per_simd": 123.2, "mix_1_wave_per_simd": 86.6, "unit": "TFLOP/s issued",
+                                           "note": "issued multiply-adds; the kernels issue 1.4x the algorithmic ones (junk slots of the row-pair layout, non-FMA instructions)"},
                 "k_psi32_moments": {"achieved": ach_mo, "frac": ach_mo / 157.3, "avg_ms": mo_avg, "flops_per_pair": 12740},
                 "k_psi32_phi (+ fill, row dots)": {"achieved": ach_ph, "frac": ach_ph / 157.3, "avg_ms": ph_avg, "flops_per_pair": 6960}}
             # the dominant kernel of this configuration is the moment kernel, not a GEMM: it is the top-level roofline
