@@ -1998,22 +1998,26 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
     const int d = desc->d;
     const bool covk = method_id_of(desc->method) >= 4;
-    (void)covk;
-    if (d > 64)
-        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= 64 (the NaN pattern of a group is a 64-bit "
-                                         "mask throughout these kernels); d = %d", d);
-    unsigned long long obs = 0;
-    for (int c = 0; c < d; ++c) { const double xv = Xs[(size_t)c * ns]; if (xv == xv) obs |= 1ull << c; }
+    if (d > (covk ? 64 : GPZ_PM_MAXD_DIAG))
+        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= %d (GL/VL/GD/VD: the pair-table kernel keeps d KB "
+                                         "of LDS per 64 basis pairs) and d <= 64 (GC/VC: 64-wide per-thread temporaries); d = %d",
+                    GPZ_PM_MAXD_DIAG, d);
+    ObsMask obs = {{0ull, 0ull, 0ull, 0ull}};
+    int nobs = 0;
+    for (int c = 0; c < d; ++c) {
+        const double xv = Xs[(size_t)c * ns];
+        if (xv == xv) { obs.w[c >> 6] |= 1ull << (c & 63); ++nobs; }
+    }
     for (int c = 0; c < d; ++c)
         for (int64_t i = 0; i < ns; ++i) {
             const double xv = Xs[(size_t)c * ns + i];
-            if ((xv == xv) != (((obs >> c) & 1ull) != 0))
+            if ((xv == xv) != obs_bit(obs, c))
                 return fail(GPZ_ERR_ARG, "gpz_predict_missing: the rows of a group must share one NaN pattern (predict.m:45-57)");
         }
-    if (obs == (d >= 64 ? ~0ull : ((1ull << d) - 1ull)))
+    if (nobs == d)
         return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
-    if (method_id_of(desc->method) >= 4)
-        return predict_missing_cov(desc, obs, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
+    if (covk)
+        return predict_missing_cov(desc, obs.w[0], theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;

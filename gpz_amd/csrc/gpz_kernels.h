@@ -331,9 +331,16 @@ void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, in
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
                        int nwg);
 
-// prediction with missing dimensions, diagonal kinds (predictDiag.m:127-297; k_pmiss.hip).  obs: bit c set = dimension c observed.
+// prediction with missing dimensions, diagonal kinds (predictDiag.m:127-297; k_pmiss.hip).  obs: bit c set = dimension c observed
+// (ObsMask: 256 bits, passed by value; the covariance kinds keep a 64-bit mask, d <= 64).
+struct ObsMask {
+    unsigned long long w[4];
+};
+#define GPZ_PM_MAXD 256        // bits of the mask
+#define GPZ_PM_MAXD_DIAG 144   // what the pair-table kernel's LDS tile (d KB per 64 pairs) allows
+static inline __host__ __device__ bool obs_bit(const ObsMask &o, int c) { return (o.w[c >> 6] >> (c & 63)) & 1ull; }
 void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
-                  unsigned long long obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
+                  ObsMask obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
 void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio);
 // covariance kinds (predictCov.m:134-337; k_pmiss_cov.hip): see launch_pmc for the work buffers
 int pmc_rec_len(int d, unsigned long long obs);
@@ -350,14 +357,14 @@ void launch_pmc_wide(hipStream_t st, unsigned long long obs, int n, long ldx, in
                      double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
                      double *work2, bool tab_ready);
 bool pmc_fast(int d, int k);   // 2 <= d <= 10, k <= 8: the register-resident kernels (needs rows_blk <= 64)
-void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned long long obs, const double *P, const double *G, double *B);
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, ObsMask obs, const double *P, const double *G, double *B);
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
                    const double *G, double *Phi);
-void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned long long obs,
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, ObsMask obs,
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec);
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
-                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec,
+                     ObsMask obs, int npq, const double *T2, const double *rec, int nrec,
                      double *sums /* [nsplit][3k][n_pad] */, int nsplit = 1);
 int pm_accum_splits(int n);
 

@@ -13,7 +13,7 @@
 // No(i,j) = exp(-1/2 sum_o (x-p_j)^2/(sigma_j [+psi_i]) - 1/2 sum_o ln(sigma_j [+psi_i]))   predictDiag.m:142-148 / :226-233
 // written to No[i*ld + j]; columns j >= m and rows i >= n are zero.
 __global__ void k_pm_no(const double *__restrict__ Xr, const double *__restrict__ Psir, int de, int n, long n_pad, int m,
-                        int ld, int d, unsigned long long obs, const double *__restrict__ P, const double *__restrict__ G,
+                        int ld, int d, ObsMask obs, const double *__restrict__ P, const double *__restrict__ G,
                         double *__restrict__ No) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const long i = blockIdx.y;
@@ -22,7 +22,7 @@ __global__ void k_pm_no(const double *__restrict__ Xr, const double *__restrict_
     if (j < m && i < n) {
         double q = 0.0, ls = 0.0;
         for (int c = 0; c < d; ++c) {
-            if (!((obs >> c) & 1ull)) continue;
+            if (!obs_bit(obs, c)) continue;
             const double g = G[(size_t)j * de + c];
             double s = 1.0 / (g * g);                                  // Sigma = Gamma.^-2
             if (Psir) s += Psir[(size_t)i * de + c];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_pm_pio(const double *__restrict__ No, i
 }
 
 // B[j*ld + i] = Nij(i,j) = exp(-1/2 sum_u (p_i-p_j)^2/(sigma_i+sigma_j) - 1/2 sum_u ln(sigma_i+sigma_j))   predictDiag.m:158
-__global__ void k_pm_nij(int m, int ld, int d, int de, unsigned long long obs, const double *__restrict__ P,
+__global__ void k_pm_nij(int m, int ld, int d, int de, ObsMask obs, const double *__restrict__ P,
                          const double *__restrict__ G, double *__restrict__ B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= ld) return;
@@ -56,7 +56,7 @@ __global__ void k_pm_nij(int m, int ld, int d, int de, unsigned long long obs, c
     if (i < m && j < m) {
         double q = 0.0, ls = 0.0;
         for (int c = 0; c < d; ++c) {
-            if ((obs >> c) & 1ull) continue;
+            if (obs_bit(obs, c)) continue;
             const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
             const double s = 1.0 / (gi * gi) + 1.0 / (gj * gj);
             const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
@@ -99,7 +99,7 @@ __device__ __forceinline__ void pair_of(long q, int *pi, int *pj) {
 //           [- 1/2 sum_o ln Cij when there is no input noise: the x-independent part of No,                    :178]
 //     c2  = 2 for j < i, 1 for j == i (2x inside the loop, minus 1x for the diagonal term after it,            :191-199)
 // Columns past the last pair are zero (B) / c2 = 0 (rec).
-__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int ldb, int d, int de, int k, unsigned long long obs,
+__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int ldb, int d, int de, int k, ObsMask obs,
                                                     int has_psi, const double *__restrict__ P,
                                                     const double *__restrict__ G, const double *__restrict__ w,
                                                     const double *__restrict__ v, const double *__restrict__ iS,
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
         if (l < m && live) {
             double qd = 0.0, ls = 0.0;
             for (int c = 0; c < d; ++c) {
-                if ((obs >> c) & 1ull) continue;
+                if (obs_bit(obs, c)) continue;
                 const double gl = G[(size_t)l * de + c];
                 const double s = 1.0 / (gl * gl) + Cij[c * 64 + lane];
                 const double dl = P[(size_t)l * de + c] - cij[c * 64 + lane];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
             const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
             qd += dl * dl / s;
             ls += log(s);
-            if (((obs >> c) & 1ull) && !has_psi) lo += log(Cij[c * 64 + lane]);
+            if (obs_bit(obs, c) && !has_psi) lo += log(Cij[c * 64 + lane]);
             r[c] = cij[c * 64 + lane];
             r[d + c] = Cij[c * 64 + lane];
         }
@@ -176,20 +176,21 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
 // gridDim.y = S splits of the chunk's pairs, each accumulating into its own slab sums[s][3k][n_pad] (summed in fixed order at
 // the end): with a few dozen rows per group one wave per row left the chip empty.
 __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr, const double *__restrict__ Psir, int de,
-                                                   int n, long n_pad, int ld, int d, int k, unsigned long long obs, int npq,
+                                                   int n, long n_pad, int ld, int d, int k, ObsMask obs, int npq,
                                                    const double *__restrict__ T2, const double *__restrict__ rec, int nrec,
                                                    double *__restrict__ sums_all) {
     double *sums = sums_all + (size_t)blockIdx.y * 3 * k * n_pad;
     const int per = (npq + gridDim.y - 1) / gridDim.y;
     const int qlo = blockIdx.y * per, qhi = min(npq, qlo + per);
-    __shared__ double sx[4][64], sps[4][64];
+    __shared__ double sx[4][GPZ_PM_MAXD], sps[4][GPZ_PM_MAXD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long i = (long)blockIdx.x * 4 + wave;
     const bool live = i < n;
-    if (live && lane < d) {
-        sx[wave][lane] = Xr[(size_t)i * de + lane];
-        sps[wave][lane] = Psir ? Psir[(size_t)i * de + lane] : 0.0;
-    }
+    if (live)
+        for (int c = lane; c < d; c += 64) {
+            sx[wave][c] = Xr[(size_t)i * de + c];
+            sps[wave][c] = Psir ? Psir[(size_t)i * de + c] : 0.0;
+        }
     __syncthreads();
     if (!live) return;
     // the 3k sums in blocks of 24 (k <= 8: one pass; more outputs walk the pairs again per block)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr,
             const double *r = rec + (size_t)qq * nrec;
             double qd = 0.0, ls = 0.0;
             for (int c = 0; c < d; ++c) {
-                if (!((obs >> c) & 1ull)) continue;
+                if (!obs_bit(obs, c)) continue;
                 const double s = r[d + c] + sps[wave][c];
                 const double dl = sx[wave][c] - r[c];
                 qd += dl * dl / s;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr,
 }
 
 void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
-                  unsigned long long obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
+                  ObsMask obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
     hipLaunchKernelGGL(k_pm_no, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, Xr, Psir, de, n, n_pad, m, ld, d, obs,
                        P, G, No);
     hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double *)No, ld, n, m, priors, Pio);
@@ -232,7 +233,7 @@ void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, 
 void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio) {
     hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, No, ld, n, m, priors, Pio);
 }
-void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, unsigned long long obs, const double *P, const double *G, double *B) {
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, ObsMask obs, const double *P, const double *G, double *B) {
     hipLaunchKernelGGL(k_pm_nij, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
 }
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
@@ -241,17 +242,19 @@ void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, i
                        Phi);
 }
 // width = number of pairs of the chunk = row stride of B (ld rows: the K dimension of the following T-GEMM)
-void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, unsigned long long obs,
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, ObsMask obs,
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec) {
-    hipLaunchKernelGGL(k_pm_pairtab, dim3(width / 64, 16), dim3(256), (size_t)2 * d * 64 * sizeof(double), st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
+    const size_t lds = (size_t)2 * d * 64 * sizeof(double);   // cij / Cij of 64 pairs: d KB (d <= GPZ_PM_MAXD_DIAG keeps it inside a CU's 160 KB)
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pm_pairtab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_pm_pairtab, dim3(width / 64, 16), dim3(256), lds, st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
                        iS, B, rec, nrec);
 }
 // Pair splits of the accumulation kernel.  A constant: the order in which a row's sums are formed must not depend on how many
 // rows the call holds (gpz_mgpu_predict cuts a group into row blocks and promises the single-device bits).
 int pm_accum_splits(int n) { (void)n; return 16; }
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
-                     unsigned long long obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit) {
+                     ObsMask obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit) {
     hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 3) / 4), nsplit), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
                        npq, T2, rec, nrec, sums);
 }

@@ -30,8 +30,9 @@
  * input noise in fp64 runs register-resident up to d = 10 and as a block elimination in f64 MFMA accumulators for
  * 10 < d <= 64 (four pairs per wave up to d = 48), the workspace form beyond.
  * gpz_predict_missing for GC/VC runs register / MFMA kernels up to d = 32 and scratch-resident kernels with 64-wide temporaries for
- * 32 < d <= 64 (correct and slow: 32 KB of scratch per thread and temporary).  Still refused (GPZ_ERR_UNSUPPORTED):
- * gpz_predict_missing with d > 64 (the NaN pattern of a group is a 64-bit mask in those kernels).  dtype = f32 with d > 20 takes
+ * 32 < d <= 64 (correct and slow: 32 KB of scratch per thread and temporary); the diagonal kinds run to d = 144 (256-bit pattern
+ * mask; the pair-table kernel keeps d KB of LDS per 64 basis pairs).  Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing
+ * with d > 64 for GC/VC, d > 144 for GL/VL/GD/VD.  dtype = f32 with d > 20 takes
  * the fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers); gpz_ctx_route says which route a context runs.
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):

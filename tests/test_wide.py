@@ -129,7 +129,7 @@ def test_cov_kind_with_more_than_1024_nan_patterns():
     _gate(model, theta, X, Y, loose=2.0)
 
 
-@pytest.mark.parametrize("method,d,k,noisy", [("VD", 22, 1, False), ("GL", 24, 9, True), ("VL", 40, 2, True)])
+@pytest.mark.parametrize("method,d,k,noisy", [("VD", 22, 1, False), ("GL", 24, 9, True), ("VL", 40, 2, True), ("VD", 70, 1, True), ("GD", 130, 1, False)])
 def test_predict_with_missing_values_wide_diag_kinds(method, d, k, noisy):
     """predictMissing / predictNoisyMissing (predictDiag.m:127-297) at d > 20 and k > 8 against the oracle."""
     m = 8
@@ -191,9 +191,10 @@ def test_predict_with_missing_values_cov_kinds_beyond_32_dimensions(method, d, n
 
 
 def test_what_is_still_refused_says_so():
-    """Prediction with missing values keeps d <= 64: the NaN pattern of a group is a 64-bit mask throughout those kernels."""
+    """Prediction with missing values: d <= 64 for GC/VC (64-wide per-thread temporaries), d <= 144 for the diagonal kinds (LDS tile
+    of the pair-table kernel)."""
     d = 66
-    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "VD", True, seed=5)
+    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "GC", True, seed=5)
     r4 = O.GPz(theta, model, X, Y, nargout=4)
     pri = np.full(5, 0.2)
     model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
