@@ -785,7 +785,11 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     // 9.88 -> 9.71 ms with 512; full c4 unchanged with 1024).  GPZ_SYRK_WGS overrides (tuning only).
     {
         const int nt = (c->mp + 127) / 128, npairs = nt * (nt + 1) / 2;
-        int target = (c->tr.n_pad / (1024 / npairs > 0 ? 1024 / npairs : 1) >= 16384) ? 1024 : 512;
+        // rows a workgroup gets at a target of T workgroups: n_pad npairs / T.  Every split is one more mp x mp slab for k_syrk_reduce to
+        // read, so short row ranges are not worth a second resident round: c2 / c3 (600 / 2000 rows per workgroup at 512) run
+        // SYRK + reduce 19 / 25 us faster at 256 workgroups (0.179 -> 0.160 ms, 0.520 -> 0.495 ms)
+        auto rows_at = [&](int T) { return (long)c->tr.n_pad * npairs / T; };
+        int target = rows_at(1024) >= 16384 ? 1024 : rows_at(512) >= 4096 ? 512 : 256;
         if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e) > 0 ? atoi(e) : target;
         // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 9 MFMAs per SIMD and K step against 16:
         // the 36 products on and above the diagonal, k_gemm.hip): the pair that minimises max(1/s1, 0.6/s2) with
@@ -1150,15 +1154,13 @@ static void stage_b(gpz_ctx *c, int o) {
     const double *S = c->comm1 + (size_t)o * c->mp * c->mp;
     {
         Stage s(c, "chol");
-        launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq);
-        launch_zero(c->st, c->logdet + o, 1);
+        launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq, c->Wm, c->logdet + o);   // clears Wm, logdet too
         for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
             launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
         }
     }
     {
         Stage s(c, "trtri");
-        launch_zero(c->st, c->Wm, (size_t)mq * mq);
         launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
         for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     }
@@ -2169,8 +2171,7 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     (void)hipMemset(alpha0, 0, (size_t)m * sizeof(double));
     (void)hipMemset(c->info, 0, 2 * sizeof(int));
     const int mq = c->mq;
-    launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq);
-    launch_zero(c->st, c->logdet, 1);
+    launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq, nullptr, c->logdet);
     for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
         launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
     }

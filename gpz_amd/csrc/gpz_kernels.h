@@ -83,7 +83,7 @@ void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp,
 #endif
 // ---- m x m factorisation pieces (k_chol.hip) -----------------------------------------------------
 // A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
-void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda);
+void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz = nullptr, double *logdet = nullptr);   // Wz (mq x mq) and *logdet are cleared when given
 // panel + trailing update of one step in a single launch (GPZ_CH_NB == 32)
 void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
 void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq);

@@ -13,10 +13,14 @@
 
 #define CH_NB GPZ_CH_NB
 
+// Also clears what the chain behind it accumulates into (two launches of k_zero less per output: an evaluation of a small problem is
+// a sequence of ~4 us launches): Wz (mq x mq, the inverse factor's workspace) and *logdet, when given.
 __global__ void k_build_sigma(const double *__restrict__ S, int lds, const double *__restrict__ alpha, int m, int mq,
-                              double *__restrict__ A, int lda) {
+                              double *__restrict__ A, int lda, double *__restrict__ Wz, double *__restrict__ logdet) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= mq) return;
+    if (Wz) Wz[(size_t)i * mq + j] = 0.0;
+    if (logdet && i == 0 && j == 0) *logdet = 0.0;
     double v;
     if (i < m && j < m) {
         v = S[(size_t)i * lds + j];
@@ -245,8 +249,9 @@ __global__ void k_fill_bext(const double *__restrict__ Sinv, int ldsi, const dou
 }
 static int bext_round32() { return getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0; }
 
-void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda) {
-    hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda);
+void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz,
+                        double *logdet) {
+    hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda, Wz, logdet);
 }
 
 void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info) {
