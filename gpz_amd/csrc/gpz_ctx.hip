@@ -329,6 +329,7 @@ struct gpz_ctx {
     bool pats_fixed = false;                        // table given by the caller (sharded runs): rows must match an entry
     unsigned char *pat_d = nullptr;
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
+    double *gc_minv = nullptr;   // GC + Psi, 10 < d <= 32 (fp64): -inv(Sigma + Psi_i) of every training row as 4 x 4 tiles (k_cpsi4_minv)
     // missing dimensions without input noise: per-pattern parameter blocks and moment slabs of the tuned kernels
     double *RcP = nullptr, *gen_tslab = nullptr, *gen_frec = nullptr, *fin_part = nullptr;
     double *gen_ws = nullptr;   // d > 20: runtime-d workspace of the general-path kernels (k_gen.hip), else nullptr
@@ -678,6 +679,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         }
         c->psi_fast = !c->psi32 && c->has_psi && psi_fast_path_available(c->d);
         c->psi_miss = c->psi_fast && (c->has_missing || c->ngroups > 1);
+        if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !getenv("GPZ_GC_MINV_OFF") &&
+            (rc = c->ar.alloc(&c->gc_minv, (size_t)(c->tr.n > 0 ? c->tr.n : 1) * cpsi4_minv_len(c->d))))
+            return rc;   // GC: one inverse per training row, shared by the basis functions (k_cpsi4_moments<.., SHARED>)
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
@@ -1255,16 +1259,18 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
                 nch = (c->tr.n + rpc - 1) / rpc;
                 if (nch < 1) nch = 1;
+                if (c->gc_minv && o == 0)   // GC: M_i = Sigma + Psi_i is inverted once per row, not once per (row, basis function)
+                    launch_cpsi4_minv(c->st, gen_rows(c->tr), c->d, c->Sig, c->psi_miss ? c->pat_d : nullptr, c->gc_minv);
                 if (c->psi_miss) {   // one launch over all NaN patterns, one record set per pattern
                     launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
                                        gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab,
-                                       c->nrec, c->pat_d, c->mom_chunktab);
+                                       c->nrec, c->pat_d, c->mom_chunktab, c->gc_minv);
                     launch_slab_sum_seg(c->st, c->gen_slab, c->mom_segtab, c->ngroups, m * c->nrec, mom);
                     continue;
                 }
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
                                    gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec,
-                                   nullptr, nullptr);
+                                   nullptr, nullptr, c->gc_minv);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
                 continue;
             }
@@ -1336,13 +1342,15 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
             nch = (c->tr.n + rpc - 1) / rpc;
             if (nch < 1) nch = 1;
+            if (c->gc_minv)
+                launch_cpsi4_minv(c->st, gen_rows(c->tr), c->d, c->Sig, c->psi_miss ? c->pat_d : nullptr, c->gc_minv);
             if (c->psi_miss) {
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
-                                   c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab, c->nrec, c->pat_d, c->mom_chunktab);
+                                   c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab, c->nrec, c->pat_d, c->mom_chunktab, c->gc_minv);
                 launch_slab_sum_seg(c->st, c->gen_slab, c->mom_segtab, c->ngroups, m * c->nrec, mom);
             } else {
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
-                                   c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec, nullptr, nullptr);
+                                   c->pr.P, c->Sig, nch, rpc, c->gen_slab, c->nrec, nullptr, nullptr, c->gc_minv);
                 launch_slab_sum(c->st, c->gen_slab, nch, m * c->nrec, mom);
             }
         } else if (c->gen) {

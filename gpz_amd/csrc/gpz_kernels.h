@@ -248,7 +248,9 @@ int launch_cpsi4_phi(hipStream_t st, const GenRows &r, int m, int d, int de, con
 int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                          const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                          int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
-                         const int *chunktab);
+                         const int *chunktab, const double *minv = nullptr);
+size_t cpsi4_minv_len(int d);   // doubles per row of the GC inverse table (k_cpsi4_minv)
+int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, const double *Sig, const unsigned char *pat, double *minv);
 // 32 < d <= 48, rows without missing values (k_cpsi4w.hip)
 bool cpsi4w_available(int d);
 int launch_cpsi4w_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
@@ -275,7 +277,7 @@ int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                        int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
-                       const int *chunktab);
+                       const int *chunktab, const double *gc_minv = nullptr);   // gc_minv: GC, 10 < d <= 32: the per-row inverse table (launch_cpsi4_minv)
 // fp32 per-pair kernels for Psi without missing dimensions, d <= 20 (k_psi32.hip).  PsiT: packed lower triangles of
 // Psi_i, element-major [e][ldp] (diag != 0: only the D diagonals), D = psi32_pad_dim(d).
 int psi32_pad_dim(int d);

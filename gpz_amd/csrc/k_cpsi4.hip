@@ -62,21 +62,44 @@ int launch_cpsi4_phi(hipStream_t st, const GenRows &r, int m, int d, int de, con
 int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                          const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                          int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
-                         const int *chunktab) {
+                         const int *chunktab, const double *minv) {
     if (!cpsi4_available(d)) return -1;
     if (nchunk <= 0) return 0;
+#define MOM_LAUNCH(ND, MS, SH)                                                                                                \
+    hipLaunchKernelGGL((k_cpsi4_moments<ND, MS, SH>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld, rowscal, w, v,  \
+                       r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, (MS) ? r.gid : nullptr,                \
+                       (MS) ? pat : nullptr, chunktab, minv)
 #define MOM_CASE(ND)                                                                                                          \
     do {                                                                                                                      \
-        if (pat)                                                                                                              \
-            hipLaunchKernelGGL((k_cpsi4_moments<ND, true>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld, rowscal, \
-                               w, v, r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, r.gid, pat, chunktab);   \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((k_cpsi4_moments<ND, false>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld,         \
-                               rowscal, w, v, r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, nullptr,       \
-                               nullptr, chunktab);                                                                            \
+        if (pat && minv) MOM_LAUNCH(ND, true, true);                                                                          \
+        else if (pat) MOM_LAUNCH(ND, true, false);                                                                            \
+        else if (minv) MOM_LAUNCH(ND, false, true);                                                                           \
+        else MOM_LAUNCH(ND, false, false);                                                                                    \
     } while (0)
     CPSI4_CASES(MOM_CASE)
 #undef MOM_CASE
+#undef MOM_LAUNCH
+    return 0;
+}
+
+// GC: -inv(Sigma + Psi_i) of every row as 4 x 4 tiles (ND x ND x 16 doubles per row), read back by k_cpsi4_moments<.., SHARED>
+size_t cpsi4_minv_len(int d) {
+    const int nd = (d + 3) / 4;
+    return (size_t)nd * nd * 16;
+}
+int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, const double *Sig, const unsigned char *pat, double *minv) {
+    if (!cpsi4_available(d)) return -1;
+    if (r.n <= 0) return 0;
+#define MINV_CASE(ND)                                                                                                         \
+    do {                                                                                                                      \
+        if (pat)                                                                                                              \
+            hipLaunchKernelGGL((k_cpsi4_minv<ND, true>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig, r.gid, pat, minv); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cpsi4_minv<ND, false>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig, nullptr, nullptr, \
+                               minv);                                                                                         \
+    } while (0)
+    CPSI4_CASES(MINV_CASE)
+#undef MINV_CASE
     return 0;
 }
 

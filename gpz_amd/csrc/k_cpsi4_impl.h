@@ -278,8 +278,55 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double
     }
 }
 
-// Moment records for k_gen_finish: block b of a wave = one basis function, rows of a chunk.  rec = [A0 | Acc1 (d) | Cacc (d*d) | r1 | r2].
+// GC (one covariance for every basis function): M_i = Sigma + Psi_i depends on the sample only, so its inverse is swept ONCE per sample
+// here and the moment kernel below (SHARED) reads it back instead of sweeping once per (sample, basis function):
+//     Minv[i][I][J][4 hi + lo] = -(M_i^-1)[4I + hi][4J + lo]      all ND x ND tiles (the upper ones are the lane transposes of the lower)
+// Block b of a wave = one sample.  Missing dimensions: identity block, as everywhere in this file.
 template <int ND, bool MISS>
+__global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_minv(const double *__restrict__ Psi3, int n, int d,
+                                                                      const double *__restrict__ Sig, const int *__restrict__ gid,
+                                                                      const unsigned char *__restrict__ pat,
+                                                                      double *__restrict__ Minv) {
+    __shared__ double ex_all[4][64];
+    const C4Lane L = c4_lane();
+    const int wave = threadIdx.x >> 6;
+    double *ex = ex_all[wave];
+    const int i = (blockIdx.x * 4 + wave) * 4 + L.b;
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const unsigned char *ob = MISS ? pat + (size_t)gid[ic] * d : nullptr;
+    const double *ps = Psi3 + (size_t)ic * d * d;
+    const int eoff = L.hi * d + L.lo;
+    double T[C4_NT(ND)];
+#pragma unroll
+    for (int I = 0; I < ND; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+            bool k = row < d && col < d;
+            if (MISS && k) k = ob[row] && ob[col];
+            const int e = min(eoff + 4 * (I * d + J), d * d - 1);
+            const double sv = ps[e] + Sig[e];
+            T[c4_lt(I, J)] = k ? sv : ((row == col) ? 1.0 : 0.0);                       // Sigma + Psi_i   GPz.m:170
+        }
+#pragma unroll
+    for (int J = 0; J <= ND; ++J) T[c4_lt(ND, J)] = 0.0;
+    double logdet;
+    c4_sweep<ND, true>(T, ex, L, &logdet);                                              // lower tiles: -M^-1
+    double *out = Minv + (size_t)ic * ND * ND * 16 + 4 * L.hi + L.lo;
+#pragma unroll
+    for (int I = 0; I < ND; ++I)
+#pragma unroll
+        for (int J = 0; J < ND; ++J) {
+            const double v = (I >= J) ? T[c4_lt(I >= J ? I : J, I >= J ? J : I)] : __shfl(T[c4_lt(I >= J ? I : J, I >= J ? J : I)], L.tl, 64);
+            if (valid) out[(I * ND + J) * 16] = v;
+        }
+}
+
+// Moment records for k_gen_finish: block b of a wave = one basis function, rows of a chunk.  rec = [A0 | Acc1 (d) | Cacc (d*d) | r1 | r2].
+//   SHARED   GC: -M_i^-1 comes from k_cpsi4_minv's table (Minv); a (sample, basis) pair then costs u' = Delta' M^-1 as ND^2 tile products
+//            and the ND(ND+1)/2 products of the sums, no sweep: O(d^2) per pair instead of O(d^3)
+template <int ND, bool MISS, bool SHARED = false>
 __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const double *__restrict__ Phi, const double *__restrict__ Tm, int ld,
                                                         const double *__restrict__ rowscal, const double *__restrict__ w,
                                                         const double *__restrict__ v, const double *__restrict__ Xr, int de,
@@ -287,7 +334,7 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
                                                         const double *__restrict__ P, const double *__restrict__ Sig,
                                                         int rows_per_chunk, double *__restrict__ slab, int nrec,
                                                         const int *__restrict__ gid, const unsigned char *__restrict__ pat,
-                                                        const int *__restrict__ chunktab) {
+                                                        const int *__restrict__ chunktab, const double *__restrict__ Minv) {
     constexpr int NTD = ND * (ND + 1) / 2;
     __shared__ double ex_all[4][64];
     const C4Lane L = c4_lane();
@@ -308,6 +355,12 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
         pv[J] = (L.hi == 0 && col < d) ? P[(size_t)jc * de + col] : 0.0;
         acc1[J] = 0.0;
     }
+    double pvc[SHARED ? ND : 1];                     // SHARED: p_j as columns, lane (hi, lo = 0) holds p[4I + hi]
+    if (SHARED) {
+#pragma unroll
+        for (int I = 0; I < ND; ++I) pvc[SHARED ? I : 0] = (L.lo == 0 && 4 * I + L.hi < d) ? P[(size_t)jc * de + 4 * I + L.hi] : 0.0;
+    }
+    const int slot16 = 4 * L.hi + L.lo;
     const double wj = w ? w[jc] : 0.0, vj = v ? v[jc] : 0.0;
     double a0 = 0.0, r1 = 0.0, r2 = 0.0;
     int r0 = chunk * rows_per_chunk, rend = min(n, r0 + rows_per_chunk);
@@ -324,8 +377,36 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
             dp = Tm[(size_t)i * ld + jc];
         }
         const unsigned char *ob = MISS ? pat + (size_t)gid[i] * d : nullptr;
-        const double *ps = Psi3 + (size_t)i * d * d;
         double T[C4_NT(ND)];
+        if (SHARED) {
+            // -M_i^-1 from the table: the lower tiles stay in T (the sums below read them), every tile feeds u' = Delta' M^-1
+            const double *mi = Minv + (size_t)i * ND * ND * 16 + slot16;
+            double dc[ND];
+#pragma unroll
+            for (int I = 0; I < ND; ++I) {
+                const int row = 4 * I + L.hi;
+                bool k = L.lo == 0 && row < d;
+                if (MISS && k) k = ob[row];
+                const double xi = Xr[(size_t)i * de + min(row, de - 1)];
+                dc[I] = k ? xi - pvc[SHARED ? I : 0] : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < ND; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J) T[c4_lt(I, J)] = mi[(I * ND + J) * 16];
+#pragma unroll
+            for (int J = 0; J < ND; ++J) {
+                double h = 0.0;
+#pragma unroll
+                for (int I = 0; I < ND; ++I) {
+                    const double z = (I >= J) ? T[c4_lt(I >= J ? I : J, I >= J ? J : I)] : mi[(I * ND + J) * 16];
+                    h = MFMA4(dc[I], z, h);                                            // row 0: sum_I Delta_I' (-M^-1)_IJ
+                }
+                T[c4_lt(ND, J)] = -h;                                                  // (M^-1 Delta)' in row 0, rows 1..3 zero
+            }
+            T[c4_lt(ND, ND)] = 0.0;
+        } else {
+        const double *ps = Psi3 + (size_t)i * d * d;
 #pragma unroll
         for (int I = 0; I < ND; ++I)
 #pragma unroll
@@ -354,6 +435,7 @@ __global__ __launch_bounds__(256, C4_MINB_MOM(ND)) void k_cpsi4_moments(const do
         T[c4_lt(ND, ND)] = 0.0;
         double logdet;
         c4_sweep<ND, true>(T, ex, L, &logdet);                                         // tiles: -M^-1; tile row ND, row 0: (M^-1 Delta)'
+        }
 #pragma unroll
         for (int I = 0; I < ND; ++I)
 #pragma unroll

@@ -36,7 +36,7 @@ int launch_cpsi4w_moments(hipStream_t st, const double *Phi, const double *T, in
     if (nchunk <= 0) return 0;
 #define MOM_CASE(ND)                                                                                                          \
     hipLaunchKernelGGL((k_cpsi4_moments<ND, false>), dim3(nchunk, (m + 15) / 16), dim3(256), 0, st, Phi, T, ld, rowscal, w, v,   \
-                       r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, nullptr, nullptr, chunktab)
+                       r.Xr, de, r.Psi3, r.n, m, d, P, Sig, rows_per_chunk, slab, nrec, nullptr, nullptr, chunktab, nullptr)
     CPSI4W_CASES(MOM_CASE)
 #undef MOM_CASE
     return 0;

@@ -304,10 +304,10 @@ int launch_psi_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const
 int launch_psi_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                        const double *v, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,
                        int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
-                       const int *chunktab) {
+                       const int *chunktab, const double *gc_minv) {
     if (cpsi4_available(d))
         return launch_cpsi4_moments(st, Phi, T, ld, rowscal, w, v, r, m, d, de, P, Sig, nchunk, rows_per_chunk, slab, nrec, pat,
-                                    chunktab);
+                                    chunktab, gc_minv);
     if (!pat && cpsi4w_available(d))
         return launch_cpsi4w_moments(st, Phi, T, ld, rowscal, w, v, r, m, d, de, P, Sig, nchunk, rows_per_chunk, slab, nrec, chunktab);
     if (d > 10)
