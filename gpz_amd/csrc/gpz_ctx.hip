@@ -330,6 +330,7 @@ struct gpz_ctx {
     unsigned char *pat_d = nullptr;
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
     double *gc_minv = nullptr;   // GC + Psi, 10 < d <= 32 (fp64): -inv(Sigma + Psi_i) of every training row as 4 x 4 tiles (k_cpsi4_minv)
+    double *gcq_A = nullptr, *gcq_B = nullptr;   // ... without missing dimensions: operands of the dense form of the PHI build (k_gcq_*)
     // missing dimensions without input noise: per-pattern parameter blocks and moment slabs of the tuned kernels
     double *RcP = nullptr, *gen_tslab = nullptr, *gen_frec = nullptr, *fin_part = nullptr;
     double *gen_ws = nullptr;   // d > 20: runtime-d workspace of the general-path kernels (k_gen.hip), else nullptr
@@ -679,9 +680,6 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
         }
         c->psi_fast = !c->psi32 && c->has_psi && psi_fast_path_available(c->d);
         c->psi_miss = c->psi_fast && (c->has_missing || c->ngroups > 1);
-        if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !getenv("GPZ_GC_MINV_OFF") &&
-            (rc = c->ar.alloc(&c->gc_minv, (size_t)(c->tr.n > 0 ? c->tr.n : 1) * cpsi4_minv_len(c->d))))
-            return rc;   // GC: one inverse per training row, shared by the basis functions (k_cpsi4_moments<.., SHARED>)
         c->nrec = 3 + c->d + c->d * c->d;
         c->nm = c->ngroups * c->nrec;                 // comm2's moment segment holds the [G][m][nrec] records
         std::vector<unsigned char> hp((size_t)c->ngroups * c->d);
@@ -774,6 +772,17 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
     if ((rc = c->ar.alloc(&c->Phi, np * mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->T, np * mp))) return bail(rc);
+    // GC + Psi in fp64, 10 < d <= 32 (evaluation contexts only: prediction and getPHI contexts have no moment stage and no T)
+    if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !getenv("GPZ_GC_MINV_OFF")) {
+        // one inverse per training row, shared by the basis functions (k_cpsi4_moments<.., SHARED>)
+        if ((rc = c->ar.alloc(&c->gc_minv, (size_t)(c->tr.n > 0 ? c->tr.n : 1) * cpsi4_minv_len(c->d)))) return bail(rc);
+        if (!c->psi_miss && !getenv("GPZ_GC_DENSE_PHI_OFF")) {   // and, without missing dimensions, the dense form of the PHI build
+            const size_t kp = (size_t)gcq_kpad(c->d);
+            if ((rc = c->ar.alloc(&c->gcq_A, np * kp))) return bail(rc);
+            if ((rc = c->ar.alloc(&c->gcq_B, kp * mp))) return bail(rc);
+            if (hipMemset(c->gcq_A, 0, np * kp * sizeof(double)) != hipSuccess) return bail(fail(GPZ_ERR_HIP, "memset failed"));
+        }
+    }
     c->fused = (k == 1) || !c->gen;   // the general GC/VC path chains r1 / r2 through its records: single output only
     if (!c->fused && (rc = c->ar.alloc(&c->dL, np * mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->lnbeta, np * k))) return bail(rc);
@@ -1087,8 +1096,19 @@ static int build_phi(gpz_ctx *c) {
                              c->pr.P, c->Sig, c->pr.Rc, c->lnS, c->Phi, c->mp);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else if (c->psi_fast) {
-            launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp,
-                           c->psi_miss ? c->pat_d : nullptr, c->mid == 4);
+            if (c->gc_minv)   // GC: Sigma + Psi_i inverted once per row - for the moment kernel, and for the dense form of the PHI build
+                launch_cpsi4_minv(c->st, gen_rows(c->tr), c->d, c->de, c->Sig, c->lnS, c->psi_miss ? c->pat_d : nullptr, c->gc_minv,
+                                  c->gcq_A, gcq_kpad(c->d));
+            if (c->gcq_A) {
+                // ln PHI = -1/2 [c_ab M^-1_ab | M^-1 x | x'M^-1 x + ln|M| - ln|Sigma|] . [p_a p_b ; -2 p ; 1]: one product on the T-GEMM kernel
+                // (c->T is free until the evaluation's own T-GEMM) and an exp
+                launch_gcq_tab(c->st, c->m, c->d, c->de, c->mp, c->pr.P, c->gcq_B);
+                launch_tgemm(c->st, c->gcq_A, gcq_kpad(c->d), c->gcq_B, c->mp, c->T, c->tr.n_pad, c->mp, nullptr, nullptr, c->m, -1, false,
+                             gcq_kpad(c->d), c->mp);
+                launch_gcq_exp(c->st, c->T, c->mp, c->tr.n, c->m, c->Phi);
+            } else
+                launch_psi_phi(c->st, gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->lnS, c->Phi, c->mp,
+                               c->psi_miss ? c->pat_d : nullptr, c->mid == 4);
             launch_gen_fill(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->mp, c->k, c->tr.Y);
         } else {
             launch_gen_phi(c->st, gen_rows(c->tr), c->m, c->mp, c->d, c->de, c->k, c->pr.P, c->Sig, c->lnS, c->pat_d,
@@ -1259,8 +1279,6 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
                 nch = (c->tr.n + rpc - 1) / rpc;
                 if (nch < 1) nch = 1;
-                if (c->gc_minv && o == 0)   // GC: M_i = Sigma + Psi_i is inverted once per row, not once per (row, basis function)
-                    launch_cpsi4_minv(c->st, gen_rows(c->tr), c->d, c->Sig, c->psi_miss ? c->pat_d : nullptr, c->gc_minv);
                 if (c->psi_miss) {   // one launch over all NaN patterns, one record set per pattern
                     launch_psi_moments(c->st, c->Phi, c->T, c->mp, c->rowscal, c->w, c->hetero ? c->pr.v : nullptr,
                                        gen_rows(c->tr), c->m, c->d, c->de, c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab,
@@ -1342,8 +1360,6 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             const int rpc = (c->tr.n + nch - 1) / nch > 0 ? (c->tr.n + nch - 1) / nch : 1;
             nch = (c->tr.n + rpc - 1) / rpc;
             if (nch < 1) nch = 1;
-            if (c->gc_minv)
-                launch_cpsi4_minv(c->st, gen_rows(c->tr), c->d, c->Sig, c->psi_miss ? c->pat_d : nullptr, c->gc_minv);
             if (c->psi_miss) {
                 launch_psi_moments(c->st, c->Phi, c->T, c->mp, nullptr, nullptr, nullptr, gen_rows(c->tr), c->m, c->d, c->de,
                                    c->pr.P, c->Sig, c->mom_nchunk, 0, c->gen_slab, c->nrec, c->pat_d, c->mom_chunktab, c->gc_minv);

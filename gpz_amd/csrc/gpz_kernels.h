@@ -250,7 +250,13 @@ int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int
                          int nchunk, int rows_per_chunk, double *slab, int nrec, const unsigned char *pat,
                          const int *chunktab, const double *minv = nullptr);
 size_t cpsi4_minv_len(int d);   // doubles per row of the GC inverse table (k_cpsi4_minv)
-int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, const double *Sig, const unsigned char *pat, double *minv);
+int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, int de, const double *Sig, const double *lnS, const unsigned char *pat,
+                      double *minv, double *qA = nullptr, int lda = 0);
+// GC + Psi without missing dimensions, dense form of the PHI build: PHI = exp(-1/2 A * B), A (n x gcq_kpad(d)) from launch_cpsi4_minv(.., qA),
+// B (gcq_kpad(d) x ldb) from launch_gcq_tab, the product on launch_tgemm
+int gcq_kpad(int d);
+void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, double *B);
+void launch_gcq_exp(hipStream_t st, const double *Q, int ld, int n, int m, double *Phi);
 // 32 < d <= 48, rows without missing values (k_cpsi4w.hip)
 bool cpsi4w_available(int d);
 int launch_cpsi4w_phi(hipStream_t st, const GenRows &r, int m, int d, int de, const double *P, const double *Sig,

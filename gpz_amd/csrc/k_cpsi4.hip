@@ -87,20 +87,58 @@ size_t cpsi4_minv_len(int d) {
     const int nd = (d + 3) / 4;
     return (size_t)nd * nd * 16;
 }
-int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, const double *Sig, const unsigned char *pat, double *minv) {
+// qA != nullptr (rows without missing dimensions): also the rows of the dense form of the PHI build (k_cpsi4_minv<.., QROW>), lda doubles apart
+int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, int de, const double *Sig, const double *lnS, const unsigned char *pat,
+                      double *minv, double *qA, int lda) {
     if (!cpsi4_available(d)) return -1;
     if (r.n <= 0) return 0;
+#define MINV_LAUNCH(ND, MS, QR)                                                                                               \
+    hipLaunchKernelGGL((k_cpsi4_minv<ND, MS, QR>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig,               \
+                       (MS) ? r.gid : nullptr, (MS) ? pat : nullptr, minv, r.Xr, de, lnS, qA, lda)
 #define MINV_CASE(ND)                                                                                                         \
     do {                                                                                                                      \
-        if (pat)                                                                                                              \
-            hipLaunchKernelGGL((k_cpsi4_minv<ND, true>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig, r.gid, pat, minv); \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((k_cpsi4_minv<ND, false>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig, nullptr, nullptr, \
-                               minv);                                                                                         \
+        if (pat) MINV_LAUNCH(ND, true, false);                                                                                \
+        else if (qA) MINV_LAUNCH(ND, false, true);                                                                            \
+        else MINV_LAUNCH(ND, false, false);                                                                                   \
     } while (0)
     CPSI4_CASES(MINV_CASE)
 #undef MINV_CASE
+#undef MINV_LAUNCH
     return 0;
+}
+
+// The m-sized table of the dense form: B[e][j], e over [p_a p_b (a >= b, packed) ; -2 p_a ; 1], zero rows up to kpad
+__global__ void k_gcq_tab(int m, int d, int de, int kpad, int ldb, const double *__restrict__ P, double *__restrict__ B) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (j >= ldb || e >= kpad) return;
+    const int K1 = d * (d + 1) / 2;
+    double v = 0.0;
+    if (j < m) {
+        if (e < K1) {
+            int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while (a * (a + 1) / 2 > e) --a;
+            while ((a + 1) * (a + 2) / 2 <= e) ++a;
+            const int b = e - a * (a + 1) / 2;
+            v = P[(size_t)j * de + a] * P[(size_t)j * de + b];
+        } else if (e < K1 + d) v = -2.0 * P[(size_t)j * de + (e - K1)];
+        else if (e == K1 + d) v = 1.0;
+    }
+    B[(size_t)e * ldb + j] = v;
+}
+// PHI = exp(-1/2 Q) on the n x m block, Q from the product above
+__global__ void k_gcq_exp(const double *__restrict__ Q, int ld, int n, int m, double *__restrict__ Phi) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= m || i >= n) return;
+    Phi[(size_t)i * ld + j] = exp(-0.5 * Q[(size_t)i * ld + j]);
+}
+int gcq_kpad(int d) { return (d * (d + 1) / 2 + d + 1 + 15) / 16 * 16; }
+void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, double *B) {
+    const int kpad = gcq_kpad(d);
+    hipLaunchKernelGGL(k_gcq_tab, dim3((ldb + 255) / 256, kpad), dim3(256), 0, st, m, d, de, kpad, ldb, P, B);
+}
+void launch_gcq_exp(hipStream_t st, const double *Q, int ld, int n, int m, double *Phi) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gcq_exp, dim3((m + 255) / 256, n), dim3(256), 0, st, Q, ld, n, m, Phi);
 }
 
 int launch_cpsi4_predict_noisy(hipStream_t st, int n, long ldx, int m, int d, int de, int k, const double *Xr, const double *Psi3,

@@ -282,11 +282,18 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_phi(const double
 // here and the moment kernel below (SHARED) reads it back instead of sweeping once per (sample, basis function):
 //     Minv[i][I][J][4 hi + lo] = -(M_i^-1)[4I + hi][4J + lo]      all ND x ND tiles (the upper ones are the lane transposes of the lower)
 // Block b of a wave = one sample.  Missing dimensions: identity block, as everywhere in this file.
-template <int ND, bool MISS>
+//   QROW   (no missing dimensions) also writes the row of the dense form of the PHI build,
+//              ln PHI_ij = -1/2 ( sum_{a>=b} c_ab M^-1_ab p_a p_b  - 2 (M^-1 x)' p  +  x' M^-1 x + ln|M| - ln|Sigma| ),   c_aa = 1, c_ab = 2,
+//          A[i] = [ c_ab M_i^-1_ab (d(d+1)/2) | M_i^-1 x_i (d) | x_i' M_i^-1 x_i + ln|M_i| - ln|Sigma| ]  against the m-sized table
+//          [ p_a p_b ; -2 p_a ; 1 ] of k_gcq_tab: one product on k_tgemm and an exp replace ND(ND+1)/2 tile products per pair.
+//          x rides along as the extra tile row of the sweep, which leaves (M^-1 x)' and -x' M^-1 x in it.
+template <int ND, bool MISS, bool QROW = false>
 __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_minv(const double *__restrict__ Psi3, int n, int d,
                                                                       const double *__restrict__ Sig, const int *__restrict__ gid,
                                                                       const unsigned char *__restrict__ pat,
-                                                                      double *__restrict__ Minv) {
+                                                                      double *__restrict__ Minv, const double *__restrict__ Xr, int de,
+                                                                      const double *__restrict__ lnS, double *__restrict__ A, int lda) {
+    static_assert(!(MISS && QROW), "the dense form of the PHI build is for rows without missing dimensions");
     __shared__ double ex_all[4][64];
     const C4Lane L = c4_lane();
     const int wave = threadIdx.x >> 6;
@@ -311,8 +318,27 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_minv(const doubl
         }
 #pragma unroll
     for (int J = 0; J <= ND; ++J) T[c4_lt(ND, J)] = 0.0;
+    if (QROW) {
+#pragma unroll
+        for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = (L.hi == 0 && 4 * J + L.lo < d) ? Xr[(size_t)ic * de + 4 * J + L.lo] : 0.0;
+    }
     double logdet;
     c4_sweep<ND, true>(T, ex, L, &logdet);                                              // lower tiles: -M^-1
+    if (QROW && valid) {
+        double *ar = A + (size_t)ic * lda;
+        const int K1 = d * (d + 1) / 2;
+#pragma unroll
+        for (int I = 0; I < ND; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const int row = 4 * I + L.hi, col = 4 * J + L.lo;
+                if (row < d && col <= row) ar[row * (row + 1) / 2 + col] = (row == col ? -1.0 : -2.0) * T[c4_lt(I, J)];
+            }
+#pragma unroll
+        for (int J = 0; J < ND; ++J)
+            if (L.hi == 0 && 4 * J + L.lo < d) ar[K1 + 4 * J + L.lo] = T[c4_lt(ND, J)];  // (M^-1 x)[4J + lo]
+        if (L.hi == 0 && L.lo == 0) ar[K1 + d] = -T[c4_lt(ND, ND)] + logdet - lnS[0];
+    }
     double *out = Minv + (size_t)ic * ND * ND * 16 + 4 * L.hi + L.lo;
 #pragma unroll
     for (int I = 0; I < ND; ++I)
