@@ -590,7 +590,8 @@ static int alloc_mm(gpz_ctx *c) {   // m x m stage buffers
     if (int e = c->ar.alloc(&c->dwda, m * k)) return e;
     if (int e = c->ar.alloc(&c->dgi, m * k)) return e;
     if (int e = c->ar.alloc(&c->logdet, k)) return e;
-    if (int e = c->ar.alloc(&c->info, 2)) return e;
+    if (int e = c->ar.alloc(&c->info, 4)) return e;   // [pivot failure, truncation flag | ticket of k_cond_norms, -]
+    HIPCHK(hipMemset(c->info, 0, 4 * sizeof(int)));
     // LAUUM split: upper 128-tiles of an mq x mq product with mq rows
     const int ntq = (c->mq + 127) / 128, npq = ntq * (ntq + 1) / 2;
     int ns = (256 + npq - 1) / npq;
@@ -850,7 +851,10 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     }
     {
         const int ncg = (c->m + 255) / 256;
-        int nc = 2048 / ncg;
+        // chunks of rows per basis-function group: every chunk writes (and k_slab_sum re-reads) m x nm sums, so few enough that the
+        // slab stays small beside Phi and T, many enough to fill 256 CUs (tools/mom_nc_sweep.sh: c2 768, c3/c4 512 chunks)
+        static const int nc_env = [] { const char *e = getenv("GPZ_MOM_NC"); return e ? atoi(e) : 0; }();
+        int nc = nc_env > 0 ? nc_env / ncg : (768 / ncg > 512 ? 768 / ncg : (2048 / ncg < 512 ? 2048 / ncg : 512));
         const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
         if (nc > max_nc) nc = max_nc;
         if (nc < 1) nc = 1;
@@ -1141,7 +1145,9 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
     }
     {
         Stage s(c, "unpack");
-        launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
+        // also clears info[0..1] and, without validation rows, the validation sums of the result block (eval_tail's layout of comm2)
+        double *vsums0 = c->va.n_pad > 0 ? nullptr : c->comm2 + (size_t)c->m * c->nm + (size_t)c->k * 2 * c->mp + (size_t)c->k * 4;
+        launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr, c->info, vsums0, gpz_ns(c->k));
         if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
     }
     if (int e = psi32_agree(c)) return e;
@@ -1429,9 +1435,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
-    } else {
-        launch_zero(c->st, vsums, gpz_ns(c->k));
-    }
+    }   // (no validation rows: k_unpack zeroed vsums at the start of the evaluation)
     {
         Stage s(c, "allreduce2");
         if (int e = allreduce(c, c->comm2, c->comm2_count)) return e;
@@ -1514,8 +1518,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
         }
         if (he == hipSuccess) {
             c->capturing = true;
-            if ((he = hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st)) != hipSuccess) { rc = -1; why = "memset"; }
-            if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";
+            if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";   // (k_unpack clears the status words)
             if (!rc && (rc = eval_tail(c, false))) why = "stage B";
             c->capturing = false;
             const hipError_t he2 = hipStreamEndCapture(c->st, &graph);
@@ -1542,8 +1545,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
         }
     }
     if (!done) {
-        HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-        if (int e = stage_a(c, theta, theta_dev)) return e;
+        if (int e = stage_a(c, theta, theta_dev)) return e;   // (k_unpack clears the status words)
         if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
         if (graphable && c->graph_state == 0) c->graph_state = 1;
     }
@@ -1571,8 +1573,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
 extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSigma_w, double *nlogML_partial) {
     if (!c || !theta || !w || !iSigma_w) return fail(GPZ_ERR_ARG, "gpz_solve: null argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-    if (int e = stage_a(c, theta)) return e;
+    if (int e = stage_a(c, theta)) return e;   // (k_unpack clears the status words)
     const size_t m = c->m, mq = c->mq;
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
     for (int o = 0; o < c->k; ++o) {

@@ -24,7 +24,7 @@ struct GpzParams {
 };
 
 void launch_unpack(hipStream_t st, const double *theta, int method_id, int m, int d, int de, int k, int hetero,
-                   GpzParams pr);
+                   GpzParams pr, int *clear2 = nullptr, double *zero_p = nullptr, int zero_n = 0);   // clear2: two status words, zero_p: zero_n doubles, set to zero by the same launch
 
 // ---- PHI build (getPHI.m:60-125) ---------------------------------------------------------------
 struct PhiArgs {

@@ -247,6 +247,30 @@ __global__ void k_fill_bext(const double *__restrict__ Sinv, int ldsi, const dou
     Bext[(size_t)i * mp + j] = round32 ? (double)(float)v : v;
     if (i == j && i < m) dgi[i] = v;
 }
+// The same with dwda = -inv(SIGMA) (alpha .* w) (GPz.m:71) formed on the way: one wave per row reads the row of inv(SIGMA) once for
+// both (the lane-strided sum and its wave reduction are k_gemv's, so dwda has k_gemv's bits) - one launch less per output.
+__global__ __launch_bounds__(256) void k_fill_bext_dwda(const double *__restrict__ Sinv, int ldsi, const double *__restrict__ w,
+                                                         const double *__restrict__ alpha, int m, int mp, int out,
+                                                         double *__restrict__ Bext, double *__restrict__ dgi,
+                                                         double *__restrict__ dwda, int round32) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= mp) return;
+    double s = 0.0;
+    for (int j = lane; j < mp; j += 64) {
+        double v = 0.0;
+        if (i < m) {
+            if (j < m) {
+                v = Sinv[(size_t)i * ldsi + j];
+                s = fma(v, w[j] * alpha[j], s);
+                if (i == j) dgi[i] = v;
+            } else if (j == m + out) v = w[i];
+        }
+        Bext[(size_t)i * mp + j] = round32 ? (double)(float)v : v;
+    }
+    s = wave_sum(s);
+    if (lane == 0 && i < m) dwda[i] = -1.0 * s;
+}
 static int bext_round32() { return getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0; }
 
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz,
@@ -283,8 +307,7 @@ void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const dou
     // w = inv(SIGMA) * (PHI' (omega beta y))   (GPz.m:70); the right-hand side is column m+out of S
     hipLaunchKernelGGL(k_gemv, dim3(nwg), dim3(256), 0, st, Sinv, ldsi, m, S + m + out, (long)lds, (const double *)nullptr,
                        1.0, w);
-    // dwda = -inv(SIGMA) * (alpha .* w)          (GPz.m:71)
-    hipLaunchKernelGGL(k_gemv, dim3(nwg), dim3(256), 0, st, Sinv, ldsi, m, (const double *)w, 1L, alpha, -1.0, dwda);
-    hipLaunchKernelGGL(k_fill_bext, dim3((mp + 255) / 256, mp), dim3(256), 0, st, Sinv, ldsi, (const double *)w, m, mp,
-                       out, Bext, dgi, bext_round32());
+    // dwda = -inv(SIGMA) * (alpha .* w)   (GPz.m:71) and Bext = [inv(SIGMA) | w], diag: one launch
+    hipLaunchKernelGGL(k_fill_bext_dwda, dim3((mp + 3) / 4), dim3(256), 0, st, Sinv, ldsi, (const double *)w, alpha, m, mp, out, Bext,
+                       dgi, dwda, bext_round32());
 }

@@ -17,7 +17,10 @@
 // method_id: 0 GL, 1 VL, 2 GD, 3 VD, 4 GC, 5 VC.  de = padded dimension used by the kernels (>= d);
 // padded entries are zero so they drop out of every sum.
 __global__ void k_unpack(const double *__restrict__ theta, int method_id, int m, int d, int de, int k, int hetero,
-                         GpzParams pr) {
+                         GpzParams pr, int *__restrict__ clear2, double *__restrict__ zero_p, int zero_n) {
+    if (clear2 && blockIdx.x == 0 && threadIdx.x < 2) clear2[threadIdx.x] = 0;   // the evaluation's status words (was a memset node of its own)
+    if (zero_p && blockIdx.x == 1)                                               // ... and a few doubles a later stage only adds to or skips
+        for (int e = threadIdx.x; e < zero_n; e += blockDim.x) zero_p[e] = 0.0;
     const int md = m * d;
     int g_dim;
     switch (method_id) {
@@ -79,8 +82,8 @@ __global__ void k_unpack(const double *__restrict__ theta, int method_id, int m,
 }
 
 void launch_unpack(hipStream_t st, const double *theta, int method_id, int m, int d, int de, int k, int hetero,
-                   GpzParams pr) {
-    hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, st, theta, method_id, m, d, de, k, hetero, pr);
+                   GpzParams pr, int *clear2, double *zero_p, int zero_n) {
+    hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, st, theta, method_id, m, d, de, k, hetero, pr, clear2, zero_p, zero_n);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ __device__ __forceinline__ double eps_of(double x) {   // MATLAB eps(x) for fini
 #define COND_NWG 64
 __global__ __launch_bounds__(256) void k_cond_norms(const double *__restrict__ S, int lds, const double *__restrict__ alpha,
                                                     const double *__restrict__ Sinv, int ldsi, int m,
-                                                    double *__restrict__ part) {
+                                                    double *part, int *info, unsigned *ticket) {
     __shared__ double sh4[4];
     double a = 0.0, b = 0.0;
     for (int i = blockIdx.x; i < m; i += COND_NWG) {
@@ -41,13 +41,24 @@ __global__ __launch_bounds__(256) void k_cond_norms(const double *__restrict__ S
     a = block_sum_256(a, sh4);
     __syncthreads();
     b = block_sum_256(b, sh4);
-    if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
-}
-__global__ __launch_bounds__(64) void k_cond_flag(const double *__restrict__ part, int m, int *info) {
-    double a = part[2 * threadIdx.x], b = part[2 * threadIdx.x + 1];
+    // The workgroup that takes the last ticket adds the COND_NWG partials in their fixed order and sets the flag (one launch
+    // instead of two: an evaluation of a small problem is a sequence of ~4 us launches); it puts the ticket counter back to zero.
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = a;
+        part[2 * blockIdx.x + 1] = b;
+        __threadfence();
+        last = (atomicAdd(ticket, 1u) == COND_NWG - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    a = part[2 * threadIdx.x];
+    b = part[2 * threadIdx.x + 1];
     a = wave_sum(a);
     b = wave_sum(b);
     if (threadIdx.x == 0) {
+        *ticket = 0u;
         const bool finite_s = (a == a) && (a < 1.0e300 * 1.0e300) && a > 0.0;
         if (finite_s) {
             const double ns = sqrt(a), ni = sqrt(b);
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(256) void k_jacobi_pinv(const double *__restrict__ 
 
 void launch_cond_flag(hipStream_t st, const double *S, int lds, const double *alpha, const double *Sinv, int ldsi, int m,
                       double *part, int *info) {
-    hipLaunchKernelGGL(k_cond_norms, dim3(COND_NWG), dim3(256), 0, st, S, lds, alpha, Sinv, ldsi, m, part);
-    hipLaunchKernelGGL(k_cond_flag, dim3(1), dim3(64), 0, st, (const double *)part, m, info);
+    // info: [pivot failure, truncation flag, ticket counter of this kernel (zero between launches), -]
+    hipLaunchKernelGGL(k_cond_norms, dim3(COND_NWG), dim3(256), 0, st, S, lds, alpha, Sinv, ldsi, m, part, info, (unsigned *)(info + 2));
 }
 
 // Pseudo-inverse of SIGMA = S + diag(alpha) (alpha may be nullptr) into Xi, ln-det of the kept part into *logdet.

@@ -111,8 +111,19 @@ __global__ __launch_bounds__(256) void k_slab_sum(const double *__restrict__ sla
     for (size_t e0 = (size_t)blockIdx.x * 16; e0 < count; e0 += (size_t)gridDim.x * 16) {
         const size_t e = e0 + el;
         double s = 0.0;
-        if (e < count)
-            for (int k = sl; k < nslab; k += 16) s += slab[(size_t)k * count + e];
+        if (e < count) {
+            // four independent chains keep four loads in flight per lane (the kernel is latency-bound: one or two WGs per CU)
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = sl;
+            for (; k + 48 < nslab; k += 64) {
+                s += slab[(size_t)k * count + e];
+                s1 += slab[(size_t)(k + 16) * count + e];
+                s2 += slab[(size_t)(k + 32) * count + e];
+                s3 += slab[(size_t)(k + 48) * count + e];
+            }
+            for (; k < nslab; k += 16) s += slab[(size_t)k * count + e];
+            s = (s + s1) + (s2 + s3);
+        }
         part[sl][el] = s;
         __syncthreads();
         if (sl == 0 && e < count) {
