@@ -156,8 +156,8 @@ def cpu_baseline(cfg, model, theta, X, y, omega, rows):
             nthreads = usable
         vec = None
         if not cfg.get("psi"):
-            # mode (ii) of BASELINE.md section 5: the same mathematics written the vectorised way (one GEMM per row chunk
-            # for the whitened differences, two n m^2 products, Cholesky inverse) - oracle/gpz_vectorised.py
+            # mode (ii) of BASELINE.md section 5: the same mathematics written the BLAS-3 way (ln PHI and the dP / dGamma sums as
+            # GEMMs over the monomials of a row, dsyrk + one n m^2 product, Cholesky inverse) - oracle/gpz_vectorised.py
             from oracle import gpz_vectorised as V
             t0 = time.perf_counter()
             fv, gv = V.GPz(theta, Omodel, Xs, ys, oms)
