@@ -18,6 +18,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gpz_hip.h"
@@ -328,6 +329,7 @@ struct gpz_ctx {
     std::vector<std::vector<unsigned char>> pats;   // observed flags per pattern (host copy)
     bool pats_fixed = false;                        // table given by the caller (sharded runs): rows must match an entry
     unsigned char *pat_d = nullptr;
+    double *prep_ws = nullptr;                            // QR workspace of the covariance kinds when Gamma_j does not fit the LDS
     double *Sig = nullptr, *iSig = nullptr, *lnS = nullptr, *Phi_v = nullptr, *gen_slab = nullptr, *psi32_raw = nullptr;
     double *gc_minv = nullptr;   // GC + Psi, 10 < d <= 32 (fp64): -inv(Sigma + Psi_i) of every training row as 4 x 4 tiles (k_cpsi4_minv)
     double *gcq_A = nullptr, *gcq_B = nullptr;   // ... without missing dimensions: operands of the dense form of the PHI build (k_gcq_*)
@@ -569,6 +571,8 @@ static int alloc_params(gpz_ctx *c) {
     if (int e = c->ar.alloc(&c->pr.G, c->kind == GPZ_KIND_COV ? m * de * de : m * de)) return e;
     if (int e = c->ar.alloc(&c->pr.G2, m * de)) return e;
     if (int e = c->ar.alloc(&c->pr.Rc, m * (de * (de + 1) / 2 + de))) return e;
+    if (const size_t wl = c->kind == GPZ_KIND_COV ? prep_cov_ws_len(c->m, c->de) : 0)
+        if (int e = c->ar.alloc(&c->prep_ws, wl)) return e;
     if (int e = c->ar.alloc(&c->pr.lnAlpha, m * k)) return e;
     if (int e = c->ar.alloc(&c->pr.alpha, m * k)) return e;
     if (int e = c->ar.alloc(&c->pr.b, k)) return e;
@@ -1148,7 +1152,7 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         // also clears info[0..1] and, without validation rows, the validation sums of the result block (eval_tail's layout of comm2)
         double *vsums0 = c->va.n_pad > 0 ? nullptr : c->comm2 + (size_t)c->m * c->nm + (size_t)c->k * 2 * c->mp + (size_t)c->k * 4;
         launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr, c->info, vsums0, gpz_ns(c->k));
-        if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
+        if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc, c->prep_ws);
     }
     if (int e = psi32_agree(c)) return e;
     if (int e = build_phi(c)) return e;
@@ -1672,7 +1676,7 @@ static void free_eval_ctx(gpz_ctx *c) { c->ar.release(); delete c; }
 static int run_phi_only(gpz_ctx *c, const double *theta) {
     HIPCHK(hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st));
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
-    if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc);
+    if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc, c->prep_ws);
     return build_phi(c);
 }
 
@@ -1898,7 +1902,7 @@ static void pmc_model_cache_release_all() {
 }
 
 // GC/VC branch of gpz_predict_missing (predictCov.m:134-337); see k_pmiss_cov.hip.
-static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, const double *theta, const double *w, const double *iSigma_w,
+static int predict_missing_cov(const gpz_desc *desc, const std::vector<unsigned char> &flags, const double *theta, const double *w, const double *iSigma_w,
                                const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
                                double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
     if (Psi && psi_kind != 2 && psi_kind != 3) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38) or n x d variances (psi_kind 3)");
@@ -1910,7 +1914,12 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (hipMemcpyAsync(c->theta_d, theta, (size_t)c->p * sizeof(double), hipMemcpyHostToDevice, c->st) != hipSuccess)
         rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
-    const int nrec = pmc_rec_len(d, obs), ntab = d * d + d + 1 + 3 * (int)k;
+    unsigned long long obs = 0ull;       // the 64-bit form of the pattern (the routes up to d = 64 take it by value)
+    int n_obs = 0;
+    for (int a = 0; a < d; ++a)
+        if (flags[a]) { ++n_obs; if (a < 64) obs |= 1ull << a; }
+    const bool generic = d > 64;          // any width: temporaries in a device workspace (k_pmiss_covg.hip)
+    const int nrec = 2 + n_obs * n_obs + n_obs * (d - n_obs) + (d - n_obs) * (d - n_obs), ntab = d * d + d + 1 + 3 * (int)k;
     const long npairs = (long)m * (m + 1) / 2;
     // the model's tables of the previous group, if it was the same model (see PmcModelCache)
     PmcModelCache *mc = pmc_model_cache(c->device);
@@ -1940,6 +1949,7 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (rb < 1) rb = 1;
     const bool fast = pmc_fast(d, (int)k);
     if (fast && rb > 64) rb = 64;   // the register-resident kernels deal the rows of a block over the lanes of a wave
+    if (generic) rb = 1;            // one row at a time: its tables are what the workspace-resident kernels read
     const int rows_blk = (int)rb;
     // pair chunks = slabs of `part`: one wave per chunk on the register-resident route (fill the chip), 64 otherwise
     const long want = fast ? 2048 : 64;
@@ -1964,6 +1974,16 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (!rc) rc = c->ar.alloc(&outb, 3 * k * np);
     double *work2 = nullptr;
     if (!rc && fast) rc = c->ar.alloc(&work2, m * ((size_t)d * (d + 1) / 2 + (size_t)d * d + d + 1));
+    // d > 64: 3 d^2 + 2 d doubles of workspace per thread, at most 2 GB of it (and at least one wave's worth) per launch
+    double *gws = nullptr, *gpat = nullptr;
+    long gthreads = 0;
+    if (!rc && generic) {
+        const size_t per = pmg_ws_per_thread(d);
+        gthreads = (long)((2048UL << 20) / (per * sizeof(double)));
+        gthreads = gthreads > 65536 ? 65536 : (gthreads < 64 ? 64 : gthreads / 64 * 64);
+        rc = c->ar.alloc(&gws, (size_t)gthreads * per);
+        if (!rc) rc = c->ar.alloc(&gpat, (size_t)(3 * d + 1) / 2 + 1);   // 3 d ints
+    }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
         if (e == hipSuccess) e = hipMemcpyAsync(iSd, iSigma_w, m * m * k * sizeof(double), hipMemcpyHostToDevice, c->st);
@@ -1973,7 +1993,13 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     if (!rc) {
         launch_zero(c->st, c->Phi, np * mp);
         launch_zero(c->st, part, (size_t)nchunk * 3 * k * np);
-        // 32 < d <= 64: the scratch-resident kernels with 64-wide temporaries (k_pmiss_cov64.hip); else every route of k_pmiss_cov.hip
+        // d > 64: workspace-resident kernels (k_pmiss_covg.hip); 32 < d <= 64: the scratch-resident kernels with 64-wide temporaries
+        // (k_pmiss_cov64.hip); else every route of k_pmiss_cov.hip
+        if (generic)
+            launch_pmc_generic(c->st, flags.data(), n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, SigU, iSigU, prd,
+                               wd, c->hetero ? c->pr.v : nullptr, iSd, rec, tab, Ex, Pio, Xhat, Phat, nchunk, ppc, part, c->Phi, hit,
+                               (int *)gpat, gws, gthreads);
+        else
         (d > 32 ? launch_pmc_wide : launch_pmc)(c->st, obs, n, (long)np, c->m, (int)mp, d, de, c->k, c->tr.Xr, c->tr.Psi3, c->pr.P, SigU,
                                                iSigU, prd, wd, c->hetero ? c->pr.v : nullptr, iSd, rows_blk, rec, tab, Ex, Pio, Xhat,
                                                Phat, nchunk, ppc, part, c->Phi, work2, hit);
@@ -2016,35 +2042,13 @@ static int predict_missing_cov(const gpz_desc *desc, unsigned long long obs, con
     return rc;
 }
 
-// predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337) for ONE group of rows sharing a NaN pattern (the caller
-// groups the rows as predict.m:45-69 does; the pattern is taken from the first row, predictDiag.m:3).
-extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
-                                   const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
-                                   double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
-    if (!desc || !theta || !w || !iSigma_w || !priors || !Xs || ns < 1 || !mu || !nu || !beta_i || !gamma)
-        return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
+// GL/VL/GD/VD branch (predictDiag.m:127-297; k_pmiss.hip).  OBS = ObsMask (the pattern by value, LDS tiles: d <= GPZ_PM_MAXD_DIAG) or
+// ObsFlags (the pattern as device bytes, uploaded here from *flags: any d).
+template <typename OBS>
+static int predict_missing_diag(const gpz_desc *desc, OBS obs, const std::vector<unsigned char> *flags, const double *theta,
+                                const double *w, const double *iSigma_w, const double *priors, const double *Xs, int64_t ns,
+                                const double *Psi, int32_t psi_kind, double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
     const int d = desc->d;
-    const bool covk = method_id_of(desc->method) >= 4;
-    if (d > (covk ? 64 : GPZ_PM_MAXD_DIAG))
-        return fail(GPZ_ERR_UNSUPPORTED, "prediction with missing values is built for d <= %d (GL/VL/GD/VD: the pair-table kernel keeps d KB "
-                                         "of LDS per 64 basis pairs) and d <= 64 (GC/VC: 64-wide per-thread temporaries); d = %d",
-                    GPZ_PM_MAXD_DIAG, d);
-    ObsMask obs = {{0ull, 0ull, 0ull, 0ull}};
-    int nobs = 0;
-    for (int c = 0; c < d; ++c) {
-        const double xv = Xs[(size_t)c * ns];
-        if (xv == xv) { obs.w[c >> 6] |= 1ull << (c & 63); ++nobs; }
-    }
-    for (int c = 0; c < d; ++c)
-        for (int64_t i = 0; i < ns; ++i) {
-            const double xv = Xs[(size_t)c * ns + i];
-            if ((xv == xv) != obs_bit(obs, c))
-                return fail(GPZ_ERR_ARG, "gpz_predict_missing: the rows of a group must share one NaN pattern (predict.m:45-57)");
-        }
-    if (nobs == d)
-        return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
-    if (covk)
-        return predict_missing_cov(desc, obs.w[0], theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
@@ -2054,6 +2058,13 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     launch_unpack(c->st, c->theta_d, c->mid, c->m, c->d, c->de, c->k, c->hetero, c->pr);
     double *No = nullptr, *Pio = nullptr, *B = nullptr, *T = nullptr, *wd = nullptr, *iSd = nullptr, *prd = nullptr,
            *rec = nullptr, *sums = nullptr, *phiw = nullptr, *outb = nullptr, *tmp = nullptr;
+    if constexpr (std::is_same<OBS, ObsFlags>::value) {
+        double *fl = nullptr;
+        rc = c->ar.alloc(&fl, (size_t)d / 8 + 1);
+        if (!rc && hipMemcpy(fl, flags->data(), (size_t)d, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: copy failed");
+        obs.f = (const unsigned char *)fl;
+    }
     const int nrec = 2 * d + 1 + 3 * (int)k;
     // pair chunks of cw * mp pairs: a NaN-pattern group is often a few dozen rows, and then the launches per chunk are what it
     // costs - wider chunks, fewer of them, as far as the chunk's T (np x width) stays under 2 GB
@@ -2128,6 +2139,45 @@ extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, co
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(GPZ_ERR_HIP, "gpz_predict_missing: kernel failed");
     free_eval_ctx(c);
     return rc;
+}
+
+// predictMissing / predictNoisyMissing (predictDiag.m:127-297, predictCov.m:134-337) for ONE group of rows sharing a NaN pattern (the caller
+// groups the rows as predict.m:45-69 does; the pattern is taken from the first row, predictDiag.m:3).
+extern "C" int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double *w, const double *iSigma_w,
+                                   const double *priors, const double *Xs, int64_t ns, const double *Psi, int32_t psi_kind,
+                                   double *mu, double *nu, double *beta_i, double *gamma, double *PHI) {
+    if (!desc || !theta || !w || !iSigma_w || !priors || !Xs || ns < 1 || !mu || !nu || !beta_i || !gamma)
+        return fail(GPZ_ERR_ARG, "gpz_predict_missing: null argument");
+    const int d = desc->d;
+    const bool covk = method_id_of(desc->method) >= 4;
+    // any d (the reference is generic in it): the tuned routes cover d <= 64 (GC/VC) and d <= GPZ_PM_MAXD_DIAG (GL/VL/GD/VD); wider
+    // inputs run the workspace-resident / LDS-free forms of the same kernels (include/gpz_hip.h has the cost line)
+    std::vector<unsigned char> flags((size_t)d, 0);
+    ObsMask obs = {{0ull, 0ull, 0ull, 0ull}};
+    int nobs = 0;
+    for (int c = 0; c < d; ++c) {
+        const double xv = Xs[(size_t)c * ns];
+        if (xv == xv) {
+            flags[c] = 1;
+            if (c < GPZ_PM_MAXD) obs.w[c >> 6] |= 1ull << (c & 63);
+            ++nobs;
+        }
+    }
+    for (int c = 0; c < d; ++c)
+        for (int64_t i = 0; i < ns; ++i) {
+            const double xv = Xs[(size_t)c * ns + i];
+            if ((xv == xv) != (flags[c] != 0))
+                return fail(GPZ_ERR_ARG, "gpz_predict_missing: the rows of a group must share one NaN pattern (predict.m:45-57)");
+        }
+    if (nobs == d)
+        return fail(GPZ_ERR_ARG, "gpz_predict_missing: no dimension is missing (use gpz_predict_full / gpz_predict_noisy)");
+    if (covk)
+        return predict_missing_cov(desc, flags, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
+    if (d > GPZ_PM_MAXD_DIAG) {
+        ObsFlags of{nullptr};
+        return predict_missing_diag(desc, of, &flags, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
+    }
+    return predict_missing_diag(desc, obs, nullptr, theta, w, iSigma_w, priors, Xs, ns, Psi, psi_kind, mu, nu, beta_i, gamma, PHI);
 }
 
 // prior = getPrior(X,Psi,theta,model,[])   (getPrior.m): N once, then the fixed point on the device; the convergence

@@ -62,8 +62,9 @@ bool phi_is_wide(int de, int k);          // d or k beyond the instantiated kern
 // runtime-d / any-k variants (k_wide.hip): same arguments and output layouts; -1 when the row tiles do not fit the LDS
 int phi_wide_rows_per_wg();
 int launch_phi_wide(hipStream_t st, const PhiArgs &a);
-int launch_prep_cov_wide(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
-void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc);
+size_t prep_cov_ws_len(int m, int de);   // workspace (doubles) the QR needs when Gamma_j does not fit the LDS (de > 142), else 0
+int launch_prep_cov_wide(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc, double *ws);
+void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc, double *ws = nullptr);
 int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is not supported
 
 // ---- MFMA contractions (k_gemm.hip) ------------------------------------------------------------
@@ -347,8 +348,14 @@ struct ObsMask {
 #define GPZ_PM_MAXD 256        // bits of the mask
 #define GPZ_PM_MAXD_DIAG 144   // what the pair-table kernel's LDS tile (d KB per 64 pairs) allows
 static inline __host__ __device__ bool obs_bit(const ObsMask &o, int c) { return (o.w[c >> 6] >> (c & 63)) & 1ull; }
+struct ObsFlags {               // any width: one byte per dimension in DEVICE memory (1 = observed); the kernels' wide instantiations
+    const unsigned char *f;
+};
+static inline __device__ bool obs_bit(const ObsFlags &o, int c) { return o.f[c] != 0; }
 void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
                   ObsMask obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
+void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                  ObsFlags obs, const double *P, const double *G, const double *priors, double *No, double *Pio);
 void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio);
 // covariance kinds (predictCov.m:134-337; k_pmiss_cov.hip): see launch_pmc for the work buffers
 int pmc_rec_len(int d, unsigned long long obs);
@@ -375,6 +382,22 @@ void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int d
                      ObsMask obs, int npq, const double *T2, const double *rec, int nrec,
                      double *sums /* [nsplit][3k][n_pad] */, int nsplit = 1);
 int pm_accum_splits(int n);
+// the same four for inputs of any width (d > GPZ_PM_MAXD_DIAG): pattern as device flags, no LDS tiles
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, ObsFlags obs, const double *P, const double *G, double *B);
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, ObsFlags obs,
+                       int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
+                       double *B, double *rec, int nrec);
+void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
+                     ObsFlags obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit);
+// covariance kinds at d > 64 (k_pmiss_covg.hip): the per-thread d x d temporaries live in a workspace in device memory.
+//   pat_dev: 3 d ints (observed | missing | unshuffle), filled by the launcher;  ws: ws_threads * pmg_ws_per_thread(d) doubles.
+// Work buffers as for launch_pmc (rows_blk = 1 is enough: one launch per row and item range).
+size_t pmg_ws_per_thread(int d);
+void launch_pmc_generic(hipStream_t st, const unsigned char *obs_host, int n, long ldx, int m, int ld, int d, int de, int k,
+                        const double *Xr, const double *Psi3, const double *P, const double *Sig, const double *iSig,
+                        const double *priors, const double *w, const double *v, const double *iS, double *rec, double *tab, double *Ex,
+                        double *Pio, double *Xhat, double *Phat, int nchunk, long pairs_per_chunk, double *part, double *Phi,
+                        bool tab_ready, int *pat_dev, double *ws, long ws_threads);
 
 // N = PHI .* exp(-1/2 ln|Sigma_oo| - 1/2 |o| ln 2pi + 1/2 |u| ln 2)   (getPHI.m:77,87,98,105,114)
 struct NormArgs {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void k_prep_cov(const double *__restrict__ G, c
     }
 }
 
-void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc) {
+void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc, double *ws) {
     dim3 g((m + 63) / 64), b(64);
     switch (de) {
         case 1: hipLaunchKernelGGL(k_prep_cov<1>, g, b, 0, st, G, P, m, de, Rc); break;
@@ -171,7 +171,7 @@ void launch_prep_cov(hipStream_t st, const double *G, const double *P, int m, in
         case 8: hipLaunchKernelGGL(k_prep_cov<8>, g, b, 0, st, G, P, m, de, Rc); break;
         case 10: hipLaunchKernelGGL(k_prep_cov<10>, g, b, 0, st, G, P, m, de, Rc); break;
         default:
-            if (de > 20) (void)launch_prep_cov_wide(st, G, P, m, de, Rc);   // runtime-d QR in LDS (k_wide.hip)
+            if (de > 20) (void)launch_prep_cov_wide(st, G, P, m, de, Rc, ws);   // runtime-d QR in LDS / in `ws` (k_wide.hip)
             else hipLaunchKernelGGL(k_prep_cov<0>, g, b, 0, st, G, P, m, de, Rc);
             break;
     }

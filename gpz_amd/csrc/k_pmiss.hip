@@ -12,8 +12,9 @@
 
 // No(i,j) = exp(-1/2 sum_o (x-p_j)^2/(sigma_j [+psi_i]) - 1/2 sum_o ln(sigma_j [+psi_i]))   predictDiag.m:142-148 / :226-233
 // written to No[i*ld + j]; columns j >= m and rows i >= n are zero.
+template <typename OBS>
 __global__ void k_pm_no(const double *__restrict__ Xr, const double *__restrict__ Psir, int de, int n, long n_pad, int m,
-                        int ld, int d, ObsMask obs, const double *__restrict__ P, const double *__restrict__ G,
+                        int ld, int d, OBS obs, const double *__restrict__ P, const double *__restrict__ G,
                         double *__restrict__ No) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const long i = blockIdx.y;
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void k_pm_pio(const double *__restrict__ No, i
 }
 
 // B[j*ld + i] = Nij(i,j) = exp(-1/2 sum_u (p_i-p_j)^2/(sigma_i+sigma_j) - 1/2 sum_u ln(sigma_i+sigma_j))   predictDiag.m:158
-__global__ void k_pm_nij(int m, int ld, int d, int de, ObsMask obs, const double *__restrict__ P,
+template <typename OBS>
+__global__ void k_pm_nij(int m, int ld, int d, int de, OBS obs, const double *__restrict__ P,
                          const double *__restrict__ G, double *__restrict__ B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= ld) return;
@@ -99,7 +101,10 @@ __device__ __forceinline__ void pair_of(long q, int *pi, int *pj) {
 //           [- 1/2 sum_o ln Cij when there is no input noise: the x-independent part of No,                    :178]
 //     c2  = 2 for j < i, 1 for j == i (2x inside the loop, minus 1x for the diagonal term after it,            :191-199)
 // Columns past the last pair are zero (B) / c2 = 0 (rec).
-__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int ldb, int d, int de, int k, ObsMask obs,
+// WIDE (d > GPZ_PM_MAXD_DIAG): the tile would not fit a CU's LDS; cij / Cij are formed where they are used (four gathers and a
+// division per dimension and row of B instead of two LDS reads: the slow, correct route for inputs of any width).
+template <typename OBS, bool WIDE>
+__global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m, int ld, int ldb, int d, int de, int k, OBS obs,
                                                     int has_psi, const double *__restrict__ P,
                                                     const double *__restrict__ G, const double *__restrict__ w,
                                                     const double *__restrict__ v, const double *__restrict__ iS,
@@ -114,14 +119,17 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
     const bool live = q < npairs;
     int i = 0, j = 0;
     if (live) pair_of(q, &i, &j);
-    for (int c = wave; c < d; c += 4) {
+    auto pair_c = [&](int c, double *Cv, double *cv) {
         const double gi = G[(size_t)i * de + c], gj = G[(size_t)j * de + c];
         const double isi = gi * gi, isj = gj * gj;
         const double C = 1.0 / (isi + isj);                                      // :173 / :257
-        Cij[c * 64 + lane] = live ? C : 1.0;
-        cij[c * 64 + lane] = live ? (P[(size_t)i * de + c] * isi + P[(size_t)j * de + c] * isj) * C : 0.0;   // :174 / :258
+        *Cv = live ? C : 1.0;
+        *cv = live ? (P[(size_t)i * de + c] * isi + P[(size_t)j * de + c] * isj) * C : 0.0;   // :174 / :258
+    };
+    if (!WIDE) {
+        for (int c = wave; c < d; c += 4) pair_c(c, &Cij[c * 64 + lane], &cij[c * 64 + lane]);
+        __syncthreads();
     }
-    __syncthreads();
     // blockIdx.y splits the rows of B (64 pairs per workgroup alone would leave the chip to 64 workgroups per chunk)
     const int lper = (ld + gridDim.y - 1) / gridDim.y, l0 = blockIdx.y * lper, l1 = min(ld, l0 + lper);
     for (int l = l0 + wave; l < l1; l += 4) {
@@ -131,8 +139,11 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
             for (int c = 0; c < d; ++c) {
                 if (obs_bit(obs, c)) continue;
                 const double gl = G[(size_t)l * de + c];
-                const double s = 1.0 / (gl * gl) + Cij[c * 64 + lane];
-                const double dl = P[(size_t)l * de + c] - cij[c * 64 + lane];
+                double Cv, cv;
+                if (WIDE) pair_c(c, &Cv, &cv);
+                else { Cv = Cij[c * 64 + lane]; cv = cij[c * 64 + lane]; }
+                const double s = 1.0 / (gl * gl) + Cv;
+                const double dl = P[(size_t)l * de + c] - cv;
                 qd += dl * dl / s;
                 ls += log(s);
             }
@@ -154,9 +165,12 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
             const double dl = P[(size_t)i * de + c] - P[(size_t)j * de + c];
             qd += dl * dl / s;
             ls += log(s);
-            if (obs_bit(obs, c) && !has_psi) lo += log(Cij[c * 64 + lane]);
-            r[c] = cij[c * 64 + lane];
-            r[d + c] = Cij[c * 64 + lane];
+            double Cv, cv;
+            if (WIDE) pair_c(c, &Cv, &cv);
+            else { Cv = Cij[c * 64 + lane]; cv = cij[c * 64 + lane]; }
+            if (obs_bit(obs, c) && !has_psi) lo += log(Cv);
+            r[c] = cv;
+            r[d + c] = Cv;
         }
         r[2 * d] = -0.5 * lz - 0.5 * qd - 0.5 * ls - 0.5 * lo;
         const double c2 = (j < i) ? 2.0 : 1.0;
@@ -175,23 +189,27 @@ __global__ __launch_bounds__(256) void k_pm_pairtab(long q0, long npairs, int m,
 // serial chain of 512 exp / divide iterations per launch (1 ms per launch whatever the group's size).
 // gridDim.y = S splits of the chunk's pairs, each accumulating into its own slab sums[s][3k][n_pad] (summed in fixed order at
 // the end): with a few dozen rows per group one wave per row left the chip empty.
+// WIDE (d > GPZ_PM_MAXD): the row's x / psi are read where they are used (wave-uniform addresses) instead of from LDS.
+template <typename OBS, bool WIDE>
 __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr, const double *__restrict__ Psir, int de,
-                                                   int n, long n_pad, int ld, int d, int k, ObsMask obs, int npq,
+                                                   int n, long n_pad, int ld, int d, int k, OBS obs, int npq,
                                                    const double *__restrict__ T2, const double *__restrict__ rec, int nrec,
                                                    double *__restrict__ sums_all) {
     double *sums = sums_all + (size_t)blockIdx.y * 3 * k * n_pad;
     const int per = (npq + gridDim.y - 1) / gridDim.y;
     const int qlo = blockIdx.y * per, qhi = min(npq, qlo + per);
-    __shared__ double sx[4][GPZ_PM_MAXD], sps[4][GPZ_PM_MAXD];
+    __shared__ double sx[4][WIDE ? 1 : GPZ_PM_MAXD], sps[4][WIDE ? 1 : GPZ_PM_MAXD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long i = (long)blockIdx.x * 4 + wave;
     const bool live = i < n;
-    if (live)
-        for (int c = lane; c < d; c += 64) {
-            sx[wave][c] = Xr[(size_t)i * de + c];
-            sps[wave][c] = Psir ? Psir[(size_t)i * de + c] : 0.0;
-        }
-    __syncthreads();
+    if (!WIDE) {
+        if (live)
+            for (int c = lane; c < d; c += 64) {
+                sx[wave][c] = Xr[(size_t)i * de + c];
+                sps[wave][c] = Psir ? Psir[(size_t)i * de + c] : 0.0;
+            }
+        __syncthreads();
+    }
     if (!live) return;
     // the 3k sums in blocks of 24 (k <= 8: one pass; more outputs walk the pairs again per block)
     for (int e0 = 0; e0 < 3 * k; e0 += 24) {
@@ -203,8 +221,10 @@ __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr,
             double qd = 0.0, ls = 0.0;
             for (int c = 0; c < d; ++c) {
                 if (!obs_bit(obs, c)) continue;
-                const double s = r[d + c] + sps[wave][c];
-                const double dl = sx[wave][c] - r[c];
+                const double pv = WIDE ? (Psir ? Psir[(size_t)i * de + c] : 0.0) : sps[wave][c];
+                const double xv = WIDE ? Xr[(size_t)i * de + c] : sx[wave][c];
+                const double s = r[d + c] + pv;
+                const double dl = xv - r[c];
                 qd += dl * dl / s;
                 if (Psir) ls += log(s);
             }
@@ -224,17 +244,29 @@ __global__ __launch_bounds__(256) void k_pm_accum(const double *__restrict__ Xr,
     }
 }
 
-void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
-                  ObsMask obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
-    hipLaunchKernelGGL(k_pm_no, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, Xr, Psir, de, n, n_pad, m, ld, d, obs,
+template <typename OBS>
+static void pm_no_t(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                    OBS obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
+    hipLaunchKernelGGL(k_pm_no<OBS>, dim3((ld + 255) / 256, (unsigned)n_pad), dim3(256), 0, st, Xr, Psir, de, n, n_pad, m, ld, d, obs,
                        P, G, No);
     hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double *)No, ld, n, m, priors, Pio);
+}
+void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                  ObsMask obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
+    pm_no_t(st, Xr, Psir, de, n, n_pad, m, ld, d, obs, P, G, priors, No, Pio);
+}
+void launch_pm_no(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int m, int ld, int d,
+                  ObsFlags obs, const double *P, const double *G, const double *priors, double *No, double *Pio) {
+    pm_no_t(st, Xr, Psir, de, n, n_pad, m, ld, d, obs, P, G, priors, No, Pio);
 }
 void launch_pm_pio(hipStream_t st, const double *No, int ld, int n, int m, const double *priors, double *Pio) {
     hipLaunchKernelGGL(k_pm_pio, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, No, ld, n, m, priors, Pio);
 }
 void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, ObsMask obs, const double *P, const double *G, double *B) {
-    hipLaunchKernelGGL(k_pm_nij, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
+    hipLaunchKernelGGL(k_pm_nij<ObsMask>, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
+}
+void launch_pm_nij(hipStream_t st, int m, int ld, int d, int de, ObsFlags obs, const double *P, const double *G, double *B) {
+    hipLaunchKernelGGL(k_pm_nij<ObsFlags>, dim3((ld + 255) / 256, ld), dim3(256), 0, st, m, ld, d, de, obs, P, G, B);
 }
 void launch_pm_phi(hipStream_t st, const double *No, const double *T1, int ld, int n, long n_pad, int m, int d, int de,
                    const double *G, double *Phi) {
@@ -246,15 +278,26 @@ void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int 
                        int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
                        double *B, double *rec, int nrec) {
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);   // cij / Cij of 64 pairs: d KB (d <= GPZ_PM_MAXD_DIAG keeps it inside a CU's 160 KB)
-    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pm_pairtab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_pairtab, dim3(width / 64, 16), dim3(256), lds, st, q0, npairs, m, ld, width, d, de, k, obs, has_psi, P, G, w, v,
-                       iS, B, rec, nrec);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pm_pairtab<ObsMask, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_pm_pairtab<ObsMask, false>), dim3(width / 64, 16), dim3(256), lds, st, q0, npairs, m, ld, width, d, de, k, obs,
+                       has_psi, P, G, w, v, iS, B, rec, nrec);
+}
+void launch_pm_pairtab(hipStream_t st, long q0, long npairs, int m, int ld, int width, int d, int de, int k, ObsFlags obs,
+                       int has_psi, const double *P, const double *G, const double *w, const double *v, const double *iS,
+                       double *B, double *rec, int nrec) {
+    hipLaunchKernelGGL((k_pm_pairtab<ObsFlags, true>), dim3(width / 64, 16), dim3(256), 0, st, q0, npairs, m, ld, width, d, de, k, obs,
+                       has_psi, P, G, w, v, iS, B, rec, nrec);
 }
 // Pair splits of the accumulation kernel.  A constant: the order in which a row's sums are formed must not depend on how many
 // rows the call holds (gpz_mgpu_predict cuts a group into row blocks and promises the single-device bits).
 int pm_accum_splits(int n) { (void)n; return 16; }
 void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
                      ObsMask obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit) {
-    hipLaunchKernelGGL(k_pm_accum, dim3((unsigned)((n + 3) / 4), nsplit), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld, d, k, obs,
-                       npq, T2, rec, nrec, sums);
+    hipLaunchKernelGGL((k_pm_accum<ObsMask, false>), dim3((unsigned)((n + 3) / 4), nsplit), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld,
+                       d, k, obs, npq, T2, rec, nrec, sums);
+}
+void launch_pm_accum(hipStream_t st, const double *Xr, const double *Psir, int de, int n, long n_pad, int ld, int d, int k,
+                     ObsFlags obs, int npq, const double *T2, const double *rec, int nrec, double *sums, int nsplit) {
+    hipLaunchKernelGGL((k_pm_accum<ObsFlags, true>), dim3((unsigned)((n + 3) / 4), nsplit), dim3(256), 0, st, Xr, Psir, de, n, n_pad, ld,
+                       d, k, obs, npq, T2, rec, nrec, sums);
 }

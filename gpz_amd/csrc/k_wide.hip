@@ -20,15 +20,18 @@
 // ---------------------------------------------------------------------------------------------
 // PHI build (getPHI.m:60-125), any d, any k.  Argument meaning as in PhiArgs / k_phi_diag / k_phi_cov.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, bool PSI, bool MASK>
+// TILES = false: the row tiles would not fit a CU's LDS (d beyond ~100 ... 300, by the number of tiles); x / psi / mask are then read
+// from the column-major arrays where they are used (lanes along rows: coalesced, served by the L1 / L2 after the first pass).
+template <int KIND, bool PSI, bool MASK, bool TILES>
 __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, d = a.d, k = a.k, m = a.m, mp = a.mp;
     const long ldx = a.ldx;
+    const size_t td = TILES ? (size_t)d : 0;
     double *xs = lds;                                   // [d][64]
-    double *pss = xs + (size_t)d * 64;                  // [d][64] when PSI
-    double *mks = pss + (PSI ? (size_t)d * 64 : 0);     // [d][64] when MASK
-    double *svs = mks + (MASK ? (size_t)d * 64 : 0);    // [k][64]
+    double *pss = xs + td * 64;                         // [d][64] when PSI
+    double *mks = pss + (PSI ? td * 64 : 0);            // [d][64] when MASK
+    double *svs = mks + (MASK ? td * 64 : 0);           // [k][64]
     double *sws = svs + (size_t)k * 64;                 // [k][64]
     long row0, rend;
     const double *Gp = a.G;
@@ -46,11 +49,15 @@ __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
     const bool valid = i < rend;
     const bool inb = a.wgtab ? valid : (i < a.n_pad);   // rows this lane may write
     const long il = inb ? i : row0;                     // clamped row for loads
-    for (int c = 0; c < d; ++c) {
-        xs[c * 64 + lane] = a.Xc[c * ldx + il];
-        if (PSI) pss[c * 64 + lane] = a.Psic[c * ldx + il];
-        if (MASK) mks[c * 64 + lane] = a.Mc[c * ldx + il];
-    }
+    if (TILES)
+        for (int c = 0; c < d; ++c) {
+            xs[c * 64 + lane] = a.Xc[c * ldx + il];
+            if (PSI) pss[c * 64 + lane] = a.Psic[c * ldx + il];
+            if (MASK) mks[c * 64 + lane] = a.Mc[c * ldx + il];
+        }
+    auto XS = [&](int c) { return TILES ? xs[c * 64 + lane] : a.Xc[c * ldx + il]; };
+    auto PS = [&](int c) { return TILES ? pss[c * 64 + lane] : a.Psic[c * ldx + il]; };
+    auto MK = [&](int c) { return TILES ? mks[c * 64 + lane] : a.Mc[c * ldx + il]; };
     for (int o = 0; o < k; ++o) { svs[o * 64 + lane] = 0.0; sws[o * 64 + lane] = 0.0; }
     const double q0 = (MASK && a.ucnt) ? a.ucnt[il] * GPZ_LOG2 : 0.0;   // |u_i| ln 2
 
@@ -66,9 +73,9 @@ __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < WB; ++jj) { lg[jj] = 0.0; pr[jj] = 1.0; }
                 for (int c = 0; c < d; ++c) {
-                    const double x = xs[c * 64 + lane];
-                    const double mk = MASK ? mks[c * 64 + lane] : 1.0;
-                    const double ps = PSI ? pss[c * 64 + lane] : 0.0;
+                    const double x = XS(c);
+                    const double mk = MASK ? MK(c) : 1.0;
+                    const double ps = PSI ? PS(c) : 0.0;
 #pragma unroll
                     for (int jj = 0; jj < WB; ++jj) {
                         const double pc = a.P[(size_t)jc[jj] * d + c], gc = Gp[(size_t)jc[jj] * d + c];   // G = gamma^2
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < WB; ++jj) s[jj] = -rj[jj][nt + aa];
                     for (int b = aa; b < d; ++b) {
-                        const double x = xs[b * 64 + lane];
+                        const double x = XS(b);
 #pragma unroll
                         for (int jj = 0; jj < WB; ++jj) s[jj] = fma(rj[jj][roff + b], x, s[jj]);
                     }
@@ -152,17 +159,25 @@ int phi_wide_rows_per_wg() { return 64; }
 
 int launch_phi_wide(hipStream_t st, const PhiArgs &a) {
     const bool psi = a.kind == GPZ_KIND_DIAG && a.Psic, mask = a.kind == GPZ_KIND_DIAG && a.Mc;
-    const size_t tiles = 1 + (psi ? 1 : 0) + (mask ? 1 : 0);
-    const size_t lds = (tiles * a.d + 2 * (size_t)a.k) * 64 * sizeof(double);
-    if (lds > 160 * 1024) return -1;
+    const size_t ntile = 1 + (psi ? 1 : 0) + (mask ? 1 : 0);
+    const size_t sums = 2 * (size_t)a.k * 64 * sizeof(double);
+    size_t lds = ntile * a.d * 64 * sizeof(double) + sums;
+    const bool tiles = lds <= 160 * 1024;
+    if (!tiles) lds = sums;
+    if (lds > 160 * 1024) return -1;                    // more than 160 outputs
     const int nwg = a.wgtab ? a.nwg_tab : (a.n_pad + 63) / 64;
     if (nwg <= 0) return 0;
-#define PW(KIND, PS, MK)                                                                                              \
+#define PW1(KIND, PS, MK, TL)                                                                                         \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            (void)hipFuncSetAttribute((const void *)k_phi_wide<KIND, PS, MK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)k_phi_wide<KIND, PS, MK, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                      \
-        hipLaunchKernelGGL((k_phi_wide<KIND, PS, MK>), dim3(nwg), dim3(64), lds, st, a);                              \
+        hipLaunchKernelGGL((k_phi_wide<KIND, PS, MK, TL>), dim3(nwg), dim3(64), lds, st, a);                          \
+    } while (0)
+#define PW(KIND, PS, MK)                                                                                              \
+    do {                                                                                                              \
+        if (tiles) PW1(KIND, PS, MK, true);                                                                           \
+        else PW1(KIND, PS, MK, false);                                                                                \
     } while (0)
     if (a.kind == GPZ_KIND_COV) PW(GPZ_KIND_COV, false, false);
     else if (psi && mask) PW(GPZ_KIND_DIAG, true, true);
@@ -170,6 +185,7 @@ int launch_phi_wide(hipStream_t st, const PhiArgs &a) {
     else if (mask) PW(GPZ_KIND_DIAG, false, true);
     else PW(GPZ_KIND_DIAG, false, false);
 #undef PW
+#undef PW1
     return 0;
 }
 
@@ -177,10 +193,13 @@ int launch_phi_wide(hipStream_t st, const PhiArgs &a) {
 // R_j = triangular factor of Gamma_j (Householder QR), c_j = R_j p_j: one wave per basis function, the matrix in LDS,
 // lanes along the columns.  Output layout of k_prep_cov.
 // ---------------------------------------------------------------------------------------------
+// WS: the matrix does not fit the LDS (de > 142): it lives in `ws` (de*de + de doubles per basis function, device memory; the barriers
+// between the phases order the wave's own stores and loads).
+template <bool WS>
 __global__ __launch_bounds__(64) void k_prep_cov_wide(const double *__restrict__ G, const double *__restrict__ P, int m, int de,
-                                                       double *__restrict__ Rc) {
+                                                       double *__restrict__ Rc, double *__restrict__ ws) {
     extern __shared__ double lds[];
-    double *A = lds;               // [de][de] row-major
+    double *A = WS ? ws + (size_t)blockIdx.x * ((size_t)de * de + de) : lds;   // [de][de] row-major
     double *v = A + (size_t)de * de;
     const int j = blockIdx.x, lane = threadIdx.x;
     const double *Gj = G + (size_t)j * de * de;
@@ -222,12 +241,20 @@ __global__ __launch_bounds__(64) void k_prep_cov_wide(const double *__restrict__
     }
 }
 
-int launch_prep_cov_wide(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc) {
+size_t prep_cov_ws_len(int m, int de) {   // doubles of workspace launch_prep_cov_wide needs (0: the QR runs in LDS)
+    const size_t per = (size_t)de * de + de;
+    return per * sizeof(double) > 160 * 1024 ? per * (size_t)m : 0;
+}
+int launch_prep_cov_wide(hipStream_t st, const double *G, const double *P, int m, int de, double *Rc, double *ws) {
     const size_t lds = ((size_t)de * de + de) * sizeof(double);
-    if (lds > 160 * 1024) return -1;
+    if (lds > 160 * 1024) {
+        if (!ws) return -1;
+        hipLaunchKernelGGL(k_prep_cov_wide<true>, dim3(m), dim3(64), 0, st, G, P, m, de, Rc, ws);
+        return 0;
+    }
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_prep_cov_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_prep_cov_wide, dim3(m), dim3(64), lds, st, G, P, m, de, Rc);
+        (void)hipFuncSetAttribute((const void *)k_prep_cov_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_prep_cov_wide<false>, dim3(m), dim3(64), lds, st, G, P, m, de, Rc, (double *)nullptr);
     return 0;
 }
 

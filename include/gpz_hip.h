@@ -25,14 +25,17 @@
  * Limits: none on d, k or the number of NaN patterns for the evaluation, getPHI, predictFull, predictNoisy, getPrior and the
  * NaN grouping (the reference is generic, getPHI.m:60-110, GPz.m:133-213).  d <= 20 and k <= 8 run the instantiated,
  * register-resident kernels; wider inputs / more outputs take runtime-d kernels with the row data in LDS (k_wide.hip) and, for
- * GC/VC with missing values, a workspace-backed form of the general path (DESIGN.md section 7 gives the cost; a row tile must
- * fit the 160 KB of LDS: d <= ~100 for the diagonal kinds with input noise and missing values, ~300 without).  GC/VC with
+ * GC/VC with missing values, a workspace-backed form of the general path (DESIGN.md section 7 gives the cost; when a row tile
+ * does not fit the 160 KB of LDS - d beyond ~100 for the diagonal kinds with input noise and missing values, ~300 without - the
+ * PHI build reads the row data where it uses it, and GC/VC beyond d = 142 factor Gamma_j in a device workspace).  GC/VC with
  * input noise in fp64 runs register-resident up to d = 10 and as a block elimination in f64 MFMA accumulators for
  * 10 < d <= 64 (four pairs per wave up to d = 48), the workspace form beyond.
  * gpz_predict_missing for GC/VC runs register / MFMA kernels up to d = 32 and scratch-resident kernels with 64-wide temporaries for
- * 32 < d <= 64 (correct and slow: 32 KB of scratch per thread and temporary); the diagonal kinds run to d = 144 (256-bit pattern
- * mask; the pair-table kernel keeps d KB of LDS per 64 basis pairs).  Still refused (GPZ_ERR_UNSUPPORTED): gpz_predict_missing
- * with d > 64 for GC/VC, d > 144 for GL/VL/GD/VD.  dtype = f32 with d > 20 takes
+ * 32 < d <= 64 (correct and slow: 32 KB of scratch per thread and temporary) and, for ANY wider input, the same kernels with their
+ * temporaries in a device workspace (k_pmiss_covg.hip: 3 d^2 + 2 d doubles per thread, at most 2 GB per launch; 9 rows of one
+ * pattern at d = 100: 0.8 s with m = 4, 2.9 s with m = 16).  The diagonal kinds run tuned to d = 144 (pattern mask by value, d KB of
+ * LDS per 64 basis pairs) and LDS-free beyond (pattern as device flags; d = 260, m = 8, 30 rows: 83 ms).  No width is refused.
+ * dtype = f32 with d > 20 takes
  * the fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers); gpz_ctx_route says which route a context runs.
  *
  * Conventions (MATLAB's, so a MEX shim is pure marshalling):

@@ -129,11 +129,16 @@ def test_cov_kind_with_more_than_1024_nan_patterns():
     _gate(model, theta, X, Y, loose=2.0)
 
 
-@pytest.mark.parametrize("method,d,k,noisy", [("VD", 22, 1, False), ("GL", 24, 9, True), ("VL", 40, 2, True), ("VD", 70, 1, True), ("GD", 130, 1, False)])
+@pytest.mark.parametrize("method,d,k,noisy", [("VD", 22, 1, False), ("GL", 24, 9, True), ("VL", 40, 2, True), ("VD", 70, 1, True), ("GD", 130, 1, False),
+                                              ("VD", 150, 2, True), ("GD", 200, 1, False), ("VD", 260, 1, True)])
 def test_predict_with_missing_values_wide_diag_kinds(method, d, k, noisy):
-    """predictMissing / predictNoisyMissing (predictDiag.m:127-297) at d > 20 and k > 8 against the oracle."""
+    """predictMissing / predictNoisyMissing (predictDiag.m:127-297) at d > 20 and k > 8 against the oracle; d > 144: the LDS-free
+    instantiations of the pair-table / accumulation kernels with the pattern as device flags (any width)."""
     m = 8
     model, theta, X, Y, _, rng = make_problem(300, d, m, k, method, True, seed=5000 + d)
+    if d > 256:   # the initial length scales put exp(lnz_i + lnz_j) beyond the double range at this width (in the reference as well): wider bumps
+        theta = theta.copy()
+        theta[m * d:2 * m * d] = 0.3 * (1.0 + 0.1 * rng.random(m * d))
     model.muX = rng.standard_normal(d) * 0.1; model.sdX = 1.0 + rng.random(d); model.muY = rng.standard_normal(k)
     r4 = O.GPz(theta, model, X, Y, nargout=4)
     pri = rng.random(m) + 0.2
@@ -162,10 +167,11 @@ def test_predict_missing_cov_kind_with_many_outputs():
         assert rel(out[i], ref[i]) <= 1e-8, name
 
 
-@pytest.mark.parametrize("method,d,noisy", [("GC", 34, False), ("VC", 40, True), ("VC", 64, False)])
+@pytest.mark.parametrize("method,d,noisy", [("GC", 34, False), ("VC", 40, True), ("VC", 64, False), ("GC", 66, False), ("VC", 72, True), ("VC", 100, False)])
 def test_predict_with_missing_values_cov_kinds_beyond_32_dimensions(method, d, noisy):
-    """predictMissing / predictNoisyMissing for GC/VC at 32 < d <= 64 (predictCov.m:134-337 is generic in d): the scratch-resident
-    kernels with 64-wide temporaries (k_pmiss_cov64.hip) against the oracle; several NaN patterns, complete rows mixed in."""
+    """predictMissing / predictNoisyMissing for GC/VC at d > 32 (predictCov.m:134-337 is generic in d): the scratch-resident
+    kernels with 64-wide temporaries (k_pmiss_cov64.hip) and, beyond d = 64, the workspace-resident ones (k_pmiss_covg.hip) against
+    the oracle; several NaN patterns, complete rows mixed in."""
     m, k = 4, 1
     model, theta, X, Y, _, rng = make_problem(120, d, m, k, method, True, seed=5300 + d)
     from helpers import recondition_gamma
@@ -190,18 +196,20 @@ def test_predict_with_missing_values_cov_kinds_beyond_32_dimensions(method, d, n
         assert rel(out[i], ref[i]) <= tol, (name, rel(out[i], ref[i]))
 
 
-def test_what_is_still_refused_says_so():
-    """Prediction with missing values: d <= 64 for GC/VC (64-wide per-thread temporaries), d <= 144 for the diagonal kinds (LDS tile
-    of the pair-table kernel)."""
-    d = 66
-    model, theta, X, Y, _, rng = make_problem(100, d, 5, 1, "GC", True, seed=5)
+def test_predict_missing_takes_any_width_through_the_c_abi():
+    """gpz_predict_missing itself (one NaN-pattern group) at d = 90, GC: no GPZ_ERR_UNSUPPORTED left on this entry point."""
+    d, m = 90, 3
+    model, theta, X, Y, _, rng = make_problem(100, d, m, 1, "GC", True, seed=5)
+    from helpers import recondition_gamma
+    theta = recondition_gamma(model, theta, rng)
     r4 = O.GPz(theta, model, X, Y, nargout=4)
-    pri = np.full(5, 0.2)
+    pri = np.full(m, 1.0 / m)
     model.sets["best"] = {"theta": theta, "w": r4.w, "iSigma_w": r4.iSigma_w, "priors": pri}
-    Xs = rng.standard_normal((10, d)); Xs[:, 3] = np.nan
-    with pytest.raises(_lib.GpzError) as ei:
-        gpz_amd.predict(Xs, model)
-    assert ei.value.code == -5
+    Xs = rng.standard_normal((5, d)); Xs[:, [3, 70, 89]] = np.nan
+    ref = O.predict_any(Xs, model)
+    out = gpz_amd.predict(Xs, model)
+    for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
+        assert rel(out[i], ref[i]) <= 1e-7, (name, rel(out[i], ref[i]))
 
 
 @pytest.mark.parametrize("method,psi,nanfrac,k", [("VD", True, 0.2, 9), ("VC", False, 0.0, 1), ("GC", False, 0.3, 2)])
@@ -235,14 +243,12 @@ def test_very_wide_inputs_use_more_than_64kb_of_lds(method, d, psi, nanfrac):
     _gate(model, theta, X, Y, Psi, loose=4.0)
 
 
-def test_row_tile_beyond_the_lds_is_refused():
-    """VD with input noise and missing values at d = 120 needs 185 KB for its three row tiles: GPZ_ERR_UNSUPPORTED from the
-    evaluation, not a launch failure."""
-    model, theta, X, Y, Psi, rng = make_problem(200, 120, 4, 1, "VD", True, seed=7300, psi=True, nanfrac=0.1)
-    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
-    try:
-        with pytest.raises(_lib.GpzError) as ei:
-            ctx.eval(theta)
-        assert ei.value.code == -5
-    finally:
-        ctx.close()
+@pytest.mark.parametrize("method,d,psi,nanfrac", [("VD", 120, True, 0.1), ("VL", 330, False, 0.0), ("GC", 150, False, 0.0), ("VC", 146, False, 0.0)])
+def test_inputs_wider_than_the_lds_tiles(method, d, psi, nanfrac):
+    """No width limit on the evaluation (the reference is generic in d): VD with input noise and missing values at d = 120 would need
+    185 KB for its three row tiles, VL at d = 330 170 KB for one - the PHI build then reads x / psi / mask where it uses them; GC / VC
+    beyond d = 142 run the Householder QR of Gamma_j in a device workspace instead of the LDS.  (Until round 4 the first two were
+    refused with GPZ_ERR_UNSUPPORTED and the last two silently skipped the QR.)"""
+    n, m, k = 200, 4, 1
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=7300 + d, psi=psi, nanfrac=nanfrac)
+    _gate(model, theta, X, Y, Psi, loose=4.0)
