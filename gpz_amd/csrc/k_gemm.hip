@@ -356,7 +356,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            OT (*sA)[128][18], OT (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
-                                           long n_pad, int ct, int kdim) {
+                                           long n_pad, int ct, int kdim, int ncol16 = 8, int slot = 0, int nslot = 1) {
     constexpr int NT = 128 * WC;
     constexpr int NI = 8 / WC;
     constexpr int Q = 1024 / NT;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     int nvalid = NI;
     if (EDGE) {
         nvalid = (mp - j0 + 15) / 16;
-        nvalid = nvalid < 0 ? 0 : (nvalid > 8 ? 8 : nvalid);
+        nvalid = nvalid < 0 ? 0 : (nvalid > ncol16 ? ncol16 : nvalid);   // ncol16 < 8: a column piece of a split tile (k_tgemm)
         nvalid = __builtin_amdgcn_readfirstlane(nvalid);
     }
     static_assert(!EDGE || 4 * NI == 8, "the row-strip deal keeps its eight accumulators in acc[4][2]");
@@ -510,8 +510,8 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
             }
         }
         if (nupart) {
-            // the consumers sum WC slots per column tile and row: this wave's sum over ALL columns of the tile goes to slot 0,
-            // zeros to the others
+            // the consumers sum WC slots per column tile and row: this wave's sum over ALL its columns of the tile goes to slot `slot`
+            // (0 for a whole edge tile, the piece index for a split tile); the first piece zeroes the slots no piece writes
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wave * 16 + crow(r);
@@ -527,8 +527,11 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                 pp += __shfl_xor(pp, 4, 64);
                 pp += __shfl_xor(pp, 8, 64);
                 if ((lane & 15) == 0) {
+                    nupart[(size_t)(ct * WC + slot) * n_pad + row] = pp;
+                    if (slot == 0)
 #pragma unroll
-                    for (int q = 0; q < WC; ++q) nupart[(size_t)(ct * WC + q) * n_pad + row] = q == 0 ? pp : 0.0;
+                        for (int q = 1; q < WC; ++q)
+                            if (q >= nslot) nupart[(size_t)(ct * WC + q) * n_pad + row] = 0.0;
                 }
             }
         }
@@ -574,13 +577,24 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
                                                         const double *__restrict__ B, int ldb,
                                                         double *__restrict__ T, int ldt, int mp, int nct,
                                                         double *__restrict__ nupart, double *__restrict__ phiw, int m,
-                                                        int mcol, long n_pad, int kdim) {
+                                                        int mcol, long n_pad, int kdim, int nfull, int npiece) {
     __shared__ OT sA[2][128][18];
     __shared__ OT sB[2][16][LDS_LD128];
+    // Tail balance: the grid is nfull whole tiles followed by the remaining tiles cut into npiece column pieces each (launch_tgemm):
+    // when the tile count leaves the last round of resident workgroups mostly empty (c2: 1568 tiles on 512 slots = 3.06 rounds),
+    // the pieces of the last 0.06 round fill the chip for a fraction of a tile's time instead of 32 tiles holding it for a whole one.
+    if ((int)blockIdx.x >= nfull) {
+        const int q = (int)blockIdx.x - nfull;
+        const int tile = nfull + q / npiece, piece = q % npiece;
+        const int rt = tile / nct, ct = tile % nct;
+        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, rt * 128, ct * 128 + piece * (128 / npiece), sA, sB, nupart, phiw, m, mcol,
+                                 n_pad, ct, kdim, 8 / npiece, piece, npiece);
+        return;
+    }
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
     // logical tiles, so the 8 column tiles of a row panel run back to back on one XCD and the 1 MB PHI panel is
     // fetched from HBM once instead of once per XCD.  Bijective for any grid size; affects speed only.
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = nfull, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
     const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
@@ -717,19 +731,38 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 
 // T (n_pad x mp, row stride ldt) = PHI (n_pad x kdim, row stride ld) * B (kdim x mp, row stride ldb).  kdim = 0: the square case
 // of the evaluation (K = mp, ldt = ld).  kdim % 16 == 0.
+// compute units of the current device (256 on MI355X); the tile kernels keep two workgroups resident on each
+static int gpz_cu_count() {
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        return cu;
+    }();
+    return n;
+}
+
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
                   double *nupart, double *phiw, int m, int mcol, bool f32_operands, int kdim, int ldt) {
     constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
     if (kdim <= 0) kdim = mp;
     if (ldt <= 0) ldt = ld;
-    dim3 grid((n_pad / 128) * nct), block(128 * WC);
+    // tail balance (see k_tgemm): the tiles of the last, partly filled round of resident workgroups are cut into column pieces
+    const int W = (n_pad / 128) * nct, C = 2 * gpz_cu_count();
+    int tail = W % C, npiece = 1;
+    static const bool no_split = getenv("GPZ_TGEMM_NO_SPLIT") != nullptr;
+    // quarter pieces only: a piece stages the same A and B slices as a whole tile, so a half costs ~0.9 of one (125k-row shard of c4,
+    // tail 136: 3.83 ms either way) and a quarter ~0.6 (c2: 231 -> 211 us, c3: 862 -> 826 us)
+    if (tail > 0 && !no_split && tail * 4 <= C) npiece = 4;
+    if (npiece == 1) tail = 0;
+    const int nfull = W - tail;
+    dim3 grid(nfull + tail * npiece), block(128 * WC);
     if (f32_operands)
         hipLaunchKernelGGL((k_tgemm<WC, float>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
-                           (long)n_pad, kdim);
+                           (long)n_pad, kdim, nfull, npiece);
     else
         hipLaunchKernelGGL((k_tgemm<WC, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
-                           (long)n_pad, kdim);
+                           (long)n_pad, kdim, nfull, npiece);
 }
 
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs) {
