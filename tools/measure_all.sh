@@ -29,7 +29,8 @@ find gpurun_out/$tag/pmc -name "*.csv" -size +4M -delete
 GPZ_PSI32_MFMA=1 python bench.py --config c5 --rows 250000 --steps 3 --warmup 1 --no-cpu-baseline > $O/c5s_mfma_route.json 2> $O/c5s_mfma_route.err
 python bench.py --config c5_f64 --rows 250000 --steps 2 --warmup 1 --no-cpu-baseline > $O/c5s_f64.json 2> $O/c5s_f64.err
 python bench.py --native-mgpu 8 --no-cpu-baseline --steps 5 > $O/c4_native_mgpu8_loopback.json 2> $O/c4_native_mgpu8_loopback.err
-for t in mfma_f32_4x4_rate mfma_valu_overlap; do
+for t in mfma_f32_4x4_rate mfma_valu_overlap mfma_f32_16x16_overlap mfma_f64_valu_overlap pk_fma_rate; do
   hipcc --offload-arch=gfx950 -O3 tools/$t.hip -o build/$t 2> /dev/null && build/$t > $O/ubench_$t.txt 2>&1
 done
+python tools/pm_wide_timing.py 2> /dev/null | grep " d=" > $O/extras_predict_missing_wide.txt
 tail -c 600 $O/c4.json; echo; tail -c 300 $O/c2.json; echo; tail -c 300 $O/c3.json; echo; tail -c 300 $O/c4_shard125k.json
