@@ -360,14 +360,19 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         tg_ms, tg_calls = tim.get("tgemm", (0.0, 0))
         tg_avg = tg_ms / max(1, tg_calls)
-        flops_tg = 2.0 * n_local * m * m              # algorithmic flops of PHI*inv(SIGMA) per launch (SURVEY §8d F_T)
+        # rows one launch covers: all of the rank's rows, or one row tile when the context streams them (GPZ_ROW_TILE / PHI + T beyond the HBM)
+        import re as _re
+        _mt = _re.search(r"streamed, (\d+) tiles of (\d+)", route or "")
+        ntiles = int(_mt.group(1)) if _mt else 1
+        n_launch = n_local / ntiles
+        flops_tg = 2.0 * n_launch * m * m             # algorithmic flops of PHI*inv(SIGMA) per launch (SURVEY §8d F_T)
         ach = flops_tg / (tg_avg * 1e-3) / 1e12 if tg_avg > 0 else 0.0
         sy_ms, sy_calls = tim.get("syrk", (0.0, 0))
         sy_avg = sy_ms / max(1, sy_calls)
-        ach_sy = (n_local * m * (m + 1.0)) / (sy_avg * 1e-3) / 1e12 if sy_avg > 0 else 0.0
+        ach_sy = (n_launch * m * (m + 1.0)) / (sy_avg * 1e-3) / 1e12 if sy_avg > 0 else 0.0
         ph_ms, ph_calls = tim.get("phi_build", (0.0, 0))
         ph_avg = ph_ms / max(1, ph_calls)
-        phi_gbs = 8.0 * (n_local * cfg["d"] + n_local * m) / (ph_avg * 1e-3) / 1e9 if ph_avg > 0 else 0.0
+        phi_gbs = 8.0 * (n_launch * cfg["d"] + n_launch * m) / (ph_avg * 1e-3) / 1e9 if ph_avg > 0 else 0.0
         f32_route = bool(cfg.get("psi")) and dtype != "f64"
         out = {
             "metric": "objective+gradient evals/sec", "value": args.steps / elapsed, "unit": "evals/s",

@@ -290,6 +290,13 @@ struct gpz_ctx {
     int nwg_rows = 1;
     double *mom_slab = nullptr;
     int nchunk = 1, rows_per_chunk = 1;
+    // Row-tile streaming (tile_rows > 0; SURVEY.md section 5 "row-tile streaming"): PHI, T and the nu partials hold ONE tile of rows and
+    // the evaluation walks the tiles twice - stage A: PHI -> PHI'W PHI accumulated over the tiles; tail: PHI again -> T-GEMM -> row
+    // scalars -> moment sums into the tile's own chunks of the slab.  The per-row vectors (ln beta, omega beta, PHI w, row scalars)
+    // stay whole.  Chosen when PHI + T would not fit the device (or forced by GPZ_ROW_TILE, tests); plain route only (no Psi, no
+    // missing values in GC/VC).
+    int tile_rows = 0, ntiles = 1, tile_nchunk = 1, tile_rpc = 1;
+    double *tile_rstats = nullptr;                        // [ntiles][GPZ_NS]: the tiles' row-scalar sums
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
     double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused path
     bool fused = true;   // dPHI formed on the fly, output by output (no dPHI / dL matrices): k == 1, or k > 1 on the tuned kernels
@@ -775,8 +782,30 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     if ((rc = alloc_mm(c))) return bail(rc);
 
     const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
-    if ((rc = c->ar.alloc(&c->Phi, np * mp))) return bail(rc);
-    if ((rc = c->ar.alloc(&c->T, np * mp))) return bail(rc);
+    {
+        // resident unless PHI + T (2 n_pad mp doubles) exceed 70 % of the free device memory; GPZ_ROW_TILE=<rows> forces a tile size
+        size_t want = 0;
+        if (const char *e = getenv("GPZ_ROW_TILE")) want = (size_t)atol(e);
+        size_t fr = 0, tot = 0;
+        if (!want && hipMemGetInfo(&fr, &tot) == hipSuccess && 2.0 * (double)np * (double)mp * 8.0 > 0.7 * (double)fr) {
+            // the largest tile whose PHI + T take half of that (the slabs and per-row vectors need the rest): every launch of the walk
+            // then still fills the chip for many rounds
+            want = (size_t)(0.35 * (double)fr / (2.0 * (double)mp * 8.0));
+            if (want < 131072) want = 131072;
+        }
+        const bool can = !c->gen && !c->has_psi;
+        if (want && can) {
+            const size_t tr = (size_t)rup((long)want, 1024);
+            if (tr < np) {
+                c->tile_rows = (int)tr;
+                c->ntiles = (int)((np + tr - 1) / tr);
+            }
+        }
+    }
+    const size_t npt = c->tile_rows ? (size_t)c->tile_rows : np;   // rows PHI / T / the nu partials hold
+    if ((rc = c->ar.alloc(&c->Phi, npt * mp))) return bail(rc);
+    if ((rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);
+    if (c->tile_rows && (rc = c->ar.alloc(&c->tile_rstats, (size_t)c->ntiles * GPZ_NS))) return bail(rc);
     // GC + Psi in fp64, 10 < d <= 32 (evaluation contexts only: prediction and getPHI contexts have no moment stage and no T)
     if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !getenv("GPZ_GC_MINV_OFF")) {
         // one inverse per training row, shared by the basis functions (k_cpsi4_moments<.., SHARED>)
@@ -806,13 +835,14 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         // rows a workgroup gets at a target of T workgroups: n_pad npairs / T.  Every split is one more mp x mp slab for k_syrk_reduce to
         // read, so short row ranges are not worth a second resident round: c2 / c3 (600 / 2000 rows per workgroup at 512) run
         // SYRK + reduce 19 / 25 us faster at 256 workgroups (0.179 -> 0.160 ms, 0.520 -> 0.495 ms)
-        auto rows_at = [&](int T) { return (long)c->tr.n_pad * npairs / T; };
+        const long np_k = (long)npt;   // rows one SYRK launch sees (a row tile when streaming)
+        auto rows_at = [&](int T) { return np_k * npairs / T; };
         int target = rows_at(1024) >= 16384 ? 1024 : rows_at(512) >= 4096 ? 512 : 256;
         if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e) > 0 ? atoi(e) : target;
         // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 9 MFMAs per SIMD and K step against 16:
         // the 36 products on and above the diagonal, k_gemm.hip): the pair that minimises max(1/s1, 0.6/s2) with
         // noff*s1 + nt*s2 workgroups inside the target.
-        const int noff = npairs - nt, max_ns = c->tr.n_pad / 64 > 0 ? c->tr.n_pad / 64 : 1;
+        const int noff = npairs - nt, max_ns = np_k / 64 > 0 ? (int)(np_k / 64) : 1;
         int s1 = 1, s2 = 1;
         double best = 1e300;
         for (int a = 1; a <= max_ns && a <= target && noff * a + nt <= (target > npairs ? target : npairs); ++a) {
@@ -825,16 +855,16 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         }
         if (const char *e = getenv("GPZ_SYRK_S1")) s1 = atoi(e) > 0 ? atoi(e) : s1;   // tuning only
         if (const char *e = getenv("GPZ_SYRK_S2")) s2 = atoi(e) > 0 ? atoi(e) : s2;
-        c->rows_per_split = rup((c->tr.n_pad + s1 - 1) / s1, 16);
-        c->nsplit = (c->tr.n_pad + c->rows_per_split - 1) / c->rows_per_split;
-        c->rows_per_split_d = rup((c->tr.n_pad + s2 - 1) / s2, 16);
-        c->nsplit_d = (c->tr.n_pad + c->rows_per_split_d - 1) / c->rows_per_split_d;
+        c->rows_per_split = rup((int)((np_k + s1 - 1) / s1), 16);
+        c->nsplit = (int)((np_k + c->rows_per_split - 1) / c->rows_per_split);
+        c->rows_per_split_d = rup((int)((np_k + s2 - 1) / s2), 16);
+        c->nsplit_d = (int)((np_k + c->rows_per_split_d - 1) / c->rows_per_split_d);
         size_t need = (size_t)(c->nsplit > c->nsplit_d ? c->nsplit : c->nsplit_d) * mp * mp;
         size_t need_l = (size_t)c->nsplit_l * c->mq * c->mq;
         c->slab_count = need > need_l ? need : need_l;
         if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
     }
-    if (c->kind == GPZ_KIND_COV && np < 1024 * 1024) {
+    if (c->kind == GPZ_KIND_COV && npt < 1024 * 1024) {   // (indexed by row with the full row stride, also when the rows are streamed)
         c->phipart_groups = 16;
         size_t rows = np > (size_t)c->va.n_pad ? np : (size_t)c->va.n_pad;
         if ((rc = c->ar.alloc(&c->phipart, (size_t)c->phipart_groups * 2 * k * rows))) return bail(rc);
@@ -849,7 +879,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         if ((rc = c->ar.alloc(&c->scal_slab, (size_t)c->nwg_rows * 4))) return bail(rc);
     } else {
         c->nslots = gpz_gemm_wave_cols() * ((c->mp + 127) / 128);
-        if ((rc = c->ar.alloc(&c->nupart, (size_t)c->nslots * np))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->nupart, (size_t)c->nslots * npt))) return bail(rc);
         if ((rc = c->ar.alloc(&c->rowscal, (size_t)4 * np))) return bail(rc);
         if ((rc = c->ar.alloc(&c->frec, (size_t)m * (c->nm + 2)))) return bail(rc);
     }
@@ -866,6 +896,13 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->rows_per_chunk = (c->tr.n + nc - 1) / nc;
         if (c->rows_per_chunk < 1) c->rows_per_chunk = 1;
         c->nchunk = c->tr.n > 0 ? (c->tr.n + c->rows_per_chunk - 1) / c->rows_per_chunk : 1;
+        if (c->tile_rows) {   // every tile gets its own run of chunks (about the same number in all)
+            int nct = nc;   // as many as a resident evaluation uses for all rows: a tile's launch fills the chip the same way
+            if (nct > c->tile_rows / 32) nct = c->tile_rows / 32 > 0 ? c->tile_rows / 32 : 1;
+            c->tile_rpc = (c->tile_rows + nct - 1) / nct;
+            c->tile_nchunk = (c->tile_rows + c->tile_rpc - 1) / c->tile_rpc;
+            c->nchunk = c->ntiles * c->tile_nchunk;
+        }
         if ((rc = c->ar.alloc(&c->mom_slab, (size_t)c->nchunk * m * (c->nm + 2)))) return bail(rc);
     }
     if ((rc = c->ar.alloc(&c->partial, (size_t)GPZ_ROWSCAL_MAX_NWG * gpz_ns(c->k)))) return bail(rc);
@@ -971,8 +1008,11 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
     const char *gs = c->graph_state == 2 ? "replayed" : c->graph_state == -1 ? "disabled (capture failed or GPZ_NO_GRAPH)"
                      : c->timing ? "off (stage timing on)" : c->desc.world > 1 ? "off (sharded)" : "eager (not captured yet)";
     const bool f32mm = c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF");
-    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA; evaluation graph: %s", phi, why,
-                    f32mm ? "fp32-operand (fp64 master sums)" : "fp64", gs);
+    char rows[96];
+    if (c->tile_rows) snprintf(rows, sizeof rows, "; rows: streamed, %d tiles of %d (PHI built twice per evaluation)", c->ntiles, c->tile_rows);
+    else rows[0] = 0;
+    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA; evaluation graph: %s%s", phi, why,
+                    f32mm ? "fp32-operand (fp64 master sums)" : "fp64", gs, rows);
 }
 
 // ---- pipeline stages -----------------------------------------------------------------------------
@@ -1139,6 +1179,54 @@ static int build_phi(gpz_ctx *c) {
     return 0;
 }
 
+// Row-tile streaming: rows [r0, r0 + rows_pad) of the training set (rows of them real) as the current contents of c->Phi.
+struct RowTile { long r0; int rows, rows_pad; };
+static RowTile row_tile(const gpz_ctx *c, int t) {
+    RowTile rt;
+    rt.r0 = (long)t * c->tile_rows;
+    const long left_pad = (long)c->tr.n_pad - rt.r0, left = (long)c->tr.n - rt.r0;
+    rt.rows_pad = (int)(left_pad < c->tile_rows ? left_pad : c->tile_rows);
+    rt.rows = (int)(left < 0 ? 0 : (left < rt.rows_pad ? left : rt.rows_pad));
+    return rt;
+}
+static int phi_tile(gpz_ctx *c, const RowTile &rt) {
+    PhiArgs a{};
+    const long r0 = rt.r0;
+    a.Xc = c->tr.Xc + r0; a.ldx = c->tr.n_pad; a.n = rt.rows; a.n_pad = rt.rows_pad;
+    a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
+    a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
+    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om ? c->tr.om + r0 : nullptr; a.Y = c->tr.Y + r0;
+    a.Phi = c->Phi; a.lnbeta = c->lnbeta + r0; a.wbeta = c->wbeta + r0; a.w = nullptr; a.phiw = nullptr;
+    a.Psic = c->tr.Psic ? c->tr.Psic + r0 : nullptr; a.Mc = c->tr.Mc ? c->tr.Mc + r0 : nullptr;
+    a.ucnt = c->tr.ucnt ? c->tr.ucnt + r0 : nullptr;
+    a.part = c->phipart; a.part_groups = c->phipart_groups;   // (row-indexed with stride ldx: the tile's rows from its base)
+    if (launch_phi(c->st, a)) return fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
+    return 0;
+}
+// Stage A of a streamed evaluation: per tile PHI -> PHI' W_o PHI, summed over the tiles in comm1.
+static int stage_a_tiles(gpz_ctx *c) {
+    const bool f32 = c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF");
+    for (int t = 0; t < c->ntiles; ++t) {
+        const RowTile rt = row_tile(c, t);
+        {
+            Stage s(c, "phi_build");
+            if (int e = phi_tile(c, rt)) return e;
+        }
+        const int nsp = (rt.rows_pad + c->rows_per_split - 1) / c->rows_per_split;
+        const int nsp_d = (rt.rows_pad + c->rows_per_split_d - 1) / c->rows_per_split_d;
+        for (int o = 0; o < c->k; ++o) {
+            {
+                Stage s(c, "syrk");
+                launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad + rt.r0, rt.rows_pad, c->mp, nsp, c->rows_per_split,
+                            nsp_d, c->rows_per_split_d, c->slab, false, f32);
+            }
+            Stage s(c, "syrk_reduce");
+            launch_syrk_reduce(c->st, c->slab, nsp, nsp_d, c->mp, c->comm1 + (size_t)o * c->mp * c->mp, c->mp, t > 0 ? 1 : 0);
+        }
+    }
+    return 0;
+}
+
 // Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
 static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nullptr) {
     if (theta_dev) {   // device-resident caller (gpz_eval_dev): theta never visits the host
@@ -1155,14 +1243,15 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         if (c->kind == GPZ_KIND_COV) launch_prep_cov(c->st, c->pr.G, c->pr.P, c->m, c->de, c->pr.Rc, c->prep_ws);
     }
     if (int e = psi32_agree(c)) return e;
-    if (int e = build_phi(c)) return e;
+    if (c->tile_rows) { if (int e = stage_a_tiles(c)) return e; }
+    else if (int e = build_phi(c)) return e;
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
     {
         Stage s(c, "row_sums");
         launch_sums1(c->st, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), sums1);
     }
-    for (int o = 0; o < c->k; ++o) {
+    for (int o = 0; o < c->k && !c->tile_rows; ++o) {
         {
             Stage s(c, "syrk");
             launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
@@ -1178,7 +1267,7 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
         Stage s(c, "allreduce1");
         if (int e = allreduce(c, c->comm1, c->comm1_count)) return e;
     }
-    c->phi_valid = true;
+    c->phi_valid = !c->tile_rows;   // streamed: c->Phi holds the last tile only
     return 0;
 }
 
@@ -1246,6 +1335,44 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
     for (int o = 0; o < c->k; ++o) {
         if (pinv) { if (int e = stage_b_pinv(c, o)) return e; }
         else stage_b(c, o);
+        if (c->tile_rows) {
+            // streamed: per tile PHI again -> T -> row scalars -> moment sums into the tile's own chunks; the sums over the tiles after the walk
+            const size_t oo = (size_t)o * c->tr.n_pad;
+            for (int t = 0; t < c->ntiles; ++t) {
+                const RowTile rt = row_tile(c, t);
+                const long r0 = rt.r0;
+                { Stage s(c, "phi_build"); if (int e = phi_tile(c, rt)) return e; }
+                {
+                    Stage s(c, "tgemm");
+                    launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, rt.rows_pad, c->mp, c->nupart, c->phiw + oo + r0, c->m, c->m + o,
+                                 c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
+                }
+                {
+                    Stage s(c, "row_scalars");
+                    launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw + oo + r0, c->tr.Y + oo + r0, c->tr.om ? c->tr.om + r0 : nullptr,
+                                       c->lnbeta + oo + r0, c->wbeta + oo + r0, rt.rows_pad, rt.rows, c->rowscal + 4 * r0, c->partial);
+                    launch_slab_sum(c->st, c->partial, row_scalars_nwg(rt.rows), GPZ_NS, c->tile_rstats + (size_t)t * GPZ_NS);
+                }
+                Stage s(c, "moments");
+                FusedMomentArgs a{};
+                a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.Xr = c->tr.Xr + r0 * c->de; a.rowscal = c->rowscal + 4 * r0; a.n = rt.rows;
+                a.m = c->m; a.d = c->de; a.kind = c->kind; a.P = c->pr.P; a.w = c->w + (size_t)o * m;
+                a.v = c->hetero ? c->pr.v + (size_t)o * m : nullptr;
+                a.rows_per_chunk = c->tile_rpc; a.nchunk = (rt.rows + c->tile_rpc - 1) / c->tile_rpc;
+                a.slab = c->mom_slab + (size_t)t * c->tile_nchunk * m * (c->nm + 2); a.nm = c->nm;
+                a.Psir = c->tr.Psir ? c->tr.Psir + r0 * c->de : nullptr; a.Mr = c->tr.Mr ? c->tr.Mr + r0 * c->de : nullptr; a.G2 = c->pr.G2;
+                if (a.nchunk > 0 && launch_moments_fused(c->st, a))
+                    return fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
+            }
+            Stage s(c, "moments");
+            launch_slab_sum(c->st, c->tile_rstats, c->ntiles, GPZ_NS, c->rstats);
+            HIPCHK(hipMemcpyAsync(scal + (size_t)o * 4, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+            const RowTile last = row_tile(c, c->ntiles - 1);
+            const int nch = (c->ntiles - 1) * c->tile_nchunk + (last.rows + c->tile_rpc - 1) / c->tile_rpc;   // the last tile's chunks end the slab
+            launch_slab_sum(c->st, c->mom_slab, nch, m * (c->nm + 2), c->frec);
+            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols + (size_t)o * 2 * mp, o > 0 ? 1 : 0);
+            continue;
+        }
         {
             Stage s(c, "tgemm");
             // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip)
@@ -1641,6 +1768,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
 
 extern "C" int gpz_get_phi(gpz_ctx *c, double *PHI) {
     if (!c || !PHI) return fail(GPZ_ERR_ARG, "gpz_get_phi: null argument");
+    if (c->tile_rows) return fail(GPZ_ERR_ARG, "gpz_get_phi: this context streams PHI in row tiles (it is never whole on the device); use gpz_phi");
     if (!c->phi_valid) return fail(GPZ_ERR_ARG, "gpz_get_phi: no evaluation has been run");
     HIPCHK(hipSetDevice(c->device));
     double *tmp = nullptr;

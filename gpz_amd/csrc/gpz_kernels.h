@@ -72,7 +72,8 @@ int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is 
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
                  int nsplit, int rows_per_split, int nsplit_d, int rows_per_split_d, double *slab, bool tri,
                  bool f32_operands = false);
-void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds);
+void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds,
+                        int accumulate = 0 /* S += instead of S = (row tiles of a streamed evaluation) */);
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

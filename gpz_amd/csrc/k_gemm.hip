@@ -321,7 +321,7 @@ __global__ __launch_bounds__(128 * WC, (std::is_same<OT, float>::value ? 2 : WC)
 
 // S[i][j] = S[j][i] = sum_s slab[s][min-tile-order(i,j)]
 __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, int nsplit_d, int mp,
-                              double *__restrict__ S, int lds) {
+                              double *__restrict__ S, int lds, int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= mp) return;
@@ -341,7 +341,8 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, i
         s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
     }
     for (; k < nsplit; ++k) s0 += p[(size_t)k * stride];
-    S[(size_t)i * lds + j] = (s0 + s1) + (s2 + s3);
+    const double t = (s0 + s1) + (s2 + s3);
+    S[(size_t)i * lds + j] = accumulate ? S[(size_t)i * lds + j] + t : t;   // accumulate: the next row tile of a streamed evaluation
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -724,9 +725,9 @@ void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, i
                            rows_per_split, nsplit_d, rows_per_split_d, slab);
 }
 
-void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds) {
+void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds, int accumulate) {
     dim3 block(256), grid((mp + 255) / 256, mp);
-    hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, nsplit_d, mp, S, lds);
+    hipLaunchKernelGGL(k_syrk_reduce, grid, block, 0, st, slab, nsplit, nsplit_d, mp, S, lds, accumulate);
 }
 
 // T (n_pad x mp, row stride ldt) = PHI (n_pad x kdim, row stride ld) * B (kdim x mp, row stride ldb).  kdim = 0: the square case

@@ -35,6 +35,9 @@
  * temporaries in a device workspace (k_pmiss_covg.hip: 3 d^2 + 2 d doubles per thread, at most 2 GB per launch; 9 rows of one
  * pattern at d = 100: 0.8 s with m = 4, 2.9 s with m = 16).  The diagonal kinds run tuned to d = 144 (pattern mask by value, d KB of
  * LDS per 64 basis pairs) and LDS-free beyond (pattern as device flags; d = 260, m = 8, 30 rows: 83 ms).  No width is refused.
+ * Rows: PHI and T (2 n mp doubles) stay on the device while they fit; beyond that the evaluation streams them in row tiles (PHI built
+ * twice per evaluation, +10 % at c4's shape; plain route: no Psi, no missing values on GC/VC) - gpz_ctx_route reports it, gpz_get_phi is
+ * refused there.
  * dtype = f32 with d > 20 takes
  * the fp64 kernels (the fp32 pair kernels hold a d <= 20 triangle in registers); gpz_ctx_route says which route a context runs.
  *

@@ -1368,3 +1368,44 @@ def test_model_tables_kept_between_nan_pattern_groups_are_keyed_by_contents():
             for i, name in enumerate(("mu", "sigma", "nu", "beta_i", "gamma", "PHI")):
                 assert rel(out[i], refs[q][i]) <= 1e-8, (q, name)
         _lib.load().gpz_release_cached_memory()
+
+
+@pytest.mark.parametrize("method,k,nanfrac,tile", [("VC", 1, 0.0, 2048), ("VD", 1, 0.0, 1024), ("GL", 2, 0.0, 2048), ("VD", 1, 0.3, 3072), ("GC", 1, 0.0, 1024)])
+def test_row_tile_streaming_matches_the_resident_evaluation(method, k, nanfrac, tile, monkeypatch):
+    """Row-tile streaming (chosen by the library when PHI + T would not fit the device, forced here by
+    GPZ_ROW_TILE): PHI, T hold one tile of rows, stage A sums PHI'W PHI over the tiles, the tail rebuilds each tile's PHI for the
+    T-GEMM, the row scalars and the moment sums.  Same result as the resident evaluation (summation order of the row splits aside) and
+    as the oracle: weights, training / validation masks, two outputs, diagonal kinds with missing values; solve-only mode as well."""
+    n, d, m = 5000, 6, 40
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=4100 + tile, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    res = {}
+    for mode in ("resident", "streamed"):
+        if mode == "streamed":
+            monkeypatch.setenv("GPZ_ROW_TILE", str(tile))
+        else:
+            monkeypatch.delenv("GPZ_ROW_TILE", raising=False)
+        ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+        try:
+            f, g = ctx.eval(theta)
+            f2, g2 = ctx.eval(theta)           # the captured graph replays the same tile walk
+            assert f2 == f and np.array_equal(g, g2)
+            assert ("streamed" in ctx.route()) == (mode == "streamed"), ctx.route()
+            w, iS, part = ctx.solve(theta)
+            res[mode] = (f, g, dict(ctx.stats), w, part)
+            if mode == "streamed":
+                with pytest.raises(_lib.GpzError):
+                    ctx.phi()
+        finally:
+            ctx.close()
+    f, g, stats, w, part = res["streamed"]
+    tol = grad_tol(ref.cond)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+    f0, g0, stats0, w0, part0 = res["resident"]
+    assert abs(f - f0) <= 1e-12 * abs(f0) and rel(g, g0) <= max(1e-11, 0.01 * tol)
+    assert rel(w, w0) <= max(1e-11, 0.01 * tol) and rel(part, part0) <= 1e-12
