@@ -787,7 +787,13 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         size_t want = 0;
         if (const char *e = getenv("GPZ_ROW_TILE")) want = (size_t)atol(e);
         size_t fr = 0, tot = 0;
-        if (!want && hipMemGetInfo(&fr, &tot) == hipSuccess && 2.0 * (double)np * (double)mp * 8.0 > 0.7 * (double)fr) {
+        if (!want && hipMemGetInfo(&fr, &tot) == hipSuccess) {   // blocks the buffer cache holds are as good as free (a failed hipMalloc releases them)
+            DevCache &dc = dev_cache();
+            std::lock_guard<std::mutex> g(dc.mu);
+            auto it = dc.held.find(c->device);
+            if (it != dc.held.end()) fr += it->second;
+        }
+        if (!want && fr && 2.0 * (double)np * (double)mp * 8.0 > 0.7 * (double)fr) {
             // the largest tile whose PHI + T take half of that (the slabs and per-row vectors need the rest): every launch of the walk
             // then still fills the chip for many rounds
             want = (size_t)(0.35 * (double)fr / (2.0 * (double)mp * 8.0));
