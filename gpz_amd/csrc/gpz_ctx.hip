@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -25,14 +26,24 @@
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
+// Error text: per thread (the caller of a failing entry point reads its own), with the most recent failure of ANY thread behind it -
+// a thread that has never failed itself (a caller whose work ran on a worker thread that did not hand its text back) still gets a
+// message instead of an empty string.
 static thread_local std::string g_err;
+static std::mutex g_err_any_mu;
+static std::string g_err_any;
+static void set_error(const char *text) {
+    g_err = text;
+    std::lock_guard<std::mutex> g(g_err_any_mu);
+    g_err_any = text;
+}
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    set_error(buf);
     return code;
 }
 #define HIPCHK(x)                                                                                   \
@@ -41,7 +52,15 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(GPZ_ERR_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" const char *gpz_last_error(void) { return g_err.c_str(); }
+extern "C" const char *gpz_last_error(void) {
+    if (g_err.empty()) {
+        static thread_local std::string other;   // (a copy: the shared text may change under the caller)
+        std::lock_guard<std::mutex> g(g_err_any_mu);
+        other = g_err_any;
+        return other.c_str();
+    }
+    return g_err.c_str();
+}
 // the same error channel for the other host-side translation units (gpz_mgpu.hip)
 int gpz_fail(int code, const char *fmt, ...) {
     char buf[768];
@@ -49,7 +68,7 @@ int gpz_fail(int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    set_error(buf);
     return code;
 }
 extern "C" int gpz_version(void) { return GPZ_VERSION; }
