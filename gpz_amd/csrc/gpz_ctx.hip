@@ -889,7 +889,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->slab_count = need > need_l ? need : need_l;
         if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
     }
-    if (c->kind == GPZ_KIND_COV && npt < 1024 * 1024) {   // (indexed by row with the full row stride, also when the rows are streamed)
+    if (npt < 1024 * 1024) {   // (indexed by row with the full row stride, also when the rows are streamed)
         c->phipart_groups = 16;
         size_t rows = np > (size_t)c->va.n_pad ? np : (size_t)c->va.n_pad;
         if ((rc = c->ar.alloc(&c->phipart, (size_t)c->phipart_groups * 2 * k * rows))) return bail(rc);

@@ -193,11 +193,15 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
                                                    double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                    double *__restrict__ wbeta, const double *__restrict__ wv,
                                                    double *__restrict__ phiw, const double *__restrict__ Psic,
-                                                   const double *__restrict__ Mc, const double *__restrict__ ucnt) {
+                                                   const double *__restrict__ Mc, const double *__restrict__ ucnt, int jgroup,
+                                                   double *__restrict__ part) {
     constexpr int KM = KGEN ? 8 : 1;
     __shared__ double tile[4][R][64][JB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * (64 * R);
+    // column group of this workgroup (few rows: the basis functions are split as well so that the grid fills the chip - lanes run along
+    // rows, and 1e5 rows are 1.5 waves per SIMD; the per-row sums of the groups are then combined by k_phi_finalize)
+    const int jlo = part ? (int)blockIdx.y * jgroup : 0, jhi = part ? min(mp, jlo + jgroup) : mp;
 
     double x[R][D], ps[PSI ? R : 1][PSI ? D : 1], mk[R][D], q0[R];
     bool valid[R];
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
 #pragma unroll
         for (int o = 0; o < KM; ++o) { sv[r][o] = 0.0; sw[r][o] = 0.0; }
 
-    for (int j0 = 0; j0 < mp; j0 += JB) {
+    for (int j0 = jlo; j0 < jhi; j0 += JB) {
 #pragma unroll 1
         for (int jj = 0; jj < JB; ++jj) {
             const int j = j0 + jj;
@@ -285,6 +289,19 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
         }
     }
 
+    if (part) {   // partial row sums of this column group (layout of k_phi_cov / k_phi_finalize)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long i = row0 + r * 64 + lane;
+#pragma unroll
+            for (int o = 0; o < KM; ++o)
+                if (o < k && i < ldx) {
+                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldx + i] = sv[r][o];
+                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldx + i] = sw[r][o];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long i = row0 + r * 64 + lane;
@@ -636,16 +653,33 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     constexpr int RP = GPZ_PHI_DIAG_RP(D);
     // few rows (fewer than two workgroups per CU at two rows per thread): one row per thread doubles the workgroups
     const bool small = (a.n_pad + 511) / 512 < 512;
+    // few rows: split the basis functions into groups (multiples of JB) until ~1024 workgroups exist (as launch_phi_cov_d does)
+    const int rr_eff = a.Psic ? RP : (small ? 1 : R);
+    const int nwg = (a.n_pad + 256 * rr_eff - 1) / (256 * rr_eff);
+    int ngroup = 1;
+    if (a.part && nwg > 0 && nwg < 1024 && !getenv("GPZ_PHI_DIAG_NO_SPLIT")) {
+        ngroup = (1024 + nwg - 1) / nwg;
+        const int maxg = (a.mp + 63) / 64;
+        if (ngroup > maxg) ngroup = maxg;
+        if (ngroup > a.part_groups) ngroup = a.part_groups;
+        if (ngroup < 1) ngroup = 1;
+    }
+    int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
+    ngroup = (a.mp + jgroup - 1) / jgroup;
+    double *part = ngroup > 1 ? a.part : nullptr;
 #define PHI_DIAG_R(KG, PS, RR) \
-    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, RR, JB>), dim3((a.n_pad + 256 * RR - 1) / (256 * RR)),                      \
+    hipLaunchKernelGGL((k_phi_diag<D, KG, PS, RR, JB>), dim3((a.n_pad + 256 * RR - 1) / (256 * RR), ngroup),              \
                        dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,                                           \
-                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt)
+                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt, jgroup, part)
 #define PHI_DIAG(KG, PS) \
     do { if (PS) PHI_DIAG_R(KG, PS, RP); else if (small) PHI_DIAG_R(KG, PS, 1); else PHI_DIAG_R(KG, PS, R); } while (0)
     if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
     else { if (a.Psic) PHI_DIAG(true, true); else PHI_DIAG(true, false); }
 #undef PHI_DIAG
 #undef PHI_DIAG_R
+    if (part)
+        hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
+                           ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
 template <int KIND>
