@@ -32,5 +32,8 @@ python bench.py --native-mgpu 8 --no-cpu-baseline --steps 5 > $O/c4_native_mgpu8
 for t in mfma_f32_4x4_rate mfma_valu_overlap mfma_f32_16x16_overlap mfma_f64_valu_overlap pk_fma_rate; do
   hipcc --offload-arch=gfx950 -O3 tools/$t.hip -o build/$t 2> /dev/null && build/$t > $O/ubench_$t.txt 2>&1
 done
+# row-tile streaming: c4's model on 2e7 rows (PHI + T beyond the HBM: the library picks the tiles) and c4 itself forced into two tiles
+python bench.py --config c4 --rows 20000000 --no-cpu-baseline --steps 3 --warmup 1 > $O/c4_n2e7_streamed.json 2> $O/c4_n2e7_streamed.err
+GPZ_ROW_TILE=524288 python bench.py --config c4 --no-cpu-baseline > $O/c4_streamed_tile512k.json 2> $O/c4_streamed_tile512k.err
 python tools/pm_wide_timing.py 2> /dev/null | grep " d=" > $O/extras_predict_missing_wide.txt
 tail -c 600 $O/c4.json; echo; tail -c 300 $O/c2.json; echo; tail -c 300 $O/c3.json; echo; tail -c 300 $O/c4_shard125k.json
