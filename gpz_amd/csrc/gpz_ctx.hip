@@ -818,7 +818,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             want = (size_t)(0.35 * (double)fr / (2.0 * (double)mp * 8.0));
             if (want < 131072) want = 131072;
         }
-        const bool can = !c->gen && !c->has_psi;
+        const bool can = !c->gen;   // every route of the row kernels (k_phi / k_rows / k_wide): diagonal kinds with or without Psi / NaNs, GC / VC plain
         if (want && can) {
             const size_t tr = (size_t)rup((long)want, 1024);
             if (tr < np) {

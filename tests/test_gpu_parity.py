@@ -1370,24 +1370,26 @@ def test_model_tables_kept_between_nan_pattern_groups_are_keyed_by_contents():
         _lib.load().gpz_release_cached_memory()
 
 
-@pytest.mark.parametrize("method,k,nanfrac,tile", [("VC", 1, 0.0, 2048), ("VD", 1, 0.0, 1024), ("GL", 2, 0.0, 2048), ("VD", 1, 0.3, 3072), ("GC", 1, 0.0, 1024)])
-def test_row_tile_streaming_matches_the_resident_evaluation(method, k, nanfrac, tile, monkeypatch):
+@pytest.mark.parametrize("method,k,nanfrac,tile,psi", [("VC", 1, 0.0, 2048, False), ("VD", 1, 0.0, 1024, False), ("GL", 2, 0.0, 2048, False),
+                                                       ("VD", 1, 0.3, 3072, False), ("GC", 1, 0.0, 1024, False), ("VD", 1, 0.2, 2048, True),
+                                                       ("VL", 2, 0.0, 1024, True)])
+def test_row_tile_streaming_matches_the_resident_evaluation(method, k, nanfrac, tile, psi, monkeypatch):
     """Row-tile streaming (chosen by the library when PHI + T would not fit the device, forced here by
     GPZ_ROW_TILE): PHI, T hold one tile of rows, stage A sums PHI'W PHI over the tiles, the tail rebuilds each tile's PHI for the
     T-GEMM, the row scalars and the moment sums.  Same result as the resident evaluation (summation order of the row splits aside) and
     as the oracle: weights, training / validation masks, two outputs, diagonal kinds with missing values; solve-only mode as well."""
     n, d, m = 5000, 6, 40
-    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=4100 + tile, nanfrac=nanfrac)
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, method, True, seed=4100 + tile, nanfrac=nanfrac, psi=psi)
     om = rng.random((n, 1)) + 0.5
     tr = rng.random(n) < 0.8
-    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
     res = {}
     for mode in ("resident", "streamed"):
         if mode == "streamed":
             monkeypatch.setenv("GPZ_ROW_TILE", str(tile))
         else:
             monkeypatch.delenv("GPZ_ROW_TILE", raising=False)
-        ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
         try:
             f, g = ctx.eval(theta)
             f2, g2 = ctx.eval(theta)           # the captured graph replays the same tile walk
