@@ -384,6 +384,33 @@ def test_full_size_directional_derivative(name):
         ctx.close()
 
 
+@pytest.mark.parametrize("name,tile", [("c4", 262144), ("c2", 32768)])
+def test_full_size_streamed_equals_resident(name, tile, monkeypatch):
+    """At BASELINE.json's sizes: the evaluation streamed in row tiles (four tiles here) is the resident evaluation up to the order of
+    the sums over row ranges."""
+    model, theta, X, Y, omega = _bench_problem(name)
+    res = []
+    for streamed in (False, True):
+        if streamed:
+            monkeypatch.setenv("GPZ_ROW_TILE", str(tile))
+        else:
+            monkeypatch.delenv("GPZ_ROW_TILE", raising=False)
+        ctx = gpz_amd.GPzContext(model, X, Y, None, omega)
+        try:
+            assert ("streamed" in ctx.route()) == streamed
+            f, g = ctx.eval(theta)
+            res.append((f, g, dict(ctx.stats)))
+        finally:
+            ctx.close()
+    (f0, g0, s0), (f1, g1, s1) = res
+    assert abs(f1 - f0) <= 1e-12 * abs(f0)
+    # a different order of the row-range sums of PHI'W PHI moves inv(SIGMA) by cond(SIGMA) eps: cond = 1.4e8 at c4 (the oracle gate
+    # there is 50 cond eps = 1.5e-6, bench.py's parity block), measured 2.6e-9
+    assert rel(g1, g0) <= 1e-7
+    for key, val in s0.items():
+        assert abs(s1[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
 def test_full_size_nesting_identity_c2():
     """GL(gamma) == VD(gamma*1) at n = 1e5, m = 200 (getPHI.m:26-40): same objective, gradients related by the
     sums of GPz.m:215-225."""
