@@ -388,6 +388,91 @@ __global__ void k_pmc_phitab(int m, int d, int de, const double *__restrict__ P,
     t[d * d + d] = rec[(size_t)i * nrec];
 }
 
+// k_pmc_prep for d <= 10 in registers: ONE Cholesky of Sigma_i permuted to [observed | missing] order gives every block of the record -
+//   L = [L_oo 0; L_uo L_uu]:  ln|Sigma_oo| = 2 sum_{c<no} ln L_cc,  inv(Sigma_oo) = W_oo' W_oo (W = inv(L), W_oo its leading block),
+//   R = Sigma_oo \ Sigma_ou = W_oo' L_uo',  CU = Sigma_uu - Sigma_uo R = L_uu L_uu' (the Schur complement),  lnz = 1/2 ln|Sigma_i| = sum_c ln L_cc
+// - with compile-time loops over D and the split point `no` as a predicate, so nothing is indexed at run time (the scratch-resident
+// version above runs its four d x d temporaries through scratch memory: 157 us per launch at d = 10, m = 200, a fifth of a
+// predict() call over 39 NaN patterns).
+template <int D>
+__global__ void k_pmc_prep_t(PmcPat pt, int m, const double *__restrict__ Sig, double *__restrict__ rec, int nrec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int no = pt.no, nu = pt.nu;
+    const double *S = Sig + (size_t)i * D * D;
+    int perm[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) perm[a] = a < no ? pt.o[a < no ? a : 0] : pt.u[a >= no ? a - no : 0];
+    double L[D * (D + 1) / 2], W[D * (D + 1) / 2], rd[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) L[PLT(a, b)] = S[perm[a] * D + perm[b]];
+    double lz = 0.0, lo = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {                        // Cholesky, packed lower triangle
+        double p = L[PLT(c, c)];
+#pragma unroll
+        for (int q = 0; q < c; ++q) p = fma(-L[PLT(c, q)], L[PLT(c, q)], p);
+        const double dd = sqrt(p);
+        L[PLT(c, c)] = dd;
+        rd[c] = 1.0 / dd;
+        const double lg = log(dd);
+        lz += lg;
+        if (c < no) lo += lg;
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double s = L[PLT(r, c)];
+#pragma unroll
+            for (int q = 0; q < c; ++q) s = fma(-L[PLT(r, q)], L[PLT(c, q)], s);
+            L[PLT(r, c)] = s * rd[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {                        // W = inv(L)
+        W[PLT(c, c)] = rd[c];
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = c; q < r; ++q) s = fma(L[PLT(r, q)], W[PLT(q, c)], s);
+            W[PLT(r, c)] = -s * rd[r];
+        }
+    }
+    double *r = rec + (size_t)i * nrec;
+    r[0] = lz;                                           // lnz = -1/2 ln|iSigma| = 1/2 ln|Sigma|   (:165)
+    r[1] = 2.0 * lo;                                     // ln|Sigma_oo|
+    double *si = r + 2, *R = si + no * no, *CU = R + no * nu;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = 0.0;                              // inv(Sigma_oo)[a][b] = sum_{q = a .. no-1} W[q][a] W[q][b]
+#pragma unroll
+            for (int q = a; q < D; ++q) s = fma(q < no ? W[PLT(q, a)] : 0.0, W[PLT(q, b)], s);
+            if (a < no) { si[a * no + b] = s; si[b * no + a] = s; }
+        }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int ru = 0; ru < D; ++ru) {
+            double s = 0.0;                              // R[a][ru - no] = sum_{q = a .. no-1} W[q][a] L[ru][q]      (:172)
+#pragma unroll
+            for (int q = a; q < D; ++q)
+                if (q <= ru) s = fma(q < no ? W[PLT(q, a)] : 0.0, L[PLT(ru > q ? ru : q, ru > q ? q : ru)], s);
+            if (a < no && ru >= no) R[a * nu + (ru - no)] = s;
+        }
+#pragma unroll
+    for (int ra = 0; ra < D; ++ra)
+#pragma unroll
+        for (int rc = 0; rc <= ra; ++rc) {
+            double s = 0.0;                              // CU = L_uu L_uu'                                           (:174)
+#pragma unroll
+            for (int q = 0; q <= rc; ++q) s = fma(q >= no ? L[PLT(ra, q)] : 0.0, L[PLT(rc, q)], s);
+            if (rc >= no) { CU[(ra - no) * nu + (rc - no)] = s; CU[(rc - no) * nu + (ra - no)] = s; }
+        }
+}
+
 template <int D>
 __global__ __launch_bounds__(64) void k_pmc_sum_s(int nrows, int row0, int m, int ld, long R, long rec_per_chunk,
                                                    const double *__restrict__ tab, int ntab, int nw,
@@ -564,7 +649,16 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
 #else
     const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !getenv("GPZ_PMC_SCRATCH");
 #endif
+#ifndef PMC_WIDE
+#define PREP_CASE(DD) case DD: hipLaunchKernelGGL(k_pmc_prep_t<DD>, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, rec, nrec); break;
+    switch (getenv("GPZ_PMC_PREP_SCRATCH") ? 0 : d) {
+        PREP_CASE(2) PREP_CASE(3) PREP_CASE(4) PREP_CASE(5) PREP_CASE(6) PREP_CASE(7) PREP_CASE(8) PREP_CASE(9) PREP_CASE(10)
+        default: hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec); break;
+    }
+#undef PREP_CASE
+#else
     hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec);
+#endif
     if (!tab_ready)   // the pair table depends on theta, w, iSigma_w only: predict.m calls once per NaN-pattern group with the same model
         hipLaunchKernelGGL(k_pmc_pairs, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, pt, m, de, k, P, Sig, iSig,
                            (const double *)rec, nrec, w, v, iS, tab, ntab);
