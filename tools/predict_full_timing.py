@@ -1,6 +1,8 @@
+"""Developer tool: wall time and host-side profile of predict() without missing values at n_s = 1e5, m = 500 (most of it is the
+n_s x m PHI output crossing PCIe).  Run on the GPU box: python tools/predict_full_timing.py"""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import gpz_amd
 from gpz_amd import _lib, api
 from helpers import make_problem
