@@ -1438,3 +1438,29 @@ def test_row_tile_streaming_matches_the_resident_evaluation(method, k, nanfrac, 
     f0, g0, stats0, w0, part0 = res["resident"]
     assert abs(f - f0) <= 1e-12 * abs(f0) and rel(g, g0) <= max(1e-11, 0.01 * tol)
     assert rel(w, w0) <= max(1e-11, 0.01 * tol) and rel(part, part0) <= 1e-12
+
+
+def test_row_tile_streaming_inside_row_shards(monkeypatch):
+    """Streaming and sharding together: three loopback shards of the native multi-GPU driver, each walking its rows in tiles of 1024
+    (the all-reduce points sit between the two walks), against the oracle and the unsharded resident evaluation."""
+    n, d, m = 9000, 5, 33
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VC", True, seed=4242)
+    tr = rng.random(n) < 0.85
+    ref = O.GPz(theta, model, X, Y, None, None, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, None, tr, ~tr)
+    try:
+        f0, g0 = ctx.eval(theta)
+    finally:
+        ctx.close()
+    monkeypatch.setenv("GPZ_ROW_TILE", "1024")
+    mg = gpz_amd.GPzMulti(model, X, Y, None, None, tr, ~tr, n_gpus=3, reducer="loopback")
+    try:
+        f, g = mg.eval(theta)
+        stats = dict(mg.stats)
+    finally:
+        mg.close()
+    tol = grad_tol(ref.cond)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= tol
+    assert abs(f - f0) <= 1e-12 * abs(f0) and rel(g, g0) <= max(1e-11, 0.01 * tol)
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
