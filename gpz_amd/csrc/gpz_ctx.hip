@@ -724,7 +724,9 @@ static int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *
             (rc = c->ar.alloc(&c->RcP, (size_t)c->ngroups * c->m * (c->de * (c->de + 1) / 2 + c->de))))
             return rc;
     }
-    if (c->d > 20 && (c->gen || c->has_psi) &&
+    // runtime-d workspace of the general-path kernels: the GC/VC routes with input noise or missing values read it in every
+    // evaluation; a diagonal kind only in gpz_predict_noisy's pair table (allocated there) - never in an evaluation context
+    if (c->d > 20 && c->gen &&
         (rc = c->ar.alloc(&c->gen_ws, (size_t)gen_rt_threads(c->d) * gen_ws_per_thread(c->d))))
         return rc;
     return alloc_params(c);
@@ -1971,6 +1973,8 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
     if (!rc) rc = c->ar.alloc(&tab, (size_t)npair * rec);
     if (!rc) rc = c->ar.alloc(&part, (size_t)nchunk * 3 * k * np);
     if (!rc) rc = c->ar.alloc(&sums, (size_t)3 * k * np);
+    if (!rc && d > 20 && !c->gen_ws)   // a diagonal kind at d > 20: the runtime-d pair table / pair sums take their temporaries from here
+        rc = c->ar.alloc(&c->gen_ws, (size_t)gen_rt_threads(d) * gen_ws_per_thread(d));
     if (!rc) rc = c->ar.alloc(&outb, (size_t)3 * k * np);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(wd, w, m * k * sizeof(double), hipMemcpyHostToDevice, c->st);

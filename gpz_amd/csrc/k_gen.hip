@@ -42,7 +42,7 @@ size_t gen_ws_per_thread(int d) { return (size_t)9 * d * d + (size_t)10 * d + 16
 // threads of the runtime-d pool: as many as 2 GiB of workspace hold, 4096 .. 65536 (whole waves)
 int gen_rt_threads(int d) {
     long t = (long)((2048UL << 20) / (gen_ws_per_thread(d) * sizeof(double)));
-    t = t < 4096 ? 4096 : (t > 65536 ? 65536 : t);
+    t = t < 1024 ? 1024 : (t > 65536 ? 65536 : t);   // (at least 16 waves; a floor of 4096 threads made the workspace 26 GB at d = 300)
     return (int)(t / 64 * 64);
 }
 
