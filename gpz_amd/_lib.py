@@ -96,6 +96,7 @@ SYMBOLS = {
     "gpz_last_error": (C.c_char_p, []),
     "gpz_version": (C.c_int, []),
     "gpz_release_cached_memory": (None, []),
+    "gpz_debug_fail_alloc": (None, [C.c_int64]),
 }
 
 _lib = None

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -112,8 +113,8 @@ static inline int rup(long v, int q) { return (int)(((v + q - 1) / q) * q); }
 // allocator (PyTorch's, a second process); 0 = no caching at all.  INTEGRATION.md, "device memory".
 static size_t cache_cap() {
     static const size_t cap = [] {
-        const char *e = getenv("GPZ_CACHE_CAP_MB");
-        return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)GPZ_CACHE_CAP_DEFAULT;
+        const long mb = gpz_options_load().cache_cap_mb;
+        return mb >= 0 ? (size_t)mb << 20 : (size_t)GPZ_CACHE_CAP_DEFAULT;
     }();
     return cap;
 }
@@ -166,18 +167,13 @@ extern "C" void gpz_release_cached_memory(void) {
     cache_release_blocks();
     pmc_model_cache_release_all();   // after the block cache's lock is gone; entries a running prediction holds are skipped
 }
-// test hook (GPZ_TEST_FAIL_ALLOC=<k>, read at every allocation): the k-th hipMalloc from now on reports out-of-memory once, so the
-// retry path can be exercised without exhausting 288 GB
+// test hook (gpz_debug_fail_alloc(k), include/gpz_hip.h): the k-th hipMalloc from now on reports out-of-memory once, so the retry
+// path can be exercised without exhausting 288 GB
+static std::atomic<long> g_alloc_fault_countdown{0};
+extern "C" void gpz_debug_fail_alloc(int64_t kth) { g_alloc_fault_countdown.store(kth > 0 ? (long)kth : 0); }
 static bool alloc_fault_due() {
-    static std::mutex mu;
-    static long countdown = -1;
-    static std::string seen;
-    const char *e = getenv("GPZ_TEST_FAIL_ALLOC");
-    if (!e) return false;
-    std::lock_guard<std::mutex> g(mu);
-    if (seen != e) { seen = e; countdown = atol(e); }
-    if (countdown <= 0) return false;
-    return --countdown == 0;
+    if (g_alloc_fault_countdown.load(std::memory_order_relaxed) <= 0) return false;
+    return g_alloc_fault_countdown.fetch_sub(1) == 1;
 }
 
 struct Arena {
@@ -276,6 +272,7 @@ struct StageTimer {
 
 struct gpz_ctx {
     gpz_desc desc;
+    gpz_options opt = gpz_options_load();   // latched for the life of the context (gpz_options.h)
     int mid = 0, kind = 0, d = 0, de = 0, m = 0, mp = 0, mq = 0, k = 1, hetero = 0, g_dim = 0;
     long p = 0;
     int device = 0;
@@ -745,6 +742,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     if (!desc || !X || !Y || !out || n_tot < 1) return fail(GPZ_ERR_ARG, "gpz_ctx_create: null argument");
     *out = nullptr;
     gpz_ctx *c = new gpz_ctx();
+    gpz_opts_scope opts_scope(&c->opt);
     int rc = setup_model(c, desc);
     if (rc) { delete c; return rc; }
     auto bail = [&](int code) {
@@ -805,8 +803,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     const size_t np = c->tr.n_pad, mp = c->mp, k = c->k, m = c->m;
     {
         // resident unless PHI + T (2 n_pad mp doubles) exceed 70 % of the free device memory; GPZ_ROW_TILE=<rows> forces a tile size
-        size_t want = 0;
-        if (const char *e = getenv("GPZ_ROW_TILE")) want = (size_t)atol(e);
+        size_t want = c->opt.row_tile > 0 ? (size_t)c->opt.row_tile : 0;
         size_t fr = 0, tot = 0;
         if (!want && hipMemGetInfo(&fr, &tot) == hipSuccess) {   // blocks the buffer cache holds are as good as free (a failed hipMalloc releases them)
             DevCache &dc = dev_cache();
@@ -834,10 +831,10 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     if ((rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);
     if (c->tile_rows && (rc = c->ar.alloc(&c->tile_rstats, (size_t)c->ntiles * GPZ_NS))) return bail(rc);
     // GC + Psi in fp64, 10 < d <= 32 (evaluation contexts only: prediction and getPHI contexts have no moment stage and no T)
-    if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !getenv("GPZ_GC_MINV_OFF")) {
+    if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !c->opt.gc_minv_off) {
         // one inverse per training row, shared by the basis functions (k_cpsi4_moments<.., SHARED>)
         if ((rc = c->ar.alloc(&c->gc_minv, (size_t)(c->tr.n > 0 ? c->tr.n : 1) * cpsi4_minv_len(c->d)))) return bail(rc);
-        if (!c->psi_miss && !getenv("GPZ_GC_DENSE_PHI_OFF")) {   // and, without missing dimensions, the dense form of the PHI build
+        if (!c->psi_miss && !c->opt.gc_dense_phi_off) {   // and, without missing dimensions, the dense form of the PHI build
             const size_t kp = (size_t)gcq_kpad(c->d);
             if ((rc = c->ar.alloc(&c->gcq_A, np * kp))) return bail(rc);
             if ((rc = c->ar.alloc(&c->gcq_B, kp * mp))) return bail(rc);
@@ -865,7 +862,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         const long np_k = (long)npt;   // rows one SYRK launch sees (a row tile when streaming)
         auto rows_at = [&](int T) { return np_k * npairs / T; };
         int target = rows_at(1024) >= 16384 ? 1024 : rows_at(512) >= 4096 ? 512 : 256;
-        if (const char *e = getenv("GPZ_SYRK_WGS")) target = atoi(e) > 0 ? atoi(e) : target;
+        if (c->opt.syrk_wgs > 0) target = c->opt.syrk_wgs;   // (developer tuning)
         // Off-diagonal tiles get s1 row ranges, diagonal tiles s2 (their workgroups run 9 MFMAs per SIMD and K step against 16:
         // the 36 products on and above the diagonal, k_gemm.hip): the pair that minimises max(1/s1, 0.6/s2) with
         // noff*s1 + nt*s2 workgroups inside the target.
@@ -880,8 +877,8 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             const double cost = 1.0 / a > 0.6 / b ? 1.0 / a : 0.6 / b;   // 0.595 measured (tools/syrk_split_sweep.py); 9/16 by MFMA count
             if (cost < best) { best = cost; s1 = a; s2 = b; }
         }
-        if (const char *e = getenv("GPZ_SYRK_S1")) s1 = atoi(e) > 0 ? atoi(e) : s1;   // tuning only
-        if (const char *e = getenv("GPZ_SYRK_S2")) s2 = atoi(e) > 0 ? atoi(e) : s2;
+        if (c->opt.syrk_s1 > 0) s1 = c->opt.syrk_s1;   // (developer tuning)
+        if (c->opt.syrk_s2 > 0) s2 = c->opt.syrk_s2;
         c->rows_per_split = rup((int)((np_k + s1 - 1) / s1), 16);
         c->nsplit = (int)((np_k + c->rows_per_split - 1) / c->rows_per_split);
         c->rows_per_split_d = rup((int)((np_k + s2 - 1) / s2), 16);
@@ -914,7 +911,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         const int ncg = (c->m + 255) / 256;
         // chunks of rows per basis-function group: every chunk writes (and k_slab_sum re-reads) m x nm sums, so few enough that the
         // slab stays small beside Phi and T, many enough to fill 256 CUs (tools/mom_nc_sweep.sh: c2 768, c3/c4 512 chunks)
-        static const int nc_env = [] { const char *e = getenv("GPZ_MOM_NC"); return e ? atoi(e) : 0; }();
+        const int nc_env = c->opt.mom_nc;   // (developer tuning)
         int nc = nc_env > 0 ? nc_env / ncg : (768 / ncg > 512 ? 768 / ncg : (2048 / ncg < 512 ? 2048 / ncg : 512));
         const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
         if (nc > max_nc) nc = max_nc;
@@ -1034,7 +1031,7 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
                                      : " [dtype f32 requested: rows with missing dimensions, fp64 route]";
     const char *gs = c->graph_state == 2 ? "replayed" : c->graph_state == -1 ? "disabled (capture failed or GPZ_NO_GRAPH)"
                      : c->timing ? "off (stage timing on)" : c->desc.world > 1 ? "off (sharded)" : "eager (not captured yet)";
-    const bool f32mm = c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF");
+    const bool f32mm = c->psi32 && !c->opt.f32_contractions_off;
     char rows[96];
     if (c->tile_rows) snprintf(rows, sizeof rows, "; rows: streamed, %d tiles of %d (PHI built twice per evaluation)", c->ntiles, c->tile_rows);
     else rows[0] = 0;
@@ -1232,7 +1229,7 @@ static int phi_tile(gpz_ctx *c, const RowTile &rt) {
 }
 // Stage A of a streamed evaluation: per tile PHI -> PHI' W_o PHI, summed over the tiles in comm1.
 static int stage_a_tiles(gpz_ctx *c) {
-    const bool f32 = c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF");
+    const bool f32 = c->psi32 && !c->opt.f32_contractions_off;
     for (int t = 0; t < c->ntiles; ++t) {
         const RowTile rt = row_tile(c, t);
         {
@@ -1283,7 +1280,7 @@ static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nu
             Stage s(c, "syrk");
             launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
                         c->rows_per_split, c->nsplit_d, c->rows_per_split_d, c->slab, false,
-                        c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));   // config 5: fp32-operand MFMAs, fp64 master sums
+                        c->psi32 && !c->opt.f32_contractions_off);   // config 5: fp32-operand MFMAs, fp64 master sums
         }
         {
             Stage s(c, "syrk_reduce");
@@ -1372,7 +1369,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
                 {
                     Stage s(c, "tgemm");
                     launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, rt.rows_pad, c->mp, c->nupart, c->phiw + oo + r0, c->m, c->m + o,
-                                 c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
+                                 c->psi32 && !c->opt.f32_contractions_off);
                 }
                 {
                     Stage s(c, "row_scalars");
@@ -1405,7 +1402,7 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip)
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
                          fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o,
-                         c->psi32 && !getenv("GPZ_F32_CONTRACTIONS_OFF"));
+                         c->psi32 && !c->opt.f32_contractions_off);
         }
         if (fused) {
             {
@@ -1648,9 +1645,10 @@ extern "C" int gpz_eval_dev(gpz_ctx *c, const double *theta_dev, double *f, doub
 static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
                        double stats[4], double diag[2]) {
     (void)g_dev;
+    gpz_opts_scope opts_scope(&c->opt);
     HIPCHK(hipSetDevice(c->device));
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
-    const bool no_graph = getenv("GPZ_NO_GRAPH") != nullptr;   // (read per call: one process can compare replay with eager launches)
+    const bool no_graph = c->opt.no_graph;   // (latched at creation: a context is either replayed or eager for its whole life)
     const bool graphable = theta && !c->g_dev_out && c->desc.world <= 1 && !c->timing && c->pinv_mode != 1 && !no_graph &&
                            c->graph_state >= 0;
     bool done = false;
@@ -1686,10 +1684,10 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
         }
         c->st = user_st;
         if (!rc && (he = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0)) != hipSuccess) { rc = -1; why = "instantiate"; }
-        if (rc && getenv("GPZ_GRAPH_DEBUG"))
+        if (rc && c->opt.graph_debug)
             fprintf(stderr, "gpz: evaluation graph: %s: %s | %s\n", why, hipGetErrorString(he), gpz_last_error());
         if (graph) (void)hipGraphDestroy(graph);
-        if (getenv("GPZ_GRAPH_DEBUG")) fprintf(stderr, "gpz: evaluation graph capture %s\n", rc ? "failed" : "ok");
+        if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph capture %s\n", rc ? "failed" : "ok");
         if (!rc) {
             c->graph_state = 2;
             HIPCHK(hipGraphLaunch(c->graph_exec, c->st));
@@ -1730,6 +1728,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
 
 extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSigma_w, double *nlogML_partial) {
     if (!c || !theta || !w || !iSigma_w) return fail(GPZ_ERR_ARG, "gpz_solve: null argument");
+    gpz_opts_scope opts_scope(&c->opt);
     HIPCHK(hipSetDevice(c->device));
     if (int e = stage_a(c, theta)) return e;   // (k_unpack clears the status words)
     const size_t m = c->m, mq = c->mq;
@@ -1840,6 +1839,7 @@ extern "C" int gpz_phi(const gpz_desc *desc, const double *theta, const double *
     if (!desc || !theta || !Xs || ns < 1) return fail(GPZ_ERR_ARG, "gpz_phi: null argument");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     int rc = run_phi_only(c, theta);
     double *tmp = nullptr, *nd = nullptr;
     if (!rc && (PHI || N)) rc = c->ar.alloc(&tmp, (size_t)ns * c->m);
@@ -1887,6 +1887,7 @@ extern "C" int gpz_predict_full(const gpz_desc *desc, const double *theta, const
     if (has_nan(Xs, ns * (int64_t)desc->d))
         return fail(GPZ_ERR_UNSUPPORTED, "gpz_predict_full: the rows have missing values (NaN): group them by pattern and call gpz_predict_missing (predict.m:45-69)");
     if (int e = make_eval_ctx(desc, Xs, ns, nullptr, 0, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
     int rc = 0;
     double *T = nullptr, *Bext = nullptr, *wd = nullptr, *Sd = nullptr, *nud = nullptr, *dgi = nullptr, *tmp = nullptr;
@@ -1953,6 +1954,7 @@ extern "C" int gpz_predict_noisy(const gpz_desc *desc, const double *theta, cons
         return fail(GPZ_ERR_UNSUPPORTED, "gpz_predict_noisy: the rows have missing values (NaN): group them by pattern and call gpz_predict_missing (predict.m:45-69)");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     const size_t m = c->m, np = c->tr.n_pad, k = c->k;
     const int d = c->d;
     int rc = run_phi_only(c, theta);
@@ -2065,6 +2067,7 @@ static int predict_missing_cov(const gpz_desc *desc, const std::vector<unsigned 
     if (Psi && psi_kind != 2 && psi_kind != 3) return fail(GPZ_ERR_ARG, "GC/VC take Psi as a d x d x n cube (fixPsi.m:22-38) or n x d variances (psi_kind 3)");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
     const int n = c->tr.n, d = c->d, de = c->de;
     int rc = 0;
@@ -2082,7 +2085,7 @@ static int predict_missing_cov(const gpz_desc *desc, const std::vector<unsigned 
     PmcModelCache *mc = pmc_model_cache(c->device);
     std::unique_lock<std::mutex> mc_lock(mc->mu);
     const size_t sig_n = m * (size_t)d * d, tab_n = (size_t)npairs * ntab;
-    bool cacheable = (tab_n + 2 * sig_n) * sizeof(double) <= (2048UL << 20) && !getenv("GPZ_PMC_NO_MODEL_CACHE");
+    bool cacheable = (tab_n + 2 * sig_n) * sizeof(double) <= (2048UL << 20) && !gpz_opts().pmc_no_model_cache;
     bool hit = cacheable && mc->tab && mc->m == (int)m && mc->d == d && mc->k == (int)k && mc->mid == c->mid &&
                mc->hetero == (int)c->hetero && mc->theta.size() == (size_t)c->p &&
                memcmp(mc->theta.data(), theta, (size_t)c->p * sizeof(double)) == 0 &&
@@ -2208,6 +2211,7 @@ static int predict_missing_diag(const gpz_desc *desc, OBS obs, const std::vector
     const int d = desc->d;
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     const size_t m = c->m, mp = c->mp, np = c->tr.n_pad, k = c->k;
     const int n = c->tr.n, de = c->de;
     int rc = 0;
@@ -2344,6 +2348,7 @@ extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double
     if (!desc || !theta || !Xs || ns < 1 || !prior) return fail(GPZ_ERR_ARG, "gpz_prior: null argument");
     gpz_ctx *c = nullptr;
     if (int e = make_eval_ctx(desc, Xs, ns, Psi, psi_kind, &c)) return e;
+    gpz_opts_scope opts_scope(&c->opt);
     const int m = c->m;
     int rc = run_phi_only(c, theta);
     double *nd = nullptr, *pd = nullptr, *slab = nullptr, *colsum = nullptr;
@@ -2388,6 +2393,7 @@ extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double
 extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, double *Xi, double *logdet, int32_t *info) {
     if (!Ain || m < 1 || !Xi || !logdet) return fail(GPZ_ERR_ARG, "gpz_inv_logdet: null argument");
     gpz_ctx *c = new gpz_ctx();
+    gpz_opts_scope opts_scope(&c->opt);
     c->device = device;
     c->m = m; c->k = 1; c->mq = rup(m, GPZ_CH_NB); c->mp = rup(m + 1, 16);
     auto bail = [&](int code) { c->ar.release(); delete c; return code; };

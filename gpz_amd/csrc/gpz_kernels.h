@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gpz_options.h"
 
 // ---- host-side helpers shared by gpz_ctx.hip and gpz_mgpu.hip ------------------------------------------------
 struct gpz_ctx;

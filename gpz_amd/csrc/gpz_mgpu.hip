@@ -491,8 +491,8 @@ extern "C" int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int3
     // A block costs a thread, a temporary context on its device and an upload of theta, w and iSigma_w (m*m*k doubles): only
     // worth it for a few thousand rows.  NaN-pattern groups are often a few dozen rows (predict.m:45-57) — those run as ONE
     // block on the first device.  An explicit device list keeps the caller's split (tests).
-    int64_t min_rows = 4096;
-    if (const char *e = getenv("GPZ_PREDICT_MIN_ROWS_PER_BLOCK")) min_rows = std::max<int64_t>(1, atoll(e));   // tests: split small groups too
+    const gpz_options call_opts = gpz_options_load();   // (no context: a snapshot per call)
+    const int64_t min_rows = call_opts.predict_min_rows_per_block;   // GPZ_PREDICT_MIN_ROWS_PER_BLOCK, default 4096 (tests: split small groups too)
     int nblk = n_gpus;
     if (!devices) nblk = (int)std::min<int64_t>(n_gpus, std::max<int64_t>(1, ns / min_rows));
     if ((int64_t)nblk > ns) nblk = (int)ns;

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_fill_bext_dwda(const double *__restrict
     s = wave_sum(s);
     if (lane == 0 && i < m) dwda[i] = -1.0 * s;
 }
-static int bext_round32() { return getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0; }
+static int bext_round32() { return gpz_opts().round_phi32 ? 1 : 0; }
 
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz,
                         double *logdet) {

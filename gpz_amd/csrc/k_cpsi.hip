@@ -345,8 +345,7 @@ __global__ __launch_bounds__(256) void k_cpsi_moments(const double *__restrict__
 }
 
 bool cpsi_available(int d) {
-    static const bool off = getenv("GPZ_CPSI_OFF") != nullptr;   // debugging switch: back to the general kernels of k_gen.hip
-    return !off && d > 10 && d <= 64;
+    return !gpz_opts().cpsi_off && d > 10 && d <= 64;   // (developer switch: back to the general kernels of k_gen.hip)
 }
 
 #define CPSI_CASES(MACRO)                   \

@@ -24,8 +24,7 @@
 #include "k_cpsi4_impl.h"
 
 bool cpsi4_available(int d) {
-    static const bool off = getenv("GPZ_CPSI4_OFF") != nullptr;   // debugging switch: the 16 x 16 tile kernels of k_cpsi.hip instead
-    return !off && d > 10 && d <= 32;
+    return !gpz_opts().cpsi4_off && d > 10 && d <= 32;   // (developer switch: the 16 x 16 tile kernels of k_cpsi.hip instead)
 }
 
 #define CPSI4_CASES(MACRO)          \

@@ -4,8 +4,7 @@
 #include "k_cpsi4_impl.h"
 
 bool cpsi4w_available(int d) {
-    static const bool off = getenv("GPZ_CPSI4_OFF") != nullptr;
-    return !off && d > 32 && d <= 48;
+    return !gpz_opts().cpsi4_off && d > 32 && d <= 48;
 }
 
 #define CPSI4W_CASES(MACRO)         \

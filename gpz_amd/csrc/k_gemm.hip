@@ -21,6 +21,16 @@
 // are FLUSHED into fp64 accumulators every GPZ_F32_FLUSH K slices (16 * GPZ_F32_FLUSH products per element), so the
 // accumulation error stays at the level of the operand rounding (tools/f32_operand_experiment.py: rounding PHI and
 // [inv(SIGMA)|w] to fp32 moves f by 2.4e-10 and g by 3.6e-7 of max|g| on a 250 000-row shard of config 5).
+#ifdef GPZ_GEMM_TRACE   // developer builds only (tools/gemm_trace.hip): per-wave timestamps of the K loop of k_tgemm
+__device__ unsigned long long *g_gemm_trace = nullptr;
+#define GPZ_TRACE_MARK(slot)                                                                                              \
+    do {                                                                                                                  \
+        if (g_gemm_trace && (threadIdx.x & 63) == 0)                                                                      \
+            g_gemm_trace[((size_t)item * 8 + (threadIdx.x >> 6)) * 6 + (slot)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define GPZ_TRACE_MARK(slot) do { } while (0)
+#endif
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 #ifndef GPZ_F32_FLUSH
@@ -357,7 +367,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            OT (*sA)[128][18], OT (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
-                                           long n_pad, int ct, int kdim, int ncol16 = 8, int slot = 0, int nslot = 1) {
+                                           long n_pad, int ct, int kdim, int ncol16 = 8, int slot = 0, int nslot = 1, int item = 0) {
     constexpr int NT = 128 * WC;
     constexpr int NI = 8 / WC;
     constexpr int Q = 1024 / NT;
@@ -466,6 +476,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     };
     OT fa0[NFA], fb0[NFB], fa1[NFA], fb1[NFB];
     rdfrag(0, 0, fa0, fb0);
+    GPZ_TRACE_MARK(1);
     auto stage = [&](auto curc, int s) {
         constexpr int cur = decltype(curc)::value;
         rdfrag(cur, 1, fa1, fb1);
@@ -496,19 +507,63 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         stage(std::integral_constant<int, 1>{}, s + 1);
     }
     if (s < nstage) stage(std::integral_constant<int, 0>{}, s);
+    GPZ_TRACE_MARK(2);
     auto res = [&](int mi, int ni, int r) -> double { return (double)acc[mi][ni][r]; };
     // row of accumulator register r inside a 16x16 tile: the f64 instruction deals rows (lane >> 4) + 4r, the f32 one 4(lane >> 4) + r
     auto crow = [&](int r) -> int { return std::is_same<OT, float>::value ? 4 * (lane >> 4) + r : (lane >> 4) + 4 * r; };
 
+    // Epilogue.  The PHI values of the fused nu sum are ALL requested before the first is used, ahead of the T stores: a load
+    // that is waited for on its own costs a memory round trip behind every store issued before it (vmcnt counts both), and 32 of
+    // those in sequence were 83 000 of a workgroup's 536 000 cycles (tools/gemm_trace.hip), with the compute unit's other
+    // workgroup usually in the same phase.  No lane-dependent branches: out-of-range columns are dropped by selects, addresses are
+    // a wave-uniform base plus one 32-bit lane offset.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     if (EDGE) {
         // row strip of this wave: rows i0 + 16 wave + crow(r), column tile p
+        const char *pbase = reinterpret_cast<const char *>(Phi + (size_t)(i0 + wv * 16) * ld + j0);
+        char *tbase = reinterpret_cast<char *>(T + (size_t)(i0 + wv * 16) * ldt + j0);
+        // two halves (column tiles 0-3 and 4-7): 16 loads in flight beside the accumulators
+        double pp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int p = 0; p < NFB; ++p) {
-            const int col = j0 + p * 16 + (lane & 15);
-            if (p < nvalid && col < mp) {
+        for (int hf = 0; hf < 2; ++hf) {
+            double ph[NFB / 2][4];
+            if (nupart) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T[(size_t)(i0 + wave * 16 + crow(r)) * ldt + col] = res(p >> 1, p & 1, r);
+                for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
+                    const int p = hf * (NFB / 2) + ph_i;
+                    const int pc = p < nvalid ? p : 0;   // (a tile past the edge re-reads tile 0; its product is dropped)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ph[ph_i][r] = *reinterpret_cast<const double *>(pbase + ((size_t)crow(r) * ld + pc * 16 + (lane & 15)) * 8);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
+                const int p = hf * (NFB / 2) + ph_i;
+                const int col = j0 + p * 16 + (lane & 15);
+                if (p < nvalid && col < mp) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<double *>(tbase + ((size_t)crow(r) * ldt + p * 16 + (lane & 15)) * 8) = res(p >> 1, p & 1, r);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nupart) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wave * 16 + crow(r);
+#pragma unroll
+                    for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
+                        const int p = hf * (NFB / 2) + ph_i;
+                        const int col = j0 + p * 16 + (lane & 15);
+                        const double t = fma(ph[ph_i][r], res(p >> 1, p & 1, r), pp[r]);
+                        pp[r] = (p < nvalid && col < m) ? t : pp[r];
+                        if (p < nvalid && col == mcol) phiw[row] = res(p >> 1, p & 1, r);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (nupart) {
             // the consumers sum WC slots per column tile and row: this wave's sum over ALL its columns of the tile goes to slot `slot`
@@ -516,60 +571,73 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wave * 16 + crow(r);
-                double pp = 0.0;
-#pragma unroll
-                for (int p = 0; p < NFB; ++p) {
-                    const int col = j0 + p * 16 + (lane & 15);
-                    if (p < nvalid && col < m) pp = fma(Phi[(size_t)row * ld + col], res(p >> 1, p & 1, r), pp);
-                    if (p < nvalid && col == mcol) phiw[row] = res(p >> 1, p & 1, r);
-                }
-                pp += __shfl_xor(pp, 1, 64);
-                pp += __shfl_xor(pp, 2, 64);
-                pp += __shfl_xor(pp, 4, 64);
-                pp += __shfl_xor(pp, 8, 64);
+                double q = pp[r];
+                q += __shfl_xor(q, 1, 64);
+                q += __shfl_xor(q, 2, 64);
+                q += __shfl_xor(q, 4, 64);
+                q += __shfl_xor(q, 8, 64);
                 if ((lane & 15) == 0) {
-                    nupart[(size_t)(ct * WC + slot) * n_pad + row] = pp;
+                    nupart[(size_t)(ct * WC + slot) * n_pad + row] = q;
                     if (slot == 0)
 #pragma unroll
-                        for (int q = 1; q < WC; ++q)
-                            if (q >= nslot) nupart[(size_t)(ct * WC + q) * n_pad + row] = 0.0;
+                        for (int qq = 1; qq < WC; ++qq)
+                            if (qq >= nslot) nupart[(size_t)(ct * WC + qq) * n_pad + row] = 0.0;
                 }
             }
         }
         return;
     }
+    const int wru = wv / WC, wcu = wv % WC;
+    const char *pbase = reinterpret_cast<const char *>(Phi + (size_t)(i0 + wru * 64) * ld + j0 + wcu * (16 * NI));
+    char *tbase = reinterpret_cast<char *>(T + (size_t)(i0 + wru * 64) * ldt + j0 + wcu * (16 * NI));
+    double *slotp = nupart ? nupart + (size_t)(ct * WC + wc) * n_pad : nullptr;
+    // two halves (rows mi = 0, 1 and 2, 3 of the wave's block): 16 loads in flight beside the 64 accumulator registers
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int hf = 0; hf < 2; ++hf) {
+        double ph[2][4][NI];
+        if (nupart) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
+            for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wr * 64 + mi * 16 + crow(r);
-                T[(size_t)row * ldt + col] = res(mi, ni, r);
-            }
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        ph[mh][r][ni] = *reinterpret_cast<const double *>(pbase + ((size_t)((hf * 2 + mh) * 16 + crow(r)) * ld + ni * 16 + (lane & 15)) * 8);
         }
-    if (nupart) {
-        double *slot = nupart + (size_t)(ct * WC + wc) * n_pad;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wr * 64 + mi * 16 + crow(r);
-                double p = 0.0;
+            for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
-                    if (col < m) p = fma(Phi[(size_t)row * ld + col], res(mi, ni, r), p);
-                    if (col == mcol) phiw[row] = res(mi, ni, r);
-                }
-                // sum over the 16 lanes that share this row (lane & 15 runs over columns)
-                p += __shfl_xor(p, 1, 64);
-                p += __shfl_xor(p, 2, 64);
-                p += __shfl_xor(p, 4, 64);
-                p += __shfl_xor(p, 8, 64);
-                if ((lane & 15) == 0) slot[row] = p;
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<double *>(tbase + ((size_t)((hf * 2 + mh) * 16 + crow(r)) * ldt + ni * 16 + (lane & 15)) * 8) = res(hf * 2 + mh, ni, r);
             }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nupart) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mi = hf * 2 + mh;
+                    const int row = i0 + wr * 64 + mi * 16 + crow(r);
+                    double p = 0.0;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int col = j0 + wc * (16 * NI) + ni * 16 + (lane & 15);
+                        const double t = fma(ph[mh][r][ni], res(mi, ni, r), p);
+                        p = (col < m) ? t : p;
+                        if (col == mcol) phiw[row] = res(mi, ni, r);
+                    }
+                    // sum over the 16 lanes that share this row (lane & 15 runs over columns)
+                    p += __shfl_xor(p, 1, 64);
+                    p += __shfl_xor(p, 2, 64);
+                    p += __shfl_xor(p, 4, 64);
+                    p += __shfl_xor(p, 8, 64);
+                    if ((lane & 15) == 0) slotp[row] = p;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -581,28 +649,38 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
                                                         int mcol, long n_pad, int kdim, int nfull, int npiece) {
     __shared__ OT sA[2][128][18];
     __shared__ OT sB[2][16][LDS_LD128];
-    // Tail balance: the grid is nfull whole tiles followed by the remaining tiles cut into npiece column pieces each (launch_tgemm):
-    // when the tile count leaves the last round of resident workgroups mostly empty (c2: 1568 tiles on 512 slots = 3.06 rounds),
-    // the pieces of the last 0.06 round fill the chip for a fraction of a tile's time instead of 32 tiles holding it for a whole one.
-    if ((int)blockIdx.x >= nfull) {
-        const int q = (int)blockIdx.x - nfull;
+    // One item per workgroup: the grid is the nfull whole tiles followed by the remaining tiles cut into npiece column pieces each
+    // (launch_tgemm): when the tile count leaves the last round of resident workgroups mostly empty (c2: 1568 tiles on 512 slots = 3.06
+    // rounds), the pieces of the last 0.06 round fill the chip for a fraction of a tile's time instead of 32 tiles holding it for a whole one.
+    // (A persistent form - two workgroups per compute unit walking the item list - was measured in round 5 and is slower: the two
+    // workgroups of a compute unit then stay in phase, both in their store epilogue at once; profiles/r05_tgemm_timeline.txt.)
+    const int item = blockIdx.x;
+#ifdef GPZ_GEMM_TRACE
+    GPZ_TRACE_MARK(0);
+    if (g_gemm_trace && (threadIdx.x & 63) == 0)
+        g_gemm_trace[((size_t)item * 8 + (threadIdx.x >> 6)) * 6 + 4] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+    struct TraceEnd { int item; __device__ ~TraceEnd() { GPZ_TRACE_MARK(3); } } trace_end{item};
+#endif
+    if (item >= nfull) {
+        const int q = item - nfull;
         const int tile = nfull + q / npiece, piece = q % npiece;
         const int rt = tile / nct, ct = tile % nct;
         tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, rt * 128, ct * 128 + piece * (128 / npiece), sA, sB, nupart, phiw, m, mcol,
-                                 n_pad, ct, kdim, 8 / npiece, piece, npiece);
+                                 n_pad, ct, kdim, 8 / npiece, piece, npiece, item);
         return;
     }
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous range of
     // logical tiles, so the 8 column tiles of a row panel run back to back on one XCD and the 1 MB PHI panel is
     // fetched from HBM once instead of once per XCD.  Bijective for any grid size; affects speed only.
-    const int nwg = nfull, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nwg = nfull, xcd = item & 7, q = nwg >> 3, r = nwg & 7;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (item >> 3);
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
-        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim);
+        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
     else
-        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim);
+        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -751,7 +829,7 @@ void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, in
     // tail balance (see k_tgemm): the tiles of the last, partly filled round of resident workgroups are cut into column pieces
     const int W = (n_pad / 128) * nct, C = 2 * gpz_cu_count();
     int tail = W % C, npiece = 1;
-    static const bool no_split = getenv("GPZ_TGEMM_NO_SPLIT") != nullptr;
+    const bool no_split = gpz_opts().tgemm_no_split;
     // quarter pieces only: a piece stages the same A and B slices as a whole tile, so a half costs ~0.9 of one (125k-row shard of c4,
     // tail 136: 3.83 ms either way) and a quarter ~0.6 (c2: 231 -> 211 us, c3: 862 -> 826 us)
     if (tail > 0 && !no_split && tail * 4 <= C) npiece = 4;

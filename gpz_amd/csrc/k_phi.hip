@@ -657,7 +657,7 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     const int rr_eff = a.Psic ? RP : (small ? 1 : R);
     const int nwg = (a.n_pad + 256 * rr_eff - 1) / (256 * rr_eff);
     int ngroup = 1;
-    if (a.part && nwg > 0 && nwg < 1024 && !getenv("GPZ_PHI_DIAG_NO_SPLIT")) {
+    if (a.part && nwg > 0 && nwg < 1024 && !gpz_opts().phi_diag_no_split) {
         ngroup = (1024 + nwg - 1) / nwg;
         const int maxg = (a.mp + 63) / 64;
         if (ngroup > maxg) ngroup = maxg;

@@ -647,11 +647,11 @@ void launch_pmc(hipStream_t st, unsigned long long obs, int n, long ldx, int m, 
 #ifdef PMC_WIDE
     const bool fast = false;
 #else
-    const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !getenv("GPZ_PMC_SCRATCH");
+    const bool fast = pmc_fast(d, k) && work2 != nullptr && rows_blk <= 64 && !gpz_opts().pmc_scratch;
 #endif
 #ifndef PMC_WIDE
 #define PREP_CASE(DD) case DD: hipLaunchKernelGGL(k_pmc_prep_t<DD>, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, rec, nrec); break;
-    switch (getenv("GPZ_PMC_PREP_SCRATCH") ? 0 : d) {
+    switch (gpz_opts().pmc_prep_scratch ? 0 : d) {
         PREP_CASE(2) PREP_CASE(3) PREP_CASE(4) PREP_CASE(5) PREP_CASE(6) PREP_CASE(7) PREP_CASE(8) PREP_CASE(9) PREP_CASE(10)
         default: hipLaunchKernelGGL(k_pmc_prep, dim3((m + 63) / 64), dim3(64), 0, st, pt, m, Sig, iSig, rec, nrec); break;
     }

@@ -584,7 +584,7 @@ int launch_psi32_phi(hipStream_t st, const double *Xr, int de, int d, const floa
     const int jgroup = (((m + ng - 1) / ng) + 7) / 8 * 8;
     ng = (m + jgroup - 1) / jgroup;
     const dim3 grid(nrb, ng);
-    const int round32 = getenv("GPZ_EXPERIMENT_ROUND_PHI32") ? 1 : 0;   // tools/f32_operand_experiment.py
+    const int round32 = gpz_opts().round_phi32 ? 1 : 0;   // tools/f32_operand_experiment.py
 #define PHI_CASE(DD)                                                                                                     \
     do {                                                                                                                 \
         if (diag)                                                                                                        \

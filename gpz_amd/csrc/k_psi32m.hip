@@ -290,10 +290,9 @@ __global__ __launch_bounds__(256, PSI32M_MINB) void k_psi32m_moments(
 }
 
 bool psi32m_available(int d) {
-    // Opt-in (GPZ_PSI32_MFMA=1, read at every evaluation so that one process can compare the two): measured 133.6 ms against 125.0 ms
-    // of the lane-per-pair kernel on config 5's 250 000-row shard - DESIGN.md section 8 has the instruction-issue model behind that.
-    const char *on = getenv("GPZ_PSI32_MFMA");
-    return on && on[0] == '1' && d >= 1 && d <= 20;
+    // Opt-in (GPZ_PSI32_MFMA=1, latched when the context is created): measured 133.6 ms against 125.0 ms of the lane-per-pair kernel
+    // on config 5's 250 000-row shard - docs/HISTORY.md has the instruction-issue model behind that.
+    return gpz_opts().psi32_mfma && d >= 1 && d <= 20;
 }
 
 int launch_psi32m_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,

@@ -292,6 +292,10 @@ int gpz_version(void);
  * basis-pair tables on the device for the next NaN-pattern group; this hands all of that back.  No reference counterpart. */
 void gpz_release_cached_memory(void);
 
+/* Test hook: the kth device allocation from now on (kth >= 1; 0 disarms) reports out-of-memory once, so the release-and-retry
+ * path of the allocator can be exercised without exhausting 288 GB.  Process-wide.  No reference counterpart. */
+void gpz_debug_fail_alloc(int64_t kth);
+
 #ifdef __cplusplus
 }
 #endif

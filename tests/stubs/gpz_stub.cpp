@@ -50,6 +50,7 @@ const char *gpz_last_error(void) { return g_err.c_str(); }
 int gpz_version(void) { return GPZ_VERSION; }
 int gpz_device_count(void) { return 2; }
 void gpz_release_cached_memory(void) {}
+void gpz_debug_fail_alloc(int64_t) {}
 int64_t gpz_theta_len_of(const gpz_desc *d) {
     if (!d || d->d < 1 || d->m < 1 || d->k < 1) return -1;
     const char a = d->method[0], b = d->method[1];

@@ -1282,7 +1282,7 @@ def test_graph_replay_of_the_evaluation_is_bitwise_the_plain_launch_sequence(met
 def test_allocation_failure_inside_predict_missing_retries_without_deadlock(kth, monkeypatch):
     """A hipMalloc that fails inside gpz_predict_missing (GC/VC) - while the call holds the model-table entry of its device - gives the
     cached BLOCKS back and retries; it must not take the entry's own (non-recursive) mutex again or free the tables the call is
-    using.  The fault is injected by GPZ_TEST_FAIL_ALLOC = k: the k-th allocation from now on reports out-of-memory
+    using.  The fault is injected by gpz_debug_fail_alloc(k): the k-th allocation from now on reports out-of-memory
     once.  Run in a worker process under a timeout so that a regression shows up as a failure, not as a hung suite."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -1312,9 +1312,10 @@ def _alloc_fault_worker(kth, q):
     Xs[5:, [0, 3]] = np.nan
     ref = O.predict_any(Xs, omdl)
     gpz_amd.predict(Xs, mdl)                               # warm: the model tables and the block cache are populated
-    os.environ["GPZ_TEST_FAIL_ALLOC"] = str(kth)
+    from gpz_amd import _lib
+    _lib.load().gpz_debug_fail_alloc(kth)
     out = gpz_amd.predict(Xs, mdl)
-    os.environ.pop("GPZ_TEST_FAIL_ALLOC")
+    _lib.load().gpz_debug_fail_alloc(0)
     for i in range(6):
         assert rel(out[i], ref[i]) <= 1e-8, i
     out = gpz_amd.predict(Xs, mdl)                         # and the cache still serves the next call
