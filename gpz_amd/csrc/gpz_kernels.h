@@ -49,7 +49,7 @@ struct PhiArgs {
     const double *Psic;  // d x ldx   (fixPsi.m layout n x d, zero where missing)
     const double *Mc;    // d x ldx
     const double *ucnt;  // ldx
-    // cov kinds: scratch for the column-group split used at small row counts ([part_groups][2][k][ldx]); nullptr disables it
+    // scratch for the column-group split used at small row counts ([part_groups][2][k][n_pad]: the rows of THIS launch); nullptr disables it
     double *part;
     int part_groups;
     // cov kinds, rows sorted by NaN pattern: one launch over all patterns.  wgtab holds 4 ints per workgroup:
@@ -254,11 +254,12 @@ int launch_cpsi4_moments(hipStream_t st, const double *Phi, const double *T, int
                          const int *chunktab, const double *minv = nullptr);
 size_t cpsi4_minv_len(int d);   // doubles per row of the GC inverse table (k_cpsi4_minv)
 int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, int de, const double *Sig, const double *lnS, const unsigned char *pat,
-                      double *minv, double *qA = nullptr, int lda = 0);
+                      double *minv, double *qA = nullptr, int lda = 0, const double *ctr = nullptr);   // ctr (with qA): the centre c of launch_gcq_centre
 // GC + Psi without missing dimensions, dense form of the PHI build: PHI = exp(-1/2 A * B), A (n x gcq_kpad(d)) from launch_cpsi4_minv(.., qA),
 // B (gcq_kpad(d) x ldb) from launch_gcq_tab, the product on launch_tgemm
 int gcq_kpad(int d);
-void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, double *B);
+void launch_gcq_centre(hipStream_t st, int m, int d, int de, const double *P, double *ctr);   // c = mean basis centre: both factors work on x - c, p - c
+void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, const double *ctr, double *B);
 void launch_gcq_exp(hipStream_t st, const double *Q, int ld, int n, int m, double *Phi);
 // 32 < d <= 48, rows without missing values (k_cpsi4w.hip)
 bool cpsi4w_available(int d);

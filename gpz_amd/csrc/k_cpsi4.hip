@@ -88,12 +88,12 @@ size_t cpsi4_minv_len(int d) {
 }
 // qA != nullptr (rows without missing dimensions): also the rows of the dense form of the PHI build (k_cpsi4_minv<.., QROW>), lda doubles apart
 int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, int de, const double *Sig, const double *lnS, const unsigned char *pat,
-                      double *minv, double *qA, int lda) {
+                      double *minv, double *qA, int lda, const double *ctr) {
     if (!cpsi4_available(d)) return -1;
     if (r.n <= 0) return 0;
 #define MINV_LAUNCH(ND, MS, QR)                                                                                               \
     hipLaunchKernelGGL((k_cpsi4_minv<ND, MS, QR>), dim3((r.n + 15) / 16), dim3(256), 0, st, r.Psi3, r.n, d, Sig,               \
-                       (MS) ? r.gid : nullptr, (MS) ? pat : nullptr, minv, r.Xr, de, lnS, qA, lda)
+                       (MS) ? r.gid : nullptr, (MS) ? pat : nullptr, minv, r.Xr, de, lnS, qA, lda, ctr)
 #define MINV_CASE(ND)                                                                                                         \
     do {                                                                                                                      \
         if (pat) MINV_LAUNCH(ND, true, false);                                                                                \
@@ -106,8 +106,18 @@ int launch_cpsi4_minv(hipStream_t st, const GenRows &r, int d, int de, const dou
     return 0;
 }
 
-// The m-sized table of the dense form: B[e][j], e over [p_a p_b (a >= b, packed) ; -2 p_a ; 1], zero rows up to kpad
-__global__ void k_gcq_tab(int m, int d, int de, int kpad, int ldb, const double *__restrict__ P, double *__restrict__ B) {
+// The dense form expands (x - p)' M^-1 (x - p) into x' M^-1 x - 2 p' M^-1 x + p' M^-1 p, which cancels (|x| / |x - p|)^2 eps of the
+// result when the inputs sit far from the origin.  Both sides therefore work on x - c and p - c, c = the mean basis centre.
+__global__ void k_gcq_centre(int m, int d, int de, const double *__restrict__ P, double *__restrict__ ctr) {
+    const int a = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < m; j += 64) s += P[(size_t)j * de + a];
+    s = wave_sum(s);
+    if (threadIdx.x == 0 && a < d) ctr[a] = s / m;
+}
+// The m-sized table of the dense form: B[e][j], e over [q_a q_b (a >= b, packed) ; -2 q_a ; 1] with q = p - c, zero rows up to kpad
+__global__ void k_gcq_tab(int m, int d, int de, int kpad, int ldb, const double *__restrict__ P, const double *__restrict__ ctr,
+                          double *__restrict__ B) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
     if (j >= ldb || e >= kpad) return;
     const int K1 = d * (d + 1) / 2;
@@ -118,8 +128,8 @@ __global__ void k_gcq_tab(int m, int d, int de, int kpad, int ldb, const double 
             while (a * (a + 1) / 2 > e) --a;
             while ((a + 1) * (a + 2) / 2 <= e) ++a;
             const int b = e - a * (a + 1) / 2;
-            v = P[(size_t)j * de + a] * P[(size_t)j * de + b];
-        } else if (e < K1 + d) v = -2.0 * P[(size_t)j * de + (e - K1)];
+            v = (P[(size_t)j * de + a] - ctr[a]) * (P[(size_t)j * de + b] - ctr[b]);
+        } else if (e < K1 + d) v = -2.0 * (P[(size_t)j * de + (e - K1)] - ctr[e - K1]);
         else if (e == K1 + d) v = 1.0;
     }
     B[(size_t)e * ldb + j] = v;
@@ -131,9 +141,12 @@ __global__ void k_gcq_exp(const double *__restrict__ Q, int ld, int n, int m, do
     Phi[(size_t)i * ld + j] = exp(-0.5 * Q[(size_t)i * ld + j]);
 }
 int gcq_kpad(int d) { return (d * (d + 1) / 2 + d + 1 + 15) / 16 * 16; }
-void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, double *B) {
+void launch_gcq_centre(hipStream_t st, int m, int d, int de, const double *P, double *ctr) {
+    hipLaunchKernelGGL(k_gcq_centre, dim3(d), dim3(64), 0, st, m, d, de, P, ctr);
+}
+void launch_gcq_tab(hipStream_t st, int m, int d, int de, int ldb, const double *P, const double *ctr, double *B) {
     const int kpad = gcq_kpad(d);
-    hipLaunchKernelGGL(k_gcq_tab, dim3((ldb + 255) / 256, kpad), dim3(256), 0, st, m, d, de, kpad, ldb, P, B);
+    hipLaunchKernelGGL(k_gcq_tab, dim3((ldb + 255) / 256, kpad), dim3(256), 0, st, m, d, de, kpad, ldb, P, ctr, B);
 }
 void launch_gcq_exp(hipStream_t st, const double *Q, int ld, int n, int m, double *Phi) {
     if (n <= 0) return;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_minv(const doubl
                                                                       const double *__restrict__ Sig, const int *__restrict__ gid,
                                                                       const unsigned char *__restrict__ pat,
                                                                       double *__restrict__ Minv, const double *__restrict__ Xr, int de,
-                                                                      const double *__restrict__ lnS, double *__restrict__ A, int lda) {
+                                                                      const double *__restrict__ lnS, double *__restrict__ A, int lda, const double *__restrict__ ctr) {
     static_assert(!(MISS && QROW), "the dense form of the PHI build is for rows without missing dimensions");
     __shared__ double ex_all[4][64];
     const C4Lane L = c4_lane();
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, C4_MINB_PHI(ND)) void k_cpsi4_minv(const doubl
     for (int J = 0; J <= ND; ++J) T[c4_lt(ND, J)] = 0.0;
     if (QROW) {
 #pragma unroll
-        for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = (L.hi == 0 && 4 * J + L.lo < d) ? Xr[(size_t)ic * de + 4 * J + L.lo] : 0.0;
+        for (int J = 0; J < ND; ++J) T[c4_lt(ND, J)] = (L.hi == 0 && 4 * J + L.lo < d) ? Xr[(size_t)ic * de + 4 * J + L.lo] - ctr[4 * J + L.lo] : 0.0;   // x - c (see k_gcq_tab)
     }
     double logdet;
     c4_sweep<ND, true>(T, ex, L, &logdet);                                              // lower tiles: -M^-1

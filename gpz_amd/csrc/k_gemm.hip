@@ -526,8 +526,8 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
         double pp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            double ph[NFB / 2][4];
-            if (nupart) {
+            double ph[NFB / 2][4] = {};
+            if (nupart && nvalid > 0) {   // (nvalid = 0: a column piece wholly past the edge - tile 0 itself is out of range)
 #pragma unroll
                 for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
                     const int p = hf * (NFB / 2) + ph_i;

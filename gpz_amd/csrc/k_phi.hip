@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
                                                    double *__restrict__ wbeta, const double *__restrict__ wv,
                                                    double *__restrict__ phiw, const double *__restrict__ Psic,
                                                    const double *__restrict__ Mc, const double *__restrict__ ucnt, int jgroup,
-                                                   double *__restrict__ part) {
+                                                   double *__restrict__ part, long ldp) {
     constexpr int KM = KGEN ? 8 : 1;
     __shared__ double tile[4][R][64][JB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
             const long i = row0 + r * 64 + lane;
 #pragma unroll
             for (int o = 0; o < KM; ++o)
-                if (o < k && i < ldx) {
-                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldx + i] = sv[r][o];
-                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldx + i] = sw[r][o];
+                if (o < k && i < ldp) {
+                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldp + i] = sv[r][o];
+                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldp + i] = sw[r][o];
                 }
         }
         return;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                                                   const double *__restrict__ omega, const double *__restrict__ Y,
                                                   double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                   double *__restrict__ wbeta, const double *__restrict__ wv,
-                                                  double *__restrict__ phiw, int jgroup, double *__restrict__ part,
+                                                  double *__restrict__ phiw, int jgroup, double *__restrict__ part, long ldp,
                                                   const int *__restrict__ wgtab) {
     constexpr int KM = KGEN ? 8 : 1;
     constexpr int NT = D * (D + 1) / 2;
@@ -546,15 +546,15 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
         __syncthreads();
     }
 
-    if (part) {   // column-split launch: partial sums [group][2][k][ldx]; k_phi_finalize combines them in fixed order
+    if (part) {   // column-split launch: partial sums [group][2][k][ldp] (ldp = the rows of this launch); k_phi_finalize combines them in fixed order
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long i = row0 + r * 64 + lane;
 #pragma unroll
             for (int o = 0; o < KM; ++o)
-                if (o < k && i < wr_end) {
-                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldx + i] = sv[r][o];
-                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldx + i] = sw[r][o];
+                if (o < k && i < wr_end && i < ldp) {
+                    part[(((size_t)blockIdx.y * 2 + 0) * k + o) * ldp + i] = sv[r][o];
+                    part[(((size_t)blockIdx.y * 2 + 1) * k + o) * ldp + i] = sw[r][o];
                 }
         }
         return;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 }
 
 // lnbeta = b + sum_g part_v[g], omega*beta, PHI*w from the column-group partial sums (fixed order: repeatable)
-__global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long ldx, long rows, int n, int k,
+__global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ngroup, long ldx, long rows, int n, int k,
                                const double *__restrict__ bvec, const double *__restrict__ omega,
                                double *__restrict__ lnbeta, double *__restrict__ wbeta, double *__restrict__ phiw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,8 +586,8 @@ __global__ void k_phi_finalize(const double *__restrict__ part, int ngroup, long
     for (int o = 0; o < k; ++o) {
         double sv = 0.0, sw = 0.0;
         for (int g = 0; g < ngroup; ++g) {
-            sv += part[(((size_t)g * 2 + 0) * k + o) * ldx + i];
-            sw += part[(((size_t)g * 2 + 1) * k + o) * ldx + i];
+            sv += part[(((size_t)g * 2 + 0) * k + o) * ldp + i];
+            sw += part[(((size_t)g * 2 + 1) * k + o) * ldp + i];
         }
         const bool valid = i < n;
         const double lb = bvec[o] + sv;
@@ -630,13 +630,13 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     dim3 grid(nwg, ngroup);
 #define PHI_COV(KG, TB) \
     hipLaunchKernelGGL((k_phi_cov<D, KG, R, JB, TB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.G, a.v, \
-                       a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part, a.wgtab)
+                       a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part, (long)a.n_pad, a.wgtab)
     if (a.wgtab) { if (a.k == 1) PHI_COV(false, true); else PHI_COV(true, true); }
     else { if (a.k == 1) PHI_COV(false, false); else PHI_COV(true, false); }
 #undef PHI_COV
     if (part)
         hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
-                           ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
+                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
 #ifndef GPZ_PHI_DIAG_RP
@@ -670,7 +670,7 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
 #define PHI_DIAG_R(KG, PS, RR) \
     hipLaunchKernelGGL((k_phi_diag<D, KG, PS, RR, JB>), dim3((a.n_pad + 256 * RR - 1) / (256 * RR), ngroup),              \
                        dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,                                           \
-                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt, jgroup, part)
+                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt, jgroup, part, (long)a.n_pad)
 #define PHI_DIAG(KG, PS) \
     do { if (PS) PHI_DIAG_R(KG, PS, RP); else if (small) PHI_DIAG_R(KG, PS, 1); else PHI_DIAG_R(KG, PS, R); } while (0)
     if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
@@ -679,7 +679,7 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
 #undef PHI_DIAG_R
     if (part)
         hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
-                           ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
+                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
 }
 
 template <int KIND>

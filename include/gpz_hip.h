@@ -282,8 +282,9 @@ int gpz_rccl_unique_id(void *id128);
 int gpz_ctx_init_rccl(gpz_ctx *ctx, const void *id128, int32_t rank, int32_t world, int32_t device);
 const char *gpz_rccl_origin(void);
 
-/* Text of the calling thread's last error; for a thread that has never failed itself, of the most recent failure on any thread
- * (work that failed on one of the library's worker threads).  Valid until the thread's next library call. */
+/* Text of the calling thread's last failure - or of a NEWER failure on another thread (work that failed on one of the library's
+ * worker threads); "" when nothing has failed.  The return code of the call is the authority, this is its text.  Valid until the
+ * thread's next library call. */
 const char *gpz_last_error(void);
 int gpz_version(void);
 

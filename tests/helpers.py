@@ -87,3 +87,26 @@ def recondition_gamma(model, theta, rng, amp=0.3):
 def grad_tol(cond):
     """Parity gate of BASELINE.md §6."""
     return max(1e-8, 50.0 * cond * 2.2e-16)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "gpz_amd", "lib", "libgpz_hip_dev.so")
+
+
+def eval_with_dev_switches(tmp_path, method, m, d, k, hetero, theta, X, Y, Psi, switches):
+    """One evaluation in a FRESH process on the developer build of the library (./build.sh --dev: -DGPZ_DEV_SWITCHES, the only build
+    in which the A/B switches of gpz_amd/csrc/gpz_options.h exist), with `switches` in its environment.  -> (f, g, info)"""
+    import subprocess
+    import sys
+    assert os.path.exists(DEV_LIB), "developer build missing: run ./build.sh --dev (or __graft_entry__.build())"
+    np.savez(tmp_path / "in.npz", theta=theta, X=X, Y=Y, Psi=(Psi if Psi is not None else np.zeros(0)), has_psi=int(Psi is not None))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import gpz_amd\n"
+            "z = np.load(%r)\n"
+            "model = gpz_amd.Model(m=%d, d=%d, k=%d, method=%r, heteroscedastic=%r)\n"
+            "ctx = gpz_amd.GPzContext(model, z['X'], z['Y'], z['Psi'] if int(z['has_psi']) else None)\n"
+            "f, g = ctx.eval(z['theta']); info = ctx.info; ctx.close()\n"
+            "np.savez(%r, f=f, g=g, info=info)\n") % (ROOT, str(tmp_path / "in.npz"), m, d, k, method, bool(hetero), str(tmp_path / "out.npz"))
+    env = dict(os.environ, GPZ_HIP_LIB=DEV_LIB, **{k_: str(v) for k_, v in switches.items()})
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    o = np.load(tmp_path / "out.npz")
+    return float(o["f"]), o["g"], int(o["info"])

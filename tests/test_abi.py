@@ -90,3 +90,17 @@ def test_theta_layout_matches_reference():
     # g_dim per method (init.m:65-86) and p = m*d + g_dim + m*k + k + 2*m*k
     for method, g in (("GL", 1), ("VL", 7), ("GD", 3), ("VD", 21), ("GC", 9), ("VC", 63)):
         assert gpz_amd.Model(m=7, d=3, method=method).g_dim == g
+
+
+def test_the_library_has_no_undefined_symbols_of_its_own():
+    """every symbol the translation units of libgpz_hip.so expect from each other is defined in it (a lazily bound ctypes load would
+    only trip over a missing one when the call is made - on the GPU box)"""
+    import subprocess
+    for name in ("libgpz_hip.so", "libgpz_hip_dev.so"):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpz_amd", "lib", name)
+        if not os.path.exists(path):
+            assert name != "libgpz_hip.so"
+            continue
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        own = [l for l in out.splitlines() if "gpz" in l.lower() or "launch_" in l]
+        assert not own, own

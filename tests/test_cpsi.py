@@ -164,11 +164,9 @@ def test_predict_with_missing_values_wide_and_many_outputs_takes_the_scratch_ker
 
 @pytest.mark.parametrize("d,switch", [(20, "GPZ_CPSI4_OFF"), (20, "GPZ_CPSI_OFF"), (40, "GPZ_CPSI4_OFF")])
 def test_the_pair_kernel_routes_agree_with_each_other(d, switch, tmp_path):
-    """the same evaluation through the route a developer switch selects in a fresh process (4 x 4 tiles -> 16 x 16 tiles -> general
+    """the same evaluation through the route a developer switch selects in a fresh process on the developer build of the library (4 x 4 tiles -> 16 x 16 tiles -> general
     kernels) against this process's default route: three independent implementations of getPHI.m:78-89 / GPz.m:164-185"""
-    import os
-    import subprocess
-    import sys
+    from helpers import eval_with_dev_switches
     n, m = 120, 5
     model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, "VC", True, 7300 + d)
     ctx = gpz_amd.GPzContext(model, X, Y, Psi)
@@ -176,17 +174,8 @@ def test_the_pair_kernel_routes_agree_with_each_other(d, switch, tmp_path):
         f, g = ctx.eval(theta)
     finally:
         ctx.close()
-    np.savez(tmp_path / "in.npz", theta=theta, X=X, Y=Y, Psi=Psi, m=m, d=d)
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import gpz_amd\n"
-            "z = np.load(%r)\n"
-            "model = gpz_amd.Model(m=int(z['m']), d=int(z['d']), k=1, method='VC', heteroscedastic=True)\n"
-            "ctx = gpz_amd.GPzContext(model, z['X'], z['Y'], z['Psi'])\n"
-            "f, g = ctx.eval(z['theta']); ctx.close()\n"
-            "np.savez(%r, f=f, g=g)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"),
-                                          str(tmp_path / "out.npz"))
-    env = dict(os.environ, **{switch: "1"})
-    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
-    o = np.load(tmp_path / "out.npz")
+    of, og, _ = eval_with_dev_switches(tmp_path, "VC", m, d, 1, True, theta, X, Y, Psi, {switch: "1"})
+    o = {"f": of, "g": og}
     assert abs(float(o["f"]) - f) <= 1e-11 * abs(f)
     assert rel(o["g"], g) <= max(1e-9, _loose(model, theta) * phi_tol(model, theta))
 
@@ -206,3 +195,28 @@ def test_missing_values_without_input_noise_wide(method, d):
     om = rng.random((n, 1)) + 0.5
     tr = rng.random(n) < 0.8
     _gate(model, theta, X, Y, None, om, tr, ~tr, loose=_loose(model, theta))
+
+
+@pytest.mark.parametrize("d", [12, 20])
+def test_gc_dense_phi_build_far_from_the_origin(d):
+    """GC + Psi, 10 < d <= 32 builds PHI as one dense product of the EXPANDED quadratic form x'M^-1 x - 2 p'M^-1 x + p'M^-1 p
+    (k_cpsi4_minv<QROW> x k_gcq_tab), which cancels (|x| / |x - p|)^2 eps when the inputs sit far from the origin.  Both factors
+    are taken about the mean basis centre: inputs and centres shifted by 3e4 length scales (1e-7 of ln PHI uncentred) must still
+    give the oracle's PHI - whose Delta = x - p never sees the offset - to the tolerance of the unshifted problem."""
+    n, m = 200, 9
+    model, theta, X, Y, Psi, rng = _problem(n, d, m, 1, "GC", True, 8100 + d)
+    shift = 3.0e4 * (1.0 + rng.random(d))
+    Xs = X + shift
+    ts = theta.copy()
+    ts[:m * d] = (theta[:m * d].reshape(d, m) + shift[:, None]).ravel()      # P is m x d column-major: P(j, a) at j + m a
+    ref = O.getPHI(X, Psi, theta, model, None)[0]                            # the same problem about the origin
+    ctx = gpz_amd.GPzContext(model, Xs, Y, Psi)
+    try:
+        assert "k_cpsi4" in ctx.route()
+        f, g = ctx.eval(ts)
+        PHI = ctx.phi()
+    finally:
+        ctx.close()
+    assert rel(PHI, ref) <= 1e-9, rel(PHI, ref)
+    r = O.GPz(theta, model, X, Y, Psi)
+    assert abs(f - r.nlogML) <= 1e-9 * abs(r.nlogML)

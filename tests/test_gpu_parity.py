@@ -525,19 +525,17 @@ def test_c5_shape_fp64_small_n():
 
 @pytest.mark.parametrize("s1,s2", [(7, 3), (5, 5), (9, 1), (1, 4), (13, 10)])
 @pytest.mark.parametrize("shape", [(5000, 300, "VD"), (3001, 129, "VC"), (2500, 100, "GL")])
-def test_syrk_uneven_row_splits(monkeypatch, s1, s2, shape):
+def test_syrk_uneven_row_splits(tmp_path, s1, s2, shape):
     """PHI' W PHI with different row-split counts for off-diagonal (s1) and diagonal (s2) 128-tiles - the form the
     cost model picks at large n - forced through the tuning overrides on small problems: 3 x 3, 2 x 2 (partial edge
-    tile) and 1 x 1 tile grids, splits that leave ranges empty, odd row counts."""
+    tile) and 1 x 1 tile grids, splits that leave ranges empty, odd row counts.  (The overrides are developer switches: the
+    evaluation runs in a fresh process on the developer build of the library.)"""
+    from helpers import eval_with_dev_switches
     n, m, method = shape
-    monkeypatch.setenv("GPZ_SYRK_S1", str(s1))
-    monkeypatch.setenv("GPZ_SYRK_S2", str(s2))
     model, theta, X, Y, _, rng = make_problem(n, 3, m, 1, method, True, seed=1000 + s1 * 16 + s2)
     ref = O.GPz(theta, model, X, Y)
-    ctx = gpz_amd.GPzContext(model, X, Y)
-    f, g = ctx.eval(theta)
-    ctx.close()
-    assert ctx.info == 0 and abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+    f, g, info = eval_with_dev_switches(tmp_path, method, m, 3, 1, True, theta, X, Y, None, {"GPZ_SYRK_S1": s1, "GPZ_SYRK_S2": s2})
+    assert info == 0 and abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
 
 
 def test_large_m_tiles():

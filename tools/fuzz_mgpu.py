@@ -19,6 +19,7 @@ for c in range(cases):
     cfg = draw(rng)
     shards = int(rng.integers(2, 7))
     model, theta, X, Y, Psi, om, tr, va = build(cfg)
+    if os.environ.get("FUZZ_VERBOSE"): print("case", c, cfg, "shards", shards, flush=True)
     ntr = int(tr.sum()) if tr is not None else X.shape[0]
     try:
         mg = gpz_amd.GPzMulti(model, X, Y, Psi, om, tr, va, n_gpus=shards, reducer="loopback", dtype="f32" if cfg["f32"] else "f64")
