@@ -203,6 +203,9 @@ def main():
                     help="single process, K shards behind gpz_mgpu_* (one host thread per shard, reduction inside the library): RCCL over "
                          "K GPUs when the node has them, else all K shards on GPU 0 with the loopback reducer (measures the driver's "
                          "threading, not scaling)")
+    ap.add_argument("--timed-events", choices=["dominant", "none"], default="dominant",
+                    help="HIP events in the timed region: around the dominant stages (graph segments with events between them; default) or "
+                         "none (the whole evaluation one graph: the latency-bound configurations, where eight extra graph launches show)")
     ap.add_argument("--validation", type=float, default=0.0,
                     help="fraction of the rows turned into validation rows (GPz.m:239-261 priced inside the step; SURVEY 8d: c2 with 0.15)")
     args = ap.parse_args()
@@ -306,9 +309,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    # The timed region runs what a caller gets: from the third evaluation on, hipGraph replays (cut into segments at the two exchange
+    # points of a sharded run).  Timing level 2 keeps that and records HIP events around the dominant stages only, BETWEEN the graph
+    # launches (events inside a graph cannot be timed on ROCm 7: tools/graph_event_probe.hip); the all-stage breakdown comes from a
+    # second pass of the same K steps with events around every stage, which runs as eager launches ("stage_pass").
+    ctx.enable_timing(2 if args.timed_events == "dominant" else 0)
+    for i in range(args.warmup):      # (the graph is recorded on the second evaluation: W >= 2 keeps the recording out of the timed region)
         ctx.eval(thetas[i])
-    ctx.enable_timing(True)
     ctx.reset_timings()
     barrier()
     t0 = time.perf_counter()
@@ -326,32 +333,48 @@ def main():
         elapsed = float(t.item())
     tim = ctx.timings()
     route = ctx.route() if hasattr(ctx, "route") else None
+    rank_routes = [ctx.route(r) for r in range(ctx.n_gpus)] if multi else None
+    # Second pass, events around EVERY stage (eager launches): the per-stage breakdown (allreduce1 / allreduce2 are the two exchange points)
+    ctx.enable_timing(1)
+    ctx.reset_timings()
+    barrier()
+    ts0 = time.perf_counter()
+    for i in range(args.steps):
+        ctx.eval(thetas[args.warmup + i])
+    barrier()
+    ts1 = time.perf_counter() - ts0
+    tim_full = ctx.timings()
+    if not tim:            # --timed-events none: the kernel times of the roofline come from the stage pass
+        tim = tim_full
+    stage_pass = {"ms_per_step": ts1 / args.steps * 1e3, "evals_per_s": args.steps / ts1,
+                  "note": "same K steps with HIP events around every stage: eager launches, not replay",
+                  "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim_full.items()}}
     per_rank = None
     if multi:
-        per_rank = [{"rank": r, "rows": ctx.rows_per_gpu[r], "rccl": rccl_origin,
-                     "stage_ms_per_eval": {k: v[0] / args.steps for k, v in ctx.timings(r).items()}} for r in range(ctx.n_gpus)]
+        per_rank = [dict({"rank": r, "rows": ctx.rows_per_gpu[r], "rccl": rccl_origin, "route": rank_routes[r],
+                          "stage_ms_per_eval": {k: v[0] / args.steps for k, v in ctx.timings(r).items()}}, **ctx.comm_info(r))
+                    for r in range(ctx.n_gpus)]
     elif use_dist:
-        # per rank: its rows, every stage (allreduce1 / allreduce2 are the two exchange points) and the RCCL it bound - the first
-        # real multi-GPU line can be read stage by stage against the single-GPU shard line (profiles/*_shard125k.json)
-        mine = {"rank": rank, "rows": n_local, "comm": comm, "rccl": rccl_origin, "route": route,
-                "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}}
+        # per rank: its rows, every stage and what the communicator itself reports (ncclCommCount / ncclCommUserRank / device + PCI bus
+        # id) - the first real multi-GPU line proves N ranks on N devices from its own output and can be read stage by stage against
+        # the single-GPU shard line (profiles/*_shard125k.json)
+        mine = dict({"rank": rank, "rows": n_local, "comm": comm, "rccl": rccl_origin, "route": route,
+                     "stage_ms_per_eval": stage_pass["stage_ms_per_eval"]}, **ctx.comm_info())
         per_rank = [None] * world if rank == 0 else None
         dist.gather_object(mine, per_rank, dst=0)
-    # Second pass with stage timing OFF: the evaluation is then replayed as one hipGraph (~40 launches; the timed region above
-    # records HIP events around every stage, which keeps it on eager launches).  Matters for the latency-bound configurations only.
-    graph_pass = None
-    if not use_dist and not multi:
-        ctx.enable_timing(False)
-        for i in range(max(3, args.warmup)):
-            ctx.eval(thetas[i % len(thetas)])
-        torch.cuda.synchronize()
-        tg0 = time.perf_counter()
-        for i in range(args.steps):
-            ctx.eval(thetas[args.warmup + i])
-        torch.cuda.synchronize()
-        tg1 = time.perf_counter() - tg0
-        graph_pass = {"ms_per_step": tg1 / args.steps * 1e3, "evals_per_s": args.steps / tg1, "route": ctx.route(),
-                      "note": "same K steps, stage timing off: one hipGraph launch per evaluation"}
+    else:
+        per_rank_single = ctx.comm_info()
+    if per_rank is not None and rank == 0 and (native or (use_dist and comm == "rccl")):
+        # self-verification of a real multi-GPU run: every rank's communicator must report N ranks, the ranks 0..N-1 once each, on N
+        # different PCI devices.  (The loopback / gloo test forms share one device and have no RCCL communicator: not checked.)
+        counts = sorted({q["nccl_count"] for q in per_rank})
+        ranks_seen = sorted(q["nccl_rank"] for q in per_rank)
+        buses = [q["pci_bus_id"] for q in per_rank]
+        if counts != [n_gpus_used] or ranks_seen != list(range(n_gpus_used)) or len(set(buses)) != n_gpus_used or "" in buses:
+            raise SystemExit(f"bench.py: the communicators do not describe {n_gpus_used} ranks on {n_gpus_used} devices: ncclCommCount {counts}, "
+                             f"ncclCommUserRank {ranks_seen}, PCI bus ids {buses}")
+    graph_pass = {"ms_per_step": elapsed / args.steps * 1e3, "evals_per_s": args.steps / elapsed, "route": route,
+                  "note": "the timed region itself: hipGraph replay" + (", events around the dominant stages only" if args.timed_events == "dominant" else ", no events")}
     finite = bool(np.isfinite(fs).all() and np.isfinite(g).all())
 
     out = None
@@ -401,22 +424,40 @@ def main():
                          "traffic": (pmc_traffic(args.config) or {}).get("tgemm_bytes_per_launch") if world == 1 and not multi and not args.n else None,
                          "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
+                         "mfma_util_counters": (pmc_traffic(args.config) or {}).get("tgemm_mfma_util") if world == 1 and not multi and not args.n else None,
                          "avg_ms": tg_avg,
                          "ubench_ceiling": F32_MFMA_UBENCH_TFLOPS if f32_route else F64_MFMA_UBENCH_TFLOPS,
                          "frac_of_ubench": ach / (F32_MFMA_UBENCH_TFLOPS if f32_route else F64_MFMA_UBENCH_TFLOPS)},
             "kernels": {"syrk_tflops_algorithmic": ach_sy, "syrk_avg_ms": sy_avg,
                         "phi_build_GBs_algorithmic": phi_gbs, "phi_build_avg_ms": ph_avg,
-                        "stage_ms_per_eval": {k: v[0] / args.steps for k, v in tim.items()}},
+                        "stage_ms_per_eval": stage_pass["stage_ms_per_eval"],
+                        "dominant_stage_ms_per_eval_in_the_timed_region": {k: v[0] / args.steps for k, v in tim.items()}},
+            # BASELINE.json's metric names it: "MFMA util on PHI'W PHI".  Flops-based from this run (n m (m+1) algorithmic flops per launch
+            # over the kernel's HIP-event time in the timed region); counter-based from the committed rocprofv3 PMC passes of the same
+            # command (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles - counters cannot be read inside this process).
+            "roofline_syrk": {"bound": "mfma", "kernel": "k_syrk (PHI' W PHI, n*m*(m+1) flops/launch: the symmetric half)" + (" on fp32-operand MFMAs" if f32_route else ""),
+                              "achieved": ach_sy, "peak": F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach_sy / (F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS), "avg_ms": sy_avg,
+                              "mfma_util_counters": (pmc_traffic(args.config) or {}).get("syrk_mfma_util") if world == 1 and not multi and not args.n else None,
+                              "counters_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
+                              "traffic": (pmc_traffic(args.config) or {}).get("syrk_bytes_per_launch") if world == 1 and not multi and not args.n else None},
+            "phi_build": {"bound": "hbm (diagonal kinds) / fp64 vector ALU (covariance kinds, SURVEY.md 8d)", "avg_ms": ph_avg,
+                          "algorithmic_GBs": phi_gbs, "peak_GBs": 8000.0, "frac": phi_gbs / 8000.0,
+                          "fabric_GBs_counters": ((pmc_traffic(args.config) or {}).get("phi_bytes_per_launch", 0.0) / (ph_avg * 1e-3) / 1e9
+                                                  if ph_avg > 0 and world == 1 and not multi and not args.n and (pmc_traffic(args.config) or {}).get("phi_bytes_per_launch") else None)},
             "finite": finite,
             # bitwise fingerprint of the last step's result (same theta sequence for every launch form)
             "check": {"f_last": float(fs[-1]).hex(), "g_sum": float(np.sum(g)).hex(), "g_absmax": float(np.max(np.abs(g))).hex()},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        else:
+            out["device"] = per_rank_single
         if route:
             out["route"] = route
         if graph_pass:
             out["graph_pass"] = graph_pass
+        out["stage_pass"] = {k: v for k, v in stage_pass.items() if k != "stage_ms_per_eval"}
         if cfg.get("psi") and not f32_route:
             # config 5 in fp64: the per-pair sweeps of k_cpsi4.hip (four pairs per wave on v_mfma_f64_4x4x4).  Algorithmic work per
             # (sample, basis) pair at d = 20 in the M = Psi + Sigma form: PHI d^3/6 + d^2 = 1733 FMA, moments d^3/2 + 2 d^2 = 4800 FMA.

@@ -97,6 +97,8 @@ SYMBOLS = {
     "gpz_version": (C.c_int, []),
     "gpz_release_cached_memory": (None, []),
     "gpz_debug_fail_alloc": (None, [C.c_int64]),
+    "gpz_ctx_comm_info": (C.c_int, [C.c_void_p, c_int32_p, C.c_char_p, C.c_int32]),
+    "gpz_mgpu_comm_info": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, C.c_char_p, C.c_int32]),
 }
 
 _lib = None

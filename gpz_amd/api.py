@@ -229,7 +229,9 @@ class GPzContext:
         return out
 
     def enable_timing(self, on=True):
-        _lib.check(self._lib.gpz_ctx_enable_timing(self._h, 1 if on else 0))
+        """on = True / 1: HIP events around every stage (eager launches); 2: around the dominant stages only (PHI build, PHI'W PHI,
+        T = PHI [inv(SIGMA) | w], moments), the evaluation still replayed as hipGraph segments; False / 0: off."""
+        _lib.check(self._lib.gpz_ctx_enable_timing(self._h, int(on)))
 
     def reset_timings(self):
         _lib.check(self._lib.gpz_ctx_reset_timings(self._h))
@@ -248,6 +250,11 @@ class GPzContext:
         buf = C.create_string_buffer(512)
         self._lib.gpz_ctx_route(self._h, buf, 512)
         return buf.value.decode()
+
+    def comm_info(self):
+        """What the RCCL communicator behind this context's all-reduce reports about itself (gpz_ctx_comm_info):
+        {"nccl_count", "nccl_rank", "nccl_device"} (-1 without an in-library communicator), "hip_device", "pci_bus_id"."""
+        return _comm_info(lambda info, bus, cap: self._lib.gpz_ctx_comm_info(self._h, info, bus, cap))
 
 
 class GPzMulti:
@@ -346,9 +353,18 @@ class GPzMulti:
         """Test hook (gpz_mgpu_debug_fail_at): the next call fails on `rank` at exchange point 1 or 2."""
         _lib.check(self._lib.gpz_mgpu_debug_fail_at(self._h, int(rank), int(exchange)))
 
+    def comm_info(self, rank=0):
+        """gpz_mgpu_comm_info of one rank (see GPzContext.comm_info)."""
+        return _comm_info(lambda info, bus, cap: self._lib.gpz_mgpu_comm_info(self._h, int(rank), info, bus, cap))
+
+    def route(self, rank=0):
+        buf = C.create_string_buffer(512)
+        self._lib.gpz_ctx_route(self._lib.gpz_mgpu_ctx(self._h, int(rank)), buf, 512)
+        return buf.value.decode()
+
     def enable_timing(self, on=True):
         for c in self._each():
-            _lib.check(self._lib.gpz_ctx_enable_timing(c, 1 if on else 0))
+            _lib.check(self._lib.gpz_ctx_enable_timing(c, int(on)))
 
     def reset_timings(self):
         for c in self._each():
@@ -370,6 +386,14 @@ class GPzMulti:
 
 def device_count():
     return int(_lib.load().gpz_device_count())
+
+
+def _comm_info(call):
+    info = (C.c_int32 * 4)()
+    bus = C.create_string_buffer(64)
+    _lib.check(call(info, bus, 64))
+    return {"nccl_count": int(info[0]), "nccl_rank": int(info[1]), "nccl_device": int(info[2]), "hip_device": int(info[3]),
+            "pci_bus_id": bus.value.decode()}
 
 
 def rccl_origin():

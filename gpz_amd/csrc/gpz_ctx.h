@@ -154,7 +154,8 @@ struct StageTimer {
     std::vector<const char *> names;
     std::vector<double> ms;
     std::vector<int64_t> calls;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    struct Pending { int idx; hipEvent_t e0, e1; bool count_call; };
+    std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
     int find(const char *n) {
@@ -231,13 +232,29 @@ struct gpz_ctx {
     void *ar_user = nullptr;
     void *priv = nullptr;                 // owned by whoever attached it (the RCCL communicator of gpz_ctx_init_rccl),
     void (*priv_free)(void *) = nullptr;  // released with the context
-    bool timing = false;
-    // One evaluation = ~40 launches on one stream between the upload of theta and the download of the result block, every argument
-    // fixed for the life of the context: from the third gpz_eval on it is replayed as a hipGraph (single rank, host theta, stage
-    // timing off).  graph_state: 0 first call (eager), 1 capture on this call, 2 replay, -1 disabled (capture failed / GPZ_NO_GRAPH)
-    hipGraphExec_t graph_exec = nullptr;
-    hipStream_t graph_st = nullptr;   // the recording runs on a stream of its own (the null stream cannot be captured); the graph is launched on st
-    int graph_state = 0;
+    int timing = 0;   // gpz_ctx_enable_timing: 0 off, 1 HIP events around every stage (eager launches), 2 around the dominant stages only
+    // One evaluation = ~150 launches on one stream between the upload of theta and the download of the result block, every argument
+    // fixed for the life of the context: from the third gpz_eval on it is REPLAYED as hipGraphs (host theta, timing 0 or 2).  The
+    // recording is cut into segments where something must happen between graph launches:
+    //   * at the two exchange points of a sharded context (world > 1): the all-reduce hook runs eagerly between two segments - on
+    //     whatever it is (RCCL inside the library, the loopback reducer of gpz_mgpu, a torch.distributed callback);
+    //   * with timing = 2, before and after the dominant stages (PHI build, PHI'W PHI, T = PHI [inv|w], moments): HIP events recorded
+    //     INSIDE a graph cannot be timed on ROCm 7 (tools/graph_event_probe.hip), events between graph launches can.
+    // One set of segments per timing mode.  state: 0 first call (eager), 1 record on this call, 2 replay, -1 disabled (recording failed
+    // / GPZ_NO_GRAPH).
+    struct GraphSeg {
+        hipGraphExec_t exec = nullptr;   // nullptr: nothing was recorded between two cuts
+        int stage = -1;                  // >= 0: events around this segment, accumulated under this stage of the timer
+        bool count_call = false;         // the first segment of a stage instance counts as its call
+        double *hook_buf = nullptr;      // all-reduce after this segment
+        size_t hook_count = 0;
+    };
+    struct GraphSet { std::vector<GraphSeg> segs; int state = 0; };
+    GraphSet gset[2];                    // [0]: timing 0, [1]: timing 2
+    GraphSet *cap = nullptr;             // the set being recorded
+    int cap_stage = -1;                  // dominant stage open while recording (timing 2)
+    bool cap_stage_first = false, cap_failed = false;
+    hipStream_t graph_st = nullptr;   // the recording runs on a stream of its own (the null stream cannot be captured); the graphs are launched on st
     bool capturing = false;
     StageTimer tm;
     bool phi_valid = false;
@@ -272,29 +289,50 @@ struct gpz_ctx {
 };
 
 // ---- stage timing ------------------------------------------------------------------------------
+namespace gpzi {
+int graph_cut(gpz_ctx *c, bool last = false);   // gpz_eval.hip: close the segment being recorded (and open the next)
+}
+inline bool stage_is_dominant(const char *name) {
+    return !strcmp(name, "tgemm") || !strcmp(name, "syrk") || !strcmp(name, "phi_build") || !strcmp(name, "moments");
+}
 struct Stage {
     gpz_ctx *c;
     int idx = -1;
+    bool cut = false;
     hipEvent_t e0{}, e1{};
     Stage(gpz_ctx *c_, const char *name) : c(c_) {
-        if (!c->timing) return;
+        if (c->capturing) {   // recording graph segments: a dominant stage becomes segments of its own, timed from outside on replay
+            if (c->timing == 2 && stage_is_dominant(name) && c->cap_stage < 0) {
+                gpzi::graph_cut(c);
+                c->cap_stage = c->tm.find(name);
+                c->cap_stage_first = true;
+                cut = true;
+            }
+            return;
+        }
+        if (c->timing == 0 || (c->timing == 2 && !stage_is_dominant(name))) return;
         idx = c->tm.find(name);
         e0 = c->tm.get();
         e1 = c->tm.get();
         (void)hipEventRecord(e0, c->st);
     }
     ~Stage() {
+        if (cut) {
+            gpzi::graph_cut(c);
+            c->cap_stage = -1;
+            return;
+        }
         if (idx < 0) return;
         (void)hipEventRecord(e1, c->st);
-        c->tm.pending.push_back({idx, {e0, e1}});
+        c->tm.pending.push_back({idx, e0, e1, true});
     }
 };
 inline void collect_timings(gpz_ctx *c) {
     for (auto &pe : c->tm.pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
-            c->tm.ms[pe.first] += ms;
-            c->tm.calls[pe.first] += 1;
+        if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+            c->tm.ms[pe.idx] += ms;
+            if (pe.count_call) c->tm.calls[pe.idx] += 1;
         }
     }
     c->tm.pending.clear();

@@ -579,7 +579,9 @@ extern "C" void gpz_ctx_destroy(gpz_ctx *c) {
     c->ar.release();
     if (c->out_h) (void)hipHostFree(c->out_h);
     if (c->theta_h) (void)hipHostFree(c->theta_h);
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    for (auto &gs : c->gset)
+        for (auto &s : gs.segs)
+            if (s.exec) (void)hipGraphExecDestroy(s.exec);
     if (c->graph_st) (void)hipStreamDestroy(c->graph_st);
     for (hipEvent_t e : c->tm.pool) (void)hipEventDestroy(e);
     delete c;
@@ -587,6 +589,11 @@ extern "C" void gpz_ctx_destroy(gpz_ctx *c) {
 namespace gpzi {
 
 }   // namespace gpzi
+bool gpz_ctx_allreduce_is(const gpz_ctx *c, int (*fn)(void *, void *, size_t, void *), void **user) {
+    if (user) *user = c->ar_user;
+    return c->ar_fn == fn;
+}
+int gpz_ctx_device(const gpz_ctx *c) { return c->device; }
 void gpz_ctx_attach_private(gpz_ctx *c, void *priv, void (*free_fn)(void *)) {
     if (c->priv && c->priv_free) c->priv_free(c->priv);
     c->priv = priv;
@@ -638,7 +645,7 @@ namespace gpzi {
 }   // namespace gpzi
 extern "C" int gpz_ctx_enable_timing(gpz_ctx *c, int enable) {
     if (!c) return gpz_fail(GPZ_ERR_ARG, "null context");
-    c->timing = enable != 0;
+    c->timing = enable < 0 ? 0 : enable > 2 ? 2 : enable;   // 0 off, 1 every stage (eager launches), 2 the dominant stages (graph segments)
     return GPZ_OK;
 }
 namespace gpzi {
@@ -682,8 +689,13 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
         why = !c->gen || !c->has_psi ? " [dtype f32 requested: no input noise on a covariance kind, nothing runs in fp32]"
               : c->d > 20            ? " [dtype f32 requested: d > 20 has no fp32 pair kernel, fp64 route]"
                                      : " [dtype f32 requested: rows with missing dimensions, fp64 route]";
-    const char *gs = c->graph_state == 2 ? "replayed" : c->graph_state == -1 ? "disabled (capture failed or GPZ_NO_GRAPH)"
-                     : c->timing ? "off (stage timing on)" : c->desc.world > 1 ? "off (sharded)" : "eager (not captured yet)";
+    const int gstate = c->gset[c->timing == 2 ? 1 : 0].state;
+    const size_t nseg = c->gset[c->timing == 2 ? 1 : 0].segs.size();
+    char gsb[96];
+    if (gstate == 2 && nseg > 1) snprintf(gsb, sizeof gsb, "replayed (%zu segments%s)", nseg, c->desc.world > 1 ? ", all-reduce between them" : "");
+    else snprintf(gsb, sizeof gsb, "%s", gstate == 2 ? "replayed" : gstate == -1 ? "disabled (recording failed)" : c->opt.no_graph ? "disabled (GPZ_NO_GRAPH)"
+                                         : c->timing == 1 ? "off (stage timing on)" : "eager (not recorded yet)");
+    const char *gs = gsb;
     const bool f32mm = c->psi32 && !c->opt.f32_contractions_off;
     char rows[96];
     if (c->tile_rows) snprintf(rows, sizeof rows, "; rows: streamed, %d tiles of %d (PHI built twice per evaluation)", c->ntiles, c->tile_rows);

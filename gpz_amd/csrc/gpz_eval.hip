@@ -22,6 +22,12 @@ static void psi32_chunks(const gpz_ctx *c, int *nch, int *rpc) {
 static int allreduce(gpz_ctx *c, double *buf, size_t count) {
     if (c->desc.world <= 1) return 0;
     if (!c->ar_fn) return gpz_fail(GPZ_ERR_COMM, "world=%d but no all-reduce hook set (gpz_ctx_set_allreduce)", c->desc.world);
+    if (c->capturing) {   // an exchange point of the recording: the hook is called between this segment and the next on every replay
+        if (graph_cut(c)) return gpz_fail(GPZ_ERR_HIP, "evaluation graph: cut at an exchange point failed");
+        c->cap->segs.back().hook_buf = buf;
+        c->cap->segs.back().hook_count = count;
+        return 0;
+    }
     if (c->ar_fn(c->ar_user, buf, count, (void *)c->st) != 0) return gpz_fail(GPZ_ERR_COMM, "all-reduce hook failed");
     return 0;
 }
@@ -613,6 +619,59 @@ extern "C" int gpz_eval_dev(gpz_ctx *c, const double *theta_dev, double *f, doub
 }
 namespace gpzi {
 
+// Close the graph segment being recorded (gpz_ctx.h: struct GraphSeg) and, unless it is the last, open the next one.
+int graph_cut(gpz_ctx *c, bool last) {
+    if (!c->capturing || !c->cap) return -1;
+    gpz_ctx::GraphSeg s;
+    s.stage = c->cap_stage;
+    s.count_call = c->cap_stage_first;
+    c->cap_stage_first = false;
+    if (!c->cap_failed) {
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(c->st, &g);
+        if (e == hipSuccess && g) {
+            size_t nn = 0;
+            e = hipGraphGetNodes(g, nullptr, &nn);
+            if (e == hipSuccess && nn > 0) e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
+        } else if (e == hipSuccess) e = hipErrorUnknown;
+        if (g) (void)hipGraphDestroy(g);
+        if (e == hipSuccess && !last) e = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->cap_failed = true;
+            if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph: segment %zu: %s\n", c->cap->segs.size(), hipGetErrorString(e));
+        }
+    }
+    c->cap->segs.push_back(s);
+    return c->cap_failed ? -1 : 0;
+}
+static void graph_set_drop(gpz_ctx::GraphSet &gs) {
+    for (auto &s : gs.segs)
+        if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    gs.segs.clear();
+}
+// One evaluation from the recorded segments: graph launches with, between them, the all-reduce hook of the exchange points and the
+// events of the dominant stages (timing 2).
+static int graph_replay(gpz_ctx *c, gpz_ctx::GraphSet &gs) {
+    for (auto &s : gs.segs) {
+        hipEvent_t e0{}, e1{};
+        if (s.stage >= 0) {
+            e0 = c->tm.get();
+            e1 = c->tm.get();
+            HIPCHK(hipEventRecord(e0, c->st));
+        }
+        if (s.exec) HIPCHK(hipGraphLaunch(s.exec, c->st));
+        if (s.stage >= 0) {
+            HIPCHK(hipEventRecord(e1, c->st));
+            c->tm.pending.push_back({s.stage, e0, e1, s.count_call});
+        }
+        if (s.hook_count && c->ar_fn(c->ar_user, s.hook_buf, s.hook_count, (void *)c->st) != 0) return gpz_fail(GPZ_ERR_COMM, "all-reduce hook failed");
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
                        double stats[4], double diag[2]) {
     (void)g_dev;
@@ -620,21 +679,15 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
     HIPCHK(hipSetDevice(c->device));
     c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
     const bool no_graph = c->opt.no_graph;   // (latched at creation: a context is either replayed or eager for its whole life)
-    const bool graphable = theta && !c->g_dev_out && c->desc.world <= 1 && !c->timing && c->pinv_mode != 1 && !no_graph &&
-                           c->graph_state >= 0;
+    gpz_ctx::GraphSet &gs = c->gset[c->timing == 2 ? 1 : 0];
+    const bool graphable = theta && !c->g_dev_out && c->timing != 1 && c->pinv_mode != 1 && !no_graph && gs.state >= 0;
     bool done = false;
-    if (graphable && c->graph_state == 2) {
+    if (graphable && gs.state == 2) {
         memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
-        if (hipGraphLaunch(c->graph_exec, c->st) == hipSuccess) {
-            HIPCHK(hipStreamSynchronize(c->st));
-            HIPCHK(hipGetLastError());
-            done = true;
-        } else {
-            (void)hipGetLastError();
-            c->graph_state = -1;
-        }
-    } else if (graphable && c->graph_state == 1) {
-        hipGraph_t graph = nullptr;
+        if (int e = graph_replay(c, gs)) return e;
+        done = true;
+    } else if (graphable && gs.state == 1) {
+        // record: nothing runs yet (the hooks of a sharded context are not called either) - the replay below is this call's evaluation
         int rc = 0;
         const char *why = "";
         hipStream_t user_st = c->st;
@@ -645,36 +698,37 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
         }
         if (he == hipSuccess) {
             c->capturing = true;
+            c->cap = &gs;
+            c->cap_stage = -1;
+            c->cap_stage_first = c->cap_failed = false;
             if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";   // (k_unpack clears the status words)
             if (!rc && (rc = eval_tail(c, false))) why = "stage B";
+            (void)graph_cut(c, true);
+            if (c->cap_failed && !rc) { rc = -1; why = "segment"; }
             c->capturing = false;
-            const hipError_t he2 = hipStreamEndCapture(c->st, &graph);
-            if (he2 != hipSuccess || !graph) { if (!rc) { rc = -1; why = "end capture"; he = he2; } }
+            c->cap = nullptr;
         } else {
             rc = -1; why = "begin capture";
         }
         c->st = user_st;
-        if (!rc && (he = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0)) != hipSuccess) { rc = -1; why = "instantiate"; }
         if (rc && c->opt.graph_debug)
             fprintf(stderr, "gpz: evaluation graph: %s: %s | %s\n", why, hipGetErrorString(he), gpz_last_error());
-        if (graph) (void)hipGraphDestroy(graph);
-        if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph capture %s\n", rc ? "failed" : "ok");
+        if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph recording %s (%zu segments)\n", rc ? "failed" : "ok", gs.segs.size());
         if (!rc) {
-            c->graph_state = 2;
-            HIPCHK(hipGraphLaunch(c->graph_exec, c->st));
-            HIPCHK(hipStreamSynchronize(c->st));
-            HIPCHK(hipGetLastError());
+            gs.state = 2;
+            memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
+            if (int e = graph_replay(c, gs)) return e;
             done = true;
-        } else {                     // not capturable here: stay on plain launches for the life of the context
+        } else {                     // not recordable here: stay on plain launches for the life of the context
             (void)hipGetLastError();
-            c->graph_exec = nullptr;
-            c->graph_state = -1;
+            graph_set_drop(gs);
+            gs.state = -1;
         }
     }
     if (!done) {
         if (int e = stage_a(c, theta, theta_dev)) return e;   // (k_unpack clears the status words)
         if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
-        if (graphable && c->graph_state == 0) c->graph_state = 1;
+        if (graphable && gs.state == 0) gs.state = 1;
     }
     // k_cond_flag (info[1], returned in slot 7 of the statistics block): SIGMA is close enough to singular that
     // inv_logdet.m may truncate -> redo the solve and everything after it through the SVD route.  PHI and the
@@ -684,7 +738,7 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
         if (int e = eval_tail(c, true)) return e;
     }
     const bool have_valid = c->va.n_pad > 0;
-    if (c->timing) collect_timings(c);
+    if (c->timing || !c->tm.pending.empty()) collect_timings(c);
     *f = c->out_h[0];
     if (g) memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
     const double *st = c->out_h + 1 + c->p;
@@ -754,7 +808,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
     HIPCHK(hipMemcpyAsync(info_h, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
-    if (c->timing) collect_timings(c);
+    if (c->timing || !c->tm.pending.empty()) collect_timings(c);
     if (info_h[0] != 0) {
         for (size_t e = 0; e < m * c->k; ++e) w[e] = NAN;
         for (size_t e = 0; e < m * m * c->k; ++e) iSigma_w[e] = NAN;

@@ -8,6 +8,8 @@
 struct gpz_ctx;
 int gpz_fail(int code, const char *fmt, ...);                      // sets gpz_last_error() of the calling thread, returns code
 void gpz_ctx_attach_private(gpz_ctx *c, void *priv, void (*free_fn)(void *));   // freed by gpz_ctx_destroy
+bool gpz_ctx_allreduce_is(const gpz_ctx *c, int (*fn)(void *, void *, size_t, void *), void **user);   // is this the hook in place? -> its user pointer
+int gpz_ctx_device(const gpz_ctx *c);
 
 // ---- theta unpacking (getPHI.m:24-40,117,122; GPz.m:28,32,50,98-101) -------------------------
 // Device parameter block produced by k_unpack from the raw theta vector.

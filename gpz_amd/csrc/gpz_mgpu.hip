@@ -58,6 +58,9 @@ struct RcclApi {
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;          // (optional: what the communicator itself reports, gpz_*_comm_info)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     std::string where;
 };
 static std::string g_rccl_why;
@@ -88,6 +91,9 @@ static RcclApi *rccl_api() {
     if (!api.f) { const char *e = dlerror(); g_rccl_why = std::string("nccl" #f ": ") + (e ? e : "symbol not found"); return nullptr; }
     BIND(GetUniqueId) BIND(CommInitRank) BIND(CommInitAll) BIND(CommDestroy) BIND(CommAbort) BIND(AllReduce) BIND(GetErrorString)
 #undef BIND
+    api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
+    api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(h, "ncclCommCuDevice");
     api.handle = h;
     return &api;
 }
@@ -564,6 +570,33 @@ extern "C" int32_t gpz_mgpu_alive(const gpz_mgpu *h) { return (h && !h->gate.is_
 extern "C" int32_t gpz_mgpu_size(const gpz_mgpu *h) { return h ? h->n : -1; }
 extern "C" int64_t gpz_mgpu_theta_len(const gpz_mgpu *h) { return h ? h->p : -1; }
 extern "C" gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t rank) { return (h && rank >= 0 && rank < h->n) ? h->ctx[rank] : nullptr; }
+// What the communicator behind an all-reduce saw of itself (a first real multi-GPU run proves N ranks on N devices from its own output).
+static int comm_info(ncclComm_t comm, int device, int32_t info[4], char *bus_id, int32_t cap) {
+    info[0] = info[1] = info[2] = -1;
+    info[3] = device;
+    RcclApi *api = comm ? rccl_api() : nullptr;
+    if (api) {
+        int v = -1;
+        if (api->CommCount && api->CommCount(comm, &v) == ncclSuccess) info[0] = v;
+        if (api->CommUserRank && api->CommUserRank(comm, &v) == ncclSuccess) info[1] = v;
+        if (api->CommCuDevice && api->CommCuDevice(comm, &v) == ncclSuccess) info[2] = v;
+    }
+    if (bus_id && cap > 0) {
+        bus_id[0] = 0;
+        if (hipDeviceGetPCIBusId(bus_id, cap, device) != hipSuccess) { (void)hipGetLastError(); bus_id[0] = 0; }
+    }
+    return GPZ_OK;
+}
+extern "C" int gpz_ctx_comm_info(const gpz_ctx *ctx, int32_t info[4], char *bus_id, int32_t cap) {
+    if (!ctx || !info) return gpz_fail(GPZ_ERR_ARG, "gpz_ctx_comm_info: null argument");
+    void *user = nullptr;
+    const bool ours = gpz_ctx_allreduce_is(ctx, rccl_hook, &user);   // the communicator of gpz_ctx_init_rccl, if that is the hook in place
+    return comm_info(ours && user ? ((RankComm *)user)->comm : nullptr, gpz_ctx_device(ctx), info, bus_id, cap);
+}
+extern "C" int gpz_mgpu_comm_info(const gpz_mgpu *h, int32_t rank, int32_t info[4], char *bus_id, int32_t cap) {
+    if (!h || !info || rank < 0 || rank >= h->n) return gpz_fail(GPZ_ERR_ARG, "gpz_mgpu_comm_info: bad argument");
+    return comm_info(h->reducer == GPZ_REDUCER_RCCL && rank < (int)h->comms.size() ? h->comms[rank] : nullptr, h->dev[rank], info, bus_id, cap);
+}
 extern "C" const char *gpz_rccl_origin(void) {
     RcclApi *api = rccl_api();
     return api ? api->where.c_str() : "";

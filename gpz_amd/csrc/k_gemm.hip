@@ -517,53 +517,17 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     // those in sequence were 83 000 of a workgroup's 536 000 cycles (tools/gemm_trace.hip), with the compute unit's other
     // workgroup usually in the same phase.  No lane-dependent branches: out-of-range columns are dropped by selects, addresses are
     // a wave-uniform base plus one 32-bit lane offset.
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
     if (EDGE) {
-        // row strip of this wave: rows i0 + 16 wave + crow(r), column tile p
-        const char *pbase = reinterpret_cast<const char *>(Phi + (size_t)(i0 + wv * 16) * ld + j0);
-        char *tbase = reinterpret_cast<char *>(T + (size_t)(i0 + wv * 16) * ldt + j0);
-        // two halves (column tiles 0-3 and 4-7): 16 loads in flight beside the accumulators
-        double pp[4] = {0.0, 0.0, 0.0, 0.0};
+        // row strip of this wave: rows i0 + 16 wave + crow(r), column tile p.  (One tile in eight: its K loop holds eight B fragments
+        // twice beside the accumulators, and a batched form of this epilogue made the compiler spill INSIDE that loop - k_tgemm
+        // 29 -> 63 ms.  The loads stay where they are used.)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            double ph[NFB / 2][4] = {};
-            if (nupart && nvalid > 0) {   // (nvalid = 0: a column piece wholly past the edge - tile 0 itself is out of range)
+        for (int p = 0; p < NFB; ++p) {
+            const int col = j0 + p * 16 + (lane & 15);
+            if (p < nvalid && col < mp) {
 #pragma unroll
-                for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
-                    const int p = hf * (NFB / 2) + ph_i;
-                    const int pc = p < nvalid ? p : 0;   // (a tile past the edge re-reads tile 0; its product is dropped)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ph[ph_i][r] = *reinterpret_cast<const double *>(pbase + ((size_t)crow(r) * ld + pc * 16 + (lane & 15)) * 8);
-                }
+                for (int r = 0; r < 4; ++r) T[(size_t)(i0 + wave * 16 + crow(r)) * ldt + col] = res(p >> 1, p & 1, r);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
-                const int p = hf * (NFB / 2) + ph_i;
-                const int col = j0 + p * 16 + (lane & 15);
-                if (p < nvalid && col < mp) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        *reinterpret_cast<double *>(tbase + ((size_t)crow(r) * ldt + p * 16 + (lane & 15)) * 8) = res(p >> 1, p & 1, r);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (nupart) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i0 + wave * 16 + crow(r);
-#pragma unroll
-                    for (int ph_i = 0; ph_i < NFB / 2; ++ph_i) {
-                        const int p = hf * (NFB / 2) + ph_i;
-                        const int col = j0 + p * 16 + (lane & 15);
-                        const double t = fma(ph[ph_i][r], res(p >> 1, p & 1, r), pp[r]);
-                        pp[r] = (p < nvalid && col < m) ? t : pp[r];
-                        if (p < nvalid && col == mcol) phiw[row] = res(p >> 1, p & 1, r);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (nupart) {
             // the consumers sum WC slots per column tile and row: this wave's sum over ALL its columns of the tile goes to slot `slot`
@@ -571,22 +535,29 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wave * 16 + crow(r);
-                double q = pp[r];
-                q += __shfl_xor(q, 1, 64);
-                q += __shfl_xor(q, 2, 64);
-                q += __shfl_xor(q, 4, 64);
-                q += __shfl_xor(q, 8, 64);
+                double pp = 0.0;
+#pragma unroll
+                for (int p = 0; p < NFB; ++p) {
+                    const int col = j0 + p * 16 + (lane & 15);
+                    if (p < nvalid && col < m) pp = fma(Phi[(size_t)row * ld + col], res(p >> 1, p & 1, r), pp);
+                    if (p < nvalid && col == mcol) phiw[row] = res(p >> 1, p & 1, r);
+                }
+                pp += __shfl_xor(pp, 1, 64);
+                pp += __shfl_xor(pp, 2, 64);
+                pp += __shfl_xor(pp, 4, 64);
+                pp += __shfl_xor(pp, 8, 64);
                 if ((lane & 15) == 0) {
-                    nupart[(size_t)(ct * WC + slot) * n_pad + row] = q;
+                    nupart[(size_t)(ct * WC + slot) * n_pad + row] = pp;
                     if (slot == 0)
 #pragma unroll
-                        for (int qq = 1; qq < WC; ++qq)
-                            if (qq >= nslot) nupart[(size_t)(ct * WC + qq) * n_pad + row] = 0.0;
+                        for (int q = 1; q < WC; ++q)
+                            if (q >= nslot) nupart[(size_t)(ct * WC + q) * n_pad + row] = 0.0;
                 }
             }
         }
         return;
     }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int wru = wv / WC, wcu = wv % WC;
     const char *pbase = reinterpret_cast<const char *>(Phi + (size_t)(i0 + wru * 64) * ld + j0 + wcu * (16 * NI));
     char *tbase = reinterpret_cast<char *>(T + (size_t)(i0 + wru * 64) * ldt + j0 + wcu * (16 * NI));

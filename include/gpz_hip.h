@@ -160,9 +160,10 @@ int gpz_get_phi(gpz_ctx *ctx, double *PHI);
 int gpz_ctx_set_pinv_mode(gpz_ctx *ctx, int mode);
 int gpz_ctx_last_pinv(const gpz_ctx *ctx, double out[4]);
 
-/* Per-stage GPU time (HIP events on the context's stream).  enable!=0 turns recording on;
- * gpz_ctx_timings copies up to `cap` accumulated stage times in ms and the call counts, returns
- * the number of stages; names are static strings. */
+/* Per-stage GPU time (HIP events on the context's stream).  enable = 1: events around every stage (the evaluation then runs as
+ * eager launches); enable = 2: around the dominant stages only (phi_build, syrk, tgemm, moments), the evaluation still replayed as
+ * hipGraph segments with the events between them; 0: off.  gpz_ctx_timings copies up to `cap` accumulated stage times in ms and the
+ * call counts, returns the number of stages; names are static strings. */
 int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);
 int gpz_ctx_timings(gpz_ctx *ctx, const char **names, double *ms, int64_t *calls, int cap);
 int gpz_ctx_reset_timings(gpz_ctx *ctx);
@@ -281,6 +282,12 @@ int gpz_mgpu_predict(const gpz_desc *desc, int32_t n_gpus, const int32_t *device
 int gpz_rccl_unique_id(void *id128);
 int gpz_ctx_init_rccl(gpz_ctx *ctx, const void *id128, int32_t rank, int32_t world, int32_t device);
 const char *gpz_rccl_origin(void);
+/* What the communicator behind a context's (a rank's) all-reduce reports about itself, so that a multi-GPU run can prove N ranks on N
+ * devices from its own output: info[0] = ncclCommCount, info[1] = ncclCommUserRank, info[2] = ncclCommCuDevice (-1 each when there is
+ * no in-library RCCL communicator: single rank, loopback reducer, a caller-supplied hook), info[3] = the HIP device ordinal of the
+ * context; bus_id (optional, cap bytes) = that device's PCI bus id.  No reference counterpart. */
+int gpz_ctx_comm_info(const gpz_ctx *ctx, int32_t info[4], char *bus_id, int32_t cap);
+int gpz_mgpu_comm_info(const gpz_mgpu *h, int32_t rank, int32_t info[4], char *bus_id, int32_t cap);
 
 /* Text of the calling thread's last failure - or of a NEWER failure on another thread (work that failed on one of the library's
  * worker threads); "" when nothing has failed.  The return code of the call is the authority, this is its text.  Valid until the

@@ -472,8 +472,15 @@ def _shard_worker(rank, world, port, q, psi=False, nanfrac=0.0, dtype="f64"):
     ctx = gpz_amd.GPzContext(model, Xs, Ys, gdist.shard_psi(rank, world, Psi, tr, va), oms, trs, vas, rank=rank,
                              world=world, allreduce=gdist.make_allreduce(), patterns=pats, dtype=dtype)
     f, g = ctx.eval(theta)
+    st = dict(ctx.stats)
+    # evaluations 2 .. 4: the graph segments are recorded on the second and replayed from then on, the all-reduce hook (here a
+    # torch.distributed callback moving CUDA buffers over gloo) running eagerly between them - bit for bit the eager result
+    for _ in range(3):
+        f2, g2 = ctx.eval(theta)
+        assert f2 == f and np.array_equal(g2, g)
+    assert "evaluation graph: replayed (" in ctx.route() and "all-reduce between them" in ctx.route(), ctx.route()
     w, iS, part = ctx.solve(theta)
-    q.put((rank, f, g, dict(ctx.stats), w, part, ctx.n_global))
+    q.put((rank, f, g, st, w, part, ctx.n_global))
     ctx.close()
     dist.destroy_process_group()
 
@@ -1363,6 +1370,62 @@ def test_graph_replay_is_bitwise_the_eager_evaluation(route, monkeypatch):
         assert ("evaluation graph: replayed" in txt) == (mode == "graph"), txt
     for (f0, g0), (f1, g1) in zip(res["graph"], res["eager"]):
         assert f0 == f1 and np.array_equal(g0, g1)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+@pytest.mark.parametrize("route", ["VC", "VD_psi", "VC_psi_f32"])
+def test_sharded_graph_replay_is_bitwise_the_eager_evaluation(shards, route, monkeypatch):
+    """A sharded context (world > 1) replays its evaluation as hipGraph SEGMENTS with the all-reduce of the two exchange points called
+    eagerly between them (every rank of the 8-GPU configuration ran ~150 eager launches per evaluation).  gpz_mgpu with the
+    loopback reducer, 2 / 3 / 8 shards on this box's GPU: five thetas replayed and with GPZ_NO_GRAPH, bit for bit; the ranks' contexts
+    say that they replay, in more than one segment."""
+    kw = {}
+    if route == "VC":
+        model, theta, X, Y, Psi, rng = make_problem(1500, 5, 24, 1, "VC", True, seed=71)
+    elif route == "VD_psi":
+        model, theta, X, Y, Psi, rng = make_problem(1300, 4, 20, 2, "VD", True, seed=72, psi=True)
+    else:
+        model, theta, X, Y, _, rng = make_problem(900, 10, 20, 1, "VC", True, seed=73, psi=True)
+        theta = _well_conditioned_gamma(model, theta, rng)
+        Psi = np.zeros((10, 10, 900)); Psi[np.arange(10), np.arange(10), :] = rng.gamma(1.0, 0.2, (10, 900))
+        kw["dtype"] = "f32"
+    tr = rng.random(X.shape[0]) < 0.85
+    thetas = [theta + 0.01 * rng.standard_normal(theta.size) for _ in range(5)]
+    res = {}
+    for mode in ("graph", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("GPZ_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("GPZ_NO_GRAPH", raising=False)
+        mg = gpz_amd.GPzMulti(model, X, Y, Psi, None, tr, ~tr, n_gpus=shards, reducer="loopback", **kw)
+        res[mode] = [mg.eval(t) for t in thetas]
+        txt = [mg.route(r) for r in range(shards)]
+        mg.close()
+        for t in txt:
+            assert ("evaluation graph: replayed (" in t and "all-reduce between them" in t) == (mode == "graph"), t
+    for (f0, g0), (f1, g1) in zip(res["graph"], res["eager"]):
+        assert f0 == f1 and np.array_equal(g0, g1)
+
+
+def test_timing_level_two_replays_and_times_the_dominant_stages():
+    """gpz_ctx_enable_timing(2): the evaluation stays a hipGraph replay, cut around the PHI build, PHI'W PHI, T = PHI [inv|w] and the
+    moment sums, whose HIP events are recorded between the graph launches; bit for bit the untimed result, one call counted per
+    evaluation and stage."""
+    model, theta, X, Y, Psi, rng = make_problem(2000, 6, 40, 1, "VC", True, seed=74)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    ref = [ctx.eval(theta) for _ in range(4)]
+    ctx.enable_timing(2)
+    for _ in range(3):
+        ctx.eval(theta)
+    ctx.reset_timings()
+    out = [ctx.eval(theta) for _ in range(5)]
+    tim = ctx.timings()
+    txt = ctx.route()
+    ctx.close()
+    assert "replayed (9 segments)" in txt, txt
+    assert all(o[0] == ref[0][0] and np.array_equal(o[1], ref[0][1]) for o in out)
+    assert set(tim) == {"phi_build", "syrk", "tgemm", "moments"}, tim
+    assert all(v[1] == 5 and v[0] > 0.0 for v in tim.values()), tim
 
 
 @pytest.mark.gpu

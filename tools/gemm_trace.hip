@@ -1,7 +1,7 @@
 // Developer tool: where does k_tgemm's wall time go?  Runs T = PHI * B at c4's shape from the product source (k_gemm.hip compiled
 // with GPZ_GEMM_TRACE: s_memtime stamps per wave at kernel entry / K-loop start / K-loop end / exit, plus HW_ID) and prints the
 // timeline statistics per compute unit: resident-workgroup coverage, prologue / loop / epilogue shares, gaps between workgroups.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igpz_amd/csrc tools/gemm_trace.hip -o build/gemm_trace
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igpz_amd/csrc tools/gemm_trace.hip gpz_amd/csrc/gpz_options.hip -o build/gemm_trace
 // Run:   build/gemm_trace [rows=1000000] [m=1000]
 #define GPZ_GEMM_TRACE 1
 #include "../gpz_amd/csrc/k_gemm.hip"

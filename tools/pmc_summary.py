@@ -48,6 +48,9 @@ with open(dst, "w") as out:
             util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
             out.write("   -> kernel cycles (GRBM/8) %.4g; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) = %.1f %%\n"
                       % (cyc, 100 * util))
+            if d.get("SQ_INSTS_VALU", 0) > 0:   # SQ_INSTS_VALU counts the MFMAs too (profiles/r05_pmc_counter_semantics.txt)
+                out.write("   -> vector instructions that are not MFMAs, per MFMA: (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA = %.2f\n"
+                          % ((d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / d["SQ_INSTS_MFMA"]))
         if "FETCH_SIZE" in d:
             out.write("   -> fabric-side bytes per launch: fetch %.2f GB (x2 corrected %.2f GB), write %.2f GB\n"
                       % (d["FETCH_SIZE"] * 1024 / 1e9, 2 * d["FETCH_SIZE"] * 1024 / 1e9, d.get("WRITE_SIZE", 0) * 1024 / 1e9))
@@ -69,6 +72,11 @@ if constants and config:
         if b is not None:
             block[name + "_bytes_per_launch"] = b
             block[name + "_kernel"] = k
+            d = data[k]
+            cyc = d.get("GRBM_GUI_ACTIVE", 0) / 8
+            if d.get("SQ_INSTS_MFMA", 0) > 0 and cyc > 0:   # counter-based MFMA utilisation (busy cycles / SIMDs / kernel cycles)
+                block[name + "_mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
+                block[name + "_valu_per_mfma"] = (d.get("SQ_INSTS_VALU", 0) - d["SQ_INSTS_MFMA"]) / d["SQ_INSTS_MFMA"]
     allc = {}
     if os.path.exists(constants):
         allc = json.load(open(constants))
