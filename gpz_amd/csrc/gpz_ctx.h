@@ -205,6 +205,7 @@ struct gpz_ctx {
     int nm = 0;
     // m x m work
     double *A = nullptr, *Lm = nullptr, *Wm = nullptr, *Tmp = nullptr, *Sinv = nullptr, *Bext = nullptr;
+    float *Bext32 = nullptr;   // dtype f32: Bext rounded once per evaluation for the fp32-operand T-GEMM
     double *w = nullptr, *dwda = nullptr, *dgi = nullptr, *logdet = nullptr;
     int *info = nullptr;
     // row epilogue / moments

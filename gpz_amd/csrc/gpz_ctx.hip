@@ -232,6 +232,8 @@ int alloc_mm(gpz_ctx *c) {   // m x m stage buffers
     if (int e = c->ar.alloc(&c->Tmp, mq2)) return e;
     if (int e = c->ar.alloc(&c->Sinv, mq2)) return e;
     if (int e = c->ar.alloc(&c->Bext, (size_t)c->mp * c->mp)) return e;
+    if (c->desc.dtype == GPZ_F32)
+        if (int e = c->ar.alloc(&c->Bext32, (size_t)c->mp * c->mp)) return e;
     if (int e = c->ar.alloc(&c->w, m * k)) return e;
     if (int e = c->ar.alloc(&c->dwda, m * k)) return e;
     if (int e = c->ar.alloc(&c->dgi, m * k)) return e;

@@ -372,10 +372,12 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
         }
         {
             Stage s(c, "tgemm");
-            // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip)
+            // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip), B = [inv(SIGMA) | w]
+            // rounded to fp32 ONCE here instead of by every workgroup while it stages it (half the operand stream; same bits)
+            const bool f32mm = c->psi32 && !c->opt.f32_contractions_off;
+            if (f32mm && c->Bext32) launch_round_f32(c->st, c->Bext, c->Bext32, (size_t)c->mp * c->mp);
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
-                         fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o,
-                         c->psi32 && !c->opt.f32_contractions_off);
+                         fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o, f32mm, 0, 0, f32mm ? c->Bext32 : nullptr);
         }
         if (fused) {
             {

@@ -80,7 +80,9 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol, bool f32_operands = false, int kdim = 0, int ldt = 0);
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands = false, int kdim = 0, int ldt = 0,
+                  const float *B32 = nullptr);   // B32 (with f32_operands): B rounded to fp32 by launch_round_f32, same leading dimension
+void launch_round_f32(hipStream_t st, const double *src, float *dst, size_t n);
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
 #ifndef GPZ_CH_NB

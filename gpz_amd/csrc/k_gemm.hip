@@ -48,6 +48,15 @@ template <> struct MfmaOf<float> {
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 template <typename OT>
+__device__ __forceinline__ typename MfmaOf<OT>::pair_t to_pair(const f2_t v) {   // an operand stored in fp32 (B of the fp32-operand T-GEMM)
+    typename MfmaOf<OT>::pair_t r;
+    r.x = (OT)v.x;
+    r.y = (OT)v.y;
+    return r;
+}
+template <typename BT> struct Pair2 { typedef d2_t t; };
+template <> struct Pair2<float> { typedef f2_t t; };
+template <typename OT>
 __device__ __forceinline__ typename MfmaOf<OT>::pair_t to_pair(const d2_t v) {
     typename MfmaOf<OT>::pair_t r;
     r.x = (OT)v.x;
@@ -362,8 +371,8 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, i
 // Optional fused epilogue (nupart != nullptr):
 //   nupart[(ct*WC + wc)*n_pad + row] = sum over this wave's columns (< m) of PHI[row][col]*T[row][col]   (GPz.m:69)
 //   phiw[row] = T[row][mcol]  (= (PHI w)_row, GPz.m:77)
-template <bool EDGE, int WC, typename OT>
-__device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int ld, const double *__restrict__ B,
+template <bool EDGE, int WC, typename OT, typename BT>
+__device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int ld, const BT *__restrict__ B,
                                            int ldb, double *__restrict__ T, int ldt, int mp, int i0, int j0,
                                            OT (*sA)[128][18], OT (*sB)[16][LDS_LD128],
                                            double *__restrict__ nupart, double *__restrict__ phiw, int m, int mcol,
@@ -390,10 +399,12 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     // (SGPR pair, advanced by scalar adds) plus one loop-invariant 32-bit byte offset per operand, and the K loop is
     // unrolled over the two LDS buffers so that every LDS address is a loop-invariant register plus an immediate.
     // Columns >= mp of the last column tile are read from the last valid pair (never stored, see the epilogue).
-    d2_t ra[Q], rb[Q];
+    typedef typename Pair2<BT>::t bpair_t;   // B as it is stored: fp64, or fp32 rounded once per evaluation (config 5: half the bytes of the
+    d2_t ra[Q];                              // operand every 128-row panel streams again)
+    bpair_t rb[Q];
     const unsigned voa = (unsigned)(((tid >> 3) * ld + (tid & 7) * 2) * 8);
-    const unsigned vob = (unsigned)(((tid >> 6) * ldb + min(j0 + (tid & 63) * 2, mp - 2)) * 8);
-    const size_t qsa = (size_t)(NT / 8) * ld * 8, qsb = (size_t)(NT / 64) * ldb * 8, ksb = (size_t)16 * ldb * 8;
+    const unsigned vob = (unsigned)(((tid >> 6) * ldb + min(j0 + (tid & 63) * 2, mp - 2)) * sizeof(BT));
+    const size_t qsa = (size_t)(NT / 8) * ld * 8, qsb = (size_t)(NT / 64) * ldb * sizeof(BT), ksb = (size_t)16 * ldb * sizeof(BT);
     const char *pa = reinterpret_cast<const char *>(Phi + (size_t)i0 * ld);
     const char *pb = reinterpret_cast<const char *>(B);
     auto gload = [&]() {   // next 16-deep slice
@@ -405,7 +416,7 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             ra[q] = *reinterpret_cast<const d2_t *>(pa + q * qsa + oa);
-            rb[q] = *reinterpret_cast<const d2_t *>(pb + q * qsb + ob);
+            rb[q] = *reinterpret_cast<const bpair_t *>(pb + q * qsb + ob);
         }
         pa += 16 * 8;
         pb += ksb;
@@ -612,9 +623,9 @@ __device__ __forceinline__ void tgemm_body(const double *__restrict__ Phi, int l
     }
 }
 
-template <int WC, typename OT>
+template <int WC, typename OT, typename BT>
 __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict__ Phi, int ld,
-                                                        const double *__restrict__ B, int ldb,
+                                                        const BT *__restrict__ B, int ldb,
                                                         double *__restrict__ T, int ldt, int mp, int nct,
                                                         double *__restrict__ nupart, double *__restrict__ phiw, int m,
                                                         int mcol, long n_pad, int kdim, int nfull, int npiece) {
@@ -623,8 +634,10 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
     // One item per workgroup: the grid is the nfull whole tiles followed by the remaining tiles cut into npiece column pieces each
     // (launch_tgemm): when the tile count leaves the last round of resident workgroups mostly empty (c2: 1568 tiles on 512 slots = 3.06
     // rounds), the pieces of the last 0.06 round fill the chip for a fraction of a tile's time instead of 32 tiles holding it for a whole one.
-    // (A persistent form - two workgroups per compute unit walking the item list - was measured in round 5 and is slower: the two
-    // workgroups of a compute unit then stay in phase, both in their store epilogue at once; profiles/r05_tgemm_timeline.txt.)
+    // (Round 5 measured two other schedules and dropped them - profiles/r05_dropped_kernel_experiments.tar.gz: PERSISTENT workgroups, two
+    // per compute unit walking the item list, stay in phase, both in their store epilogue at once (33.8 ms against 29.3); FOUR 4-wave
+    // workgroups per CU on 128 x 64 tiles overlap the epilogues but lose more inside the K loop, the LDS holding no four 16-deep
+    // double-buffered stages (29.9 - 30.5 ms).)
     const int item = blockIdx.x;
 #ifdef GPZ_GEMM_TRACE
     GPZ_TRACE_MARK(0);
@@ -637,7 +650,7 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
         const int q = item - nfull;
         const int tile = nfull + q / npiece, piece = q % npiece;
         const int rt = tile / nct, ct = tile % nct;
-        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, rt * 128, ct * 128 + piece * (128 / npiece), sA, sB, nupart, phiw, m, mcol,
+        tgemm_body<true, WC, OT, BT>(Phi, ld, B, ldb, T, ldt, mp, rt * 128, ct * 128 + piece * (128 / npiece), sA, sB, nupart, phiw, m, mcol,
                                  n_pad, ct, kdim, 8 / npiece, piece, npiece, item);
         return;
     }
@@ -649,9 +662,9 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
     const int rt = lb / nct, ct = lb % nct;
     const int i0 = rt * 128, j0 = ct * 128;
     if (j0 + 128 <= mp)
-        tgemm_body<false, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
+        tgemm_body<false, WC, OT, BT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
     else
-        tgemm_body<true, WC, OT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
+        tgemm_body<true, WC, OT, BT>(Phi, ld, B, ldb, T, ldt, mp, i0, j0, sA, sB, nupart, phiw, m, mcol, n_pad, ct, kdim, 8, 0, 1, item);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -791,8 +804,16 @@ static int gpz_cu_count() {
     return n;
 }
 
+__global__ void k_round_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+void launch_round_f32(hipStream_t st, const double *src, float *dst, size_t n) {
+    hipLaunchKernelGGL(k_round_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
-                  double *nupart, double *phiw, int m, int mcol, bool f32_operands, int kdim, int ldt) {
+                  double *nupart, double *phiw, int m, int mcol, bool f32_operands, int kdim, int ldt, const float *B32) {
     constexpr int WC = GPZ_GEMM_WC;
     const int nct = (mp + 127) / 128;
     if (kdim <= 0) kdim = mp;
@@ -807,11 +828,14 @@ void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, in
     if (npiece == 1) tail = 0;
     const int nfull = W - tail;
     dim3 grid(nfull + tail * npiece), block(128 * WC);
-    if (f32_operands)
-        hipLaunchKernelGGL((k_tgemm<WC, float>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
+    if (f32_operands && B32)   // B already rounded to fp32 (launch_round_f32, once per evaluation): same bits, half the operand stream
+        hipLaunchKernelGGL((k_tgemm<WC, float, float>), grid, block, 0, st, Phi, ld, B32, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
+                           (long)n_pad, kdim, nfull, npiece);
+    else if (f32_operands)
+        hipLaunchKernelGGL((k_tgemm<WC, float, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
                            (long)n_pad, kdim, nfull, npiece);
     else
-        hipLaunchKernelGGL((k_tgemm<WC, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
+        hipLaunchKernelGGL((k_tgemm<WC, double, double>), grid, block, 0, st, Phi, ld, B, ldb, T, ldt, mp, nct, nupart, phiw, m, mcol,
                            (long)n_pad, kdim, nfull, npiece);
 }
 
