@@ -15,7 +15,7 @@ if "--constants" in argv:
 if "--config" in argv:
     i = argv.index("--config"); config = argv[i + 1]; del argv[i:i + 2]
 base, dst = argv[0].rstrip("/") + "/", argv[1]
-what = argv[2] if len(argv) > 2 else ("--steps 2 --warmup 1 --no-cpu-baseline\n"
+what = argv[2] if len(argv) > 2 else ("--steps 2 --warmup 2 --no-cpu-baseline\n"
                                       "# (c4: n=1e6 d=10 m=1000 VC hetero, 1 x MI355X")
 
 
