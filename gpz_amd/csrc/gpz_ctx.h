@@ -206,6 +206,8 @@ struct gpz_ctx {
     // m x m work
     double *A = nullptr, *Lm = nullptr, *Wm = nullptr, *Tmp = nullptr, *Sinv = nullptr, *Bext = nullptr;
     float *Bext32 = nullptr;   // dtype f32: Bext rounded once per evaluation for the fp32-operand T-GEMM
+    char *oz_A = nullptr, *oz_B = nullptr;   // GPZ_TGEMM_INT8: digit planes of PHI and of Bext (k_oz.hip)
+    double *oz_cs = nullptr;                 // column scales of Bext
     double *w = nullptr, *dwda = nullptr, *dgi = nullptr, *logdet = nullptr;
     int *info = nullptr;
     // row epilogue / moments

@@ -466,6 +466,14 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         }
     }
     c->fused = (k == 1) || !c->gen;   // the general GC/VC path chains r1 / r2 through its records: single output only
+#ifdef GPZ_DEV_SWITCHES
+    // the int8-sliced T-GEMM (developer build, GPZ_TGEMM_INT8): fp64 contexts whose PHI lies in [0, 1] - no input noise on a covariance kind - with PHI resident
+    if (c->opt.tgemm_int8 && c->desc.dtype != GPZ_F32 && !c->tile_rows && !(c->gen && c->has_psi) && oz_prepare_device() == 0) {
+        if ((rc = c->ar.alloc(&c->oz_A, oz_a_bytes((long)np, c->mp)))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->oz_B, oz_b_bytes(c->mp)))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->oz_cs, (size_t)c->mp))) return bail(rc);
+    }
+#endif
     if (!c->fused && (rc = c->ar.alloc(&c->dL, np * mp))) return bail(rc);
     if ((rc = c->ar.alloc(&c->lnbeta, np * k))) return bail(rc);
     if ((rc = c->ar.alloc(&c->wbeta, np * k))) return bail(rc);

@@ -375,9 +375,21 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
             // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip), B = [inv(SIGMA) | w]
             // rounded to fp32 ONCE here instead of by every workgroup while it stages it (half the operand stream; same bits)
             const bool f32mm = c->psi32 && !c->opt.f32_contractions_off;
+#ifdef GPZ_DEV_SWITCHES
+            if (c->oz_A && !f32mm) {
+                // developer build, GPZ_TGEMM_INT8: the same product as 28 exact int8 GEMMs of digit planes on the int8 matrix pipe
+                if (o == 0) launch_oz_slice_a(c->st, c->Phi, c->mp, (long)c->tr.n_pad, c->m, c->mp, c->oz_A);
+                launch_oz_slice_b(c->st, c->Bext, c->mp, c->mp, c->mp, c->oz_cs, c->oz_B);
+                launch_oz_tgemm(c->st, c->oz_A, c->oz_B, c->oz_cs, c->Phi, c->mp, c->T, c->mp, (long)c->tr.n_pad, c->mp,
+                                fused ? c->nupart : nullptr, fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o);
+            } else {
+#else
+            {
+#endif
             if (f32mm && c->Bext32) launch_round_f32(c->st, c->Bext, c->Bext32, (size_t)c->mp * c->mp);
             launch_tgemm(c->st, c->Phi, c->mp, c->Bext, c->mp, c->T, c->tr.n_pad, c->mp, fused ? c->nupart : nullptr,
                          fused ? c->phiw + (size_t)o * c->tr.n_pad : c->phiw, c->m, c->m + o, f32mm, 0, 0, f32mm ? c->Bext32 : nullptr);
+            }
         }
         if (fused) {
             {

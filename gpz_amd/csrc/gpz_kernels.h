@@ -83,6 +83,14 @@ void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, in
                   double *nupart, double *phiw, int m, int mcol, bool f32_operands = false, int kdim = 0, int ldt = 0,
                   const float *B32 = nullptr);   // B32 (with f32_operands): B rounded to fp32 by launch_round_f32, same leading dimension
 void launch_round_f32(hipStream_t st, const double *src, float *dst, size_t n);
+// ---- T = PHI * B on the int8 matrix pipe (k_oz.hip): 7 x 7 digit planes, 28 exact int32 products --------------------------------
+size_t oz_a_bytes(long n_pad, int mp);
+size_t oz_b_bytes(int mp);
+int oz_prepare_device();   // once per device, before the first launch_oz_tgemm
+void launch_oz_slice_a(hipStream_t st, const double *Phi, int ld, long n_pad, int m, int mp, char *Apl);      // PHI in [0, 1], columns < m
+void launch_oz_slice_b(hipStream_t st, const double *B, int ldb, int krows, int mp, double *cs, char *Bpl);   // cs: mp column scales
+void launch_oz_tgemm(hipStream_t st, const char *Apl, const char *Bpl, const double *cs, const double *Phi, int ld, double *T, int ldt,
+                     long n_pad, int mp, double *nupart, double *phiw, int m, int mcol);                      // outputs as launch_tgemm's
 void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp, int ld, int mq, int gs);
 
 #ifndef GPZ_CH_NB

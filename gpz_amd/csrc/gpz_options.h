@@ -35,6 +35,7 @@ struct gpz_options {
     bool round_phi32 = false;            // GPZ_EXPERIMENT_ROUND_PHI32  (tools/f32_operand_experiment.py)
     bool cpsi_off = false;               // GPZ_CPSI_OFF              fp64 GC/VC + Psi: general kernels instead of 16 x 16 tiles
     bool cpsi4_off = false;              // GPZ_CPSI4_OFF             ... instead of 4 x 4 tiles
+    bool tgemm_int8 = false;             // GPZ_TGEMM_INT8            T = PHI [inv(SIGMA) | w] as 28 int8 products of digit planes (k_oz.hip: measured, not faster)
     int syrk_wgs = 0, syrk_s1 = 0, syrk_s2 = 0;   // GPZ_SYRK_WGS / _S1 / _S2   row-split tuning of k_syrk
     int mom_nc = 0;                      // GPZ_MOM_NC                chunk count of the moment kernels
 };

@@ -33,6 +33,7 @@ gpz_options gpz_options_load() {
     o.round_phi32 = env_set("GPZ_EXPERIMENT_ROUND_PHI32");
     o.cpsi_off = env_set("GPZ_CPSI_OFF");
     o.cpsi4_off = env_set("GPZ_CPSI4_OFF");
+    o.tgemm_int8 = env_set("GPZ_TGEMM_INT8");
     o.syrk_wgs = (int)env_long("GPZ_SYRK_WGS", 0);
     o.syrk_s1 = (int)env_long("GPZ_SYRK_S1", 0);
     o.syrk_s2 = (int)env_long("GPZ_SYRK_S2", 0);

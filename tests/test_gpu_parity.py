@@ -1407,6 +1407,25 @@ def test_sharded_graph_replay_is_bitwise_the_eager_evaluation(shards, route, mon
         assert f0 == f1 and np.array_equal(g0, g1)
 
 
+@pytest.mark.parametrize("shape", [(3000, 4, 100, "VD"), (4100, 6, 300, "VC"), (2600, 3, 130, "GL")])
+def test_int8_sliced_tgemm_route_agrees_with_the_fp64_mfma_route(tmp_path, shape):
+    """T = PHI [inv(SIGMA) | w] as 28 exact int8 products of 7 x 7 balanced base-256 digit planes on v_mfma_i32_32x32x32_i8 (k_oz.hip;
+    developer build, GPZ_TGEMM_INT8 - measured at c4 and not faster): objective and gradient of the whole evaluation
+    against the fp64 MFMA route of this process and against the oracle.  Partial column panels (m = 100, 130, 300), a K that is no
+    multiple of 32, rows padded to the 128-row panel."""
+    from helpers import eval_with_dev_switches
+    n, d, m, method = shape
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, method, True, seed=4000 + m)
+    ref = O.GPz(theta, model, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    ctx.close()
+    f, g, info = eval_with_dev_switches(tmp_path, method, m, d, 1, True, theta, X, Y, None, {"GPZ_TGEMM_INT8": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-13 * abs(f0) and rel(g, g0) <= 1e-11, (abs(f - f0) / abs(f0), rel(g, g0))
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+
+
 def test_timing_level_two_replays_and_times_the_dominant_stages():
     """gpz_ctx_enable_timing(2): the evaluation stays a hipGraph replay, cut around the PHI build, PHI'W PHI, T = PHI [inv|w] and the
     moment sums, whose HIP events are recorded between the graph launches; bit for bit the untimed result, one call counted per
