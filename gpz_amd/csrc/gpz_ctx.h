@@ -2,7 +2,8 @@
 // helpers the host translation units share.
 //   gpz_arena.hip    error text, released-buffer cache, allocation test hook
 //   gpz_ctx.hip      context creation / destruction, accessors, gpz_ctx_route
-//   gpz_eval.hip     the evaluation pipeline: stage A (PHI, PHI'W PHI), the m x m stage, the tail; gpz_eval / gpz_solve; graph capture
+//   gpz_eval.hip     the evaluation pipeline: stage A (PHI, PHI'W PHI), the m x m stage, the tail; gpz_solve, gpz_get_phi
+//   gpz_graph.hip    one evaluation as recorded hipGraph segments: recording, cuts, replay; gpz_eval / gpz_eval_dev
 //   gpz_predict.hip  the stand-alone entry points (gpz_phi, gpz_predict_*, gpz_prior, gpz_inv_logdet, gpz_dxy, gpz_nan_groups)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -351,4 +352,6 @@ int setup_data(gpz_ctx *c, int64_t n_tot, const double *X, const double *Y, cons
                const double *omega, const uint8_t *training, const uint8_t *validation, const uint8_t *patterns = nullptr,
                int32_t n_patterns = 0);
 int build_phi(gpz_ctx *c);
+int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nullptr);   // gpz_eval.hip: unpack .. all-reduce 1
+int eval_tail(gpz_ctx *c, bool pinv);                                                // gpz_eval.hip: the m x m stage .. result copy
 }   // namespace gpzi

@@ -225,7 +225,7 @@ static int stage_a_tiles(gpz_ctx *c) {
 }
 
 // Stage A: theta -> PHI, ln beta, omega*beta, S_o = PHI' W_o PHI (incl. PHI' W_o y), sums; all-reduce #1.
-static int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev = nullptr) {
+int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev) {
     if (theta_dev) {   // device-resident caller (gpz_eval_dev): theta never visits the host
         HIPCHK(hipMemcpyAsync(c->theta_d, theta_dev, (size_t)c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
     } else {
@@ -322,7 +322,7 @@ static int stage_b_pinv(gpz_ctx *c, int o) {
 
 // Everything of an evaluation after stage A (SIGMA partials reduced): solve, T-GEMM, row epilogue, moments, validation,
 // all-reduce #2, finish, result copy.  pinv selects the inverse: Cholesky (false) or truncating SVD (true).
-static int eval_tail(gpz_ctx *c, bool pinv) {
+int eval_tail(gpz_ctx *c, bool pinv) {
     const size_t mp = c->mp, m = c->m, k = c->k;
     double *mom = c->comm2;
     double *cols = mom + m * c->nm;
@@ -611,158 +611,6 @@ static int eval_tail(gpz_ctx *c, bool pinv) {
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
     return 0;
-}
-
-static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
-                       double stats[4], double diag[2]);
-
-}   // namespace gpzi
-extern "C" int gpz_eval(gpz_ctx *c, const double *theta, double *f, double *g, double stats[4], double diag[2]) {
-    if (!c || !theta || !f || !g) return gpz_fail(GPZ_ERR_ARG, "gpz_eval: null argument");
-    return eval_common(c, theta, nullptr, f, g, nullptr, stats, diag);
-}
-namespace gpzi {
-
-}   // namespace gpzi
-extern "C" int gpz_eval_dev(gpz_ctx *c, const double *theta_dev, double *f, double *g_dev, double stats[4], double diag[2]) {
-    if (!c || !theta_dev || !f || !g_dev) return gpz_fail(GPZ_ERR_ARG, "gpz_eval_dev: null argument");
-    c->g_dev_out = g_dev;
-    const int rc = eval_common(c, nullptr, theta_dev, f, nullptr, g_dev, stats, diag);
-    c->g_dev_out = nullptr;
-    return rc;
-}
-namespace gpzi {
-
-// Close the graph segment being recorded (gpz_ctx.h: struct GraphSeg) and, unless it is the last, open the next one.
-int graph_cut(gpz_ctx *c, bool last) {
-    if (!c->capturing || !c->cap) return -1;
-    gpz_ctx::GraphSeg s;
-    s.stage = c->cap_stage;
-    s.count_call = c->cap_stage_first;
-    c->cap_stage_first = false;
-    if (!c->cap_failed) {
-        hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(c->st, &g);
-        if (e == hipSuccess && g) {
-            size_t nn = 0;
-            e = hipGraphGetNodes(g, nullptr, &nn);
-            if (e == hipSuccess && nn > 0) e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
-        } else if (e == hipSuccess) e = hipErrorUnknown;
-        if (g) (void)hipGraphDestroy(g);
-        if (e == hipSuccess && !last) e = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            c->cap_failed = true;
-            if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph: segment %zu: %s\n", c->cap->segs.size(), hipGetErrorString(e));
-        }
-    }
-    c->cap->segs.push_back(s);
-    return c->cap_failed ? -1 : 0;
-}
-static void graph_set_drop(gpz_ctx::GraphSet &gs) {
-    for (auto &s : gs.segs)
-        if (s.exec) (void)hipGraphExecDestroy(s.exec);
-    gs.segs.clear();
-}
-// One evaluation from the recorded segments: graph launches with, between them, the all-reduce hook of the exchange points and the
-// events of the dominant stages (timing 2).
-static int graph_replay(gpz_ctx *c, gpz_ctx::GraphSet &gs) {
-    for (auto &s : gs.segs) {
-        hipEvent_t e0{}, e1{};
-        if (s.stage >= 0) {
-            e0 = c->tm.get();
-            e1 = c->tm.get();
-            HIPCHK(hipEventRecord(e0, c->st));
-        }
-        if (s.exec) HIPCHK(hipGraphLaunch(s.exec, c->st));
-        if (s.stage >= 0) {
-            HIPCHK(hipEventRecord(e1, c->st));
-            c->tm.pending.push_back({s.stage, e0, e1, s.count_call});
-        }
-        if (s.hook_count && c->ar_fn(c->ar_user, s.hook_buf, s.hook_count, (void *)c->st) != 0) return gpz_fail(GPZ_ERR_COMM, "all-reduce hook failed");
-    }
-    HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev, double *f, double *g, double *g_dev,
-                       double stats[4], double diag[2]) {
-    (void)g_dev;
-    gpz_opts_scope opts_scope(&c->opt);
-    HIPCHK(hipSetDevice(c->device));
-    c->pinv_last[0] = c->pinv_last[1] = c->pinv_last[2] = c->pinv_last[3] = 0.0;
-    const bool no_graph = c->opt.no_graph;   // (latched at creation: a context is either replayed or eager for its whole life)
-    gpz_ctx::GraphSet &gs = c->gset[c->timing == 2 ? 1 : 0];
-    const bool graphable = theta && !c->g_dev_out && c->timing != 1 && c->pinv_mode != 1 && !no_graph && gs.state >= 0;
-    bool done = false;
-    if (graphable && gs.state == 2) {
-        memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
-        if (int e = graph_replay(c, gs)) return e;
-        done = true;
-    } else if (graphable && gs.state == 1) {
-        // record: nothing runs yet (the hooks of a sharded context are not called either) - the replay below is this call's evaluation
-        int rc = 0;
-        const char *why = "";
-        hipStream_t user_st = c->st;
-        hipError_t he = c->graph_st ? hipSuccess : hipStreamCreate(&c->graph_st);
-        if (he == hipSuccess) {
-            c->st = c->graph_st;
-            he = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
-        }
-        if (he == hipSuccess) {
-            c->capturing = true;
-            c->cap = &gs;
-            c->cap_stage = -1;
-            c->cap_stage_first = c->cap_failed = false;
-            if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";   // (k_unpack clears the status words)
-            if (!rc && (rc = eval_tail(c, false))) why = "stage B";
-            (void)graph_cut(c, true);
-            if (c->cap_failed && !rc) { rc = -1; why = "segment"; }
-            c->capturing = false;
-            c->cap = nullptr;
-        } else {
-            rc = -1; why = "begin capture";
-        }
-        c->st = user_st;
-        if (rc && c->opt.graph_debug)
-            fprintf(stderr, "gpz: evaluation graph: %s: %s | %s\n", why, hipGetErrorString(he), gpz_last_error());
-        if (c->opt.graph_debug) fprintf(stderr, "gpz: evaluation graph recording %s (%zu segments)\n", rc ? "failed" : "ok", gs.segs.size());
-        if (!rc) {
-            gs.state = 2;
-            memcpy(c->theta_h, theta, (size_t)c->p * sizeof(double));
-            if (int e = graph_replay(c, gs)) return e;
-            done = true;
-        } else {                     // not recordable here: stay on plain launches for the life of the context
-            (void)hipGetLastError();
-            graph_set_drop(gs);
-            gs.state = -1;
-        }
-    }
-    if (!done) {
-        if (int e = stage_a(c, theta, theta_dev)) return e;   // (k_unpack clears the status words)
-        if (int e = eval_tail(c, c->pinv_mode == 1)) return e;
-        if (graphable && gs.state == 0) gs.state = 1;
-    }
-    // k_cond_flag (info[1], returned in slot 7 of the statistics block): SIGMA is close enough to singular that
-    // inv_logdet.m may truncate -> redo the solve and everything after it through the SVD route.  PHI and the
-    // reduced partials of stage A are still in place; every rank sees the same SIGMA and takes the same branch.
-    if (c->pinv_mode == 0 && c->out_h[1 + c->p + 7] != 0.0) {
-        HIPCHK(hipMemsetAsync(c->info, 0, 2 * sizeof(int), c->st));
-        if (int e = eval_tail(c, true)) return e;
-    }
-    const bool have_valid = c->va.n_pad > 0;
-    if (c->timing || !c->tm.pending.empty()) collect_timings(c);
-    *f = c->out_h[0];
-    if (g) memcpy(g, c->out_h + 1, (size_t)c->p * sizeof(double));
-    const double *st = c->out_h + 1 + c->p;
-    if (stats) {
-        stats[0] = st[0];
-        stats[1] = st[1];
-        if (have_valid) { stats[2] = st[2]; stats[3] = st[3]; }
-    }
-    if (diag) { diag[0] = st[4]; diag[1] = st[5]; }
-    return GPZ_OK;
 }
 
 }   // namespace gpzi
