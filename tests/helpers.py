@@ -98,7 +98,9 @@ def eval_with_dev_switches(tmp_path, method, m, d, k, hetero, theta, X, Y, Psi, 
     in which the A/B switches of gpz_amd/csrc/gpz_options.h exist), with `switches` in its environment.  -> (f, g, info)"""
     import subprocess
     import sys
-    assert os.path.exists(DEV_LIB), "developer build missing: run ./build.sh --dev (or __graft_entry__.build())"
+    if not os.path.exists(DEV_LIB):      # (normally built by __graft_entry__.build() and shipped in-tree; a bare checkout builds it here)
+        subprocess.run(["bash", os.path.join(ROOT, "build.sh"), "--dev"], cwd=ROOT, check=True, capture_output=True, timeout=1800)
+    assert os.path.exists(DEV_LIB), "developer build missing: ./build.sh --dev failed"
     np.savez(tmp_path / "in.npz", theta=theta, X=X, Y=Y, Psi=(Psi if Psi is not None else np.zeros(0)), has_psi=int(Psi is not None))
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import gpz_amd\n"
             "z = np.load(%r)\n"
