@@ -60,6 +60,18 @@ def pmc_traffic(config):
         return None
 
 
+def ranks_describe_n_devices(per_rank, n):
+    """A real N-GPU run proves itself from its own output: every rank's communicator must report N ranks (ncclCommCount), the ranks
+    0 .. N-1 must appear once each (ncclCommUserRank), on N different PCI devices.  -> None, or the reason as text."""
+    counts = sorted({q.get("nccl_count") for q in per_rank})
+    ranks_seen = sorted(q.get("nccl_rank") for q in per_rank)
+    buses = [q.get("pci_bus_id") for q in per_rank]
+    if len(per_rank) != n or counts != [n] or ranks_seen != list(range(n)) or len(set(buses)) != n or "" in buses or None in buses:
+        return (f"the communicators do not describe {n} ranks on {n} devices: {len(per_rank)} rank records, ncclCommCount {counts}, "
+                f"ncclCommUserRank {ranks_seen}, PCI bus ids {buses}")
+    return None
+
+
 def synth(cfg, n=None):
     """Synthetic problem of SURVEY.md §8d: default_rng(1) data, default_rng(2) theta perturbation."""
     from gpz_amd.api import Model
@@ -365,14 +377,10 @@ def main():
     else:
         per_rank_single = ctx.comm_info()
     if per_rank is not None and rank == 0 and (native or (use_dist and comm == "rccl")):
-        # self-verification of a real multi-GPU run: every rank's communicator must report N ranks, the ranks 0..N-1 once each, on N
-        # different PCI devices.  (The loopback / gloo test forms share one device and have no RCCL communicator: not checked.)
-        counts = sorted({q["nccl_count"] for q in per_rank})
-        ranks_seen = sorted(q["nccl_rank"] for q in per_rank)
-        buses = [q["pci_bus_id"] for q in per_rank]
-        if counts != [n_gpus_used] or ranks_seen != list(range(n_gpus_used)) or len(set(buses)) != n_gpus_used or "" in buses:
-            raise SystemExit(f"bench.py: the communicators do not describe {n_gpus_used} ranks on {n_gpus_used} devices: ncclCommCount {counts}, "
-                             f"ncclCommUserRank {ranks_seen}, PCI bus ids {buses}")
+        # self-verification of a real multi-GPU run (the loopback / gloo test forms share one device and have no RCCL communicator: not checked)
+        why = ranks_describe_n_devices(per_rank, n_gpus_used)
+        if why:
+            raise SystemExit("bench.py: " + why)
     graph_pass = {"ms_per_step": elapsed / args.steps * 1e3, "evals_per_s": args.steps / elapsed, "route": route,
                   "note": "the timed region itself: hipGraph replay" + (", events around the dominant stages only" if args.timed_events == "dominant" else ", no events")}
     finite = bool(np.isfinite(fs).all() and np.isfinite(g).all())

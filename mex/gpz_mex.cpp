@@ -238,6 +238,17 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (!strcmp(cmd, "reset")) { cleanup(); gpz_release_cached_memory(); return; }   /* also the buffers the library keeps between calls */
     if (!strcmp(cmd, "builds")) { plhs[0] = mxCreateDoubleScalar((double)g_builds); return; }
     if (!strcmp(cmd, "gpus")) { plhs[0] = mxCreateDoubleScalar(g_mg ? (double)gpz_mgpu_size(g_mg) : 0.0); return; }
+    if (!strcmp(cmd, "comm")) {   /* what each rank's communicator reports about itself: [ncclCommCount ncclCommUserRank ncclCommCuDevice hipDevice] per row */
+        const int n = g_mg ? (int)gpz_mgpu_size(g_mg) : 0;
+        plhs[0] = mxCreateDoubleMatrix((mwSize)n, 4, mxREAL);
+        double *o = mxGetPr(plhs[0]);
+        for (int r = 0; r < n; ++r) {
+            int32_t info[4];
+            if (gpz_mgpu_comm_info(g_mg, r, info, NULL, 0)) mexErrMsgIdAndTxt("gpz:lib", "%s", gpz_last_error());
+            for (int q = 0; q < 4; ++q) o[r + (size_t)q * n] = (double)info[q];
+        }
+        return;
+    }
     /* ---- stand-alone entries (no context) ---- */
     if (!strcmp(cmd, "getphi")) {
         if (nrhs != 5) mexErrMsgIdAndTxt("gpz:usage", "getphi needs model,theta,X,Psi");

@@ -68,7 +68,7 @@ static void call(const char *what, int nlhs, std::vector<const mxArray *> args, 
 int main() {
     const int n = 37, d = 3, m = 5, k = 2;
     mxArray *cmd_eval = mexrt_string("eval"), *cmd_solve = mexrt_string("solve"), *cmd_phi = mexrt_string("phi");
-    mxArray *cmd_reset = mexrt_string("reset"), *cmd_gpus = mexrt_string("gpus"), *cmd_builds = mexrt_string("builds");
+    mxArray *cmd_reset = mexrt_string("reset"), *cmd_gpus = mexrt_string("gpus"), *cmd_builds = mexrt_string("builds"), *cmd_comm = mexrt_string("comm");
     mxArray *X = mat(n, d), *Y = mat(n, k), *om = mat(n, 1, 1.0);
     std::vector<unsigned char> trb(n), vab(n);
     for (int i = 0; i < n; ++i) { trb[i] = i % 4 != 0; vab[i] = !trb[i]; }
@@ -129,6 +129,7 @@ int main() {
         mxArray *f32 = model(d, m, k, "VD", true, "f32", 2.0, "loopback");
         call("eval with dtype / n_gpus / reducer", 3, {cmd_eval, th, f32, X, Y, none, none, none, none}, nullptr);
         call("gpus", 1, {cmd_gpus}, nullptr);
+        call("comm", 1, {cmd_comm}, nullptr);
         mxArray *baddt = model(d, m, k, "VD", true, "f16");
         call("eval bad dtype", 1, {cmd_eval, th, baddt, X, Y, none, none, none, none}, "gpz:model");
         mxArray *badred = model(d, m, k, "VD", true, nullptr, 1.0, "tree");

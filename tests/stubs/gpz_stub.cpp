@@ -87,6 +87,13 @@ int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32_t *, int32
 }
 void gpz_mgpu_destroy(gpz_mgpu *h) { delete h; }
 int32_t gpz_mgpu_size(const gpz_mgpu *h) { return h ? h->n_gpus : 0; }
+int gpz_mgpu_comm_info(const gpz_mgpu *h, int32_t rank, int32_t info[4], char *bus, int32_t cap) {
+    if (!h || !info || rank < 0 || rank >= h->n_gpus) return fail(GPZ_ERR_ARG, "gpz_mgpu_comm_info: bad argument");
+    info[0] = info[1] = info[2] = -1;
+    info[3] = 0;
+    if (bus && cap > 0) bus[0] = 0;
+    return 0;
+}
 int32_t gpz_mgpu_alive(const gpz_mgpu *h) { return h ? 1 : 0; }
 int64_t gpz_mgpu_theta_len(const gpz_mgpu *h) { return h ? h->p : -1; }
 gpz_ctx *gpz_mgpu_ctx(gpz_mgpu *h, int32_t r) { return (h && r >= 0 && r < h->n_gpus) ? &h->ctx[r] : nullptr; }

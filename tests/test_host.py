@@ -280,3 +280,20 @@ def test_train_over_three_loopback_shards_reproduces_the_single_context_run():
     for name in ("last", "best"):
         assert rel(m3.sets[name]["theta"], m1.sets[name]["theta"]) <= 1e-7
         assert rel(m3.sets[name]["w"], m1.sets[name]["w"]) <= 1e-6
+
+
+def test_bench_refuses_rank_records_that_do_not_describe_n_devices():
+    """bench.py --gpus N gathers what every rank's RCCL communicator reports about itself (gpz_*_comm_info) and must fail unless that
+    is N ranks, 0 .. N-1 once each, on N different PCI devices (the first real multi-GPU run has to prove itself)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    good = [{"nccl_count": 4, "nccl_rank": r, "pci_bus_id": "0000:%02x:00.0" % (5 + r)} for r in range(4)]
+    assert bench.ranks_describe_n_devices(good, 4) is None
+    assert "ncclCommCount" in bench.ranks_describe_n_devices([dict(q, nccl_count=2) for q in good], 4)           # a smaller communicator
+    assert bench.ranks_describe_n_devices([dict(q, nccl_rank=0) for q in good], 4)                                 # a rank twice
+    assert bench.ranks_describe_n_devices([dict(q, pci_bus_id=good[0]["pci_bus_id"]) for q in good], 4)            # ranks sharing a device
+    assert bench.ranks_describe_n_devices(good[:3], 4)                                                             # a rank missing
+    assert bench.ranks_describe_n_devices([dict(q, nccl_count=-1, nccl_rank=-1) for q in good], 4)                 # no in-library communicator

@@ -265,6 +265,8 @@ def test_gateway_reducer_field_and_loopback_shards():
     one = mex(2, "eval", theta, model_struct(model, n_gpus=1.0), X, Y, None, None, None, None)
     three = mex(2, "eval", theta, model_struct(model, n_gpus=3.0, reducer="loopback"), X, Y, None, None, None, None)
     assert mex(1, "gpus") == 3.0
+    comm = mex(1, "comm")      # per rank [ncclCommCount ncclCommUserRank ncclCommCuDevice hipDevice]: no RCCL communicator behind loopback shards
+    assert comm.shape == (3, 4) and np.all(comm[:, :3] == -1.0) and np.all(comm[:, 3] == 0.0)
     assert abs(one[0][0, 0] - three[0][0, 0]) <= 1e-12 * abs(one[0][0, 0]) and rel(three[1], one[1]) <= 1e-9
     with pytest.raises(MexError) as e:
         mex(1, "eval", theta, model_struct(model, reducer="carrier-pigeon"), X, Y, None, None, None, None)
