@@ -1,6 +1,7 @@
-mkdir -p gpurun_out/r05f
-for spec in "fuzz_parity.py 300 50501" "fuzz_parity.py 200 50502 wide" "fuzz_predict.py 200 50503" "fuzz_predict.py 120 50504 wide" "fuzz_f32.py 60 50505" "fuzz_mgpu.py 120 50506" "fuzz_sharded.py 40 50507 2"; do
+# Round-5 long fuzz pass (GPU box): fresh seeds on the final code of the round
+mkdir -p gpurun_out/r05f2
+for spec in "fuzz_parity.py 1000 60601" "fuzz_parity.py 600 60602 wide" "fuzz_predict.py 600 60603" "fuzz_predict.py 300 60604 wide" "fuzz_f32.py 150 60605" "fuzz_mgpu.py 300 60606" "fuzz_sharded.py 80 60607 2"; do
   set -- $spec
-  timeout 1500 python tools/$@ 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/r05f/$1_$3.txt
-  echo "== $spec"; tail -2 gpurun_out/r05f/$1_$3.txt
+  timeout 2400 python tools/$@ 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/r05f2/$1_$3.txt
+  echo "== $spec"; tail -1 gpurun_out/r05f2/$1_$3.txt
 done
