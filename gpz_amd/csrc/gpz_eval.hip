@@ -276,12 +276,11 @@ static void stage_b(gpz_ctx *c, int o) {
         Stage s(c, "chol");
         launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq, c->Wm, c->logdet + o);   // clears Wm, logdet too
         for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-            launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet + o, c->info);
+            launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet + o, c->info);   // + the diagonal blocks of inv(L)
         }
     }
     {
         Stage s(c, "trtri");
-        launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
         for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     }
     {

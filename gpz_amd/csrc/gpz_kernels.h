@@ -100,8 +100,8 @@ void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp,
 // A (mq x lda, mq % 32 == 0) <- S[0:m,0:m] + diag(alpha), identity on the padding.
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz = nullptr, double *logdet = nullptr);   // Wz (mq x mq) and *logdet are cleared when given
 // panel + trailing update of one step in a single launch (GPZ_CH_NB == 32)
-void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info);
-void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq);
+// one step: panel + trailing update, the factor into Lm, the diagonal block of inv(L) into W (W cleared beforehand; nullptr: not wanted)
+void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info);
 void launch_zero(hipStream_t st, double *p, size_t count);
 // Bext (mp x mp) <- [inv | w column at m | 0]; iS (m x m col-major == row-major, symmetric) copy; w, dwda, diag.
 void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const double *S, int lds, const double *alpha,

@@ -616,12 +616,10 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     (void)hipMemset(alpha0, 0, (size_t)m * sizeof(double));
     (void)hipMemset(c->info, 0, 2 * sizeof(int));
     const int mq = c->mq;
-    launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq, nullptr, c->logdet);
+    launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq, c->Wm, c->logdet);   // clears Wm too
     for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-        launch_chol_step(c->st, c->A, c->Lm, mq, mq, k0, c->logdet, c->info);
+        launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet, c->info);
     }
-    launch_zero(c->st, c->Wm, (size_t)mq * mq);
-    launch_trtri_diag(c->st, c->Lm, c->Wm, mq, mq);
     for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
                     true);

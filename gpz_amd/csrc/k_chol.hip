@@ -12,6 +12,16 @@
 #include "gpz_kernels.h"
 
 #define CH_NB GPZ_CH_NB
+#ifdef GPZ_CHOL_TRACE   // developer builds only (tools/chol_trace.hip): s_memtime stamps of the phases of one factorisation step
+__device__ unsigned long long *g_chol_trace = nullptr;
+#define CH_MARK(slot)                                                                                                     \
+    do {                                                                                                                  \
+        if (g_chol_trace && (threadIdx.x & 63) == 0 && blockIdx.x < 4)                                                    \
+            g_chol_trace[(((size_t)(k0 / CH_NB) * 4 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CH_MARK(slot) do { } while (0)
+#endif
 
 // Also clears what the chain behind it accumulates into (two launches of k_zero less per output: an evaluation of a small problem is
 // a sequence of ~4 us launches): Wz (mq x mq, the inverse factor's workspace) and *logdet, when given.
@@ -31,93 +41,210 @@ __global__ void k_build_sigma(const double *__restrict__ S, int lds, const doubl
     A[(size_t)i * lda + j] = v;
 }
 
+// Wave-uniform broadcast of one lane's double: two v_readlane_b32 into a scalar pair (the lane index is a compile-time constant in
+// the unrolled loops below).  __shfl compiles to ds_bpermute - an LDS round trip per value on the serial chain of the panel.
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // Cholesky of a 32x32 block held one row per lane (lanes 0..31 of one wave), fully unrolled so every index is a
 // compile-time register index.  Column c: the pivot and the multipliers l_cc',c travel between lanes through
-// v_readlane (wave-uniform broadcasts), no LDS round trips and no barriers.  Returns the first bad pivot (1-based, 0 = ok).
-__device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane) {
-    int bad = 0;
+// v_readlane (wave-uniform broadcasts), no LDS round trips and no barriers.  Every finished column is POSTED to LDS
+// (D[.][c], Dinv[c], then *posted = c + 1) so the waves that solve the panel rows follow one column behind instead of waiting
+// for the whole block (LDS operations of one wave complete in order: a wave that sees the counter sees the column).
+// Returns the first bad pivot (1-based, 0 = ok).
+#define CH_POST 8   // columns per posting of the diagonal block's factor (posting the last group column by column was measured: slower)
+// A lone wave issues an instruction every ~7 cycles (a v_fma_f64 every ~12.6), so the block's time is its instruction count.  Only the
+// updates inside a group of 8 columns go lane-to-lane (v_readlane pairs); a finished group updates the columns behind it as ONE small
+// product on the f64 MFMA with both operands read back from the posted columns (after column 7: columns 8..15 of every row, K = 8;
+// after column 15: the trailing 16 x 16 block, K = 16; after column 23: columns 24..31, K = 8) and an LDS transposition of the result
+// (tools/chol_trace.hip: 22 600 cycles with ds_bpermute shuffles -> 16 100 with v_readlane -> 12 000 with the K = 16 product -> see
+// DESIGN.md).  The pivot check is one ballot at the end: a non-positive pivot leaves NaN on that diagonal entry.
+__device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane, double (*D)[CH_NB + 1], double *Dinv, int *posted, int *badpiv,
+                                           double (*Ct)[CH_NB / 2 + 1]) {
+    constexpr int H = CH_NB / 2, G = CH_POST;
+    static_assert(CH_NB == 32 && CH_POST == 8, "the deferred products below are written for 32 = 4 x 8");
+    const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) {
-        const double piv = __shfl(a[c], c, 64);                 // a_cc lives in lane c
-        if (!(piv > 0.0) && bad == 0) bad = c + 1;
-        const double invd = rsqrt(piv);                         // one reciprocal square root instead of sqrt + divide:
-        const double d = piv * invd;                            // both sit on the 32-step serial chain of the panel
+        const double piv = bcast_lane(a[c], c);                 // a_cc lives in lane c
+        // 1/sqrt(piv): v_rsq_f64 and one third-order correction (the library's sequence without its special-case selects);
+        // one reciprocal square root instead of sqrt + divide: both sit on the 32-step serial chain of the panel
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double e = fma(y0 * -piv, y0, 1.0);
+        const double invd = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+        const double d = piv * invd;
         const double l = a[c] * invd;                           // l_rc for this lane's row r (meaningful for r >= c)
         a[c] = (lane == c) ? d : l;
+        D[lane][c] = a[c];                                      // rows < c are never read (the solves use D[q][c], q > c)
+        // 1/d for the row solves and the inverse's diagonal: invd = 1/sqrt(piv) is up to ~5 ulp away from the reciprocal of the ROUNDED
+        // d (d carries its own rounding and twice invd's); one Newton step, off the chain.  Wave-uniform, every lane stores it.
+        Dinv[c] = fma(fma(-d, invd, 1.0), invd, invd);
 #pragma unroll
-        for (int cc = c + 1; cc < CH_NB; ++cc) {
-            const double lcc = __shfl(l, cc, 64);               // l_cc,c
+        for (int cc = c + 1; cc < (c / G + 1) * G; ++cc) {
+            const double lcc = bcast_lane(l, cc);               // l_cc,c
             a[cc] = fma(-l, lcc, a[cc]);                        // a_r,cc -= l_rc * l_cc,c   (used for r >= cc)
         }
+        if (c == G - 1) {
+            // columns 8..15 of all rows: C = D[:, 0..7] * D[0..15, 0..7]'  (two row blocks; columns 0..7 of C are not used)
+            d4_t acc0 = d4_t{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+            for (int kb = 0; kb < G / 4; ++kb) {
+                const double v0 = D[li][4 * kb + lk], v1 = D[H + li][4 * kb + lk];
+                acc0 = MFMA_F64(v0, v0, acc0);
+                acc1 = MFMA_F64(v1, v0, acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Ct[lk + 4 * r][li] = acc0[r]; Ct[H + lk + 4 * r][li] = acc1[r]; }
+#pragma unroll
+            for (int j = G; j < H; ++j) a[j] -= Ct[lane & (CH_NB - 1)][j];
+        }
+        if (c == H - 1) {
+            // rows 16..31, columns 16..31: A22 -= L21 L21' with L21 = D[16.., 0..15]; both MFMA operands are the same registers
+            d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < H / 4; ++kb) {
+                const double v = D[H + li][4 * kb + lk];
+                acc = MFMA_F64(v, v, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ct[lk + 4 * r][li] = acc[r];
+#pragma unroll
+            for (int j = 0; j < H; ++j) a[H + j] -= Ct[li][j];               // row 16 + i lives in lane 16 + i
+        }
+        if (c == H + G - 1) {
+            // rows 16..31, columns 24..31, K = columns 16..23
+            d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < G / 4; ++kb) {
+                const double v = D[H + li][H + 4 * kb + lk];
+                acc = MFMA_F64(v, v, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ct[lk + 4 * r][li] = acc[r];
+#pragma unroll
+            for (int j = G; j < H; ++j) a[H + j] -= Ct[li][j];
+        }
+        if ((c + 1) % CH_POST == 0) {
+            if (c + 1 == CH_NB) {                               // before the last posting: the wave that reports it waits for that
+                double dg = 1.0;
+#pragma unroll
+                for (int q = 0; q < CH_NB; ++q) dg = (lane == q) ? a[q] : dg;
+                const unsigned long long nb = __ballot(lane < CH_NB && !(dg > 0.0));
+                *badpiv = nb ? __ffsll((long long)nb) : 0;      // first bad pivot, 1-based
+            }
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(posted, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+        }
     }
-    return bad;
+    return 0;
+}
+
+// Sum over lanes 0..31 of a wave through DPP (quad swaps, mirrors) and two v_readlane pairs: ~25 instructions without an LDS trip.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum_lanes32(double v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror: every lane of a 16-lane row holds the row's sum
+    return bcast_lane(v, 0) + bcast_lane(v, 16);
+}
+
+// Columns [C0, C0 + NC) of the row solve x * inv(L11)' for one row per lane, applied to the entries before QE (column-oriented:
+// the updates of one column are independent of each other; a row-oriented dot product is one dependent chain per entry).
+template <int C0, int NC, int QE>
+__device__ __forceinline__ void solve_cols(double (&x)[CH_NB], const double (*D)[CH_NB + 1], const double *Dinv, const int *posted) {
+    while (__hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < C0 + NC) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = C0; c < C0 + NC; ++c) {
+        x[c] *= Dinv[c];
+#pragma unroll
+        for (int q = c + 1; q < QE; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
+    }
+    // applied before the next posting is waited for (the optimiser otherwise sinks every multiply-add below the last wait and
+    // parks the factor in scratch)
+#pragma unroll
+    for (int q = 0; q < CH_NB; ++q) asm volatile("" : "+v"(x[q]));
+}
+
+// The 64 rows of one wave against the posted factor.  Columns 0..15 and 16..31 are solved lane-wise; between them the update
+// X2 -= X1 * L21' (half of the multiply-adds) is one product on the f64 MFMA: X1 goes to its final place in Xw early, L21 is read from
+// the posted columns, the result passes through the still unused half of Xw on its way back to one row per lane.
+__device__ __forceinline__ void solve_rows(double (&x)[CH_NB], int lane, const double (*D)[CH_NB + 1], const double *Dinv, const int *posted,
+                                           double (*Xw)[CH_NB + 1]) {
+    constexpr int H = CH_NB / 2;
+    static_assert(CH_NB == 4 * CH_POST, "four postings per block");
+    const int li = lane & 15, lk = lane >> 4;
+    solve_cols<0, CH_POST, H>(x, D, Dinv, posted);
+    solve_cols<CH_POST, CH_POST, H>(x, D, Dinv, posted);
+#pragma unroll
+    for (int c = 0; c < H; ++c) Xw[lane][c] = x[c];
+    d4_t acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < H / 4; ++kb) {
+        const double bv = D[H + li][4 * kb + lk];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA_F64(Xw[rt * 16 + li][4 * kb + lk], bv, acc[rt]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[rt * 16 + lk + 4 * r][H + li] = acc[rt][r];
+#pragma unroll
+    for (int j = 0; j < H; ++j) x[H + j] -= Xw[lane][H + j];
+    solve_cols<2 * CH_POST, CH_POST, CH_NB>(x, D, Dinv, posted);
+    solve_cols<3 * CH_POST, CH_POST, CH_NB>(x, D, Dinv, posted);
+#pragma unroll
+    for (int c = H; c < CH_NB; ++c) Xw[lane][c] = x[c];
 }
 
 // One whole step of the right-looking factorisation in a single launch (CH_NB == 32): every workgroup owns one
 // 64x64 tile (tm >= tn) of the trailing matrix.  Wave 0 factors the diagonal block at k0 in registers (redundantly
-// per workgroup: it must never observe another workgroup's write-back, hence the separate factor buffer Lm) while waves 1 and 2 already hold the panel rows of row blocks tm and tn in
-// registers; after the barrier they solve their rows against L11, park the result in LDS, and all four waves apply
-// the rank-32 update to the tile on the f64 MFMA.  The row solves are repeated by every tile of a block row/column
+// per workgroup: it must never observe another workgroup's write-back, hence the separate factor buffer Lm) and posts it column
+// by column; waves 1 and 2 hold the panel rows of row blocks tm and tn in registers and apply each column as it is posted
+// (the step is one serial chain - tools/chol_trace.hip: of 48 600 cycles per step the factorisation took 22 600 through LDS
+// shuffles, the solve another 9 800 behind a barrier; now the solve ends one column after the factorisation); wave 3 of tile (0, 0)
+// writes the factor's diagonal block and the log-determinant meanwhile.  The solved rows are parked in LDS, and all four
+// waves apply the rank-32 update to the tile on the f64 MFMA.  The row solves are repeated by every tile of a block row/column
 // (about half the tile's own flops) in exchange for half the launches of the panel + trailing pair: the step is
 // bound by launch-to-launch latency, not by arithmetic.  Reads of this step touch only columns < k0 + 32 of A,
 // writes only columns >= k0 + 32, so the update is safely in place.
-__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ Lm, int lda, int mq,
-                                                    int k0, double *__restrict__ logdet, int *__restrict__ info) {
-    __shared__ double D[CH_NB][CH_NB + 1];
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ Lm, double *__restrict__ Wd, int lda,
+                                                    int mq, int k0, double *__restrict__ logdet, int *__restrict__ info) {
+    __shared__ double D[64][CH_NB + 1];                                    // rows 32..63: lanes without a row (stores without a branch)
     __shared__ double Dinv[CH_NB];
     __shared__ double Xs[2][64][CH_NB + 1];
+    __shared__ double Ct[CH_NB][CH_NB / 2 + 1];
+    __shared__ int posted, badpiv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int t0 = k0 + CH_NB;
+    if (tid == 0) posted = 0;
     // tile index -> (tm, tn), tm >= tn
     int tm = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
     while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
     while (tm * (tm + 1) / 2 > (int)blockIdx.x) --tm;
     const int tn = (int)blockIdx.x - tm * (tm + 1) / 2;
-    // this wave's part of the trailing tile is fetched first, so its latency hides behind the factorisation
+    CH_MARK(0);
     const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
-    double cold[2][2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = t0 + tm * 64 + wr * 32 + a * 16 + lk + 4 * r;
-                const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
-                cold[a][b][r] = (gr < mq && gc < mq) ? A[(size_t)gr * lda + gc] : 0.0;
-            }
     double x[CH_NB];
     int row = -1;
+    const bool winv = Wd != nullptr && blockIdx.x == 0 && wave == 2;
     if (wave == 0) {
         const int r = lane & (CH_NB - 1);
         const double *ar = A + (size_t)(k0 + r) * lda + k0;
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) x[c] = ar[c];
-        const int bad = chol32_rows(x, lane);
-        if (lane < CH_NB) {
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) D[lane][c] = (c <= lane) ? x[c] : 0.0;
-            Dinv[lane] = 1.0 / D[lane][lane];
-            if (blockIdx.x == 0) {
-                double *lr = Lm + (size_t)(k0 + lane) * lda + k0;
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c) lr[c] = (c <= lane) ? x[c] : 0.0;
-            }
-        }
-        if (blockIdx.x == 0) {
-            // one logarithm per lane (lane c holds l_cc) and a wave sum, instead of 32 logarithms in sequence on the
-            // critical path of the workgroup that also owns tile (0, 0)
-            double dg = 1.0;
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) dg = (lane == c) ? x[c] : dg;
-            double ld = log(dg);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) ld += __shfl_xor(ld, off, 64);
-            if (lane == 0) {
-                *logdet += 2.0 * ld;                                       // inv_logdet.m:15
-                if (bad && *info == 0) *info = k0 + bad;
-            }
-        }
     } else if (wave <= 2) {
         const int blk = wave == 1 ? tm : tn;
         row = t0 + blk * 64 + lane;
@@ -131,28 +258,68 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
             for (int c = 0; c < CH_NB; ++c) x[c] = 0.0;
         }
     }
-    __syncthreads();
-    if (wave == 1 || wave == 2) {
-        if (row >= 0) {
-            // column-oriented substitution: the updates of one column are independent of each other (a row-oriented
-            // dot product is one dependent chain of up to 31 multiply-adds per entry)
+    // this wave's part of the trailing tile: fetched behind the panel rows (loads return in order and the factorisation waits for
+    // the rows only), its latency hides behind the factorisation
+    double cold[2][2][4];
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
-                x[c] *= Dinv[c];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int q = c + 1; q < CH_NB; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = t0 + tm * 64 + wr * 32 + a * 16 + lk + 4 * r;
+                const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
+                cold[a][b][r] = (gr < mq && gc < mq) ? A[(size_t)gr * lda + gc] : 0.0;
             }
-            if (tn == 0 && wave == 1) {
-                double *lr = Lm + (size_t)row * lda + k0;
+    __syncthreads();                                                       // posted = 0 is visible
+    if (wave == 0) {
+#ifdef GPZ_CHOL_TRACE
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        CH_MARK(1);
+        chol32_rows(x, lane, D, Dinv, &posted, &badpiv, Ct);
+        CH_MARK(2);
+    } else if (wave <= 2) {
+        CH_MARK(3);
+        // Wave 2 of tile (0, 0) has no rows of its own (a diagonal tile's two row blocks coincide): it produces the diagonal block
+        // of the triangular inverse instead.  Lane c starts from the unit row e_c, and the row solve leaves e_c inv(L11)' = column c
+        // of inv(L11) in it (exact zeros above the diagonal) - the code path of the panel rows, at no cost in time.
+        if (winv) {
 #pragma unroll
-                for (int c = 0; c < CH_NB; ++c) lr[c] = x[c];
+            for (int c = 0; c < CH_NB; ++c) x[c] = (lane == c) ? 1.0 : 0.0;
+        }
+        solve_rows(x, lane, D, Dinv, &posted, Xs[wave - 1]);
+        CH_MARK(4);
+    } else {
+        if (blockIdx.x == 0) {
+            // wave 3 of tile (0, 0): the factor's diagonal block, posting by posting, and the log-determinant, beside the solves
+            double *lr = Lm + (size_t)(k0 + (lane & (CH_NB - 1))) * lda + k0;
+#pragma unroll
+            for (int c0 = 0; c0 < CH_NB; c0 += CH_POST) {
+                while (__hip_atomic_load(&posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < c0 + CH_POST) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                if (lane < CH_NB) {
+#pragma unroll
+                    for (int c = c0; c < c0 + CH_POST; ++c) lr[c] = (c <= lane) ? D[lane][c] : 0.0;
+                }
+            }
+            const double ld = sum_lanes32(lane < CH_NB ? log(D[lane & (CH_NB - 1)][lane & (CH_NB - 1)]) : 0.0);   // one logarithm per lane
+            if (lane == 0) {
+                *logdet += 2.0 * ld;                                           // inv_logdet.m:15
+                const int bad = __hip_atomic_load(&badpiv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bad && *info == 0) *info = k0 + bad;
             }
         }
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) Xs[wave - 1][lane][c] = x[c];
     }
     __syncthreads();
-    if (t0 + tm * 64 >= mq) return;                                        // last step: nothing below the diagonal block
+    CH_MARK(5);
+    if (t0 + tm * 64 >= mq) {                                              // last step: nothing below the diagonal block
+        if (winv && lane < CH_NB) {
+#pragma unroll
+            for (int r = 0; r < CH_NB; ++r) Wd[(size_t)(k0 + r) * lda + k0 + lane] = x[r];
+        }
+        return;
+    }
     const double (*Xm)[CH_NB + 1] = Xs[0];
     const double (*Xn)[CH_NB + 1] = Xs[tm == tn ? 0 : 1];
     d4_t acc[2][2];
@@ -172,6 +339,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
     }
+    CH_MARK(6);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -182,41 +350,17 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
                 const int gc = t0 + tn * 64 + wc * 32 + b * 16 + li;
                 if (gr < mq && gc < mq) A[(size_t)gr * lda + gc] = cold[a][b][r] - acc[a][b][r];
             }
-}
-
-// W(diag block) = inv(L(diag block)) for every 32x32 diagonal block; one 64-thread workgroup each.
-__global__ __launch_bounds__(64) void k_trtri_diag(const double *__restrict__ L, double *__restrict__ W, int ld) {
-    __shared__ double Ls[CH_NB][CH_NB + 1];
-    __shared__ double Ws[CH_NB][CH_NB + 1];
-    const int k0 = blockIdx.x * CH_NB, tid = threadIdx.x;
-    for (int e = tid; e < CH_NB * CH_NB; e += 64) {
-        const int r = e / CH_NB, c = e % CH_NB;
-        Ls[r][c] = L[(size_t)(k0 + r) * ld + k0 + c];
-        Ws[r][c] = 0.0;
-    }
-    __syncthreads();
-    if (tid < CH_NB) {
-        // Column c of W in registers, every loop with compile-time bounds: entries above the diagonal are kept as zeros, so the sums run
-        // over q < r for every lane (the same values and order as sums from q = c: the leading terms are exact zeros).  The version with
-        // the column in LDS and lane-dependent bounds paid an LDS round trip per term: 20 us per launch, 2 us of arithmetic.
-        const int c = tid;
-        double w[CH_NB];
+    // the inverse's diagonal block and the panel's solved rows (rows of the factor) are issued last: nobody's input in this launch
+    if (winv && lane < CH_NB) {
 #pragma unroll
-        for (int r = 0; r < CH_NB; ++r) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < r; ++q) s = fma(Ls[r][q], w[q], s);
-            const double rd = 1.0 / Ls[r][r];                     // one division per row (wave-uniform)
-            w[r] = (r == c) ? rd : (r > c ? -s * rd : 0.0);
-        }
-#pragma unroll
-        for (int r = 0; r < CH_NB; ++r) Ws[r][c] = w[r];
+        for (int r = 0; r < CH_NB; ++r) Wd[(size_t)(k0 + r) * lda + k0 + lane] = x[r];
     }
-    __syncthreads();
-    for (int e = tid; e < CH_NB * CH_NB; e += 64) {
-        const int r = e / CH_NB, c = e % CH_NB;
-        W[(size_t)(k0 + r) * ld + k0 + c] = Ws[r][c];
+    if (wave == 1 && tn == 0 && row >= 0) {
+        double *lr = Lm + (size_t)row * lda + k0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) lr[c] = x[c];
     }
+    CH_MARK(7);
 }
 
 __global__ void k_zero(double *__restrict__ p, size_t count) {
@@ -286,13 +430,9 @@ void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *
     hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda, Wz, logdet);
 }
 
-void launch_chol_step(hipStream_t st, double *A, double *Lm, int lda, int mq, int k0, double *logdet, int *info) {
+void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info) {
     const int M = mq - k0 - CH_NB, nt = (M + 63) / 64, tiles = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, st, A, Lm, lda, mq, k0, logdet, info);
-}
-
-void launch_trtri_diag(hipStream_t st, const double *L, double *W, int ld, int mq) {
-    hipLaunchKernelGGL(k_trtri_diag, dim3(mq / CH_NB), dim3(64), 0, st, L, W, ld);
+    hipLaunchKernelGGL(k_chol_step, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, st, A, Lm, W, lda, mq, k0, logdet, info);
 }
 
 void launch_zero(hipStream_t st, double *p, size_t count) {
