@@ -78,6 +78,7 @@ void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, i
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds,
                         int accumulate = 0 /* S += instead of S = (row tiles of a streamed evaluation) */);
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
+int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,
                   double *nupart, double *phiw, int m, int mcol, bool f32_operands = false, int kdim = 0, int ldt = 0,

@@ -672,13 +672,15 @@ __global__ __launch_bounds__(128 * WC, WC) void k_tgemm(const double *__restrict
 // ---------------------------------------------------------------------------------------------
 // C[M x N] (row-major, stride ldc) = alpha * A[M x K] * B[K x N] over k in [kbeg, kend) only (both multiples of 16):
 // the callers' operands are triangular, so half of every product is structurally zero.  A and B row-major (lda, ldb,
-// both multiples of 4 with 32-byte aligned rows).  One workgroup computes the 64x64 tile (tm, tn); the next 16-deep
-// slice is fetched into registers (row-wise, 32 bytes per lane) while the current one is multiplied.
+// both multiples of 4 with 32-byte aligned rows).  One workgroup computes the 64x64 tile (tm, tn).  The products are short and
+// alone on their compute unit, so a 16-deep slice is bound by the latency of its operands (they come from another XCD's writes):
+// slices are fetched into registers TWO ahead (two register sets, row-wise, 32 bytes per lane) and the LDS tiles are double
+// buffered - one barrier per slice (one slice ahead and two barriers: 2 600 cycles per slice for 1 024 of MFMA work).
 __device__ void gemm_tile_64(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
                              double *__restrict__ C, long ldc, int M, int N, int kbeg, int kend, double alpha, int tm,
                              int tn) {
-    __shared__ double sA[16][LDS_LD64];
-    __shared__ double sB[16][LDS_LD64];
+    __shared__ double sA[2][16][LDS_LD64];
+    __shared__ double sB[2][16][LDS_LD64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i0 = tm * 64, j0 = tn * 64;
@@ -693,34 +695,50 @@ __device__ void gemm_tile_64(const double *__restrict__ A, long lda, const doubl
     const bool aok = i0 + ar < M, bok = j0 + bc < N;   // N is a multiple of 4
     const double *ap = A + (size_t)(i0 + ar) * lda + ak;
     const double *bp = B + (size_t)bk * ldb + j0 + bc;
-    d2_t ra[2], rb[2];
-    auto gload = [&](int k0) {
+    struct Regs { d2_t a[2], b[2]; } r0, r1;
+    auto gload = [&](Regs &r, int k0) {
         const d2_t z = {0.0, 0.0};
-        ra[0] = aok ? *reinterpret_cast<const d2_t *>(ap + k0) : z;
-        ra[1] = aok ? *reinterpret_cast<const d2_t *>(ap + k0 + 2) : z;
-        rb[0] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb) : z;
-        rb[1] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb + 2) : z;
+        r.a[0] = aok ? *reinterpret_cast<const d2_t *>(ap + k0) : z;
+        r.a[1] = aok ? *reinterpret_cast<const d2_t *>(ap + k0 + 2) : z;
+        r.b[0] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb) : z;
+        r.b[1] = bok ? *reinterpret_cast<const d2_t *>(bp + (size_t)k0 * ldb + 2) : z;
     };
-    if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        sA[ak + 0][ar] = ra[0][0]; sA[ak + 1][ar] = ra[0][1]; sA[ak + 2][ar] = ra[1][0]; sA[ak + 3][ar] = ra[1][1];
-        *reinterpret_cast<d2_t *>(&sB[bk][bc]) = rb[0];
-        *reinterpret_cast<d2_t *>(&sB[bk][bc + 2]) = rb[1];
-        __syncthreads();
-        if (k0 + 16 < kend) gload(k0 + 16);
+    auto park = [&](const Regs &r, int buf) {
+        sA[buf][ak + 0][ar] = r.a[0][0]; sA[buf][ak + 1][ar] = r.a[0][1]; sA[buf][ak + 2][ar] = r.a[1][0]; sA[buf][ak + 3][ar] = r.a[1][1];
+        *reinterpret_cast<d2_t *>(&sB[buf][bk][bc]) = r.b[0];
+        *reinterpret_cast<d2_t *>(&sB[buf][bk][bc + 2]) = r.b[1];
+    };
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int kr = kk * 4 + (lane >> 4);
             double a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = sA[kr][wr * 32 + mi * 16 + (lane & 15)];
+            for (int mi = 0; mi < 2; ++mi) a[mi] = sA[buf][kr][wr * 32 + mi * 16 + (lane & 15)];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = sB[kr][wc * 32 + ni * 16 + (lane & 15)];
+            for (int ni = 0; ni < 2; ++ni) b[ni] = sB[buf][kr][wc * 32 + ni * 16 + (lane & 15)];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = MFMA_F64(a[mi], b[ni], acc[mi][ni]);
         }
+    };
+    if (kbeg < kend) {
+        gload(r0, kbeg);
+        if (kbeg + 16 < kend) gload(r1, kbeg + 16);
+        park(r0, 0);
+        __syncthreads();
+    }
+    // slice s sits in LDS buffer s & 1; slice s + 1 in the other register set; slice s + 2 is requested into the set slice s came from
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        if (k0 + 32 < kend) gload(r0, k0 + 32);
+        multiply(0);
+        if (k0 + 16 >= kend) break;
+        park(r1, 1);
+        __syncthreads();
+        if (k0 + 48 < kend) gload(r1, k0 + 48);
+        multiply(1);
+        if (k0 + 32 < kend) park(r0, 0);
         __syncthreads();
     }
 #pragma unroll
@@ -795,7 +813,7 @@ void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nspl
 // T (n_pad x mp, row stride ldt) = PHI (n_pad x kdim, row stride ld) * B (kdim x mp, row stride ldb).  kdim = 0: the square case
 // of the evaluation (K = mp, ldt = ld).  kdim % 16 == 0.
 // compute units of the current device (256 on MI355X); the tile kernels keep two workgroups resident on each
-static int gpz_cu_count() {
+int gpz_cu_count() {
     static const int n = [] {
         int dev = 0, cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;

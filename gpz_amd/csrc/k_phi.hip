@@ -600,6 +600,26 @@ __global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ng
     }
 }
 
+// Column groups of a PHI build with few rows.  Lanes run along rows, so `nwg` workgroups may not fill the chip; the basis functions
+// are then split into groups (multiples of JB columns) whose per-row sums k_phi_finalize combines.  The choice minimises
+// (rounds of resident workgroups) x (columns per workgroup + its fixed part): "about 1024 workgroups" put c2 at 1173 workgroups for
+// 1024 resident ones - two rounds of 80 columns where one round of 104 does (85 -> 55 us), and c3 at three rounds of 48 for one of 104.
+static int phi_pick_groups(int nwg, int mp, int JB, int resident_per_cu, int max_groups) {
+    const int cap = resident_per_cu * gpz_cu_count();
+    int best = 1;
+    long best_cost = -1;
+    for (int g = 1; g <= max_groups; ++g) {
+        const int jg = ((mp + g - 1) / g + JB - 1) / JB * JB, ge = (mp + jg - 1) / jg;
+        if (ge != g) continue;                                   // this count collapses to a smaller one
+        const long rounds = ((long)nwg * g + cap - 1) / cap;
+        // 16 columns' worth of prologue per workgroup; many short rounds pack better than few long ones (c4: four rounds of 504 columns
+        // measure 5 % faster than two of 1008), hence the 10 % / rounds
+        const long cost = rounds * (jg + 16) * (10 * rounds + 1) / rounds;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return best;
+}
+
 // 4 rows per thread and 8-wide blocks while [tile | params] fits twice in a CU's LDS; else 2 rows
 template <int D>
 struct PhiCovShape {
@@ -615,14 +635,12 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     const int rows_per_wg = 4 * 64 * R;
     const int nwg = a.wgtab ? a.nwg_tab : (a.n_pad + rows_per_wg - 1) / rows_per_wg;
     if (nwg <= 0) return;
-    // few rows: split the basis functions into groups (multiples of JB) until ~1024 workgroups exist
+    // few rows: split the basis functions into groups as well (two workgroups of this kernel are resident per CU)
     int ngroup = 1;
     if (a.part && nwg < 1024) {
-        ngroup = (1024 + nwg - 1) / nwg;
-        const int maxg = (a.mp + 63) / 64;
-        if (ngroup > maxg) ngroup = maxg;
-        if (ngroup > a.part_groups) ngroup = a.part_groups;
-        if (ngroup < 1) ngroup = 1;
+        int maxg = (a.mp + 63) / 64;
+        if (maxg > a.part_groups) maxg = a.part_groups;
+        ngroup = phi_pick_groups(nwg, a.mp, JB, 2, maxg < 1 ? 1 : maxg);
     }
     int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
     ngroup = (a.mp + jgroup - 1) / jgroup;
@@ -653,16 +671,14 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     constexpr int RP = GPZ_PHI_DIAG_RP(D);
     // few rows (fewer than two workgroups per CU at two rows per thread): one row per thread doubles the workgroups
     const bool small = (a.n_pad + 511) / 512 < 512;
-    // few rows: split the basis functions into groups (multiples of JB) until ~1024 workgroups exist (as launch_phi_cov_d does)
     const int rr_eff = a.Psic ? RP : (small ? 1 : R);
     const int nwg = (a.n_pad + 256 * rr_eff - 1) / (256 * rr_eff);
     int ngroup = 1;
     if (a.part && nwg > 0 && nwg < 1024 && !gpz_opts().phi_diag_no_split) {
-        ngroup = (1024 + nwg - 1) / nwg;
-        const int maxg = (a.mp + 63) / 64;
-        if (ngroup > maxg) ngroup = maxg;
-        if (ngroup > a.part_groups) ngroup = a.part_groups;
-        if (ngroup < 1) ngroup = 1;
+        int maxg = (a.mp + 63) / 64;
+        if (maxg > a.part_groups) maxg = a.part_groups;
+        // resident workgroups per CU: the transposition tile is 4 x rows x 64 x 17 doubles (one row per thread: 34 KB, four fit)
+        ngroup = phi_pick_groups(nwg, a.mp, JB, rr_eff == 1 ? 4 : 2, maxg < 1 ? 1 : maxg);
     }
     int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
     ngroup = (a.mp + jgroup - 1) / jgroup;

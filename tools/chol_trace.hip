@@ -6,6 +6,7 @@
 // Run:   build/chol_trace [m=1000]
 #define GPZ_CHOL_TRACE 1
 #include "../gpz_amd/csrc/k_chol.hip"
+#include "../gpz_amd/csrc/k_gemm.hip"
 #include <stdio.h>
 #include <vector>
 #include <math.h>
@@ -33,6 +34,8 @@ int main(int argc, char **argv) {
         launch_build_sigma(st, dS, m, dal, m, mq, A, mq, Wz, logdet);
         for (int k0 = 0; k0 < mq; k0 += CH_NB) launch_chol_step(st, A, Lm, Wz, mq, mq, k0, logdet, info);
     };
+    double *Tmp; (void)hipMalloc(&Tmp, (size_t)mq * mq * 8);
+    auto inverse = [&]() { for (int gs = CH_NB; gs < mq; gs *= 2) launch_trtri_level(st, Lm, Wz, Tmp, mq, mq, gs); };
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms;
     for (int rep = 0; rep < 3; ++rep) {
@@ -47,6 +50,17 @@ int main(int argc, char **argv) {
         (void)hipEventRecord(e0, st); (void)hipGraphLaunch(ge, st); (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("graph chain: %.1f us = %.2f us per step\n", ms * 1e3, ms * 1e3 / nsteps);
+    }
+    {   // the levels of the triangular inverse behind the factorisation, as a graph of their own
+        hipGraph_t g2; hipGraphExec_t ge2;
+        (void)hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal); inverse(); (void)hipStreamEndCapture(st, &g2);
+        (void)hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipGraphLaunch(ge, st);
+            (void)hipEventRecord(e0, st); (void)hipGraphLaunch(ge2, st); (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("graph of the inverse's levels (gs = 32 .. %d): %.1f us\n", mq / 2, ms * 1e3);
+        }
     }
     double ld; int inf; (void)hipMemcpy(&ld, logdet, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
     printf("logdet %.12g info %d\n", ld, inf);
@@ -65,7 +79,13 @@ int main(int argc, char **argv) {
                     double s = 0; for (int q = 0; q < CH_NB; ++q) s += hL[(size_t)(b * CH_NB + i) * mq + b * CH_NB + q] * hW[(size_t)(b * CH_NB + q) * mq + b * CH_NB + j];
                     eW = fmax(eW, fabs(s - (i == j ? 1.0 : 0.0)));
                 }
-        printf("max |L L' - A| = %.3g   max |L_kk W_kk - I| over the diagonal blocks = %.3g\n", eA, eW);
+        double eF = 0;
+        for (int i = 0; i < mq; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0; for (int q = j; q <= i; ++q) s += hL[(size_t)i * mq + q] * hW[(size_t)q * mq + j];
+                eF = fmax(eF, fabs(s - (i == j ? 1.0 : 0.0)));
+            }
+        printf("max |L L' - A| = %.3g   max |L_kk W_kk - I| over the diagonal blocks = %.3g   max |L W - I| = %.3g\n", eA, eW, eF);
     }
     // traced pass
     const size_t nrec = (size_t)nsteps * 4 * 4 * 8;

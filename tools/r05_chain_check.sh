@@ -1,4 +1,4 @@
-# after the m x m chain rework: GPU suite, then the latency-bound configurations and the default workload
+# after the m x m chain rework and the column-group choice of the PHI build: GPU suite, then the latency-bound configurations and the default workload
 mkdir -p gpurun_out/r05d
 python -m pytest tests -m gpu -x -q > gpurun_out/r05d/pytest_gpu.log 2>&1
 tail -3 gpurun_out/r05d/pytest_gpu.log
@@ -7,4 +7,4 @@ python bench.py --config c3 --timed-events none --no-cpu-baseline > gpurun_out/r
 python bench.py --rows 125000 --no-cpu-baseline > gpurun_out/r05d/c4_shard125k.json 2> gpurun_out/r05d/c4_shard125k.err
 python bench.py --no-cpu-baseline > gpurun_out/r05d/c4.json 2> gpurun_out/r05d/c4.err
 for f in c2 c3 c4_shard125k c4; do python -c "
-import json,sys; d=json.loads(open('gpurun_out/r05d/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d.get('parity'))"; done
+import json,sys; d=json.loads(open('gpurun_out/r05d/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['stage_pass']['ms_per_step'], {k: round(v,4) for k,v in d.get('stage_ms_per_eval', d.get('stages',{})).items()} if isinstance(d.get('stage_ms_per_eval', d.get('stages')), dict) else '')"; done
