@@ -8,6 +8,7 @@
 // read feeding the thread's R rows, software-pipelined row by row of R_j under sched_barrier.  Every 8 (cov) / 16 (diag)
 // basis functions the wave transposes its block through LDS and writes PHI row-major.  The heteroscedastic noise model
 // ln beta_i = b + PHI v (getPHI.m:116-125) is a per-thread running sum, so PHI is touched once.
+#include <type_traits>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -233,21 +234,26 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
 #pragma unroll
                 for (int r = 0; r < R; ++r) { q[r] = q0[r]; pr[r] = 1.0; }
                 const double *pj = P + (size_t)j * D, *gj = G + (size_t)j * D;   // G = gamma^2 = 1/sigma
+                // two copies of the sum, with and without the observed-mask factor: complete inputs do not pay a multiply per dimension
+                auto quad = [&](auto masked) {
 #pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    const double pc = pj[c], gc = gj[c];
+                    for (int c = 0; c < D; ++c) {
+                        const double pc = pj[c], gc = gj[c];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double dl = (x[r][c] - pc) * mk[r][c];
-                        if (PSI) {
-                            const double u = fma(ps[r][c], gc, 1.0);       // 1 + psi/sigma  (psi = 0 where missing)
-                            q[r] = fma(dl * dl, gc * gpz_rcp(u), q[r]);    // Delta^2/(psi+sigma)
-                            pr[r] *= u;
-                        } else {
-                            q[r] = fma(dl * dl, gc, q[r]);                 // getPHI.m:97  Delta.^2 ./ Sigma
+                        for (int r = 0; r < R; ++r) {
+                            double dl = x[r][c] - pc;
+                            if (decltype(masked)::value) dl *= mk[r][c];
+                            if (PSI) {
+                                const double u = fma(ps[r][c], gc, 1.0);   // 1 + psi/sigma  (psi = 0 where missing)
+                                q[r] = fma(dl * dl, gc * gpz_rcp(u), q[r]);   // Delta^2/(psi+sigma)
+                                pr[r] *= u;
+                            } else {
+                                q[r] = fma(dl * dl, gc, q[r]);             // getPHI.m:97  Delta.^2 ./ Sigma
+                            }
                         }
                     }
-                }
+                };
+                if (Mc) quad(std::true_type{}); else quad(std::false_type{});
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (PSI) q[r] += log(pr[r]);                           // sum_c ln(1 + psi/sigma)
@@ -274,7 +280,9 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
             }
         }
         if (Phi) {
-            __syncthreads();
+            // tile[wave] belongs to this wave alone and a wave's LDS operations complete in order: the transposition needs no
+            // workgroup barrier (two per 16 columns kept the four waves in lockstep), only the program order of its writes and reads
+            __builtin_amdgcn_wave_barrier();
             // wave-uniform base + 32-bit lane offset; each store instruction covers 64/JB rows x JB columns
             constexpr int RPI = 64 / JB;                    // rows per store instruction
             double *base = Phi + (size_t)row0 * mp + j0;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
                 const int r = qq / JB, it = qq % JB;
                 base[loff + (unsigned)(r * 64 + it * RPI) * (unsigned)mp] = tile[wave][r][it * RPI + lr][lc];
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -601,22 +609,28 @@ __global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ng
 }
 
 // Column groups of a PHI build with few rows.  Lanes run along rows, so `nwg` workgroups may not fill the chip; the basis functions
-// are then split into groups (multiples of JB columns) whose per-row sums k_phi_finalize combines.  The choice minimises
-// (rounds of resident workgroups) x (columns per workgroup + its fixed part): "about 1024 workgroups" put c2 at 1173 workgroups for
-// 1024 resident ones - two rounds of 80 columns where one round of 104 does (85 -> 55 us), and c3 at three rounds of 48 for one of 104.
-static int phi_pick_groups(int nwg, int mp, int JB, int resident_per_cu, int max_groups) {
-    const int cap = resident_per_cu * gpz_cu_count();
-    int best = 1;
+// are then split into groups (multiples of JB columns) whose per-row sums k_phi_finalize combines.  Both kernels are bound by the
+// vector ALU their co-resident workgroups share, so a launch takes (workgroups on the busiest CU) x (columns per workgroup + its
+// prologue in columns' worth), with at least `min_wgs` workgroups' worth of time per CU (fewer cannot hide the parameter loads).
+// c2 (391 row blocks, 208 columns): g = 1 .. 13 measured 136, 84, 83, 93, 78, -, 75, ..., 74 us and the model ranks them the same
+// ("about 1024 workgroups" chose g = 3).  Among choices within 1 % the largest wins (c4: two groups 4.34 ms, one 4.44).
+static int phi_pick_groups(int nwg, int mp, int JB, int min_wgs, int prologue_cols, int max_groups) {
+    const int ncu = gpz_cu_count();
+    long cost[65];
     long best_cost = -1;
+    if (max_groups > 64) max_groups = 64;
     for (int g = 1; g <= max_groups; ++g) {
         const int jg = ((mp + g - 1) / g + JB - 1) / JB * JB, ge = (mp + jg - 1) / jg;
+        cost[g] = -1;
         if (ge != g) continue;                                   // this count collapses to a smaller one
-        const long rounds = ((long)nwg * g + cap - 1) / cap;
-        // 16 columns' worth of prologue per workgroup; many short rounds pack better than few long ones (c4: four rounds of 504 columns
-        // measure 5 % faster than two of 1008), hence the 10 % / rounds
-        const long cost = rounds * (jg + 16) * (10 * rounds + 1) / rounds;
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }
+        long per_cu = ((long)nwg * g + ncu - 1) / ncu;
+        if (per_cu < min_wgs) per_cu = min_wgs;
+        cost[g] = per_cu * (jg + prologue_cols);
+        if (best_cost < 0 || cost[g] < best_cost) best_cost = cost[g];
     }
+    int best = 1;
+    for (int g = 1; g <= max_groups; ++g)
+        if (cost[g] >= 0 && cost[g] * 100 <= best_cost * 101) best = g;
     return best;
 }
 
@@ -635,12 +649,12 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     const int rows_per_wg = 4 * 64 * R;
     const int nwg = a.wgtab ? a.nwg_tab : (a.n_pad + rows_per_wg - 1) / rows_per_wg;
     if (nwg <= 0) return;
-    // few rows: split the basis functions into groups as well (two workgroups of this kernel are resident per CU)
+    // few rows: split the basis functions into groups as well
     int ngroup = 1;
     if (a.part && nwg < 1024) {
-        int maxg = (a.mp + 63) / 64;
+        int maxg = a.mp / (4 * JB);                                                      // at least 32 columns per group
         if (maxg > a.part_groups) maxg = a.part_groups;
-        ngroup = phi_pick_groups(nwg, a.mp, JB, 2, maxg < 1 ? 1 : maxg);
+        ngroup = phi_pick_groups(nwg, a.mp, JB, 2, 8, maxg < 1 ? 1 : maxg);   // two workgroups of this kernel are resident per CU
     }
     int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
     ngroup = (a.mp + jgroup - 1) / jgroup;
@@ -675,10 +689,9 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
     const int nwg = (a.n_pad + 256 * rr_eff - 1) / (256 * rr_eff);
     int ngroup = 1;
     if (a.part && nwg > 0 && nwg < 1024 && !gpz_opts().phi_diag_no_split) {
-        int maxg = (a.mp + 63) / 64;
+        int maxg = a.mp / JB;                                                            // down to one transposition block per group
         if (maxg > a.part_groups) maxg = a.part_groups;
-        // resident workgroups per CU: the transposition tile is 4 x rows x 64 x 17 doubles (one row per thread: 34 KB, four fit)
-        ngroup = phi_pick_groups(nwg, a.mp, JB, rr_eff == 1 ? 4 : 2, maxg < 1 ? 1 : maxg);
+        ngroup = phi_pick_groups(nwg, a.mp, JB, 3, 3, maxg < 1 ? 1 : maxg);   // three workgroups per CU hide the parameter loads
     }
     int jgroup = ((a.mp + ngroup - 1) / ngroup + JB - 1) / JB * JB;
     ngroup = (a.mp + jgroup - 1) / jgroup;

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r05d
+python -m pytest tests -m gpu -x -q > gpurun_out/r05d/pytest_gpu.log 2>&1; tail -2 gpurun_out/r05d/pytest_gpu.log
 python bench.py --config c2 --timed-events none --no-cpu-baseline > gpurun_out/r05d/c2.json 2> gpurun_out/r05d/c2.err
 python bench.py --config c3 --timed-events none --no-cpu-baseline > gpurun_out/r05d/c3.json 2> gpurun_out/r05d/c3.err
 python bench.py --rows 125000 --no-cpu-baseline > gpurun_out/r05d/c4_shard125k.json 2> gpurun_out/r05d/c4_shard125k.err
