@@ -6,7 +6,7 @@
 // triangular inverse and inv(SIGMA) = inv(L)' * inv(L) on the f64 MFMA SYRK kernel; logdet =
 // 2*sum(log(diag(L))).  The matrix is padded with an identity block to a multiple of 32 so every
 // panel is full.  A non-positive pivot is reported through *info (results are NaN then); the
-// rank-truncating branch of inv_logdet.m:7-12 is not reproduced ("deviations").
+// rank-truncating branch of inv_logdet.m:7-12 is k_pinv.hip (taken when the certificate of DESIGN.md section 5 fails).
 #include <stdlib.h>
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
@@ -49,20 +49,20 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky of a 32x32 block held one row per lane (lanes 0..31 of one wave), fully unrolled so every index is a
-// compile-time register index.  Column c: the pivot and the multipliers l_cc',c travel between lanes through
-// v_readlane (wave-uniform broadcasts), no LDS round trips and no barriers.  Every finished column is POSTED to LDS
-// (D[.][c], Dinv[c], then *posted = c + 1) so the waves that solve the panel rows follow one column behind instead of waiting
-// for the whole block (LDS operations of one wave complete in order: a wave that sees the counter sees the column).
-// Returns the first bad pivot (1-based, 0 = ok).
 #define CH_POST 8   // columns per posting of the diagonal block's factor (posting the last group column by column was measured: slower)
+// Cholesky of a 32x32 block held one row per lane (lanes 0..31 of one wave; lanes 32..63 carry copies), fully unrolled so every
+// index is a compile-time register index.  Column c: the pivot and the multipliers l_cc',c travel between lanes through v_readlane
+// (wave-uniform broadcasts), no LDS round trips and no barriers.  Finished columns are POSTED to LDS (D[.][c], Dinv[c], then
+// *posted = c + 1 after every CH_POST columns) so the waves that solve the panel rows follow one group behind instead of waiting
+// for the whole block (LDS operations of one wave complete in order: a wave that sees the counter sees the columns).
 // A lone wave issues an instruction every ~7 cycles (a v_fma_f64 every ~12.6), so the block's time is its instruction count.  Only the
-// updates inside a group of 8 columns go lane-to-lane (v_readlane pairs); a finished group updates the columns behind it as ONE small
-// product on the f64 MFMA with both operands read back from the posted columns (after column 7: columns 8..15 of every row, K = 8;
-// after column 15: the trailing 16 x 16 block, K = 16; after column 23: columns 24..31, K = 8) and an LDS transposition of the result
-// (tools/chol_trace.hip: 22 600 cycles with ds_bpermute shuffles -> 16 100 with v_readlane -> 12 000 with the K = 16 product -> see
-// DESIGN.md).  The pivot check is one ballot at the end: a non-positive pivot leaves NaN on that diagonal entry.
-__device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane, double (*D)[CH_NB + 1], double *Dinv, int *posted, int *badpiv,
+// updates inside a group of 8 columns go lane-to-lane; a finished group updates the columns behind it as ONE small product on the f64
+// MFMA with both operands read back from the posted columns (after column 7: columns 8..15 of every row, K = 8; after column 15:
+// the trailing 16 x 16 block, K = 16; after column 23: columns 24..31, K = 8) and an LDS transposition of the result
+// (tools/chol_trace.hip, profiles/r05_chol_step_timeline.txt: 22 600 cycles with ds_bpermute shuffles -> 16 100 with v_readlane ->
+// 12 000 with the K = 16 product -> 8 000).  The pivot check is one ballot at the end (*badpiv = first bad pivot, 1-based, 0 = none):
+// a non-positive pivot leaves NaN on that diagonal entry.
+__device__ __forceinline__ void chol32_rows(double (&a)[CH_NB], int lane, double (*D)[CH_NB + 1], double *Dinv, int *posted, int *badpiv,
                                            double (*Ct)[CH_NB / 2 + 1]) {
     constexpr int H = CH_NB / 2, G = CH_POST;
     static_assert(CH_NB == 32 && CH_POST == 8, "the deferred products below are written for 32 = 4 x 8");
@@ -140,7 +140,6 @@ __device__ __forceinline__ int chol32_rows(double (&a)[CH_NB], int lane, double 
             asm volatile("" ::: "memory");
         }
     }
-    return 0;
 }
 
 // Sum over lanes 0..31 of a wave through DPP (quad swaps, mirrors) and two v_readlane pairs: ~25 instructions without an LDS trip.

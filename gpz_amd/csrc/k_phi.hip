@@ -639,7 +639,11 @@ template <int D>
 struct PhiCovShape {
     static constexpr int NP = D * (D + 1) / 2 + D;
     static constexpr bool BIG = (4 * 4 * 64 * 9 + 8 * NP) * 8 * 2 <= 160 * 1024;
+#ifdef GPZ_PHI_COV_R   // measured at c4: two rows per thread (124 VGPRs, three workgroups per CU) 5.08 ms against 4.16 ms with four
+    static constexpr int R = GPZ_PHI_COV_R;
+#else
     static constexpr int R = BIG ? 4 : 2;
+#endif
 };
 
 template <int D>

@@ -39,4 +39,11 @@ for t in ozaki_probe graph_event_probe; do
   hipcc --offload-arch=gfx950 -O3 tools/$t.hip -o build/$t 2> /dev/null && build/$t > $O/ubench_$t.txt 2>&1
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igpz_amd/csrc tools/gemm_trace.hip gpz_amd/csrc/gpz_options.hip -o build/gemm_trace 2> /dev/null && build/gemm_trace > $O/tgemm_timeline.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igpz_amd/csrc tools/chol_trace.hip gpz_amd/csrc/gpz_options.hip -o build/chol_trace 2> /dev/null && (build/chol_trace 1000; build/chol_trace 500; build/chol_trace 200) > $O/chol_step_timeline.txt 2>&1
+# kernel statistics of the latency-bound configurations
+for cfg in c2 c3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -- python bench.py --config $cfg --timed-events none --no-cpu-baseline --steps 50 > /dev/null 2>&1
+  find $O/prof_$cfg -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$cfg.csv \;
+  rm -rf $O/prof_$cfg
+done
 tail -c 400 $O/c4.json; echo; cat $O/scaling_prediction.log | tail -30
