@@ -343,13 +343,12 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, i
                               double *__restrict__ S, int lds, int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
-    if (j >= mp) return;
+    if (j >= mp || i > j) return;                            // the upper triangle is summed (coalesced reads of the slabs) and written to
+                                                             // both places: summing the mirror from its own side read every slab by columns
     const int ti = i >> 7, tj = j >> 7;
-    const bool upper = (ti < tj) || (ti == tj && i <= j);
     const int nsplit = (ti == tj) ? nsplit_d : nsplit_off;
-    const size_t src = upper ? ((size_t)i * mp + j) : ((size_t)j * mp + i);
     const size_t stride = (size_t)mp * mp;
-    const double *p = slab + src;
+    const double *p = slab + (size_t)i * mp + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;           // four chains, eight loads in flight: the sum is latency bound
     int k = 0;
     for (; k + 8 <= nsplit; k += 8) {
@@ -361,7 +360,9 @@ __global__ void k_syrk_reduce(const double *__restrict__ slab, int nsplit_off, i
     }
     for (; k < nsplit; ++k) s0 += p[(size_t)k * stride];
     const double t = (s0 + s1) + (s2 + s3);
-    S[(size_t)i * lds + j] = accumulate ? S[(size_t)i * lds + j] + t : t;   // accumulate: the next row tile of a streamed evaluation
+    // accumulate: the next row tile of a streamed evaluation (the mirror is added from its own previous value: S stays symmetric)
+    S[(size_t)i * lds + j] = accumulate ? S[(size_t)i * lds + j] + t : t;
+    if (i != j) S[(size_t)j * lds + i] = accumulate ? S[(size_t)j * lds + i] + t : t;
 }
 
 // ---------------------------------------------------------------------------------------------
