@@ -550,6 +550,17 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         // slab stays small beside Phi and T, many enough to fill 256 CUs (tools/mom_nc_sweep.sh: c2 768, c3/c4 512 chunks)
         const int nc_env = c->opt.mom_nc;   // (developer tuning)
         int nc = nc_env > 0 ? nc_env / ncg : (768 / ncg > 512 ? 768 / ncg : (2048 / ncg < 512 ? 2048 / ncg : 512));
+        if (nc_env <= 0 && c->kind == GPZ_KIND_COV) {
+            // covariance kinds (two workgroups resident per CU): whole rounds of 512 workgroups with ~2000 rows per chunk - the slab
+            // costs 2 x m x nm x 8 bytes per chunk whatever the rows.  Measured at m = 1000 (moments stage, ms; workgroups 512 / 1024 /
+            // 2048): 125 000 rows 0.57 / 0.60 / 0.66, 250 000 rows 1.06 / 1.10 / 1.16, 500 000 rows 2.19 / 2.11 / 2.22, 10^6 rows
+            // 4.67 / 4.60 / 4.46; c3 (m = 500) 0.27 / 0.30 / -.
+            long rounds = ((long)c->tr.n * ncg + 1024 * 1000 - 1) / (1024 * 1000);
+            if (rounds < 1) rounds = 1;
+            if (rounds > 4) rounds = 4;
+            nc = (int)(512 * rounds / ncg);
+            if (nc < 1) nc = 1;
+        }
         const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
         if (nc > max_nc) nc = max_nc;
         if (nc < 1) nc = 1;
