@@ -23,14 +23,16 @@ __device__ __forceinline__ double eps_of(double x) {   // MATLAB eps(x) for fini
 // flag[0] (info[1]) |= 1 when the reference might truncate: 1/||inv||_F <= 4 m eps(||SIGMA||_F), or the Cholesky failed.
 // (s_min >= 1/||inv||_F and tol <= m eps(||SIGMA||_F): outside that region inv_logdet.m keeps every singular value.)
 // A non-finite SIGMA is left alone: svd() raises in the reference and the evaluation returns NaN here.
-#define COND_NWG 64
+#define COND_NWG 256   // workgroups at m >= 512 (64 below: the ticket costs more than the rows); 64 at m = 1000 read their rows for 25 us
 __global__ __launch_bounds__(256) void k_cond_norms(const double *__restrict__ S, int lds, const double *__restrict__ alpha,
                                                     const double *__restrict__ Sinv, int ldsi, int m,
                                                     double *part, int *info, unsigned *ticket) {
     __shared__ double sh4[4];
     double a = 0.0, b = 0.0;
-    for (int i = blockIdx.x; i < m; i += COND_NWG) {
+    const unsigned nwg = gridDim.x;                              // 64 or COND_NWG
+    for (int i = blockIdx.x; i < m; i += (int)nwg) {
         const double *sr = S + (size_t)i * lds, *ir = Sinv + (size_t)i * ldsi;
+#pragma unroll 4
         for (int j = threadIdx.x; j < m; j += 256) {
             double v = sr[j];
             if (i == j) v += alpha[i];
@@ -41,20 +43,23 @@ __global__ __launch_bounds__(256) void k_cond_norms(const double *__restrict__ S
     a = block_sum_256(a, sh4);
     __syncthreads();
     b = block_sum_256(b, sh4);
-    // The workgroup that takes the last ticket adds the COND_NWG partials in their fixed order and sets the flag (one launch
+    // The workgroup that takes the last ticket adds the partials in their fixed order and sets the flag (one launch
     // instead of two: an evaluation of a small problem is a sequence of ~4 us launches); it puts the ticket counter back to zero.
     __shared__ int last;
     if (threadIdx.x == 0) {
         part[2 * blockIdx.x] = a;
         part[2 * blockIdx.x + 1] = b;
         __threadfence();
-        last = (atomicAdd(ticket, 1u) == COND_NWG - 1) ? 1 : 0;
+        last = (atomicAdd(ticket, 1u) == nwg - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!last || threadIdx.x >= 64) return;
     __threadfence();
-    a = part[2 * threadIdx.x];
-    b = part[2 * threadIdx.x + 1];
+    a = 0.0; b = 0.0;
+    for (unsigned q = 0; q < nwg / 64; ++q) {
+        a += part[2 * (threadIdx.x + 64 * q)];
+        b += part[2 * (threadIdx.x + 64 * q) + 1];
+    }
     a = wave_sum(a);
     b = wave_sum(b);
     if (threadIdx.x == 0) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void k_jacobi_pinv(const double *__restrict__ 
 void launch_cond_flag(hipStream_t st, const double *S, int lds, const double *alpha, const double *Sinv, int ldsi, int m,
                       double *part, int *info) {
     // info: [pivot failure, truncation flag, ticket counter of this kernel (zero between launches), -]
-    hipLaunchKernelGGL(k_cond_norms, dim3(COND_NWG), dim3(256), 0, st, S, lds, alpha, Sinv, ldsi, m, part, info, (unsigned *)(info + 2));
+    hipLaunchKernelGGL(k_cond_norms, dim3(m >= 512 ? COND_NWG : 64), dim3(256), 0, st, S, lds, alpha, Sinv, ldsi, m, part, info, (unsigned *)(info + 2));
 }
 
 // Pseudo-inverse of SIGMA = S + diag(alpha) (alpha may be nullptr) into Xi, ln-det of the kept part into *logdet.
