@@ -215,7 +215,7 @@ def test_matlab_style_entry_and_globals():
     gpz_amd.reset()
 
 
-@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 100, 257, 1000])
+@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 63, 64, 65, 96, 100, 129, 257, 500, 1000])   # panels of 32, tiles of 64: every edge of the blocked chain
 def test_inv_logdet(m):
     rng = np.random.default_rng(m)
     A = rng.standard_normal((m, 2 * m + 3)); S = A @ A.T + 0.5 * np.eye(m)
