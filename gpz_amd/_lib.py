@@ -28,7 +28,8 @@ class gpz_desc(C.Structure):
         ("rank", C.c_int32),
         ("world", C.c_int32),
         ("dtype", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("omega_cols", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -86,6 +86,15 @@ def _f64(a, ndim=None):
     return np.asfortranarray(a)
 
 
+def _omega(omega, n_tot, k):
+    """omega as the reference takes it: n x 1 (one weight per row for every output) or n x k (per-output weights,
+    GPz.m:48 ``omega(training,:)``; getOmega.m:19 returns ``(1+Y).^-2``, n x k for a k-column Y)."""
+    om = _f64(omega, 2)
+    if om is not None and (om.ndim != 2 or om.shape[0] != n_tot or om.shape[1] not in (1, k)):
+        raise ValueError("omega must be n x 1 or n x k")
+    return om
+
+
 def _mask(a, n):
     if a is None:
         return None
@@ -113,10 +122,7 @@ class GPzContext:
         n_tot = X.shape[0]
         if X.shape[1] != model.d or Y.shape != (n_tot, model.k):
             raise ValueError("X must be n x d and Y n x k")
-        om = _f64(omega, 2)
-        if om is not None:
-            if om.shape[1] != 1 or om.shape[0] != n_tot:
-                raise ValueError("omega must be n x 1")
+        om = _omega(omega, n_tot, model.k)
         psi_kind = 0
         psi = None
         if Psi is not None:
@@ -126,6 +132,7 @@ class GPzContext:
         self._va = _mask(validation, n_tot)
         self.model = model
         self._desc = _desc(model, device, stream, rank, world, dtype)
+        self._desc.omega_cols = 0 if om is None else om.shape[1]
         h = C.c_void_p()
         pat = None
         if patterns is not None:
@@ -274,9 +281,7 @@ class GPzMulti:
         n_tot = X.shape[0]
         if X.shape[1] != model.d or Y.shape != (n_tot, model.k):
             raise ValueError("X must be n x d and Y n x k")
-        om = _f64(omega, 2)
-        if om is not None and om.shape != (n_tot, 1):
-            raise ValueError("omega must be n x 1")
+        om = _omega(omega, n_tot, model.k)
         psi, psi_kind = None, 0
         if Psi is not None:
             psi = _f64(Psi)
@@ -291,6 +296,7 @@ class GPzMulti:
             n_gpus = dev.size
         self.model = model
         self._desc = _desc(model, 0, None, 0, 1, dtype)
+        self._desc.omega_cols = 0 if om is None else om.shape[1]
         h = C.c_void_p()
         _lib.check(lib.gpz_mgpu_create(
             C.byref(self._desc), int(n_gpus or 0), None if dev is None else dev.ctypes.data_as(_lib.c_int32_p),

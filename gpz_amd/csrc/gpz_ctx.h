@@ -134,7 +134,8 @@ struct RowSet {          // a device-resident row selection of the data
     double *Xc = nullptr;   // de x n_pad
     double *Xr = nullptr;   // n_pad x de
     double *Y = nullptr;    // k x n_pad
-    double *om = nullptr;   // n_pad (nullptr => ones)
+    double *om = nullptr;   // n_pad, or k x n_pad for an n x k omega (nullptr => ones)
+    long om_ld = 0;         // omega of output o, row i: om[o*om_ld + i]; 0 = one column for every output (GPz.m:48)
     // diagonal kinds only: input-noise variances and the observed-dimension mask (nullptr => absent)
     double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)
     double *Mc = nullptr, *Mr = nullptr;       // 1.0 observed / 0.0 missing
@@ -237,6 +238,8 @@ struct gpz_ctx {
     void *priv = nullptr;                 // owned by whoever attached it (the RCCL communicator of gpz_ctx_init_rccl),
     void (*priv_free)(void *) = nullptr;  // released with the context
     int timing = 0;   // gpz_ctx_enable_timing: 0 off, 1 HIP events around every stage (eager launches), 2 around the dominant stages only
+    bool time_rest = false;   // level 3: the replay of level 2 with events around EVERY segment and around the all-reduce hooks as well, so that
+                              // (wall time of a call) - (sum of all stage times) = what the device spent between segments: launch-to-launch gaps
     // One evaluation = ~150 launches on one stream between the upload of theta and the download of the result block, every argument
     // fixed for the life of the context: from the third gpz_eval on it is REPLAYED as hipGraphs (host theta, timing 0 or 2).  The
     // recording is cut into segments where something must happen between graph launches:

@@ -171,10 +171,14 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
     if (int e = c->ar.alloc(&rs.Y, np * k)) return e;
     HIPCHK(hipMemcpy(rs.Y, hy.data(), np * k * sizeof(double), hipMemcpyHostToDevice));
     if (omega) {
-        std::vector<double> ho(np, 0.0);
-        for (size_t r = 0; r < idx.size(); ++r) ho[r] = omega[idx[r]];
-        if (int e = c->ar.alloc(&rs.om, np)) return e;
-        HIPCHK(hipMemcpy(rs.om, ho.data(), np * sizeof(double), hipMemcpyHostToDevice));
+        // omega(selection,:) of GPz.m:48: n x 1 (one weight per row for every output) or n x k (getOmega.m:19 on a k-column Y)
+        const int oc = c->desc.omega_cols > 1 ? c->desc.omega_cols : 1;
+        std::vector<double> ho(np * (size_t)oc, 0.0);
+        for (int o = 0; o < oc; ++o)
+            for (size_t r = 0; r < idx.size(); ++r) ho[(size_t)o * np + r] = omega[(size_t)o * n_tot + idx[r]];
+        if (int e = c->ar.alloc(&rs.om, np * oc)) return e;
+        HIPCHK(hipMemcpy(rs.om, ho.data(), np * oc * sizeof(double), hipMemcpyHostToDevice));
+        rs.om_ld = oc > 1 ? (long)np : 0;
     }
     return 0;
 }
@@ -190,6 +194,8 @@ int setup_model(gpz_ctx *c, const gpz_desc *desc) {
     c->mid = method_id_of(desc->method);
     if (c->mid < 0) return gpz_fail(GPZ_ERR_ARG, "unknown method '%.2s'", desc->method);
     if (desc->d < 1 || desc->m < 1 || desc->k < 1) return gpz_fail(GPZ_ERR_ARG, "d, m, k must be >= 1");
+    if (desc->omega_cols > 1 && desc->omega_cols != desc->k)
+        return gpz_fail(GPZ_ERR_ARG, "omega must be n x 1 or n x k (omega_cols = %d, k = %d)", desc->omega_cols, desc->k);
     c->kind = c->mid >= 4 ? GPZ_KIND_COV : GPZ_KIND_DIAG;
     c->d = desc->d;
     c->de = pad_dim(desc->d);
@@ -667,6 +673,7 @@ namespace gpzi {
 extern "C" int gpz_ctx_enable_timing(gpz_ctx *c, int enable) {
     if (!c) return gpz_fail(GPZ_ERR_ARG, "null context");
     c->timing = enable < 0 ? 0 : enable > 2 ? 2 : enable;   // 0 off, 1 every stage (eager launches), 2 the dominant stages (graph segments)
+    c->time_rest = enable >= 3;                              // 3: as 2, plus the other segments ("rest") and the exchange points ("exchange")
     return GPZ_OK;
 }
 namespace gpzi {

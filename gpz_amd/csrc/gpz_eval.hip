@@ -84,7 +84,7 @@ static int phi_by_pattern(gpz_ctx *c, RowSet &rs, double *Phi, double *lnbeta, d
     a.m = c->m; a.mp = c->mp; a.d = de; a.k = c->k; a.kind = GPZ_KIND_COV;
     a.P = c->pr.P; a.G = c->RcP;
     a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b;
-    a.omega = rs.om;
+    a.omega = rs.om; a.om_ld = rs.om_ld;
     a.Y = (with_y && rs.Y) ? rs.Y : nullptr;
     a.Phi = Phi;
     a.lnbeta = lnbeta; a.wbeta = wbeta;
@@ -160,14 +160,14 @@ int build_phi(gpz_ctx *c) {
                            c->Phi, c->tr.Y, c->gen_ws);
         }
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
-                          c->tr.om, nullptr, c->lnbeta, c->wbeta, nullptr);
+                          c->tr.om, nullptr, c->lnbeta, c->wbeta, nullptr, c->tr.om_ld);
     } else {
         Stage s(c, "phi_build");
         PhiArgs a{};
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
-        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = c->tr.Y;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.om_ld = c->tr.om_ld; a.Y = c->tr.Y;
         a.Phi = c->Phi; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.w = nullptr; a.phiw = nullptr;
         a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
         a.part = a.n_pad <= c->phipart_rows ? c->phipart : nullptr; a.part_groups = c->phipart_groups;
@@ -192,7 +192,7 @@ static int phi_tile(gpz_ctx *c, const RowTile &rt) {
     a.Xc = c->tr.Xc + r0; a.ldx = c->tr.n_pad; a.n = rt.rows; a.n_pad = rt.rows_pad;
     a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
     a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
-    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om ? c->tr.om + r0 : nullptr; a.Y = c->tr.Y + r0;
+    a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om ? c->tr.om + r0 : nullptr; a.om_ld = c->tr.om_ld; a.Y = c->tr.Y + r0;
     a.Phi = c->Phi; a.lnbeta = c->lnbeta + r0; a.wbeta = c->wbeta + r0; a.w = nullptr; a.phiw = nullptr;
     a.Psic = c->tr.Psic ? c->tr.Psic + r0 : nullptr; a.Mc = c->tr.Mc ? c->tr.Mc + r0 : nullptr;
     a.ucnt = c->tr.ucnt ? c->tr.ucnt + r0 : nullptr;
@@ -245,7 +245,7 @@ int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev) {
     double *sums1 = c->comm1 + (size_t)c->k * c->mp * c->mp;
     {
         Stage s(c, "row_sums");
-        launch_sums1(c->st, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_sums1(c->st, c->tr.om, c->tr.om_ld, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), sums1);
     }
     for (int o = 0; o < c->k && !c->tile_rows; ++o) {
@@ -346,7 +346,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
                 {
                     Stage s(c, "row_scalars");
                     launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw + oo + r0, c->tr.Y + oo + r0, c->tr.om ? c->tr.om + r0 : nullptr,
-                                       c->lnbeta + oo + r0, c->wbeta + oo + r0, rt.rows_pad, rt.rows, c->rowscal + 4 * r0, c->partial);
+                                       c->lnbeta + oo + r0, c->wbeta + oo + r0, rt.rows_pad, rt.rows, c->rowscal + 4 * r0, c->partial, (long)o * c->tr.om_ld);
                     launch_slab_sum(c->st, c->partial, row_scalars_nwg(rt.rows), GPZ_NS, c->tile_rstats + (size_t)t * GPZ_NS);
                 }
                 Stage s(c, "moments");
@@ -395,7 +395,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
                 Stage s(c, "row_scalars");
                 const size_t oo = (size_t)o * c->tr.n_pad;   // this output's columns of the k x n_pad row arrays
                 launch_row_scalars(c->st, c->nupart, c->nslots, c->phiw + oo, c->tr.Y + oo, c->tr.om, c->lnbeta + oo,
-                                   c->wbeta + oo, c->tr.n_pad, c->tr.n, c->rowscal, c->partial);
+                                   c->wbeta + oo, c->tr.n_pad, c->tr.n, c->rowscal, c->partial, (long)o * c->tr.om_ld);
                 launch_slab_sum(c->st, c->partial, row_scalars_nwg(c->tr.n), GPZ_NS, c->rstats);
                 HIPCHK(hipMemcpyAsync(scal + (size_t)o * 4, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             }
@@ -472,7 +472,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             Stage s(c, "row_epilogue");
             RowArgs a{};
             a.Phi = c->Phi; a.T = c->T; a.ld = c->mp; a.n = c->tr.n; a.m = c->m; a.mp = c->mp; a.k = c->k; a.out = o;
-            a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.ldx = c->tr.n_pad;
+            a.y = c->tr.Y; a.omega = c->tr.om; a.om_ld = c->tr.om_ld; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta; a.ldx = c->tr.n_pad;
             a.w = c->w + (size_t)o * m; a.v = c->hetero ? c->pr.v + (size_t)o * m : nullptr;
             a.dL = c->dL; a.colslab = c->colslab; a.scal = c->scal_slab; a.nwg = c->nwg_rows;
             launch_row_epilogue(c->st, a);
@@ -544,7 +544,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
     if (have_valid && c->gen && !c->has_psi) {
         Stage s(c, "validation");
         if (int e = phi_by_pattern(c, c->va, nullptr, c->lnbeta_v, nullptr, c->w, c->phiw_v, false)) return e;
-        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->va.om_ld, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     } else if (have_valid && c->gen) {
         Stage s(c, "validation");
@@ -562,7 +562,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
         }
         launch_gen_rowdot(c->st, c->Phi_v, c->mp, c->va.n, c->va.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, c->w, c->lnbeta_v, nullptr, c->phiw_v);
-        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->va.om_ld, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     } else if (have_valid) {
         Stage s(c, "validation");
@@ -570,11 +570,11 @@ int eval_tail(gpz_ctx *c, bool pinv) {
         a.Xc = c->va.Xc; a.ldx = c->va.n_pad; a.n = c->va.n; a.n_pad = c->va.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
-        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.Y = nullptr;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.om_ld = c->va.om_ld; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta_v; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw_v;
         a.Psic = c->va.Psic; a.Mc = c->va.Mc; a.ucnt = c->va.ucnt;
         if (launch_phi(c->st, a)) return gpz_fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
-        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
+        launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->va.om_ld, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
     }   // (no validation rows: k_unpack zeroed vsums at the start of the evaluation)
     {
@@ -643,7 +643,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
     if (nlogML_partial && c->gen) {
         launch_gen_rowdot(c->st, c->Phi, c->mp, c->tr.n, c->tr.n_pad, c->m, c->k, c->hetero ? c->pr.v : nullptr, c->pr.b,
                           nullptr, c->w, c->lnbeta, nullptr, c->phiw);
-        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->tr.om_ld, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), c->rstats);
         if (int e = allreduce(c, c->rstats, gpz_ns(c->k))) return e;
         launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,
@@ -654,11 +654,11 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         a.Xc = c->tr.Xc; a.ldx = c->tr.n_pad; a.n = c->tr.n; a.n_pad = c->tr.n_pad;
         a.m = c->m; a.mp = c->mp; a.d = c->de; a.k = c->k; a.kind = c->kind;
         a.P = c->pr.P; a.G = (c->kind == GPZ_KIND_COV) ? c->pr.Rc : c->pr.G2;
-        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.Y = nullptr;
+        a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.om_ld = c->tr.om_ld; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw;
         a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
         if (launch_phi(c->st, a)) return gpz_fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
-        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
+        launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->tr.om_ld, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), c->rstats);
         if (int e = allreduce(c, c->rstats, gpz_ns(c->k))) return e;
         launch_solve_partial(c->st, c->pr, c->w, c->logdet, c->comm1 + (size_t)c->k * c->mp * c->mp, c->rstats, c->m,

@@ -40,6 +40,7 @@ int graph_cut(gpz_ctx *c, bool last) {
             if (e == hipSuccess && nn > 0) e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
         } else if (e == hipSuccess) e = hipErrorUnknown;
         if (g) (void)hipGraphDestroy(g);
+        if (e == hipSuccess && c->opt.debug_fail_cut > 0 && (int)c->cap->segs.size() + 1 == c->opt.debug_fail_cut) e = hipErrorUnknown;   // (developer build: test hook)
         if (e == hipSuccess && !last) e = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -58,19 +59,27 @@ static void graph_set_drop(gpz_ctx::GraphSet &gs) {
 // One evaluation from the recorded segments: graph launches with, between them, the all-reduce hook of the exchange points and the
 // events of the dominant stages (timing 2).
 static int graph_replay(gpz_ctx *c, gpz_ctx::GraphSet &gs) {
+    const bool all = c->timing == 2 && c->time_rest;   // level 3: every segment and every exchange point between events
+    const int rest = all ? c->tm.find("rest") : -1, exch = all ? c->tm.find("exchange") : -1;
     for (auto &s : gs.segs) {
         hipEvent_t e0{}, e1{};
-        if (s.stage >= 0) {
+        const int stage = s.stage >= 0 ? s.stage : ((all && s.exec) ? rest : -1);
+        if (stage >= 0) {
             e0 = c->tm.get();
             e1 = c->tm.get();
             HIPCHK(hipEventRecord(e0, c->st));
         }
         if (s.exec) HIPCHK(hipGraphLaunch(s.exec, c->st));
-        if (s.stage >= 0) {
+        if (stage >= 0) {
             HIPCHK(hipEventRecord(e1, c->st));
-            c->tm.pending.push_back({s.stage, e0, e1, s.count_call});
+            c->tm.pending.push_back({stage, e0, e1, s.stage >= 0 ? s.count_call : true});
         }
-        if (s.hook_count && c->ar_fn(c->ar_user, s.hook_buf, s.hook_count, (void *)c->st) != 0) return gpz_fail(GPZ_ERR_COMM, "all-reduce hook failed");
+        if (s.hook_count) {
+            hipEvent_t h0{}, h1{};
+            if (all) { h0 = c->tm.get(); h1 = c->tm.get(); HIPCHK(hipEventRecord(h0, c->st)); }
+            if (c->ar_fn(c->ar_user, s.hook_buf, s.hook_count, (void *)c->st) != 0) return gpz_fail(GPZ_ERR_COMM, "all-reduce hook failed");
+            if (all) { HIPCHK(hipEventRecord(h1, c->st)); c->tm.pending.push_back({exch, h0, h1, true}); }
+        }
     }
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
@@ -107,11 +116,26 @@ static int eval_common(gpz_ctx *c, const double *theta, const double *theta_dev,
             c->cap_stage = -1;
             c->cap_stage_first = c->cap_failed = false;
             if (!rc && (rc = stage_a(c, theta, nullptr))) why = "stage A";   // (k_unpack clears the status words)
+            if (!rc && c->cap_failed) { rc = -1; why = "segment"; }          // a cut inside stage A failed: stop recording here
             if (!rc && (rc = eval_tail(c, false))) why = "stage B";
             (void)graph_cut(c, true);
             if (c->cap_failed && !rc) { rc = -1; why = "segment"; }
             c->capturing = false;
             c->cap = nullptr;
+            if (rc) {
+                // A cut that failed (hipStreamEndCapture / hipGraphInstantiate / the re-opened capture) leaves graph_st NOT capturing:
+                // whatever the pipeline issued after it ran for real on graph_st, without the all-reduce hooks, into the buffers the
+                // eager evaluation below is about to write from the user's stream.  Close a capture that is still open, then wait for
+                // graph_st: the eager evaluation starts from theta and overwrites everything those launches left behind.
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(c->graph_st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+                    hipGraph_t g = nullptr;
+                    (void)hipStreamEndCapture(c->graph_st, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                }
+                (void)hipStreamSynchronize(c->graph_st);
+                (void)hipGetLastError();
+            }
         } else {
             rc = -1; why = "begin capture";
         }

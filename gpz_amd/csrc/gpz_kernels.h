@@ -40,7 +40,8 @@ struct PhiArgs {
     const double *P, *G; // see GpzParams (G = G2 for diag kinds, Rc for cov kinds)
     const double *v;     // m x k or nullptr
     const double *b;     // k
-    const double *omega; // n or nullptr (ones)
+    const double *omega; // n, or k x om_ld (omega[o*om_ld + i]: an n x k omega, GPz.m:48), or nullptr (ones)
+    long om_ld;          // 0: one column for every output
     const double *Y;     // k x ldx (Y[o*ldx + i]) or nullptr: written into PHI columns m..m+k-1
     double *Phi;         // n_pad x mp row-major, or nullptr (reduction-only mode)
     double *lnbeta;      // k x ldx
@@ -127,6 +128,7 @@ struct RowArgs {
     const double *Phi; double *T; int ld;   // T is overwritten with dPHI (k==1) or accumulated into dL
     int n, m, mp, k, out;                   // out = output index being processed
     const double *y, *omega, *lnbeta, *wbeta; long ldx;
+    long om_ld;                             // omega[out*om_ld + i]; 0 = an n x 1 omega for every output
     const double *w, *v;                    // column `out` of w (m), v (m) (v may be nullptr)
     double *dL;                             // n_pad x ld accumulator when k>1 (else nullptr)
     double *colslab;                        // [nwg][2][mp]: per-workgroup partial PHI'c, PHI'dbeta
@@ -161,7 +163,7 @@ inline int row_scalars_nwg(int n) {   // one workgroup per 512 rows, 128 .. 1024
 }
 void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
                         const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
-                        double *rowscal, double *partial);
+                        double *rowscal, double *partial, long om_off = 0);   // om_off: this output's column of an n x k omega (o * om_ld)
 struct FusedMomentArgs {
     const double *Phi, *T; int ld;
     const double *Xr, *rowscal;
@@ -212,9 +214,9 @@ void launch_finish(hipStream_t st, const FinishArgs &a);
 __host__ __device__ inline int gpz_ns(int k) { return GPZ_NS + (k > 8 ? k - 8 : 0); }
 __host__ __device__ inline int gpz_ns_idx(int base, int o) { return o < 8 ? base + o : GPZ_NS + (o - 8); }
 #define GPZ_SMALL_NWG 128
-void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, const double *lnbeta,
+void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, long om_ld, const double *lnbeta,
                       long ldx, int n, int k, double *partial);
-void launch_sums1(hipStream_t st, const double *omega, const double *lnbeta, long ldx, int n, int k, double *partial);
+void launch_sums1(hipStream_t st, const double *omega, long om_ld, const double *lnbeta, long ldx, int n, int k, double *partial);
 // nlogML partial of the solve-only mode (GPz.m:81-82), one value per output.
 void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const double *logdet, const double *sums1,
                           const double *rstats, int m, int k, double *out);
@@ -325,7 +327,7 @@ int launch_psi32_moments(hipStream_t st, const double *Phi, const double *T, int
                          int nrec);
 void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
                        const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
-                       double *phiw);
+                       double *phiw, long om_ld = 0);   // omega[o*om_ld + i]
 void launch_gen_moments(hipStream_t st, const double *Phi, const double *T, int ld, const double *rowscal, const double *w,
                         const double *v, const GenRows &r, int g, int row_begin, int nrows, const unsigned char *pat, int m,
                         int d, int de, const double *P, const double *Sig, int nchunk, int rows_per_chunk, double *slab,

@@ -312,6 +312,8 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
     if (n_gpus <= 0) n_gpus = ndev;                                   // default: every GPU of the node
     const int d = desc->d, k = desc->k;
     if (d < 1 || k < 1 || desc->m < 1) return gpz_fail(GPZ_ERR_ARG, "d, m, k must be >= 1");
+    if (desc->omega_cols > 1 && desc->omega_cols != k)
+        return gpz_fail(GPZ_ERR_ARG, "omega must be n x 1 or n x k (omega_cols = %d, k = %d)", desc->omega_cols, k);
     gpz_mgpu *h = new gpz_mgpu();
     h->n = n_gpus;
     h->reducer = reducer;
@@ -368,8 +370,10 @@ extern "C" int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32
         for (int o = 0; o < k; ++o)
             for (int64_t q = 0; q < nr; ++q) Yr[(size_t)o * nr + q] = Y[(size_t)o * n_tot + rows[q]];
         if (omega) {
-            Or.resize((size_t)nr);
-            for (int64_t q = 0; q < nr; ++q) Or[q] = omega[rows[q]];
+            const int oc = desc->omega_cols > 1 ? desc->omega_cols : 1;   // n_tot x 1 or n_tot x k (GPz.m:48)
+            Or.resize((size_t)nr * oc);
+            for (int o = 0; o < oc; ++o)
+                for (int64_t q = 0; q < nr; ++q) Or[(size_t)o * nr + q] = omega[(size_t)o * n_tot + rows[q]];
         }
         if (psi_kind == 1 || psi_kind == 3) {
             Pr.resize((size_t)nr * d);

@@ -192,7 +192,7 @@ __global__ void k_gen_fill(double *__restrict__ Phi, int ld, int n, int n_pad, i
 // lnbeta = b + PHI v, omega*beta, PHI w: one wave per row over an existing PHI (getPHI.m:116-125, GPz.m:43-48).
 __global__ __launch_bounds__(256) void k_gen_rowdot(const double *__restrict__ Phi, int ld, int n, long ldx, int m, int k,
                                                      const double *__restrict__ v, const double *__restrict__ bvec,
-                                                     const double *__restrict__ omega, const double *__restrict__ wv,
+                                                     const double *__restrict__ omega, long om_ld, const double *__restrict__ wv,
                                                      double *__restrict__ lnbeta, double *__restrict__ wbeta,
                                                      double *__restrict__ phiw) {
     const int lane = threadIdx.x & 63;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_gen_rowdot(const double *__restrict__ P
             const bool valid = i < n;
             const double lb = bvec[o] + sv;
             lnbeta[(size_t)o * ldx + i] = valid ? lb : 0.0;
-            if (wbeta) wbeta[(size_t)o * ldx + i] = valid ? (omega ? omega[i] : 1.0) * exp(-lb) : 0.0;
+            if (wbeta) wbeta[(size_t)o * ldx + i] = valid ? (omega ? omega[(size_t)o * om_ld + i] : 1.0) * exp(-lb) : 0.0;
             if (phiw) phiw[(size_t)o * ldx + i] = sw;
         }
     }
@@ -822,8 +822,8 @@ void launch_gen_fill(hipStream_t st, double *Phi, int ld, int n, int n_pad, int 
 
 void launch_gen_rowdot(hipStream_t st, const double *Phi, int ld, int n, long ldx, int m, int k, const double *v,
                        const double *b, const double *omega, const double *w, double *lnbeta, double *wbeta,
-                       double *phiw) {
-    hipLaunchKernelGGL(k_gen_rowdot, dim3((unsigned)((ldx + 3) / 4)), dim3(256), 0, st, Phi, ld, n, ldx, m, k, v, b, omega, w,
+                       double *phiw, long om_ld) {
+    hipLaunchKernelGGL(k_gen_rowdot, dim3((unsigned)((ldx + 3) / 4)), dim3(256), 0, st, Phi, ld, n, ldx, m, k, v, b, omega, om_ld, w,
                        lnbeta, wbeta, phiw);
 }
 

@@ -190,7 +190,7 @@ template <int D, bool KGEN, bool PSI, int R, int JB>
 __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
                                                    const double *__restrict__ P, const double *__restrict__ G,
                                                    const double *__restrict__ v, const double *__restrict__ bvec,
-                                                   const double *__restrict__ omega, const double *__restrict__ Y,
+                                                   const double *__restrict__ omega, long om_ld, const double *__restrict__ Y,
                                                    double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                    double *__restrict__ wbeta, const double *__restrict__ wv,
                                                    double *__restrict__ phiw, const double *__restrict__ Psic,
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
                 const double lb = bvec[o] + sv[r][o];                      // getPHI.m:119,124
                 lnbeta[(size_t)o * ldx + i] = valid[r] ? lb : 0.0;
                 if (wbeta) {
-                    const double om = omega ? omega[i] : 1.0;
+                    const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
                     wbeta[(size_t)o * ldx + i] = valid[r] ? om * exp(-lb) : 0.0;   // GPz.m:43,48
                 }
                 if (phiw) phiw[(size_t)o * ldx + i] = sw[r][o];
@@ -384,7 +384,7 @@ template <int D, bool KGEN, int R, int JB, bool TAB>
 __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ Xc, long ldx, int n, int m, int mp, int k,
                                                   const double *__restrict__ Rc,
                                                   const double *__restrict__ v, const double *__restrict__ bvec,
-                                                  const double *__restrict__ omega, const double *__restrict__ Y,
+                                                  const double *__restrict__ omega, long om_ld, const double *__restrict__ Y,
                                                   double *__restrict__ Phi, double *__restrict__ lnbeta,
                                                   double *__restrict__ wbeta, const double *__restrict__ wv,
                                                   double *__restrict__ phiw, int jgroup, double *__restrict__ part, long ldp,
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
                 const double lb = bvec[o] + sv[r][o];                      // getPHI.m:119,124
                 lnbeta[(size_t)o * ldx + i] = valid[r] ? lb : 0.0;
                 if (wbeta) {
-                    const double om = omega ? omega[i] : 1.0;
+                    const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
                     wbeta[(size_t)o * ldx + i] = valid[r] ? om * exp(-lb) : 0.0;   // GPz.m:43,48
                 }
                 if (phiw) phiw[(size_t)o * ldx + i] = sw[r][o];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void k_phi_cov(const double *__restrict__ X
 
 // lnbeta = b + sum_g part_v[g], omega*beta, PHI*w from the column-group partial sums (fixed order: repeatable)
 __global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ngroup, long ldx, long rows, int n, int k,
-                               const double *__restrict__ bvec, const double *__restrict__ omega,
+                               const double *__restrict__ bvec, const double *__restrict__ omega, long om_ld,
                                double *__restrict__ lnbeta, double *__restrict__ wbeta, double *__restrict__ phiw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
@@ -601,7 +601,7 @@ __global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ng
         const double lb = bvec[o] + sv;
         lnbeta[(size_t)o * ldx + i] = valid ? lb : 0.0;
         if (wbeta) {
-            const double om = omega ? omega[i] : 1.0;
+            const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
             wbeta[(size_t)o * ldx + i] = valid ? om * exp(-lb) : 0.0;
         }
         if (phiw) phiw[(size_t)o * ldx + i] = valid ? sw : 0.0;   // rows past the data carry no partial sums
@@ -666,13 +666,13 @@ static void launch_phi_cov_d(hipStream_t st, const PhiArgs &a) {
     dim3 grid(nwg, ngroup);
 #define PHI_COV(KG, TB) \
     hipLaunchKernelGGL((k_phi_cov<D, KG, R, JB, TB>), grid, dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.G, a.v, \
-                       a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part, (long)a.n_pad, a.wgtab)
+                       a.b, a.omega, a.om_ld, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, jgroup, part, (long)a.n_pad, a.wgtab)
     if (a.wgtab) { if (a.k == 1) PHI_COV(false, true); else PHI_COV(true, true); }
     else { if (a.k == 1) PHI_COV(false, false); else PHI_COV(true, false); }
 #undef PHI_COV
     if (part)
         hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
-                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
+                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.om_ld, a.lnbeta, a.wbeta, a.phiw);
 }
 
 #ifndef GPZ_PHI_DIAG_RP
@@ -703,7 +703,7 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
 #define PHI_DIAG_R(KG, PS, RR) \
     hipLaunchKernelGGL((k_phi_diag<D, KG, PS, RR, JB>), dim3((a.n_pad + 256 * RR - 1) / (256 * RR), ngroup),              \
                        dim3(256), 0, st, a.Xc, a.ldx, a.n, a.m, a.mp, a.k, a.P,                                           \
-                       a.G, a.v, a.b, a.omega, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt, jgroup, part, (long)a.n_pad)
+                       a.G, a.v, a.b, a.omega, a.om_ld, a.Y, a.Phi, a.lnbeta, a.wbeta, a.w, a.phiw, a.Psic, a.Mc, a.ucnt, jgroup, part, (long)a.n_pad)
 #define PHI_DIAG(KG, PS) \
     do { if (PS) PHI_DIAG_R(KG, PS, RP); else if (small) PHI_DIAG_R(KG, PS, 1); else PHI_DIAG_R(KG, PS, R); } while (0)
     if (a.k == 1) { if (a.Psic) PHI_DIAG(false, true); else PHI_DIAG(false, false); }
@@ -712,7 +712,7 @@ static void launch_phi_kd(hipStream_t st, const PhiArgs &a) {
 #undef PHI_DIAG_R
     if (part)
         hipLaunchKernelGGL(k_phi_finalize, dim3((unsigned)((a.n_pad + 255) / 256)), dim3(256), 0, st, (const double *)part,
-                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.lnbeta, a.wbeta, a.phiw);
+                           (long)a.n_pad, ngroup, a.ldx, (long)a.n_pad, a.n, a.k, a.b, a.omega, a.om_ld, a.lnbeta, a.wbeta, a.phiw);
 }
 
 template <int KIND>

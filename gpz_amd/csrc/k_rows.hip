@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_row_epilogue(RowArgs a) {
         const double delta = sh_phiw - yo[i];
         const double lb = lbo[i];
         const double beta = exp(-lb);                                      // GPz.m:43
-        const double om = a.omega ? a.omega[i] : 1.0;
+        const double om1 = a.omega ? a.omega[i] : 1.0;                     // omega(training): the first column  GPz.m:236
+        const double om = a.omega ? a.omega[(size_t)a.out * a.om_ld + i] : 1.0;
         const double ob = wbo[i];                                          // omega*beta, GPz.m:48
         const double dbeta = 0.5 * (-beta) * (1.0 / beta - (delta * delta + nu)) * om;   // GPz.m:93
         const double c = ob * delta;                                       // GPz.m:79
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_row_epilogue(RowArgs a) {
             }
         }
         s0 = fma(c, delta, s0);
-        s1 = fma(om, delta * delta, s1);
+        s1 = fma(om1, delta * delta, s1);
         s2 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));            // GPz.m:237  log(beta) = -lnBeta_i
         s3 += dbeta;
         __syncthreads();
@@ -356,7 +357,7 @@ int launch_moments(hipStream_t st, const MomentArgs &a) {
 // Row scalars from the T-GEMM epilogue's partial sums (GPz.m:69,77-79,93) + the scalar sums of GPz.m:81,94,236-237.
 __global__ __launch_bounds__(256) void k_row_scalars(const double *__restrict__ nupart, int nslots,
                                                       const double *__restrict__ phiw, const double *__restrict__ y,
-                                                      const double *__restrict__ omega,
+                                                      const double *__restrict__ omega, long om_off,
                                                       const double *__restrict__ lnbeta,
                                                       const double *__restrict__ wbeta, long n_pad, int n,
                                                       double *__restrict__ rowscal, double *__restrict__ partial) {
@@ -378,14 +379,15 @@ __global__ __launch_bounds__(256) void k_row_scalars(const double *__restrict__ 
         const double delta = phiw[i] - y[i];
         const double lb = lnbeta[i];
         const double beta = exp(-lb);
-        const double om = omega ? omega[i] : 1.0;
+        const double om = omega ? omega[om_off + i] : 1.0;                  // this output's column of an n x k omega
+        const double om1 = omega ? omega[i] : 1.0;                          // omega(training): the first column  GPz.m:236
         const double ob = wbeta[i];
         const double dbeta = 0.5 * (-beta) * (1.0 / beta - (delta * delta + nu)) * om;   // GPz.m:93
         const double c = ob * delta;
         double *rs = rowscal + (size_t)i * 4;
         rs[0] = ob; rs[1] = c; rs[2] = dbeta; rs[3] = 0.0;
         s0 = fma(c, delta, s0);
-        s1 = fma(om, delta * delta, s1);
+        s1 = fma(om1, delta * delta, s1);
         s2 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
         s3 += dbeta;
     }
@@ -402,8 +404,8 @@ __global__ __launch_bounds__(256) void k_row_scalars(const double *__restrict__ 
 
 void launch_row_scalars(hipStream_t st, const double *nupart, int nslots, const double *phiw, const double *y,
                         const double *omega, const double *lnbeta, const double *wbeta, long n_pad, int n,
-                        double *rowscal, double *partial) {
-    hipLaunchKernelGGL(k_row_scalars, dim3(row_scalars_nwg(n)), dim3(256), 0, st, nupart, nslots, phiw, y, omega, lnbeta, wbeta,
+                        double *rowscal, double *partial, long om_off) {
+    hipLaunchKernelGGL(k_row_scalars, dim3(row_scalars_nwg(n)), dim3(256), 0, st, nupart, nslots, phiw, y, omega, om_off, lnbeta, wbeta,
                        n_pad, n, rowscal, partial);
 }
 
@@ -797,22 +799,23 @@ void launch_finish(hipStream_t st, const FinishArgs &a) {
 // partial[wg][0] = sum omega*delta^2 (all outputs), [1] = sum omega*(-0.5 beta delta^2 + 0.5 ln beta),
 // [2+o] = sum omega*beta*delta^2 for output o, with delta = phiw - y.   (GPz.m:81,236-237,258-259)
 __global__ __launch_bounds__(256) void k_row_stats(const double *__restrict__ phiw, const double *__restrict__ y,
-                                                    const double *__restrict__ omega,
+                                                    const double *__restrict__ omega, long om_ld,
                                                     const double *__restrict__ lnbeta, long ldx, int n, int k,
                                                     double *__restrict__ partial) {
     __shared__ double sh4[4];
     double s0 = 0.0, s1 = 0.0, cnt = 0.0;
     double so[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double om = omega ? omega[i] : 1.0;
+        const double om1 = omega ? omega[i] : 1.0;   // omega(training) of GPz.m:236,258: the first column of an n x k omega
         cnt += 1.0;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             if (o < k) {
+                const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
                 const double delta = phiw[(size_t)o * ldx + i] - y[(size_t)o * ldx + i];
                 const double lb = lnbeta[(size_t)o * ldx + i];
                 const double beta = exp(-lb);
-                s0 = fma(om, delta * delta, s0);
+                s0 = fma(om1, delta * delta, s0);
                 s1 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
                 so[o] = fma(om * beta, delta * delta, so[o]);
             }
@@ -835,11 +838,11 @@ __global__ __launch_bounds__(256) void k_row_stats(const double *__restrict__ ph
     for (int o = 8; o < k; ++o) {   // more than 8 outputs: one more pass over the rows per extra output (records grow by k - 8)
         double t = 0.0, t0 = 0.0, t1 = 0.0;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-            const double om = omega ? omega[i] : 1.0;
+            const double om1 = omega ? omega[i] : 1.0, om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
             const double delta = phiw[(size_t)o * ldx + i] - y[(size_t)o * ldx + i];
             const double lb = lnbeta[(size_t)o * ldx + i];
             const double beta = exp(-lb);
-            t0 = fma(om, delta * delta, t0);
+            t0 = fma(om1, delta * delta, t0);
             t1 += om * (-0.5 * beta * delta * delta + 0.5 * (-lb));
             t = fma(om * beta, delta * delta, t);
         }
@@ -854,18 +857,22 @@ __global__ __launch_bounds__(256) void k_row_stats(const double *__restrict__ ph
 }
 
 // partial[wg][0] = sum omega, [1+o] = sum_i omega_i lnbeta_io      (GPz.m:82,110)
-__global__ __launch_bounds__(256) void k_sums1(const double *__restrict__ omega, const double *__restrict__ lnbeta,
+__global__ __launch_bounds__(256) void k_sums1(const double *__restrict__ omega, long om_ld, const double *__restrict__ lnbeta,
                                                 long ldx, int n, int k, double *__restrict__ partial) {
     __shared__ double sh4[4];
     double s0 = 0.0, cnt = 0.0;
     double so[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double om = omega ? omega[i] : 1.0;
-        s0 += om;
+        // sum(sum(omega(training,:))) of GPz.m:110: an n x 1 omega counts once, an n x k omega every column
+        if (!om_ld) s0 += omega ? omega[i] : 1.0;
         cnt += 1.0;
 #pragma unroll
         for (int o = 0; o < 8; ++o)
-            if (o < k) so[o] = fma(om, lnbeta[(size_t)o * ldx + i], so[o]);
+            if (o < k) {
+                const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
+                if (om_ld) s0 += om;
+                so[o] = fma(om, lnbeta[(size_t)o * ldx + i], so[o]);
+            }
     }
     s0 = block_sum_256(s0, sh4);
     __syncthreads();
@@ -880,12 +887,17 @@ __global__ __launch_bounds__(256) void k_sums1(const double *__restrict__ omega,
         if (threadIdx.x == 0) pw[1 + o] = t;
     }
     for (int o = 8; o < k; ++o) {
-        double t = 0.0;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-            t = fma(omega ? omega[i] : 1.0, lnbeta[(size_t)o * ldx + i], t);
+        double t = 0.0, ts = 0.0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const double om = omega ? omega[(size_t)o * om_ld + i] : 1.0;
+            if (om_ld) ts += om;
+            t = fma(om, lnbeta[(size_t)o * ldx + i], t);
+        }
         __syncthreads();
         t = block_sum_256(t, sh4);
-        if (threadIdx.x == 0) pw[gpz_ns_idx(1, o)] = t;
+        __syncthreads();
+        ts = block_sum_256(ts, sh4);
+        if (threadIdx.x == 0) { pw[gpz_ns_idx(1, o)] = t; pw[0] += ts; }
     }
 }
 
@@ -914,12 +926,12 @@ void launch_solve_partial(hipStream_t st, GpzParams pr, const double *w, const d
 }
 
 #define SMALL_NWG GPZ_SMALL_NWG
-void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, const double *lnbeta,
+void launch_row_stats(hipStream_t st, const double *phiw, const double *y, const double *omega, long om_ld, const double *lnbeta,
                       long ldx, int n, int k, double *partial) {
-    hipLaunchKernelGGL(k_row_stats, dim3(SMALL_NWG), dim3(256), 0, st, phiw, y, omega, lnbeta, ldx, n, k, partial);
+    hipLaunchKernelGGL(k_row_stats, dim3(SMALL_NWG), dim3(256), 0, st, phiw, y, omega, om_ld, lnbeta, ldx, n, k, partial);
 }
-void launch_sums1(hipStream_t st, const double *omega, const double *lnbeta, long ldx, int n, int k, double *partial) {
-    hipLaunchKernelGGL(k_sums1, dim3(SMALL_NWG), dim3(256), 0, st, omega, lnbeta, ldx, n, k, partial);
+void launch_sums1(hipStream_t st, const double *omega, long om_ld, const double *lnbeta, long ldx, int n, int k, double *partial) {
+    hipLaunchKernelGGL(k_sums1, dim3(SMALL_NWG), dim3(256), 0, st, omega, om_ld, lnbeta, ldx, n, k, partial);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void k_phi_wide(PhiArgs a) {
             const double lb = a.b[o] + svs[o * 64 + lane];                     // getPHI.m:119,124
             a.lnbeta[(size_t)o * ldx + i] = valid ? lb : 0.0;
             if (a.wbeta) {
-                const double om = a.omega ? a.omega[i] : 1.0;
+                const double om = a.omega ? a.omega[(size_t)o * a.om_ld + i] : 1.0;
                 a.wbeta[(size_t)o * ldx + i] = valid ? om * exp(-lb) : 0.0;    // GPz.m:43,48
             }
             if (a.phiw) a.phiw[(size_t)o * ldx + i] = valid ? sws[o * 64 + lane] : 0.0;

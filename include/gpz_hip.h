@@ -92,7 +92,10 @@ typedef struct gpz_desc {
                                * master sums, PHI*inv(SIGMA) with fp32 accumulation).  Delta, ln PHI, PHI, every sum over
                                * rows, the m x m stage, theta, f and g stay fp64; every other configuration ignores the
                                * flag and runs the fp64 path bit for bit.  Gates: 1e-4 on f, 1e-3 on g (of max|g|) */
-    int32_t reserved[3];
+    int32_t omega_cols;       /* columns of omega: 0 or 1 = n_tot x 1, one weight per row for every output; k = n_tot x k,
+                               * per-output weights (GPz.m:48 omega(training,:); getOmega.m:19 returns (1+Y).^-2, n x k for a
+                               * k-column Y).  The two RMSE statistics read omega(training) = the FIRST column (GPz.m:236,258) */
+    int32_t reserved[2];
 } gpz_desc;
 #define GPZ_F64 0
 #define GPZ_F32 1
@@ -102,7 +105,7 @@ typedef struct gpz_desc {
  * a single-process caller leaves it unset. */
 typedef int (*gpz_allreduce_fn)(void *user, void *buf, size_t count, void *stream);
 
-/* Build the evaluation context.  X is n_tot x d, Y n_tot x k, omega n_tot x 1 (NULL = ones),
+/* Build the evaluation context.  X is n_tot x d, Y n_tot x k, omega n_tot x 1 or n_tot x k (desc->omega_cols; NULL = ones),
  * training/validation n_tot x 1 logical (NULL = all rows / no validation), all HOST pointers,
  * column-major.  psi_kind: 0 none; 1 = n_tot x d (after fixPsi, diag kinds); 2 = d x d x n_tot cube (GC/VC);
  * 3 = n_tot x d per-dimension variances for GC/VC, meaning the diagonal cubes fixPsi.m:27-31 builds from them
@@ -164,7 +167,9 @@ int gpz_ctx_last_pinv(const gpz_ctx *ctx, double out[4]);
  * eager launches); enable = 2: around the dominant stages only (phi_build, syrk, tgemm, moments), the evaluation still replayed as
  * hipGraph segments with the events between them; 0: off.  gpz_ctx_timings copies up to `cap` accumulated stage times in ms and the
  * call counts, returns the number of stages; names are static strings. */
-int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);
+int gpz_ctx_enable_timing(gpz_ctx *ctx, int enable);   /* 3: level 2 plus events around every other segment ("rest") and around the
+                                                          * all-reduce hooks ("exchange"): wall time of a call minus the sum of all stage times is then what the device spent BETWEEN
+                                                          * segments - the launch-to-launch gaps of a replayed evaluation */
 int gpz_ctx_timings(gpz_ctx *ctx, const char **names, double *ms, int64_t *calls, int cap);
 int gpz_ctx_reset_timings(gpz_ctx *ctx);
 /* Which kernel family this context's rows run on (e.g. dtype = GPZ_F32 with missing values or d > 20 takes the fp64 pair kernels:

@@ -14,9 +14,14 @@
 //        what the live context was built from: model fields, array sizes, data pointers, and the CONTENT of the arrays:
 //        Y, omega, training and validation are hashed completely on every call (MATLAB edits an unshared variable in
 //        place and keeps its pointer — `training(bad) = false` between two train() calls must not evaluate on stale
-//        device data; 18 MB at n = 1e6, ~2 ms), X and Psi (the big ones: 6.4 GB at config 5) by 256 strided samples plus
-//        pointer and size — after editing X or Psi in place call gpz_mex('reset').  Anything different rebuilds the
-//        context.  model.n_gpus (optional) = number of GPUs, default all of the node; the rows are sharded across them
+//        device data; 18 MB at n = 1e6, ~2 ms).  X and Psi (the big ones: 80 MB at config 4, 6.4 GB as cubes at config 5)
+//        are compared on EVERY call by pointer, size and 256 strided samples, and by a complete 64-bit content hash
+//        (computed when the context is built, on all host cores) that is re-checked every K-th call: an in-place edit
+//        of X or Psi is caught at the latest K-1 evaluations later, rebuilds the context and counts in 'verify_info'.
+//        K = model.verify_every when given (1 = every call: exact); otherwise K is chosen from measured times so that
+//        the hashing costs at most 2 % of the evaluations it guards (K = ceil(hash seconds / (0.02 x evaluation
+//        seconds)), 1 .. 64; c4: 80 MB hash ~2 ms on 16 cores against 55 ms => K = 2).  Anything different rebuilds
+//        the context.  omega is n x 1 or n x model.k (GPz.m:48 `omega(training,:)`, getOmega.m:19).  model.n_gpus (optional) = number of GPUs, default all of the node; the rows are sharded across them
 //        and reduced with RCCL inside the library (gpz_mgpu_*); model.reducer = 'loopback' (optional) puts model.n_gpus
 //        shards on ONE device with the library's own reducer (single-GPU hosts, tests).
 //        model.dtype = 'f32' (optional) selects the fp32 per-pair factorisations of GC/VC with input noise.
@@ -31,9 +36,16 @@
 //   gpz_mex('pinv_mode', mode)                                         branch of inv_logdet.m:7-12 (0 auto, 1 always, -1 never)
 //   n = gpz_mex('gpus')                                                GPUs the live context runs on (0: none)
 //   n = gpz_mex('builds')                                              how many times a device context was (re)built so far
+//   v = gpz_mex('verify_info')                                         [K, seconds per complete hash of X and Psi, seconds of the last
+//                                                                       evaluation, rebuilds caused by an in-place edit of X / Psi]
 //   gpz_mex('reset')                                                   drop the device context (clear global / new data)
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
+#include <math.h>
+#include <unistd.h>
+#include <pthread.h>
 #include "mex.h"
 #include "gpz_hip.h"
 
@@ -52,9 +64,15 @@ typedef struct {
 static gpz_mgpu *g_mg = NULL;
 static closure_key g_key;
 static int g_m = 0, g_k = 0, g_pinv = 0, g_locked = 0, g_builds = 0;
+/* the exact identity of X and Psi: complete content hashes taken at build time, re-checked every g_every-th call */
+static uint64_t g_full[2];
+static int g_every = 1, g_since = 0, g_stale = 0;
+static double g_hash_s = 0.0, g_eval_s = 0.0;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static void cleanup(void) {
     if (g_mg) { gpz_mgpu_destroy(g_mg); g_mg = NULL; }
+    g_eval_s = 0.0;   /* times of another closure say nothing about the next */
 }
 static const double *opt(const mxArray *a) { return (a && !mxIsEmpty(a)) ? mxGetPr(a) : NULL; }
 static const uint8_t *optmask(const mxArray *a) {
@@ -141,6 +159,61 @@ static uint64_t hash_bytes(const unsigned char *p, size_t nbytes) {
     return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]) + nbytes;
 }
 
+/* The complete hash of a big array on all host cores: 4 MB chunks dealt to threads, the chunk hashes combined in chunk order (the
+ * result does not depend on the number of threads). */
+#define HCHUNK ((size_t)4 << 20)
+typedef struct { const unsigned char *p; size_t nbytes, nchunk; uint64_t *out; int t, nt; } hash_job;
+static void *hash_worker(void *arg) {
+    hash_job *j = (hash_job *)arg;
+    for (size_t c = (size_t)j->t; c < j->nchunk; c += (size_t)j->nt) {
+        const size_t lo = c * HCHUNK, len = j->nbytes - lo < HCHUNK ? j->nbytes - lo : HCHUNK;
+        j->out[c] = hash_bytes(j->p + lo, len);
+    }
+    return NULL;
+}
+static uint64_t hash_bytes_all_cores(const unsigned char *p, size_t nbytes) {
+    if (nbytes <= HCHUNK) return hash_bytes(p, nbytes);
+    const size_t nchunk = (nbytes + HCHUNK - 1) / HCHUNK;
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = nc < 1 ? 1 : (nc > 16 ? 16 : (int)nc);
+    if ((size_t)nt > nchunk) nt = (int)nchunk;
+    uint64_t *out = (uint64_t *)calloc(nchunk, sizeof(uint64_t));
+    if (!out) mexErrMsgIdAndTxt("gpz:alloc", "out of memory");
+    pthread_t th[16];
+    hash_job job[16];
+    int started = 0;
+    for (int t = 0; t < nt; ++t) {
+        job[t].p = p; job[t].nbytes = nbytes; job[t].nchunk = nchunk; job[t].out = out; job[t].t = t; job[t].nt = nt;
+        if (t == nt - 1 || pthread_create(&th[t], NULL, hash_worker, &job[t])) {   /* the last share (and any a thread could not be had for) here */
+            for (int u = t; u < nt; ++u) { job[u] = job[t]; job[u].t = u; hash_worker(&job[u]); }
+            break;
+        }
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    const uint64_t h = hash_bytes((const unsigned char *)out, nchunk * sizeof(uint64_t)) + nbytes;
+    free(out);
+    return h;
+}
+static void full_hashes(const mxArray *X, const mxArray *Psi, uint64_t out[2]) {
+    const mxArray *a[2] = {X, Psi};
+    for (int q = 0; q < 2; ++q)
+        out[q] = (a[q] && !mxIsEmpty(a[q]))
+                     ? hash_bytes_all_cores((const unsigned char *)mxGetData(a[q]), mxGetNumberOfElements(a[q]) * mxGetElementSize(a[q])) : 0;
+}
+/* K of the header comment: model.verify_every, or from the measured hash and evaluation times (2 % budget) */
+static int verify_every_of(const mxArray *model) {
+    const mxArray *v = mxIsStruct(model) ? mxGetField(model, 0, "verify_every") : NULL;
+    if (v && !mxIsEmpty(v)) {
+        const double k = mxGetScalar(v);
+        if (!(k >= 1.0) || k != floor(k)) mexErrMsgIdAndTxt("gpz:model", "model.verify_every must be an integer >= 1");
+        return k > 1e6 ? 1000000 : (int)k;
+    }
+    if (g_eval_s <= 0.0) return 1;                 /* nothing timed yet: check */
+    const double k = ceil(g_hash_s / (0.02 * g_eval_s));
+    return k < 1.0 ? 1 : (k > 64.0 ? 64 : (int)k);
+}
+
 /* What the live context was built from.  Bitwise: NaN payloads compare like any other bits.  q: 0 X, 1 Y, 2 Psi, 3 omega,
  * 4 training, 5 validation — X and Psi are sampled, the n-sized arrays are hashed completely (an in-place edit of ONE mask
  * element must rebuild the context). */
@@ -177,9 +250,21 @@ static void ensure_context(const mxArray *const *args) {
     key_of(model, args + 1, &key);
     // a handle a failed rank has left dead (GPZ_ERR_COMM with the RCCL reducer) is rebuilt like a changed closure: a MATLAB caller has no
     // other way to get rid of it than gpz_mex('reset')
-    if (g_mg && gpz_mgpu_alive(g_mg) && !memcmp(&key, &g_key, sizeof key)) return;
-    cleanup();
     const mxArray *X = args[1], *Y = args[2], *Psi = args[3], *om = args[4];
+    uint64_t full[2];
+    int have_full = 0;
+    if (g_mg && gpz_mgpu_alive(g_mg) && !memcmp(&key, &g_key, sizeof key)) {
+        g_every = verify_every_of(model);
+        if (++g_since < g_every) return;
+        g_since = 0;
+        const double t0 = now_s();
+        full_hashes(X, Psi, full);
+        g_hash_s = now_s() - t0;
+        have_full = 1;
+        if (full[0] == g_full[0] && full[1] == g_full[1]) return;
+        ++g_stale;                                 /* X or Psi was edited in place where the samples do not look */
+    }
+    cleanup();
     need_double(X, "X", 0); need_double(Y, "Y", 0); need_double(Psi, "Psi", 1); need_double(om, "omega", 1);
     int32_t n_gpus = 0;
     gpz_desc d = desc_of(model, &n_gpus);
@@ -187,14 +272,22 @@ static void ensure_context(const mxArray *const *args) {
     const mwSize n = mxGetM(X);
     if (mxGetN(X) != (mwSize)d.d || mxGetM(Y) != n || mxGetN(Y) != (mwSize)d.k)
         mexErrMsgIdAndTxt("gpz:size", "X must be n x model.d and Y n x model.k");
-    for (int q = 4; q <= 6; ++q)
+    for (int q = 5; q <= 6; ++q)
         if (args[q] && !mxIsEmpty(args[q]) && mxGetNumberOfElements(args[q]) < n)
-            mexErrMsgIdAndTxt("gpz:size", "omega / training / validation must have one entry per row of X");
+            mexErrMsgIdAndTxt("gpz:size", "training / validation must have one entry per row of X");
+    if (om && !mxIsEmpty(om)) {   /* omega(training,:) of GPz.m:48: n x 1, or n x k (getOmega.m:19 on a k-column Y) */
+        if (mxGetM(om) == n && mxGetN(om) == (mwSize)d.k && d.k > 1) d.omega_cols = d.k;
+        else if (mxGetNumberOfElements(om) != n) mexErrMsgIdAndTxt("gpz:size", "omega must be n x 1 or n x model.k");
+    }
     if (gpz_mgpu_create(&d, n_gpus, NULL, reducer_of(model), (int64_t)n, mxGetPr(X), mxGetPr(Y), opt(Psi), psi_kind_of(Psi, &d),
                         opt(om), optmask(args[5]), optmask(args[6]), &g_mg))
         mexErrMsgIdAndTxt("gpz:create", "%s", gpz_last_error());
     g_key = key;
     ++g_builds;
+    if (!have_full) { const double t0 = now_s(); full_hashes(X, Psi, full); g_hash_s = now_s() - t0; }
+    g_full[0] = full[0]; g_full[1] = full[1];
+    g_since = 0;
+    g_every = verify_every_of(model);
     g_m = d.m; g_k = d.k;
     if (g_pinv)
         for (int32_t r = 0; r < gpz_mgpu_size(g_mg); ++r) (void)gpz_ctx_set_pinv_mode(gpz_mgpu_ctx(g_mg, r), g_pinv);
@@ -237,6 +330,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gpz:usage", "first argument: command");
     if (!strcmp(cmd, "reset")) { cleanup(); gpz_release_cached_memory(); return; }   /* also the buffers the library keeps between calls */
     if (!strcmp(cmd, "builds")) { plhs[0] = mxCreateDoubleScalar((double)g_builds); return; }
+    if (!strcmp(cmd, "verify_info")) {
+        plhs[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
+        double *o = mxGetPr(plhs[0]);
+        o[0] = (double)g_every; o[1] = g_hash_s; o[2] = g_eval_s; o[3] = (double)g_stale;
+        return;
+    }
     if (!strcmp(cmd, "gpus")) { plhs[0] = mxCreateDoubleScalar(g_mg ? (double)gpz_mgpu_size(g_mg) : 0.0); return; }
     if (!strcmp(cmd, "comm")) {   /* what each rank's communicator reports about itself: [ncclCommCount ncclCommUserRank ncclCommCuDevice hipDevice] per row */
         const int n = g_mg ? (int)gpz_mgpu_size(g_mg) : 0;
@@ -332,8 +431,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             mxArray *g = mxCreateDoubleMatrix(p, 1, mxREAL);
             mxArray *st = mxCreateDoubleMatrix(4, 1, mxREAL);
             mxGetPr(st)[2] = mxGetNaN(); mxGetPr(st)[3] = mxGetNaN();
+            const double t0 = now_s();
             if (gpz_mgpu_eval(g_mg, theta, &f, mxGetPr(g), mxGetPr(st), NULL))
                 mexErrMsgIdAndTxt("gpz:eval", "%s", gpz_last_error());
+            g_eval_s = now_s() - t0;
             plhs[0] = mxCreateDoubleScalar(f);
             if (nlhs > 1) plhs[1] = g; else mxDestroyArray(g);
             if (nlhs > 2) plhs[2] = st; else mxDestroyArray(st);

@@ -35,7 +35,7 @@ def g_dim_of(method, m, d):
     return {"GL": 1, "VL": m, "GD": d, "VD": m * d, "GC": d * d, "VC": d * d * m}[method]
 
 
-def draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac):
+def draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac, omega_cols=1):
     """seeded inputs of one GPz() call (no oracle code involved: plain NumPy)"""
     X = rng.standard_normal((n, d))
     A = rng.standard_normal((d, k)) / np.sqrt(d)
@@ -69,7 +69,7 @@ def draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac):
         miss[miss.all(axis=1), 0] = False
         X = X.copy()
         X[miss] = np.nan
-    omega = rng.random((n, 1)) + 0.5
+    omega = rng.random((n, omega_cols)) + 0.5            # n x 1, or n x k: per-output weights (GPz.m:48 omega(training,:))
     training = rng.random(n) < 0.75
     return dict(theta=theta, X=X, Y=Y, Psi=Psi, omega=omega, training=training, validation=~training)
 
@@ -99,15 +99,23 @@ GPZ_CASES += [("VC", 1, True, True, 0.0, 40, 13, 4), ("GC", 1, True, True, 0.3, 
               ("VC", 1, True, False, 0.3, 30, 21, 3), ("VC", 1, True, True, 0.0, 24, 34, 3)]
 
 
+# per-output weights: omega n x k (what getOmega.m:19 returns for a k-column Y); (.., n, d, m, "omk").  omega(training) in the two RMSE
+# statistics is then the FIRST column (GPz.m:236,258), omega(training,:) everywhere else (GPz.m:48,82,93,110,237,259)
+GPZ_CASES += [("VD", 2, True, False, 0.0, 70, 3, 5, "omk"), ("VC", 2, True, False, 0.0, 70, 3, 5, "omk"),
+              ("GC", 3, True, True, 0.3, 70, 3, 5, "omk"), ("VL", 2, False, True, 0.0, 70, 3, 5, "omk")]
+
+
 def gpz_case_name(c):
+    if len(c) > 8:
+        return "ref_gpz_%s_k%d_h%d_p%d_n%d_omk" % (c[0], c[1], int(c[2]), int(c[3]), int(c[4] > 0))
     return "ref_gpz_%s_k%d_h%d_p%d_n%d" % (c[0], c[1], int(c[2]), int(c[3]), int(c[4] > 0)) + ("_d%d" % c[6] if len(c) > 5 else "")
 
 
 def make_gpz(case, seed):
     method, k, hetero, psi, nanfrac = case[:5]
-    n, d, m = case[5:] if len(case) > 5 else (70, 3, 5)
+    n, d, m = case[5:8] if len(case) > 5 else (70, 3, 5)
     rng = np.random.default_rng(seed)
-    pr = draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac)
+    pr = draw_problem(rng, n, d, m, k, method, hetero, psi, nanfrac, omega_cols=(k if len(case) > 8 else 1))
     out = run_gpz(ML.Interp(), method, m, d, k, hetero, pr)
     return dict(method=method, m=m, d=d, k=k, heteroscedastic=int(hetero), has_psi=int(psi),
                 Psi=(pr["Psi"] if psi else np.zeros(0)), **{key: pr[key] for key in ("theta", "X", "Y", "omega", "training", "validation")},
@@ -529,13 +537,18 @@ def main():
     if not ML.available():
         raise SystemExit("the reference tree is not present: fixtures can only be generated where /root/reference exists")
     os.makedirs(GOLD, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""      # optional: regenerate only the fixtures whose name contains this
     for name, make in all_fixtures().items():
+        if only not in name:
+            continue
         data = make()
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
         print("wrote", name, flush=True)
     # which builtins of the interpreter the executed files reached (calls each): the list tests/test_reference_run.py pins one by one
     # against MATLAB's documentation
     import json
+    if only:
+        return
     with open(os.path.join(GOLD, "mlite_builtins_reached.json"), "w") as fh:
         json.dump(dict(sorted(ML.BUILTINS_REACHED.items())), fh, indent=0)
 

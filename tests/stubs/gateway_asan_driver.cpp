@@ -136,6 +136,25 @@ int main() {
         call("eval bad reducer", 1, {cmd_eval, th, badred, X, Y, none, none, none, none}, "gpz:model");
         for (mxArray *a : {th, incomplete, badmethod, f32, baddt, badred}) mxDestroyArray(a);
     }
+    {   // per-output weights (omega n x k), the complete hash of a big X on several threads (> 4 MB: chunked), verify_every / verify_info
+        const int nb = 150001, db = 5;                                    // 6 MB of X: two chunks
+        mxArray *Xb = mat(nb, db), *Yb = mat(nb, k), *omk = mat(nb, k, 1.0), *om3 = mat(nb, k + 1, 1.0), *omrow = mat(nb - 1, k, 1.0);
+        mxArray *th = mat((size_t)theta_len(db, m, k, "VD", true), 1);
+        mxArray *mo = model(db, m, k, "VD");
+        mexrt_set_field(mo, "verify_every", scalar(1.0));
+        mxArray *mo0 = model(db, m, k, "VD");
+        mexrt_set_field(mo0, "verify_every", scalar(0.0));
+        mxArray *c_vi = mexrt_string("verify_info");
+        call("eval omega n x k", 3, {cmd_eval, th, mo, Xb, Yb, none, omk, none, none}, nullptr);
+        call("eval again: complete hash re-checked", 1, {cmd_eval, th, mo, Xb, Yb, none, omk, none, none}, nullptr);
+        mxGetPr(Xb)[12345] += 1.0;                                        // in-place edit between the samples: stale context rebuilt
+        call("eval after an in-place edit of X", 1, {cmd_eval, th, mo, Xb, Yb, none, omk, none, none}, nullptr);
+        call("verify_info", 1, {c_vi}, nullptr);
+        call("eval omega n x (k+1)", 1, {cmd_eval, th, mo, Xb, Yb, none, om3, none, none}, "gpz:size");
+        call("eval omega (n-1) x k", 1, {cmd_eval, th, mo, Xb, Yb, none, omrow, none, none}, "gpz:size");
+        call("eval verify_every = 0", 1, {cmd_eval, th, mo0, Xb, Yb, none, omk, none, none}, "gpz:model");
+        for (mxArray *a : {Xb, Yb, omk, om3, omrow, th, mo, mo0, c_vi}) mxDestroyArray(a);
+    }
     {   // small entries
         mxArray *c_il = mexrt_string("inv_logdet"), *c_dxy = mexrt_string("dxy"), *c_pm = mexrt_string("pinv_mode"), *c_x = mexrt_string("nonsense");
         mxArray *A = mat(4, 4), *Ar = mat(4, 3), *B = mat(6, 3), *Cm = mat(5, 2), *mode1 = scalar(1.0), *mode5 = scalar(5.0);

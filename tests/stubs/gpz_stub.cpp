@@ -77,7 +77,7 @@ int gpz_mgpu_create(const gpz_desc *desc, int32_t n_gpus, const int32_t *, int32
     for (int64_t i = 0; validation && i < n_tot; ++i) nv += validation[i];
     h->n_train = nt;
     h->data_sum = sum(X, (size_t)n_tot * desc->d) + sum(Y, (size_t)n_tot * desc->k) + sum(Psi, psi_len(desc, n_tot, psi_kind)) +
-                  sum(omega, omega ? (size_t)n_tot : 0) + (double)nv;
+                  sum(omega, omega ? (size_t)n_tot * (size_t)(desc->omega_cols > 1 ? desc->omega_cols : 1) : 0) + (double)nv;   // reads every element the gateway promises (n x 1 or n x k)
     for (int r = 0; r < h->n_gpus; ++r) {
         const int64_t lo = (int64_t)r * nt / h->n_gpus, hi = (int64_t)(r + 1) * nt / h->n_gpus;
         h->ctx.push_back({hi - lo, desc->m, 0});

@@ -103,3 +103,61 @@ def test_injected_rank_failure_is_reported_and_does_not_hang():
             mg.eval(theta)
         assert ei.value.code == -4 and "dead" in str(ei.value)
         mg.close()
+
+
+# ---- the first multi-GPU line cannot pass unverified ---------------------------------------------------------
+def _verdict_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = bench.rccl_init_verdict(dist, torch, None, rank)                                    # every rank has its communicator
+    bad = bench.rccl_init_verdict(dist, torch, "RuntimeError('ncclCommInitRank failed')" if rank == 1 else None, rank)
+    q.put((rank, ok, bad))
+    dist.destroy_process_group()
+
+
+def test_a_failed_in_library_rccl_init_is_fatal_on_every_rank():
+    """bench.py under a launcher: when gpz_ctx_init_rccl fails on ANY rank, every rank learns it and the run dies with a message — it
+    used to continue on the torch.distributed hook with a line on stderr, and the self-verification was then skipped.  World-2 gloo on
+    CPU: rank 1 reports the failure, both ranks get the verdict; no failure -> None on both."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_verdict_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, bad in got:
+        assert ok is None
+        assert bad and "refusing to continue" in bad and "GPZ_BENCH_COMM=torch" in bad
+    assert "ncclCommInitRank failed" in got[1][2] and "another rank failed" in got[0][2]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "falling back to the torch.distributed hook" not in src            # the silent route change is gone
+    assert 'raise SystemExit("bench.py: " + why)' in src
+
+
+def test_rank_records_of_either_route_must_describe_n_ranks_on_n_devices():
+    """ranks_describe_n_devices on the records bench.py gathers: in-library RCCL communicators and torch.distributed process groups
+    alike must show N ranks, ranks 0..N-1 once each, N distinct PCI devices; anything else is the reason the run exits with."""
+    sys.path.insert(0, ROOT)
+    import bench
+    good = [{"nccl_count": 4, "nccl_rank": r, "pci_bus_id": "0000:%02x:00.0" % (5 + r)} for r in range(4)]
+    assert bench.ranks_describe_n_devices(good, 4) is None
+    hook = [dict(q, comm_record="torch.distributed process group (nccl)") for q in good]
+    assert bench.ranks_describe_n_devices(hook, 4) is None
+    same_dev = [dict(q, pci_bus_id="0000:05:00.0") for q in good]
+    assert "PCI bus ids" in bench.ranks_describe_n_devices(same_dev, 4)
+    assert bench.ranks_describe_n_devices(good[:3], 4) and bench.ranks_describe_n_devices(good, 8)
+    no_comm = [dict(q, nccl_count=-1, nccl_rank=-1) for q in good]             # a rank without any communicator record
+    assert bench.ranks_describe_n_devices(no_comm, 4)
+    dup = [dict(q, nccl_rank=0) for q in good]
+    assert bench.ranks_describe_n_devices(dup, 4)

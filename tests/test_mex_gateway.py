@@ -258,6 +258,76 @@ def test_gateway_optional_model_fields():
 
 
 @pytest.mark.gpu
+def test_gateway_per_output_weights_and_exact_identity_of_the_big_arrays():
+    """(1) omega n x k through the gateway (GPz.m:48 omega(training,:); getOmega.m:19 on a k-column Y), any other shape refused.
+    (2) X and Psi are sampled on every call and hashed completely every K-th: an in-place edit of an element NO sample looks at
+    (MATLAB: X(i, c) = v on an unshared variable keeps the pointer) is caught at the latest K - 1 evaluations later — with
+    model.verify_every = 1 on the very next call — rebuilds the device context and evaluates on the new data (the closure
+    semantics of train.m:40: f sees the arrays as they are when it is called)."""
+    n, d, m, k = 1500, 5, 16, 2
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, k, "VD", True, seed=71, psi=True)
+    om = rng.random((n, k)) + 0.5
+    om[:, 1] *= 2.0
+    tr = rng.random(n) < 0.8
+    mex = Mex()
+    ms = model_struct(model, verify_every=1.0)
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    f, g, st = mex(3, "eval", theta, ms, X, Y, Psi, om, tr, ~tr)
+    assert abs(f[0, 0] - ref.nlogML) <= 1e-8 * abs(ref.nlogML) and rel(g.ravel(), ref.grad) <= grad_tol(ref.cond)
+    for q, key in enumerate(["trainRMSE", "trainLL", "validRMSE", "validLL"]):
+        assert abs(st[q, 0] - ref.stats[key]) <= 1e-10 * max(1.0, abs(ref.stats[key]))
+    for bad in (np.ones((n, 3)), np.ones((n - 1, 1)), np.ones((n - 1, 2))):
+        with pytest.raises(MexError) as e:
+            mex(1, "eval", theta, ms, X, Y, Psi, bad, tr, ~tr)
+        assert e.value.ident == "gpz:size"
+    mex(0, "reset")
+    # held arrays: one build for many evaluations; an edit where the 256 samples do not look
+    mex.hold(X, Y, Psi, om, tr)
+    b0 = mex(1, "builds")[0, 0]
+    stale0 = mex(1, "verify_info")[0, 3]
+    fa = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    fb = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 1 and fa[0, 0] == fb[0, 0]
+    step = X.size // 256
+    row = next(i for i in np.flatnonzero(tr) if i % step != 0 and i != X.size - 1)      # flat index i = row i of column 0
+    mex.poke(X, int(row), X[row, 0] + 0.75)
+    X2 = X.copy(); X2[row, 0] += 0.75
+    fc = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    ref_c = O.GPz(theta, model, X2, Y, Psi, om, tr, None)
+    info = mex(1, "verify_info")
+    assert mex(1, "builds")[0, 0] == b0 + 2 and info[0, 0] == 1.0 and info[0, 3] == stale0 + 1 and info[0, 1] > 0.0
+    assert fc[0, 0] != fa[0, 0] and abs(fc[0, 0] - ref_c.nlogML) <= 1e-8 * abs(ref_c.nlogML)
+    prow = next(i for i in np.flatnonzero(tr) if i % (Psi.size // 256) != 0)
+    mex.poke(Psi, int(prow), Psi[prow, 0] + 0.5)
+    Psi2 = Psi.copy(); Psi2[prow, 0] += 0.5
+    fd = mex(1, "eval", theta, ms, X, Y, Psi, om, tr, None)
+    ref_d = O.GPz(theta, model, X2, Y, Psi2, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 3 and abs(fd[0, 0] - ref_d.nlogML) <= 1e-8 * abs(ref_d.nlogML)
+    # verify_every = 4: the edit is seen on the 4th call after the last check, not before; never later
+    ms4 = model_struct(model, verify_every=4.0)
+    f0 = mex(1, "eval", theta, ms4, X, Y, Psi, om, tr, None)            # same closure, same context: call 1 of 4
+    assert mex(1, "builds")[0, 0] == b0 + 3 and f0[0, 0] == fd[0, 0]
+    mex.poke(X, int(row), X2[row, 0] - 0.75)                             # back to the original value
+    seen = []
+    for _ in range(4):
+        seen.append(mex(1, "eval", theta, ms4, X, Y, Psi, om, tr, None)[0, 0])
+    ref_e = O.GPz(theta, model, X, Y, Psi2, om, tr, None)
+    assert mex(1, "builds")[0, 0] == b0 + 4 and seen[0] == fd[0, 0]     # stale for at most K - 1 = 3 calls ...
+    assert abs(seen[-1] - ref_e.nlogML) <= 1e-8 * abs(ref_e.nlogML)     # ... and right from the K-th on
+    # no verify_every field: K follows the measured times (hash <= 2 % of the evaluations), between 1 and 64
+    mex(1, "eval", theta, model_struct(model), X, Y, Psi, om, tr, None)
+    mex(1, "eval", theta, model_struct(model), X, Y, Psi, om, tr, None)
+    info = mex(1, "verify_info")
+    assert 1.0 <= info[0, 0] <= 64.0 and info[0, 2] > 0.0
+    with pytest.raises(MexError) as e:
+        mex(1, "eval", theta, model_struct(model, verify_every=0.0), X, Y, Psi, om, tr, None)
+    assert e.value.ident == "gpz:model"
+    mex.release()
+    mex(0, "reset")
+    mex.lib.mexrt_unload()
+
+
+@pytest.mark.gpu
 def test_gateway_reducer_field_and_loopback_shards():
     """model.reducer = 'loopback': model.n_gpus shards on one device behind the same gateway (single-GPU MATLAB hosts)."""
     model, theta, X, Y, Psi, rng = make_problem(900, 4, 8, 1, "VD", True, seed=8)

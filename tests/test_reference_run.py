@@ -53,7 +53,7 @@ def predict_inputs(g):
 
 
 def test_fixture_inventory():
-    assert len(GPZ) == len(RR.GPZ_CASES) == 35 and len(PRED) == len(RR.PREDICT_CASES) == 28
+    assert len(GPZ) == len(RR.GPZ_CASES) == 39 and len(PRED) == len(RR.PREDICT_CASES) == 28
     assert all(os.path.exists(os.path.join(GOLDEN, f + ".npz")) for f in ["ref_misc", "ref_lbfgs_mem", "ref_minfunc"] + TRAIN)
     assert len(MF_LS) == 13 and len(MF_RUN) == 6
 
