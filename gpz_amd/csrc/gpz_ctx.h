@@ -135,6 +135,7 @@ struct RowSet {          // a device-resident row selection of the data
     double *Xr = nullptr;   // n_pad x de
     double *Y = nullptr;    // k x n_pad
     double *om = nullptr;   // n_pad, or k x n_pad for an n x k omega (nullptr => ones)
+    double *xmu = nullptr;  // de: column means of the rows (missing entries count as 0): centre of k_small_tail's feature expansion
     long om_ld = 0;         // omega of output o, row i: om[o*om_ld + i]; 0 = one column for every output (GPz.m:48)
     // diagonal kinds only: input-noise variances and the observed-dimension mask (nullptr => absent)
     double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)
@@ -226,6 +227,9 @@ struct gpz_ctx {
     double *tile_rstats = nullptr;                        // [ntiles][GPZ_NS]: the tiles' row-scalar sums
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
     double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused path
+    bool small_tail = false;   // mp <= 256, k = 1, no Psi / missing values / row tiles: T-GEMM + row scalars + moments as ONE kernel (k_small.hip), T never allocated
+    int st_nwg = 0, st_nf = 0;
+    double *st_slab = nullptr, *st_raw = nullptr;
     bool fused = true;   // dPHI formed on the fly, output by output (no dPHI / dL matrices): k == 1, or k > 1 on the tuned kernels
     double *phipart = nullptr;   // PHI-build column-group partial sums (small row counts)
     int phipart_groups = 0;
@@ -300,7 +304,7 @@ namespace gpzi {
 int graph_cut(gpz_ctx *c, bool last = false);   // gpz_eval.hip: close the segment being recorded (and open the next)
 }
 inline bool stage_is_dominant(const char *name) {
-    return !strcmp(name, "tgemm") || !strcmp(name, "syrk") || !strcmp(name, "phi_build") || !strcmp(name, "moments");
+    return !strcmp(name, "tgemm") || !strcmp(name, "syrk") || !strcmp(name, "phi_build") || !strcmp(name, "moments") || !strcmp(name, "tail_small");
 }
 struct Stage {
     gpz_ctx *c;

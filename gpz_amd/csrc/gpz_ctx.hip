@@ -73,6 +73,16 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
             h[(size_t)c_ * np + r] = (xv != xv) ? 0.0 : xv;
         }
     if (int e = up2(h, &rs.Xc, &rs.Xr, need_xr)) return e;
+    {   // column means (k_small_tail expands its moment sums about them)
+        std::vector<double> mu((size_t)de, 0.0);
+        for (int c_ = 0; c_ < d && !idx.empty(); ++c_) {
+            double s = 0.0;
+            for (size_t r = 0; r < idx.size(); ++r) s += h[(size_t)c_ * np + r];
+            mu[c_] = s / (double)idx.size();
+        }
+        if (int e = c->ar.alloc(&rs.xmu, (size_t)de)) return e;
+        HIPCHK(hipMemcpy(rs.xmu, mu.data(), (size_t)de * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (any_missing || c->has_missing) {
         c->has_missing = true;
         hm.assign(np * (size_t)de, 1.0);
@@ -458,7 +468,17 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     }
     const size_t npt = c->tile_rows ? (size_t)c->tile_rows : np;   // rows PHI / T / the nu partials hold
     if ((rc = c->ar.alloc(&c->Phi, npt * mp))) return bail(rc);
-    if ((rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);
+    // Few basis functions (m + k <= 256 columns, one output, no input noise, nothing missing, rows resident): the product with
+    // [inv(SIGMA) | w], the row scalars and the moment sums are ONE kernel that keeps whole rows of T in registers (k_small.hip).
+    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->has_missing && !c->tile_rows && desc->dtype == GPZ_F64 &&
+                    small_tail_fits(c->kind, c->de, c->mp) && !c->opt.small_tail_off;
+    if (!c->small_tail && (rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);   // (T = PHI [inv(SIGMA) | w] exists in memory only on the other routes)
+    if (c->small_tail) {
+        c->st_nwg = small_tail_nwg();
+        c->st_nf = small_tail_features(c->kind, c->de);
+        if ((rc = c->ar.alloc(&c->st_slab, (size_t)c->st_nwg * m * (c->st_nf + 2)))) return bail(rc);
+        if ((rc = c->ar.alloc(&c->st_raw, (size_t)m * (c->st_nf + 2)))) return bail(rc);
+    }
     if (c->tile_rows && (rc = c->ar.alloc(&c->tile_rstats, (size_t)c->ntiles * GPZ_NS))) return bail(rc);
     // GC + Psi in fp64, 10 < d <= 32 (evaluation contexts only: prediction and getPHI contexts have no moment stage and no T)
     if (c->psi_fast && c->mid == 4 && cpsi4_available(c->d) && !c->opt.gc_minv_off) {
@@ -728,8 +748,9 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
     char rows[96];
     if (c->tile_rows) snprintf(rows, sizeof rows, "; rows: streamed, %d tiles of %d (PHI built twice per evaluation)", c->ntiles, c->tile_rows);
     else rows[0] = 0;
-    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA; evaluation graph: %s%s", phi, why,
-                    f32mm ? "fp32-operand (fp64 master sums)" : "fp64", gs, rows);
+    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA%s; evaluation graph: %s%s", phi, why,
+                    f32mm ? "fp32-operand (fp64 master sums)" : "fp64",
+                    c->small_tail ? ", T-GEMM + row scalars + moments in one kernel (k_small_tail: T stays in registers)" : "", gs, rows);
 }
 namespace gpzi {
 

@@ -369,6 +369,24 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols + (size_t)o * 2 * mp, o > 0 ? 1 : 0);
             continue;
         }
+        if (c->small_tail) {
+            // T = PHI [inv(SIGMA) | w], nu, the row scalars, dPHI and the moment sums in one kernel; T stays in registers (k_small.hip)
+            Stage s(c, "tail_small");
+            SmallTailArgs a{};
+            a.Phi = c->Phi; a.ld = c->mp; a.B = c->Bext; a.ldb = c->mp;
+            a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind;
+            a.Xr = c->tr.Xr; a.xmu = c->tr.xmu;
+            a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta;
+            a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
+            a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf;
+            launch_small_tail(c->st, a, c->st_nwg);
+            launch_slab_sum(c->st, c->partial, c->st_nwg, GPZ_NS, c->rstats);
+            HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+            launch_slab_sum(c->st, c->st_slab, c->st_nwg, m * (c->st_nf + 2), c->st_raw);
+            launch_small_convert(c->st, c->st_raw, c->m, c->de, c->kind, c->st_nf, c->pr.P, c->tr.xmu, c->frec, c->nm);
+            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols, 0);
+            continue;
+        }
         {
             Stage s(c, "tgemm");
             // dtype f32 with the fp32 pair kernels active (config 5): fp32-operand MFMA contractions (k_gemm.hip), B = [inv(SIGMA) | w]

@@ -79,6 +79,29 @@ void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, i
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds,
                         int accumulate = 0 /* S += instead of S = (row tiles of a streamed evaluation) */);
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
+
+// ---- few basis functions: T-GEMM + row scalars + moment sums in one kernel, T never written (k_small.hip) -----------------------
+struct SmallTailArgs {
+    const double *Phi; int ld;              // n_pad x ld row-major (columns m .. m+k-1 hold y)
+    const double *B; int ldb;               // mp x ldb: [inv(SIGMA) | w]
+    int n, n_pad, m, mp, d, kind;           // d = padded dimension of Xr / P
+    const double *Xr, *xmu;                 // n_pad x d rows; d column means (centre of the feature expansion)
+    const double *y, *omega, *lnbeta, *wbeta;   // n_pad each (omega may be nullptr)
+    const double *w, *v;                    // m; without the heteroscedastic term v = w and vscale = 0 (no branch in the kernel)
+    double vscale;
+    double *phiw;                           // n_pad: PHI w
+    double *slab;                           // [nwg][m][nf + 2]: raw sums about xmu, PHI'c, PHI'dbeta
+    double *partial;                        // [nwg][GPZ_NS]: sum c delta, sum omega delta^2, sum LL, sum dbeta
+    int ncu;                                // compute units (set by the launcher)
+    int stagger;                            // start delay of the second workgroup of a compute unit, in s_sleep(127) units of 8128 cycles (set by the launcher)
+    int nf;                                 // features: 1 + 2d (diagonal kinds), 1 + d + d(d+1)/2 (covariance kinds)
+};
+int small_tail_features(int kind, int d);
+bool small_tail_fits(int kind, int d, int mp);   // mp <= 256 columns and <= 32 features
+int small_tail_nwg();                            // persistent workgroups: two per compute unit
+void launch_small_tail(hipStream_t st, const SmallTailArgs &a, int nwg);
+void launch_small_convert(hipStream_t st, const double *raw, int m, int d, int kind, int nf, const double *P, const double *xmu,
+                          double *frec, int nm);   // raw sums -> the records of k_moments_fused: [M1 | S | PHI'c, PHI'dbeta] per basis function
 int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

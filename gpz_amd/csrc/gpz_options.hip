@@ -39,6 +39,7 @@ gpz_options gpz_options_load() {
     o.syrk_s2 = (int)env_long("GPZ_SYRK_S2", 0);
     o.mom_nc = (int)env_long("GPZ_MOM_NC", 0);
     o.debug_fail_cut = (int)env_long("GPZ_DEBUG_FAIL_CUT", 0);
+    o.small_tail_off = env_set("GPZ_SMALL_TAIL_OFF");
 #endif
     return o;
 }

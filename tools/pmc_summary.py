@@ -31,7 +31,7 @@ for f in ("sq", "sq2", "fetch", "write"):
     for k, cs in load(base + f + "/p_counter_collection.csv").items():
         for c, v in cs.items():
             data.setdefault(k, {})[c] = sum(v) / len(v)
-keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_"))]
+keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_", "void k_small_tail"))]
 with open(dst, "w") as out:
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py " + what + "; one counter group per pass; tools/pmc_run.sh)\n"
               "# per-launch averages.  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles;\n"
