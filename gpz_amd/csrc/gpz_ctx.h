@@ -136,6 +136,7 @@ struct RowSet {          // a device-resident row selection of the data
     double *Y = nullptr;    // k x n_pad
     double *om = nullptr;   // n_pad, or k x n_pad for an n x k omega (nullptr => ones)
     double *xmu = nullptr;  // de: column means of the rows (missing entries count as 0): centre of k_small_tail's feature expansion
+    double *Xs = nullptr;   // n_pad x (de + 2): rows [1 | x - xmu | 0] (zero rows past n) - what k_small_tail builds its features from
     long om_ld = 0;         // omega of output o, row i: om[o*om_ld + i]; 0 = one column for every output (GPz.m:48)
     // diagonal kinds only: input-noise variances and the observed-dimension mask (nullptr => absent)
     double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)

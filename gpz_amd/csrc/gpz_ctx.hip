@@ -82,6 +82,15 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
         }
         if (int e = c->ar.alloc(&rs.xmu, (size_t)de)) return e;
         HIPCHK(hipMemcpy(rs.xmu, mu.data(), (size_t)de * sizeof(double), hipMemcpyHostToDevice));
+        if (need_xr && !c->gen && c->k == 1) {   // (the evaluation's training rows; k_small_tail is a single-output route)
+            std::vector<double> xs(np * (size_t)(de + 2), 0.0);
+            for (size_t r = 0; r < idx.size(); ++r) {
+                xs[r * (de + 2)] = 1.0;
+                for (int c_ = 0; c_ < d; ++c_) xs[r * (de + 2) + 1 + c_] = h[(size_t)c_ * np + r] - mu[c_];
+            }
+            if (int e = c->ar.alloc(&rs.Xs, np * (size_t)(de + 2))) return e;
+            HIPCHK(hipMemcpy(rs.Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     if (any_missing || c->has_missing) {
         c->has_missing = true;
@@ -470,7 +479,7 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     if ((rc = c->ar.alloc(&c->Phi, npt * mp))) return bail(rc);
     // Few basis functions (m + k <= 256 columns, one output, no input noise, nothing missing, rows resident): the product with
     // [inv(SIGMA) | w], the row scalars and the moment sums are ONE kernel that keeps whole rows of T in registers (k_small.hip).
-    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->has_missing && !c->tile_rows && desc->dtype == GPZ_F64 &&
+    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->has_missing && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
                     small_tail_fits(c->kind, c->de, c->mp) && !c->opt.small_tail_off;
     if (!c->small_tail && (rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);   // (T = PHI [inv(SIGMA) | w] exists in memory only on the other routes)
     if (c->small_tail) {

@@ -375,10 +375,10 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             SmallTailArgs a{};
             a.Phi = c->Phi; a.ld = c->mp; a.B = c->Bext; a.ldb = c->mp;
             a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind;
-            a.Xr = c->tr.Xr; a.xmu = c->tr.xmu;
+            a.Xs = c->tr.Xs;
             a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta;
             a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
-            a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf;
+            a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf; a.stagger = c->opt.small_stagger;
             launch_small_tail(c->st, a, c->st_nwg);
             launch_slab_sum(c->st, c->partial, c->st_nwg, GPZ_NS, c->rstats);
             HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));

@@ -85,7 +85,7 @@ struct SmallTailArgs {
     const double *Phi; int ld;              // n_pad x ld row-major (columns m .. m+k-1 hold y)
     const double *B; int ldb;               // mp x ldb: [inv(SIGMA) | w]
     int n, n_pad, m, mp, d, kind;           // d = padded dimension of Xr / P
-    const double *Xr, *xmu;                 // n_pad x d rows; d column means (centre of the feature expansion)
+    const double *Xs;                       // n_pad x (d + 2) rows [1 | x - mu | 0], mu = the column means (centre of the feature expansion)
     const double *y, *omega, *lnbeta, *wbeta;   // n_pad each (omega may be nullptr)
     const double *w, *v;                    // m; without the heteroscedastic term v = w and vscale = 0 (no branch in the kernel)
     double vscale;

@@ -78,7 +78,9 @@ __device__ __forceinline__ void chol32_rows(double (&a)[CH_NB], int lane, double
         const double d = piv * invd;
         const double l = a[c] * invd;                           // l_rc for this lane's row r (meaningful for r >= c)
         a[c] = (lane == c) ? d : l;
-        D[lane][c] = a[c];                                      // rows < c are never read (the solves use D[q][c], q > c)
+        D[lane][c] = a[c];                                      // rows < c: written (every lane stores), with the row's stale a_rc times 1/d - finite
+                                                                // for finite input; the solves never read them (D[q][c], q > c), the MFMA products
+                                                                // below read them into outputs nobody uses
         // 1/d for the row solves and the inverse's diagonal: invd = 1/sqrt(piv) is up to ~5 ulp away from the reciprocal of the ROUNDED
         // d (d carries its own rounding and twice invd's); one Newton step, off the chain.  Wave-uniform, every lane stores it.
         Dinv[c] = fma(fma(-d, invd, 1.0), invd, invd);
@@ -135,9 +137,9 @@ __device__ __forceinline__ void chol32_rows(double (&a)[CH_NB], int lane, double
                 const unsigned long long nb = __ballot(lane < CH_NB && !(dg > 0.0));
                 *badpiv = nb ? __ffsll((long long)nb) : 0;      // first bad pivot, 1-based
             }
-            asm volatile("" ::: "memory");
-            __hip_atomic_store(posted, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
+            // RELEASE: the plain LDS stores of D / Dinv / badpiv above are complete before the count is visible (an s_waitcnt lgkmcnt(0)
+            // in front of the store; the hand-off used to rest on one wave's DS operations completing in order - ADVICE r05)
+            __hip_atomic_store(posted, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -161,8 +163,7 @@ __device__ __forceinline__ double sum_lanes32(double v) {
 // the updates of one column are independent of each other; a row-oriented dot product is one dependent chain per entry).
 template <int C0, int NC, int QE>
 __device__ __forceinline__ void solve_cols(double (&x)[CH_NB], const double (*D)[CH_NB + 1], const double *Dinv, const int *posted) {
-    while (__hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < C0 + NC) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
+    while (__hip_atomic_load(posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < C0 + NC) __builtin_amdgcn_s_sleep(1);   // ACQUIRE: pairs with the poster's release
 #pragma unroll
     for (int c = C0; c < C0 + NC; ++c) {
         x[c] *= Dinv[c];
@@ -295,8 +296,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
             double *lr = Lm + (size_t)(k0 + (lane & (CH_NB - 1))) * lda + k0;
 #pragma unroll
             for (int c0 = 0; c0 < CH_NB; c0 += CH_POST) {
-                while (__hip_atomic_load(&posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < c0 + CH_POST) __builtin_amdgcn_s_sleep(2);
-                asm volatile("" ::: "memory");
+                while (__hip_atomic_load(&posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < c0 + CH_POST) __builtin_amdgcn_s_sleep(2);
                 if (lane < CH_NB) {
 #pragma unroll
                     for (int c = c0; c < c0 + CH_POST; ++c) lr[c] = (c <= lane) ? D[lane][c] : 0.0;

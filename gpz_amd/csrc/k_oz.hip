@@ -14,6 +14,10 @@
 // [column panel of 64][K step][plane q][2 KB], chunk (column c, half h) likewise (k contiguous per column).  A workgroup stages one K
 // step (7 x 4 KB + 7 x 2 KB = 42 KB, contiguous in both plane arrays) per LDS-DMA piece of 1 KiB (global_load_lds_dwordx4), three
 // stages deep; 8 waves (2 per SIMD) on a 128 x 64 tile, each a 32 x 32 block with all seven levels (112 accumulator registers).
+//
+// STATUS (round 6): developer build only, not the default and not going to be - DESIGN.md section 8 has the arithmetic of the go / no-go.
+// Known limitation of this measured-and-archived route: the slicing assumes FINITE operands with PHI in [0, 1]; a NaN /
+// Inf in PHI or B (an evaluation whose Cholesky failed) becomes finite digits here, where the fp64 route propagates the NaN.
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 

@@ -616,9 +616,11 @@ __global__ void k_phi_finalize(const double *__restrict__ part, long ldp, int ng
 // ("about 1024 workgroups" chose g = 3).  Among choices within 1 % the largest wins (c4: two groups 4.34 ms, one 4.44).
 static int phi_pick_groups(int nwg, int mp, int JB, int min_wgs, int prologue_cols, int max_groups) {
     const int ncu = gpz_cu_count();
-    long cost[65];
+    constexpr int MAXG = 64;                                     // (the callers' part_groups is 16: phipart holds that many partial sums per row)
+    long cost[MAXG + 1];
     long best_cost = -1;
-    if (max_groups > 64) max_groups = 64;
+    if (max_groups > MAXG) max_groups = MAXG;
+    if (max_groups < 1) max_groups = 1;
     for (int g = 1; g <= max_groups; ++g) {
         const int jg = ((mp + g - 1) / g + JB - 1) / JB * JB, ge = (mp + jg - 1) / jg;
         cost[g] = -1;

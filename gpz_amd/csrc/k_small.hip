@@ -7,21 +7,29 @@
 //
 // k_tgemm + k_row_scalars + k_moments_fused write T (n x m), read it back with PHI, and are bound by exactly that traffic once m is
 // small: at n = 1e5, m = 200 (BASELINE config 2) they take 197 + 7 + 156 us for 106 us of MFMA work.  With mp = ceil16(m + k) <= 256 a
-// workgroup holds WHOLE ROWS of T in its accumulators - 64 rows x mp columns over 8 waves - so everything after the product happens
-// on registers and T never exists in memory:
-//   * waves (wr, wc), wr = 0..1, wc = 0..3: rows 32 wr .. 32 wr + 31 of the block, 16-column blocks gb = 4 q + wc' (q < NQ) of the
-//     columns, wc' = wc for wr = 0 and 3 - wc for wr = 1, so that the two waves of a SIMD carry 2 NQ - 1 blocks where the count is
-//     not a multiple of four (mp = 208: 13 blocks = 4 + 3 + 3 + 3);
-//   * K loop as in k_tgemm (16-deep slices of PHI and B staged global -> registers -> LDS, double buffered, one barrier per slice);
-//   * nu: every wave's partial row sums over its own columns meet in LDS; one thread per row forms the row scalars and the
-//     evaluation's scalar sums; the accumulators are overwritten with dPHI;
-//   * the moment sums are MFMAs again: accumulator register r of a 16 x 16 block of dPHI IS the A operand (j along M, the four rows
-//     4r .. 4r + 3 along K) of a product with the block's row FEATURES [1 | x - mu | (x - mu)^2 or the packed products (x - mu)(x - mu)'],
-//     staged in LDS as the B operand - 2 feature blocks of 16 cover d <= 15 (diagonal kinds) and d <= 6 (covariance kinds);
-//     the sums about the basis centres follow from these raw sums per basis function (k_small_convert; mu = the column means
-//     of the training inputs, so that |x - mu| is of the order of the data's spread and the expansion loses spread^2 / length^2 ulps);
-//   * workgroups are PERSISTENT (one per compute unit) and walk the 64-row blocks, so the moment sums stay in registers for the
-//     whole launch and leave as ONE record per workgroup half; rows are summed in a fixed order (no atomics: repeatable bit for bit).
+// workgroup holds WHOLE ROWS of T in its accumulators - 32 rows x mp columns over 4 waves - so everything after the product happens
+// on registers and T never exists in memory (the context does not allocate it):
+//   * wave w owns the 16-column blocks gb = 4 q + w' (q < NQ; w' = w, or 3 - w in the second workgroup of a compute unit, so that the
+//     SIMD which hosts wave w of both carries 2 NQ - 1 blocks where the count is not a multiple of four: mp = 208 is 4 + 3 + 3 + 3)
+//     for ALL 32 rows: two row strips x NQ blocks of accumulators;
+//   * the block's rows of PHI are staged ONCE into LDS (32 x mp, one barrier) and serve as the A operand of every K step and as
+//     PHI_ij of the epilogue; the B operand [inv(SIGMA) | w] needs no LDS and no barrier - a wave's columns are its own, so it
+//     streams them from L2 with buffer loads four K steps ahead;
+//   * nu: the waves' partial row sums over their own columns meet in LDS; one thread per row forms the row scalars and the
+//     evaluation's scalar sums;
+//   * dPHI_ij = -ob_i PHI_ij U_ij with U = T + delta_i w_j - (dbeta_i / ob_i) v_j: U is one more K step, -ob_i goes into the row
+//     FEATURES, PHI_ij U_ij stays in the accumulators (see small_tail_run);
+//   * the moment sums are MFMAs again: accumulator register r of a 16 x 16 block IS the A operand (j along M, the four rows
+//     4r .. 4r + 3 along K) of a product with the block's features -ob_i [1 | x - mu | (x - mu)^2 or the packed products
+//     (x - mu)(x - mu)'], staged in LDS as the B operand - 2 feature blocks of 16 cover d <= 15 (diagonal kinds) and d <= 6
+//     (covariance kinds); the sums about the basis centres follow from these raw sums per basis function (k_small_convert; mu = the
+//     column means of the training inputs, so |x - mu| is of the order of the data's spread and the expansion loses
+//     spread^2 / length^2 ulps);
+//   * workgroups are PERSISTENT (two per compute unit) and walk the 32-row blocks, so the moment sums stay in registers for the whole
+//     launch and leave as ONE record per workgroup; rows are summed in a fixed order (no atomics: repeatable bit for bit).
+// Measured at c2 (profiles/r06_*): 259 us against 377 us for the three kernels it replaces; of a block's 85 000 cycles 40 000 are its
+// K loop (26 600 of MFMA issue) - the two workgroups of a compute unit overlap each other's staging and epilogue only partly
+// (tools/small_trace.hip prints the phase times; one workgroup per compute unit runs a block in 53 000 cycles).
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -35,11 +43,13 @@ __device__ unsigned long long *g_small_trace = nullptr;
 #else
 #define SM_MARK(slot) do { } while (0)
 #endif
-#define SM_LDA 258    // row stride of the PHI block in LDS (doubles; mp <= 256): 2 (mod 4), i.e. 4 (mod 8) banks - the 16 rows of an A-operand
+#define SM_LDA 262    // row stride of the PHI block in LDS (doubles; mp <= 256, plus the four columns of the U step's A operand): 2 (mod 4), i.e. 4 (mod 8) banks - the 16 rows of an A-operand
                       // read (one k each) start 4 banks apart, 8 bytes each: conflict-free (260 = 8 banks apart: rows r and r + 8 collided,
                       // SQ_LDS_BANK_CONFLICT was half of the kernel's LDS cycles); the accumulator-layout read is 16 consecutive doubles per row
 #define SM_LDE 48     // row stride of the feature tile (doubles): 32 features + padding, 16 (mod 32)
+#ifndef SM_PD
 #define SM_PD 4       // K steps of B (4 k each) in flight per wave: three steps = 24 MFMAs of this wave (48 with its partner on the SIMD) cover an L2 round trip
+#endif
 
 // Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: four rotate-and-add steps on the vector ALU
 // (v_mov_b32_dpp row_ror) instead of four LDS crossbar round trips (ds_bpermute, what __shfl_xor compiles to).
@@ -61,24 +71,36 @@ __device__ __forceinline__ double row_sum16(double p) {
 // NQW = column blocks of THIS wave (wave-uniform; a launch mixes NQ and NQ - 1 where the block count is not a multiple of four), F2 = a
 // second block of 16 features exists.  Everything the wave indexes its blocks with is a compile-time constant: no branch around an MFMA,
 // every LDS address a register plus an immediate.
+//
+// The vector ALU is the scarce resource here, not the matrix pipe: while the other workgroup of the compute unit is inside its K loop,
+// every vector instruction of this one waits behind an MFMA in flight (tools/small_trace.hip: a phase of n vector instructions takes
+// ~64 n cycles then), so whatever can be expressed as one more MFMA step or as a scalar / memory / LDS instruction is:
+//   * dPHI_ij = (-ob_i T_ij - c_i w_j + dbeta_i v_j) PHI_ij = -ob_i PHI_ij U_ij,  U = T + delta_i w_j - (dbeta_i / ob_i) v_j  (c = ob delta):
+//     U is ONE MORE K STEP of the product - A = [delta_i, -dbeta_i / ob_i, 0, 0] parked behind the PHI block in LDS, B = [w; v; 0; 0] -
+//     and the row factor -ob_i goes into the FEATURES (32 x 32 values per block instead of 32 x mp elements): one multiply per element;
+//   * operands arrive through buffer loads (resource in SGPRs, loop-invariant VGPR offset, scalar row / K offset): no address arithmetic;
+//   * the feature table of a thread (which two entries of the centred row [1 | x - mu] it multiplies) is fixed before the block loop.
 template <int NQW, bool F2>
 __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *smem, int wce) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, mp = a.mp, ld = a.ld;
-    double *sA = smem;                          // [32][SM_LDA]: the block's rows of PHI (A operand of the product, PHI_ij of the epilogue)
-    double *sE = sA + 32 * SM_LDA;              // [32][SM_LDE]: row features
+    double *sA = smem;                          // [32][SM_LDA]: the block's rows of PHI (A operand of the product, PHI_ij of the epilogue); columns mp .. mp+3: [delta, -dbeta/ob, 0, 0]
+    double *sE = sA + 32 * SM_LDA;              // [32][SM_LDE]: row features times -omega beta
     double *sNu = sE + 32 * SM_LDE;             // [4][32]: partial nu of the four column groups
     double *sPw = sNu + 4 * 32;                 // [32]: (PHI w)_i
-    double *sRs = sPw + 32;                     // [32][4]: omega*beta, c, dbeta of the block's rows
+    double *sRs = sPw + 32;                     // [32][4]: c, dbeta of the block's rows
 
     d4_t Mq[NQW > 0 ? NQW : 1][2];        // moment sums of this wave's column blocks: [block][feature block]
     double r1[NQW > 0 ? NQW : 1], r2[NQW > 0 ? NQW : 1];   // PHI'c, PHI'dbeta partial sums over this lane's rows (column 16 gb + (lane & 15))
+    double fbu[NQW > 0 ? NQW : 1];        // B fragment of the U step: row 0 = w, row 1 = v (times vscale), rows 2, 3 = 0
     int vo[NQW > 0 ? NQW : 1];
 #pragma unroll
     for (int q = 0; q < NQW; ++q) {
         Mq[q][0] = (d4_t){0.0, 0.0, 0.0, 0.0};
         Mq[q][1] = (d4_t){0.0, 0.0, 0.0, 0.0};
         r1[q] = r2[q] = 0.0;
+        const int col = (4 * q + wce) * 16 + (lane & 15), cc = col < m ? col : m - 1;   // (PHI_ij = 0 beyond m: any finite value does)
+        fbu[q] = (lane >> 4) == 0 ? a.w[cc] : (lane >> 4) == 1 ? a.vscale * a.v[cc] : 0.0;
         // B operand straight from global memory (L2): the column blocks are this wave's alone, so LDS would add a copy and a barrier
         // and no reuse.  Lane l of K step kg reads B[4 kg + (l >> 4)][16 gb + (l & 15)]: four 128-byte runs, as a BUFFER load - resource
         // in SGPRs, one loop-invariant 32-bit byte offset per column block, the K step as the scalar offset: no vector ALU per load
@@ -98,6 +120,31 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
     // column m of B is w: T[:, m] = PHI w (GPz.m:77) sits in block (m >> 4) = 4 qm + wce of ONE wave, lanes with (lane & 15) == (m & 15)
     const int qm = (((m >> 4) - wce) & 3) == 0 ? ((m >> 4) - wce) >> 2 : -1;
     const bool pwlane = (lane & 15) == (m & 15);
+    // staging: wave w takes rows 8 w .. 8 w + 7 of the block, a lane the double2 at columns 2 lane and 128 + 2 lane
+    const int c2 = lane * 2;
+    const bool in0 = c2 < mp, in1 = c2 + 128 < mp;
+    // features: thread (row tid >> 3) multiplies entries pa, pb of its centred row [1 | x - mu | 0] for the four features 4 (tid & 7) + u
+    // (entry 0 = the constant 1, entry d + 1 = 0 for the features past nf); the eight indices packed in two registers
+    unsigned fpa = 0, fpb = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int f = (tid & 7) * 4 + u;
+        int ia = 0, ib = 0;
+        if (f >= a.nf) ia = ib = a.d + 1;
+        else if (f >= 1) {
+            if (f <= a.d) ia = f;
+            else if (a.kind == GPZ_KIND_DIAG) ia = ib = f - a.d;
+            else {
+                int e2 = f - 1 - a.d, aa = 0;                    // packed upper triangle, row aa: a.d - aa entries
+                while (e2 >= a.d - aa) { e2 -= a.d - aa; ++aa; }
+                ia = aa + 1; ib = aa + e2 + 1;
+            }
+        }
+        fpa |= (unsigned)ia << (8 * u);
+        fpb |= (unsigned)ib << (8 * u);
+    }
+    const int xs_ld = a.d + 2;
+    if (tid < 32) { sA[tid * SM_LDA + mp + 2] = 0.0; sA[tid * SM_LDA + mp + 3] = 0.0; }   // rows 2, 3 of the U step's A operand
     int it = 0;
     for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x, ++it) {
         const int i0 = blk * 32;
@@ -106,68 +153,50 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
         // addresses and constants out of the block loop - some 150 registers held for the whole kernel, spilled around the MFMA loop.
         unsigned oz = 0;
         asm volatile("" : "+v"(oz));
-        // the row-scalar inputs of this block's rows (threads 0..31), requested now: they are needed two barriers later
-        double ry = 0.0, rlb = 0.0, rom = 1.0, rob = 0.0;
-        if (tid < 32 && i0 + tid < a.n) {
-            const int i = i0 + tid;
-            ry = a.y[i]; rlb = a.lnbeta[i]; rob = a.wbeta[i];
-            if (a.omega) rom = a.omega[i];
-        }
-        // ---- stage the block's rows of PHI (32 x mp, coalesced double2 reads) and their features
-        {   // wave w: rows 8 w .. 8 w + 7, a lane two double2 per row (mp <= 256).  ALL loads are issued before the first is used (one memory
-            // round trip per block, not sixteen: the accumulators are not live here, so the 64 registers exist)
-            const int c2 = lane * 2;
-            const bool in0 = c2 < mp, in1 = c2 + 128 < mp;
-            const double *src = a.Phi + (size_t)(i0 + wv * 8) * ld + (in0 ? c2 : 0);
-            const double *src1 = a.Phi + (size_t)(i0 + wv * 8) * ld + (in1 ? c2 + 128 : 0);
+        // ---- stage the block's rows of PHI (32 x mp).  ALL loads are issued before the first is used (one memory round trip per block:
+        // the accumulators are not live here, so the 64 registers exist)
+        {
+            // (resource = this block's 32 rows: base pointer and size are scalars; row offset as the scalar offset, column as the lane's)
+            const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void *)(a.Phi + (size_t)i0 * ld), 0, 32 * ld * 8, 0x00020000);
+            const int srow = wv * 8 * ld * 8;
             double *dst = sA + (wv * 8) * SM_LDA + c2;
             d2_t v0[8], v1[8];
+            if (in0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                v0[r] = *reinterpret_cast<const d2_t *>(src + (size_t)r * ld);
-                v1[r] = *reinterpret_cast<const d2_t *>(src1 + (size_t)r * ld);
+                for (int r = 0; r < 8; ++r) v0[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rP, c2 * 8, srow + r * ld * 8, 0));
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // columns >= m (y, padding) become zero in LDS: they meet zero rows of B in the product, and the epilogue's PHI_ij, j < m, needs no mask
-            const double k0 = c2 < m ? 1.0 : 0.0, k1 = c2 + 1 < m ? 1.0 : 0.0, k2 = c2 + 128 < m ? 1.0 : 0.0, k3 = c2 + 129 < m ? 1.0 : 0.0;
+            if (in1) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                d2_t u = v0[r], t = v1[r];
-                u.x *= k0; u.y *= k1; t.x *= k2; t.y *= k3;
-                if (in0) *reinterpret_cast<d2_t *>(dst + r * SM_LDA) = u;
-                if (in1) *reinterpret_cast<d2_t *>(dst + r * SM_LDA + 128) = t;
+                for (int r = 0; r < 8; ++r) v1[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rP, (c2 + 128) * 8, srow + r * ld * 8, 0));
             }
-        }
-        {   // thread: row tid >> 3, features 4 (tid & 7) .. + 3.  The four values' inputs are requested together (one memory round trip, not four)
-            const int r = tid >> 3, f0 = (tid & 7) * 4, i = i0 + r;
-            const bool rowin = i < a.n;
-            const double *xi = a.Xr + (size_t)(rowin ? i : 0) * a.d;
-            int ia[4], ib[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u;
-                ia[u] = ib[u] = -1;                                      // -1: the constant 1 (f = 0) or an unused feature
-                if (f >= 1 && f < a.nf) {
-                    if (f <= a.d) ia[u] = f - 1;
-                    else if (a.kind == GPZ_KIND_DIAG) ia[u] = ib[u] = f - 1 - a.d;
-                    else {
-                        int e2 = f - 1 - a.d, aa = 0;                    // packed upper triangle, row aa: a.d - aa entries
-                        while (e2 >= a.d - aa) { e2 -= a.d - aa; ++aa; }
-                        ia[u] = aa; ib[u] = aa + e2;
-                    }
-                }
-            }
+            // features (times -omega beta of the row: the row factor of dPHI lives here, see above)
+            const int r = tid >> 3, i = i0 + r;
+            const double *xs = a.Xs + (size_t)i * xs_ld;
             double xa[4], xb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                xa[u] = ia[u] >= 0 ? xi[ia[u]] - a.xmu[ia[u]] : 1.0;
-                xb[u] = ib[u] >= 0 ? xi[ib[u]] - a.xmu[ib[u]] : 1.0;
+            for (int u = 0; u < 4; ++u) { xa[u] = xs[(fpa >> (8 * u)) & 255]; xb[u] = xs[(fpb >> (8 * u)) & 255]; }
+            const double nob = -a.wbeta[i];                    // (rows >= n: omega beta = 0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (in0) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<d2_t *>(dst + rr * SM_LDA) = v0[rr];
+                // columns >= m (y, padding) become zero in LDS: they meet zero rows of B in the product, and the epilogue's PHI_ij, j < m, needs no mask
+                if (c2 + 1 >= m) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) { if (c2 >= m) dst[rr * SM_LDA] = 0.0; dst[rr * SM_LDA + 1] = 0.0; }
+                }
+            }
+            if (in1) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<d2_t *>(dst + rr * SM_LDA + 128) = v1[rr];
+                if (c2 + 129 >= m) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) { if (c2 + 128 >= m) dst[rr * SM_LDA + 128] = 0.0; dst[rr * SM_LDA + 129] = 0.0; }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u;
-                sE[r * SM_LDE + f] = (rowin && f < a.nf) ? xa[u] * xb[u] : 0.0;
-            }
+            for (int u = 0; u < 4; ++u) sE[r * SM_LDE + (tid & 7) * 4 + u] = nob * (xa[u] * xb[u]);
+            __builtin_amdgcn_sched_barrier(0);   // (the first B fragments are requested after the staging registers are free)
         }
         // ---- T block = PHI(i0 .. i0+31, :) * B: no barrier inside, every wave runs its own columns
         d4_t acc[2][NQW > 0 ? NQW : 1];
@@ -191,17 +220,11 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 // A fragments of the NEXT step are requested before this step's burst (the row is wider than K: the read past the last step is harmless)
                 const double na0 = (pa0 + oz)[4 * (kg + p + 1)], na1 = (pa0 + oz)[16 * SM_LDA + 4 * (kg + p + 1)];
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef SM_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int q = 0; q < NQW; ++q) {
                     acc[0][q] = MFMA_F64(fa0, fb[p][q], acc[0][q]);
                     acc[1][q] = MFMA_F64(fa1, fb[p][q], acc[1][q]);
                 }
-#ifdef SM_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < NQW; ++q) fb[p][q] = bload(vo[q], so);   // SM_PD steps ahead; past the last row of B the buffer load returns 0 (unused)
@@ -213,6 +236,13 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
             }
         }
         SM_MARK(3);
+        // the row-scalar inputs of this block's rows (threads 0..31), requested now: they are needed a phase and a barrier later
+        double ry = 0.0, rlb = 0.0, rom = 1.0, rob = 0.0;
+        if (tid < 32 && i0 + tid < a.n) {
+            const int i = i0 + tid;
+            ry = a.y[i]; rlb = a.lnbeta[i]; rob = a.wbeta[i];
+            if (a.omega) rom = a.omega[i];
+        }
         // ---- nu partials and PHI w (PHI_ij from the LDS block, accumulator layout: row (lane >> 4) + 4 r, column lane & 15)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -241,43 +271,46 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
         // ---- row scalars (GPz.m:43,48,77-79,93) and the scalar sums of GPz.m:81,94,236-237: one thread per row
         if (tid < 32) {
             const int i = i0 + tid;
-            double ob = 0.0, cc = 0.0, db = 0.0;
+            double cc = 0.0, db = 0.0, delta = 0.0, g = 0.0;
             if (i < a.n) {
                 const double nu = ((sNu[tid] + sNu[32 + tid]) + sNu[64 + tid]) + sNu[96 + tid];
                 const double pw = sPw[tid];
-                const double delta = pw - ry;
-                const double lb = rlb, om = rom;
-                ob = rob;                                                // omega beta, GPz.m:48
+                delta = pw - ry;
+                const double lb = rlb, om = rom, ob = rob;               // ob = omega beta, GPz.m:48
                 // dbeta = 0.5 (-beta) (1/beta - (delta^2 + nu)) omega  (GPz.m:93)  =  0.5 (omega beta (delta^2 + nu) - omega): no exp, no divide
                 db = 0.5 * (ob * fma(delta, delta, nu) - om);
                 cc = ob * delta;
+                g = ob > 0.0 ? db * gpz_rcp(ob) : 0.0;
                 s0 = fma(cc, delta, s0);
                 s1 = fma(om, delta * delta, s1);
                 s2 += -0.5 * (cc * delta + om * lb);                     // omega (-0.5 beta delta^2 + 0.5 ln beta), ln beta = -lnBeta_i   GPz.m:237
                 s3 += db;
                 a.phiw[i] = pw;
             }
-            sRs[tid * 4 + 0] = ob; sRs[tid * 4 + 1] = cc; sRs[tid * 4 + 2] = db;
+            sRs[tid * 4 + 0] = cc; sRs[tid * 4 + 1] = db;
+            sA[tid * SM_LDA + mp] = delta; sA[tid * SM_LDA + mp + 1] = -g;   // A operand of the U step
         }
         __syncthreads();
         SM_MARK(5);
-        // ---- dPHI in the accumulators, PHI'c / PHI'dbeta, then the moment products
-        double wj[NQW > 0 ? NQW : 1], vj[NQW > 0 ? NQW : 1];
+        // ---- U = T + delta w' - (dbeta / ob) v': one more K step
+        {
+            const double ua0 = (pa0 + oz)[mp], ua1 = (pa0 + oz)[16 * SM_LDA + mp];
 #pragma unroll
-        for (int q = 0; q < NQW; ++q) {
-            const int col = (4 * q + wce) * 16 + (lane & 15), cc = col < m ? col : m - 1;   // (PHI_ij = 0 beyond m: any finite value does)
-            wj[q] = (a.w + oz)[cc];
-            vj[q] = a.vscale * (a.v + oz)[cc];               // (homoscedastic: v points at w, vscale = 0)
+            for (int q = 0; q < NQW; ++q) {
+                acc[0][q] = MFMA_F64(ua0, fbu[q], acc[0][q]);
+                acc[1][q] = MFMA_F64(ua1, fbu[q], acc[1][q]);
+            }
         }
+        // ---- PHI_ij U_ij in the accumulators (the row factor -ob_i is in the features), PHI'c / PHI'dbeta, then the moment products
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double ob = (prs + oz)[(t * 16 + 4 * r) * 4 + 0], cc = (prs + oz)[(t * 16 + 4 * r) * 4 + 1], db = (prs + oz)[(t * 16 + 4 * r) * 4 + 2];
+                const double cc = (prs + oz)[(t * 16 + 4 * r) * 4 + 0], db = (prs + oz)[(t * 16 + 4 * r) * 4 + 1];
 #pragma unroll
                 for (int q = 0; q < NQW; ++q) {
                     const double ph = (pc + oz)[(t * 16 + 4 * r) * SM_LDA + 64 * q];
-                    acc[t][q][r] = (-ob * acc[t][q][r] - cc * wj[q] + db * vj[q]) * ph;
+                    acc[t][q][r] *= ph;
                     r1[q] = fma(ph, cc, r1[q]);
                     r2[q] = fma(ph, db, r2[q]);
                 }
@@ -380,7 +413,7 @@ int small_tail_nwg() { return 2 * gpz_cu_count(); }   // persistent workgroups: 
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
     SmallTailArgs a = a0;
     a.ncu = gpz_cu_count();
-    if (a.stagger <= 0) a.stagger = 5;
+    if (a.stagger <= 0) a.stagger = 4;   // (tools/r06_small_stagger.sh: 2 .. 5 within 1 %, none or > 5 slower by 2 %)
     const int nq = ((a.mp >> 4) + 3) / 4;
     const size_t lds = ((size_t)32 * SM_LDA + 32 * SM_LDE + 4 * 32 + 32 + 32 * 4) * sizeof(double);
     dim3 g(nwg), b(256);

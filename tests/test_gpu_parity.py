@@ -352,7 +352,14 @@ def test_stage_timings_api():
     ctx.eval(theta); ctx.eval(theta)
     t = ctx.timings()
     ctx.close()
-    assert t["tgemm"][1] == 2 and t["syrk"][0] > 0 and t["phi_build"][0] > 0
+    assert t["tail_small"][1] == 2 and t["syrk"][0] > 0 and t["phi_build"][0] > 0      # (m + 1 <= 256 columns: the one-kernel tail, k_small.hip)
+    model, theta, X, Y, _, rng = make_problem(2000, 5, 300, 1, "VD", True, seed=3)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    ctx.enable_timing(True)
+    ctx.eval(theta); ctx.eval(theta)
+    t = ctx.timings()
+    ctx.close()
+    assert t["tgemm"][1] == 2 and t["moments"][1] == 2 and t["row_scalars"][0] > 0
 
 
 # ---- full-size cases: properties that do not need the oracle at size ---------------------------------
@@ -1153,7 +1160,7 @@ def test_mgpu_one_device_equals_plain_context_bitwise():
     f, g = mg.eval(theta)
     mg.enable_timing(True)
     mg.eval(theta)
-    assert mg.timings(0)["tgemm"][1] == 1
+    assert mg.timings(0)["tail_small"][1] == 1
     mg.close()
     one = gpz_amd.GPzContext(model, X, Y)
     f1, g1 = one.eval(theta)
@@ -1430,11 +1437,12 @@ def test_int8_sliced_tgemm_route_agrees_with_the_fp64_mfma_route(tmp_path, shape
     assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
 
 
-def test_timing_level_two_replays_and_times_the_dominant_stages():
+@pytest.mark.parametrize("m,stages,nseg", [(40, {"phi_build", "syrk", "tail_small"}, 7), (300, {"phi_build", "syrk", "tgemm", "moments"}, 9)])
+def test_timing_level_two_replays_and_times_the_dominant_stages(m, stages, nseg):
     """gpz_ctx_enable_timing(2): the evaluation stays a hipGraph replay, cut around the PHI build, PHI'W PHI, T = PHI [inv|w] and the
     moment sums, whose HIP events are recorded between the graph launches; bit for bit the untimed result, one call counted per
     evaluation and stage."""
-    model, theta, X, Y, Psi, rng = make_problem(2000, 6, 40, 1, "VC", True, seed=74)
+    model, theta, X, Y, Psi, rng = make_problem(2000, 6, m, 1, "VC", True, seed=74)
     ctx = gpz_amd.GPzContext(model, X, Y)
     ref = [ctx.eval(theta) for _ in range(4)]
     ctx.enable_timing(2)
@@ -1445,9 +1453,9 @@ def test_timing_level_two_replays_and_times_the_dominant_stages():
     tim = ctx.timings()
     txt = ctx.route()
     ctx.close()
-    assert "replayed (9 segments)" in txt, txt
+    assert "replayed (%d segments)" % nseg in txt, txt
     assert all(o[0] == ref[0][0] and np.array_equal(o[1], ref[0][1]) for o in out)
-    assert set(tim) == {"phi_build", "syrk", "tgemm", "moments"}, tim
+    assert set(tim) == stages, tim
     assert all(v[1] == 5 and v[0] > 0.0 for v in tim.values()), tim
 
 
@@ -1668,3 +1676,124 @@ def test_a_failed_segment_cut_while_recording_falls_back_to_eager_launches_with_
     assert "replayed" not in str(o["route"]), str(o["route"])
     for q, (f, g) in enumerate(want):
         assert o["f"][q] == f and np.array_equal(o["g"][q], g), q
+
+
+# ---- few basis functions: T-GEMM + row scalars + moment sums in one kernel (k_small.hip), T never in memory --------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,n,d,m", [
+    ("VD", 3000, 10, 200),    # BASELINE config 2's shape: 13 column blocks (4 + 3 + 3 + 3), two feature blocks
+    ("VD", 2000, 10, 255),    # mp = 256: the widest (NQ = 4 on every wave)
+    ("GD", 1500, 7, 100),     # one feature block (1 + 2 d = 15), 7 column blocks
+    ("VL", 1000, 1, 25),      # demo_sinc's shape: d = 1, two column blocks
+    ("GL", 700, 3, 15),       # mp = 16: a single column block - three waves of a workgroup own no column at all
+    ("VC", 2500, 6, 120),     # covariance kind at the widest d the features fit (1 + 6 + 21 = 28)
+    ("GC", 1200, 2, 50),      # demo_2D's shape
+    ("VC", 900, 4, 47),       # m + 1 = 48: the y column opens no block of its own
+    ("VD", 5000, 12, 63),     # m + 1 = 64, 1 + 2 d = 25 features
+    ("VD", 40, 3, 5)])        # fewer rows than one 32-row block per workgroup: most workgroups idle
+@pytest.mark.parametrize("hetero", [True, False])
+def test_small_tail_route_against_oracle(method, n, d, m, hetero):
+    """mp = ceil16(m + 1) <= 256 and <= 32 moment features: gpz_eval runs k_small_tail.  Against the oracle with weights, a training
+    mask and validation rows; the route text names the kernel; two further calls (record, replay) return the same bits."""
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, method, hetero, seed=8300 + n + m)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        f2, g2 = ctx.eval(theta)
+        f3, g3 = ctx.eval(theta)
+        stats = dict(ctx.stats)
+        route = ctx.route()
+    finally:
+        ctx.close()
+    assert "k_small_tail" in route, route
+    assert f2 == f and f3 == f and np.array_equal(g, g2) and np.array_equal(g, g3)
+    tol = grad_tol(ref.cond)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= tol, (rel(g, ref.grad), tol)
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
+@pytest.mark.gpu
+def test_small_tail_is_not_taken_where_it_does_not_apply():
+    """k > 1, input noise, missing values, more than 256 columns, more than 32 features: the separate kernels (and the same oracle parity,
+    covered by the tests above) - the route text must not name k_small_tail."""
+    cases = [dict(k=2), dict(psi=True), dict(nanfrac=0.2), dict(m=256), dict(method="VC", d=7), dict(method="VD", d=16)]
+    for kw in cases:
+        method, d, m, k = kw.get("method", "VD"), kw.get("d", 4), kw.get("m", 40), kw.get("k", 1)
+        model, theta, X, Y, Psi, rng = make_problem(600, d, m, k, method, True, seed=11, psi=kw.get("psi", False), nanfrac=kw.get("nanfrac", 0.0))
+        ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+        try:
+            ctx.eval(theta)
+            assert "k_small_tail" not in ctx.route(), (kw, ctx.route())
+        finally:
+            ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,m", [("VD", 10, 200), ("VC", 5, 90), ("GL", 2, 30)])
+def test_small_tail_route_agrees_with_the_separate_kernels(tmp_path, method, d, m):
+    """The same evaluation through k_tgemm + k_row_scalars + k_moments_fused (developer build, GPZ_SMALL_TAIL_OFF): the two routes differ
+    in summation order and in where dbeta is formed (no exp / divide in k_small_tail), so they agree to rounding, far inside the gate."""
+    from helpers import eval_with_dev_switches
+    model, theta, X, Y, _, rng = make_problem(4000, d, m, 1, method, True, seed=4400 + m)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    assert "k_small_tail" in ctx.route()
+    ctx.close()
+    f, g, info = eval_with_dev_switches(tmp_path, method, m, d, 1, True, theta, X, Y, None, {"GPZ_SMALL_TAIL_OFF": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-13 * abs(f0) and rel(g, g0) <= 1e-10, (abs(f - f0) / abs(f0), rel(g, g0))
+
+
+@pytest.mark.gpu
+def test_small_tail_moment_sums_far_from_the_origin():
+    """The moment sums are expanded about the column means of the training inputs (sum dp (x - p)^2 = R2 - 2 q R1 + q^2 R0, q = p - mu):
+    inputs 1e4 standard deviations away from the origin (un-normalised data) must not cost the gradient its digits - against the oracle
+    and against the same data shifted back to the origin (the objective does not depend on a common shift of X and P)."""
+    n, d, m = 2000, 5, 60
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VD", True, seed=515)
+    shift = 1.0e4 * (1.0 + rng.random(d))
+    Xs = X + shift
+    theta_s = theta.copy()
+    theta_s[:m * d] = (theta[:m * d].reshape((m, d), order="F") + shift).reshape(-1, order="F")
+    ref = O.GPz(theta_s, model, Xs, Y)
+    a = gpz_amd.GPzContext(model, Xs, Y)
+    b = gpz_amd.GPzContext(model, X, Y)
+    try:
+        fs, gs = a.eval(theta_s)
+        f0, g0 = b.eval(theta)
+        assert "k_small_tail" in a.route()
+    finally:
+        a.close()
+        b.close()
+    assert abs(fs - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(gs, ref.grad) <= max(grad_tol(ref.cond), 1e-7)
+    assert abs(fs - f0) <= 1e-9 * abs(f0) and rel(gs, g0) <= 1e-7, (abs(fs - f0) / abs(f0), rel(gs, g0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_small_tail_inside_row_shards(shards):
+    """Row shards (loopback reducer) each run k_small_tail on their rows; the raw moment sums of every shard are about ITS column
+    means and are converted per shard before the second all-reduce."""
+    n, d, m = 3001, 6, 70
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VD", True, seed=97)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    mg = gpz_amd.GPzMulti(model, X, Y, None, om, tr, ~tr, n_gpus=shards, reducer="loopback")
+    try:
+        f, g = mg.eval(theta)
+        f2, g2 = mg.eval(theta)
+        f3, g3 = mg.eval(theta)
+        assert "k_small_tail" in mg.route(0)
+        stats = dict(mg.stats)
+    finally:
+        mg.close()
+    assert f2 == f and f3 == f and np.array_equal(g, g2) and np.array_equal(g, g3)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key

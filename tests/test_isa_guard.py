@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
-def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path):
-    asm = tmp_path / "k_gemm.s"
+@pytest.mark.parametrize("unit,kernels", [("k_gemm", ("k_tgemm", "k_syrk")), ("k_small", ("k_small_tail",))])
+def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path, unit, kernels):
+    asm = tmp_path / (unit + ".s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                     "-I" + os.path.join(ROOT, "gpz_amd", "csrc"), "-S", "--cuda-device-only",
-                    os.path.join(ROOT, "gpz_amd", "csrc", "k_gemm.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
+                    os.path.join(ROOT, "gpz_amd", "csrc", unit + ".hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
     lines = asm.read_text().splitlines()
     kernel = block = None
     nmfma = nscratch = 0
@@ -27,7 +28,7 @@ def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path):
             bad.append((kernel, block, nmfma, nscratch))
 
     for l in lines:
-        m = re.match(r"^(_Z\w*(k_tgemm|k_syrk)\w*):", l)
+        m = re.match(r"^(_Z\w*(%s)\w*):" % "|".join(kernels), l)
         if m:
             close()
             kernel, block, nmfma, nscratch = m.group(1), "entry", 0, 0
@@ -49,5 +50,5 @@ def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path):
             nmfma += 1
         elif t.startswith("scratch_"):
             nscratch += 1
-    assert seen == {"k_tgemm", "k_syrk"}, seen
+    assert seen == set(kernels), seen
     assert not bad, bad

@@ -31,6 +31,13 @@ for f in ("sq", "sq2", "fetch", "write"):
     for k, cs in load(base + f + "/p_counter_collection.csv").items():
         for c, v in cs.items():
             data.setdefault(k, {})[c] = sum(v) / len(v)
+# average duration per kernel from the kernel-trace pass of the same command (trace/t_kernel_stats.csv), when it is there
+dur_ns = {}
+try:
+    for r in csv.DictReader(open(base + "trace/t_kernel_stats.csv")):
+        dur_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
+except Exception:
+    pass
 keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_", "void k_small_tail"))]
 with open(dst, "w") as out:
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py " + what + "; one counter group per pass; tools/pmc_run.sh)\n"
@@ -54,6 +61,12 @@ with open(dst, "w") as out:
         if "FETCH_SIZE" in d:
             out.write("   -> fabric-side bytes per launch: fetch %.2f GB (x2 corrected %.2f GB), write %.2f GB\n"
                       % (d["FETCH_SIZE"] * 1024 / 1e9, 2 * d["FETCH_SIZE"] * 1024 / 1e9, d.get("WRITE_SIZE", 0) * 1024 / 1e9))
+            if k in dur_ns and dur_ns[k] > 0:
+                tot = (2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024
+                out.write("   -> average duration %.1f us (kernel trace of the same command): %.2f TB/s at the fabric (x2-corrected fetch + write)\n"
+                          % (dur_ns[k] / 1e3, tot / dur_ns[k] / 1e3))
+                if cyc > 0:
+                    out.write("   -> kernel clock = kernel cycles / duration = %.2f GHz\n" % (cyc / dur_ns[k]))
 print(open(dst).read())
 
 if constants and config:

@@ -55,6 +55,30 @@ if base:
     for p in out["per_n"]:
         if "predicted_ms_per_eval" in p:
             p["predicted_efficiency_vs_1gpu"] = base["predicted_ms_per_eval"] / (p["n_gpus"] * p["predicted_ms_per_eval"])
+# config 5 (n = 2e6, d = 20, m = 2000, VC + diagonal Psi, dtype f32): the full problem on one GPU and the rows one of 8 ranks holds
+M5, D5, MP5 = 2000, 20, 2016
+AR1_5 = 8 * (MP5 * MP5 + 4)
+AR2_5 = 8 * (M5 * (D5 * D5 + D5 + 3) + 2 * MP5 + 8)
+c5 = {"workload": "c5: n=2e6 d=20 m=2000 VC heteroscedastic + diagonal Psi, dtype f32 (fp32 pair kernels, fp32-operand MFMA contractions)",
+      "status": "PREDICTION from single-GPU measurements + the ring all-reduce model above; no N > 1 run exists on this pool",
+      "allreduce_bytes": {"exchange_1": AR1_5, "exchange_2": AR2_5}, "per_n": []}
+for n, name in ((1, "c5_full_1gpu.json"), (8, "c5s.json")):
+    try:
+        d = line(f"{src}/{name}")
+    except Exception as e:  # noqa: BLE001
+        c5["per_n"].append({"n_gpus": n, "error": repr(e)})
+        continue
+    ar_ms = (allreduce(AR1_5, n) + allreduce(AR2_5, n)) * 1e3
+    c5["per_n"].append({"n_gpus": n, "rows_per_gpu": 2_000_000 // n, "measured_ms_single_gpu": d["ms_per_step"], "allreduce_estimate_ms": ar_ms,
+                        "predicted_ms_per_eval": d["ms_per_step"] + ar_ms, "predicted_evals_per_s": 1e3 / (d["ms_per_step"] + ar_ms),
+                        "stage_ms_per_eval": d.get("kernels", {}).get("stage_ms_per_eval", {})})
+b5 = next((q for q in c5["per_n"] if q.get("n_gpus") == 1 and "predicted_ms_per_eval" in q), None)
+for q in c5["per_n"]:
+    if b5 and "predicted_ms_per_eval" in q:
+        q["predicted_efficiency_vs_1gpu"] = b5["predicted_ms_per_eval"] / (q["n_gpus"] * q["predicted_ms_per_eval"])
+out["c5"] = c5
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({"per_n": [{k: p.get(k) for k in ("n_gpus", "measured_shard_ms_single_gpu", "allreduce_estimate_ms", "predicted_evals_per_s",
-                                                   "predicted_efficiency_vs_1gpu")} for p in out["per_n"]]}, indent=1))
+                                                   "predicted_efficiency_vs_1gpu")} for p in out["per_n"]],
+                  "c5": [{k: q.get(k) for k in ("n_gpus", "measured_ms_single_gpu", "allreduce_estimate_ms", "predicted_evals_per_s",
+                                                "predicted_efficiency_vs_1gpu")} for q in c5["per_n"]]}, indent=1))

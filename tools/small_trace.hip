@@ -18,23 +18,23 @@ __global__ void k_fill(double *p, size_t n, unsigned seed, double scale) {
 }
 
 int main(int argc, char **argv) {
-    const int n = argc > 1 ? atoi(argv[1]) : 100000, m = argc > 2 ? atoi(argv[2]) : 200, d = argc > 3 ? atoi(argv[3]) : 10, stg = argc > 4 ? atoi(argv[4]) : 0;
-    const int mp = (m + 1 + 15) / 16 * 16, n_pad = (n + 1023) / 1024 * 1024, nwg = 2 * gpz_cu_count();
+    const int n = argc > 1 ? atoi(argv[1]) : 100000, m = argc > 2 ? atoi(argv[2]) : 200, d = argc > 3 ? atoi(argv[3]) : 10, stg = argc > 4 ? atoi(argv[4]) : 0, wpc = argc > 5 ? atoi(argv[5]) : 2;
+    const int mp = (m + 1 + 15) / 16 * 16, n_pad = (n + 1023) / 1024 * 1024, nwg = wpc * gpz_cu_count();
     SmallTailArgs a{};
     double *Phi, *B, *Xr, *xmu, *y, *lnb, *wb, *w, *v, *phiw, *slab, *partial;
     a.nf = small_tail_features(GPZ_KIND_DIAG, d);
-    (void)hipMalloc(&Phi, (size_t)n_pad * mp * 8); (void)hipMalloc(&B, (size_t)mp * mp * 8); (void)hipMalloc(&Xr, (size_t)n_pad * d * 8);
+    (void)hipMalloc(&Phi, (size_t)n_pad * mp * 8); (void)hipMalloc(&B, (size_t)mp * mp * 8); (void)hipMalloc(&Xr, (size_t)n_pad * (d + 2) * 8);
     (void)hipMalloc(&xmu, d * 8); (void)hipMalloc(&y, n_pad * 8); (void)hipMalloc(&lnb, n_pad * 8); (void)hipMalloc(&wb, n_pad * 8);
     (void)hipMalloc(&w, m * 8); (void)hipMalloc(&v, m * 8); (void)hipMalloc(&phiw, n_pad * 8);
     (void)hipMalloc(&slab, (size_t)nwg * m * (a.nf + 2) * 8); (void)hipMalloc(&partial, (size_t)nwg * GPZ_NS * 8);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Phi, (size_t)n_pad * mp, 1u, 1.0);
     hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, B, (size_t)mp * mp, 2u, 1e-2);
-    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, Xr, (size_t)n_pad * d, 3u, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, Xr, (size_t)n_pad * (d + 2), 3u, 1.0);
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, 0, xmu, (size_t)d, 4u, 0.5);
     for (double *q : {y, lnb, wb}) hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, q, (size_t)n_pad, 5u, 1.0);
     for (double *q : {w, v}) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, 0, q, (size_t)m, 6u, 1.0);
     a.Phi = Phi; a.ld = mp; a.B = B; a.ldb = mp; a.n = n; a.n_pad = n_pad; a.m = m; a.mp = mp; a.d = d; a.kind = GPZ_KIND_DIAG;
-    a.Xr = Xr; a.xmu = xmu; a.y = y; a.omega = nullptr; a.lnbeta = lnb; a.wbeta = wb; a.w = w; a.v = v; a.vscale = 1.0; a.phiw = phiw;
+    a.Xs = Xr; a.y = y; a.omega = nullptr; a.lnbeta = lnb; a.wbeta = wb; a.w = w; a.v = v; a.vscale = 1.0; a.phiw = phiw;
     a.slab = slab; a.partial = partial; a.stagger = stg;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
