@@ -498,6 +498,9 @@ def main():
                          "traffic_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
                          "traffic_note": (pmc_traffic(args.config) or {}).get("note"),
                          "mfma_util_counters": (pmc_traffic(args.config) or {}).get("tgemm_mfma_util") if world == 1 and not multi and not args.n else None,
+                         # the clock the kernel ran at in the committed PMC pass (GRBM cycles / kernel-trace duration) and the MFMA peak at THAT
+                         # clock: flops-based frac x (2.4 / clock) is what the counter-based utilisation should be read against
+                         "kernel_clock_ghz_counters": (pmc_traffic(args.config) or {}).get("tgemm_kernel_clock_ghz") if world == 1 and not multi and not args.n else None,
                          "avg_ms": tg_avg,
                          "ubench_ceiling": F32_MFMA_UBENCH_TFLOPS if f32_route else F64_MFMA_UBENCH_TFLOPS,
                          "frac_of_ubench": ach / (F32_MFMA_UBENCH_TFLOPS if f32_route else F64_MFMA_UBENCH_TFLOPS)},
@@ -512,6 +515,8 @@ def main():
                               "achieved": ach_sy, "peak": F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_sy / (F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS), "avg_ms": sy_avg,
                               "mfma_util_counters": (pmc_traffic(args.config) or {}).get("syrk_mfma_util") if world == 1 and not multi and not args.n else None,
+                              "kernel_clock_ghz_counters": (pmc_traffic(args.config) or {}).get("syrk_kernel_clock_ghz") if world == 1 and not multi and not args.n else None,
+                              "mfma_instructions_counters": (pmc_traffic(args.config) or {}).get("syrk_mfma_instructions") if world == 1 and not multi and not args.n else None,
                               "counters_source": (pmc_traffic(args.config) or {}).get("source") if world == 1 and not multi and not args.n else None,
                               "traffic": (pmc_traffic(args.config) or {}).get("syrk_bytes_per_launch") if world == 1 and not multi and not args.n else None},
             "phi_build": {"bound": "hbm (diagonal kinds) / fp64 vector ALU (covariance kinds, SURVEY.md 8d)", "avg_ms": ph_avg,

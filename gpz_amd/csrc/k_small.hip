@@ -27,9 +27,10 @@
 //     spread^2 / length^2 ulps);
 //   * workgroups are PERSISTENT (two per compute unit) and walk the 32-row blocks, so the moment sums stay in registers for the whole
 //     launch and leave as ONE record per workgroup; rows are summed in a fixed order (no atomics: repeatable bit for bit).
-// Measured at c2 (profiles/r06_*): 259 us against 377 us for the three kernels it replaces; of a block's 85 000 cycles 40 000 are its
-// K loop (26 600 of MFMA issue) - the two workgroups of a compute unit overlap each other's staging and epilogue only partly
-// (tools/small_trace.hip prints the phase times; one workgroup per compute unit runs a block in 53 000 cycles).
+// Measured at c2 (profiles/r06_*): 232 us (with its five small follow-up launches) against 377 us for the three kernels it replaces;
+// a block takes 68 000 cycles of which 33 500 are its K loop (26 600 of MFMA issue) - the two workgroups of a compute unit overlap
+// each other's staging and epilogue only partly; 3136 blocks on 512 workgroups are 7 rounds for 6.1 of work
+// (tools/small_trace.hip prints the phase times: profiles/r06_small_tail_timeline.txt).
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
@@ -43,6 +44,7 @@ __device__ unsigned long long *g_small_trace = nullptr;
 #else
 #define SM_MARK(slot) do { } while (0)
 #endif
+#define SM_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g), (__attribute__((address_space(3))) void *)(l), 16, 0, 0)
 #define SM_LDA 262    // row stride of the PHI block in LDS (doubles; mp <= 256, plus the four columns of the U step's A operand): 2 (mod 4), i.e. 4 (mod 8) banks - the 16 rows of an A-operand
                       // read (one k each) start 4 banks apart, 8 bytes each: conflict-free (260 = 8 banks apart: rows r and r + 8 collided,
                       // SQ_LDS_BANK_CONFLICT was half of the kernel's LDS cycles); the accumulator-layout read is 16 consecutive doubles per row
@@ -66,6 +68,35 @@ __device__ __forceinline__ double row_sum16(double p) {
     p += row_ror<2>(p);
     p += row_ror<1>(p);
     return p;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// EIGHT values per lane summed over the 16 lanes of a DPP row with a transposing butterfly: 52 vector instructions instead of the 96 of
+// eight row_sum16.  Four pairings that together generate all 16 lanes - row mirror (l <-> 15 - l), half-row mirror (l <-> l ^ 7), quad
+// mirror (l <-> l ^ 3), neighbour (l <-> l ^ 1); at each of the first three a lane keeps the half of its values that its bit 3 / 2 / 1
+// selects and hands the other half to its partner.  Afterwards lane l holds the row's total of value 4 b3 + 2 b2 + b1 (bits of l & 15).
+__device__ __forceinline__ double row_sum16x8(const double (&v)[8], int lane) {
+    double a[4], b[2];
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double keep = b3 ? v[k + 4] : v[k], send = b3 ? v[k] : v[k + 4];
+        a[k] = keep + dpp_f64<0x140>(send);                      // row_mirror
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double keep = b2 ? a[k + 2] : a[k], send = b2 ? a[k] : a[k + 2];
+        b[k] = keep + dpp_f64<0x141>(send);                      // row_half_mirror
+    }
+    const double keep = b1 ? b[1] : b[0], send = b1 ? b[0] : b[1];
+    double c = keep + dpp_f64<0x1B>(send);                       // quad_perm [3, 2, 1, 0]
+    c += dpp_f64<0xB1>(c);                                       // quad_perm [1, 0, 3, 2]
+    return c;
 }
 
 // NQW = column blocks of THIS wave (wave-uniform; a launch mixes NQ and NQ - 1 where the block count is not a multiple of four), F2 = a
@@ -120,6 +151,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
     // column m of B is w: T[:, m] = PHI w (GPz.m:77) sits in block (m >> 4) = 4 qm + wce of ONE wave, lanes with (lane & 15) == (m & 15)
     const int qm = (((m >> 4) - wce) & 3) == 0 ? ((m >> 4) - wce) >> 2 : -1;
     const bool pwlane = (lane & 15) == (m & 15);
+    const double cmask = (lane & 15) < (m & 15) ? 1.0 : 0.0;   // block qm: its columns >= m hold y and padding (PHI_ij = 0 there)
     // staging: wave w takes rows 8 w .. 8 w + 7 of the block, a lane the double2 at columns 2 lane and 128 + 2 lane
     const int c2 = lane * 2;
     const bool in0 = c2 < mp, in1 = c2 + 128 < mp;
@@ -153,21 +185,20 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
         // addresses and constants out of the block loop - some 150 registers held for the whole kernel, spilled around the MFMA loop.
         unsigned oz = 0;
         asm volatile("" : "+v"(oz));
-        // ---- stage the block's rows of PHI (32 x mp).  ALL loads are issued before the first is used (one memory round trip per block:
-        // the accumulators are not live here, so the 64 registers exist)
+        // ---- stage the block's rows of PHI (32 x mp) with LDS-DMA loads (global_load_lds_dwordx4: lane l of a wave puts its 16 bytes at
+        // LDS base + 16 l, i.e. a wave moves 128 consecutive doubles of one row): no registers, no vector ALU, all sixteen requests of
+        // a wave in flight at once.  (Through registers the sixteen double2 per lane were 64 VGPRs on top of the moment accumulators:
+        // the four-block waves spilled here, 4 600 cycles per block - profiles/r06_small_tail_timeline.txt.)
         {
-            // (resource = this block's 32 rows: base pointer and size are scalars; row offset as the scalar offset, column as the lane's)
-            const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void *)(a.Phi + (size_t)i0 * ld), 0, 32 * ld * 8, 0x00020000);
-            const int srow = wv * 8 * ld * 8;
-            double *dst = sA + (wv * 8) * SM_LDA + c2;
-            d2_t v0[8], v1[8];
+            const double *g0 = a.Phi + (size_t)(i0 + wv * 8) * ld + c2;
+            double *l0 = sA + (wv * 8) * SM_LDA;
             if (in0) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v0[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rP, c2 * 8, srow + r * ld * 8, 0));
+                for (int r = 0; r < 8; ++r) SM_GLDS(g0 + (size_t)r * ld, l0 + r * SM_LDA);
             }
             if (in1) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v1[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rP, (c2 + 128) * 8, srow + r * ld * 8, 0));
+                for (int r = 0; r < 8; ++r) SM_GLDS(g0 + (size_t)r * ld + 128, l0 + r * SM_LDA + 128);
             }
             // features (times -omega beta of the row: the row factor of dPHI lives here, see above)
             const int r = tid >> 3, i = i0 + r;
@@ -176,27 +207,8 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
 #pragma unroll
             for (int u = 0; u < 4; ++u) { xa[u] = xs[(fpa >> (8 * u)) & 255]; xb[u] = xs[(fpb >> (8 * u)) & 255]; }
             const double nob = -a.wbeta[i];                    // (rows >= n: omega beta = 0)
-            __builtin_amdgcn_sched_barrier(0);
-            if (in0) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<d2_t *>(dst + rr * SM_LDA) = v0[rr];
-                // columns >= m (y, padding) become zero in LDS: they meet zero rows of B in the product, and the epilogue's PHI_ij, j < m, needs no mask
-                if (c2 + 1 >= m) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) { if (c2 >= m) dst[rr * SM_LDA] = 0.0; dst[rr * SM_LDA + 1] = 0.0; }
-                }
-            }
-            if (in1) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<d2_t *>(dst + rr * SM_LDA + 128) = v1[rr];
-                if (c2 + 129 >= m) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) { if (c2 + 128 >= m) dst[rr * SM_LDA + 128] = 0.0; dst[rr * SM_LDA + 129] = 0.0; }
-                }
-            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) sE[r * SM_LDE + (tid & 7) * 4 + u] = nob * (xa[u] * xb[u]);
-            __builtin_amdgcn_sched_barrier(0);   // (the first B fragments are requested after the staging registers are free)
         }
         // ---- T block = PHI(i0 .. i0+31, :) * B: no barrier inside, every wave runs its own columns
         d4_t acc[2][NQW > 0 ? NQW : 1];
@@ -210,6 +222,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
 #pragma unroll
             for (int q = 0; q < NQW; ++q) fb[p][q] = bload(vo[q], p * kstep);
         SM_MARK(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA loads of this wave have landed (the compiler does not track them for the barrier)
         __syncthreads();
         SM_MARK(2);
         double fa0 = (pa0 + oz)[0], fa1 = (pa0 + oz)[16 * SM_LDA];
@@ -244,19 +257,25 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
             if (a.omega) rom = a.omega[i];
         }
         // ---- nu partials and PHI w (PHI_ij from the LDS block, accumulator layout: row (lane >> 4) + 4 r, column lane & 15)
+        {
+            double pv[8];                                        // value 4 t + r: this lane's columns of row 16 t + (lane >> 4) + 4 r
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double p = 0.0;
+                for (int r = 0; r < 4; ++r) {
+                    double p = 0.0;
 #pragma unroll
-                for (int q = 0; q < NQW; ++q) {
-                    const double ph = (pc + oz)[(t * 16 + 4 * r) * SM_LDA + 64 * q];
-                    p = fma(ph, acc[t][q][r], p);
+                    for (int q = 0; q < NQW; ++q) {
+                        double ph = (pc + oz)[(t * 16 + 4 * r) * SM_LDA + 64 * q];
+                        if (q == qm) ph *= cmask;                  // (wave-uniform condition)
+                        p = fma(ph, acc[t][q][r], p);
+                    }
+                    pv[4 * t + r] = p;
                 }
-                p = row_sum16(p);
-                if ((lane & 15) == 0) sNu[wce * 32 + t * 16 + (lane >> 4) + 4 * r] = p;
-            }
+            const double tot = row_sum16x8(pv, lane);            // lane l: value k = (l >> 1) & 7 summed over the 16 columns-lanes of its row group
+            const int k = (lane >> 1) & 7;
+            if ((lane & 1) == 0) sNu[wce * 32 + (k >> 2) * 16 + (lane >> 4) + 4 * (k & 3)] = tot;
+        }
 #pragma unroll
         for (int q = 0; q < NQW; ++q)
             if (q == qm) {                                       // (wave-uniform)
@@ -309,7 +328,8 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 const double cc = (prs + oz)[(t * 16 + 4 * r) * 4 + 0], db = (prs + oz)[(t * 16 + 4 * r) * 4 + 1];
 #pragma unroll
                 for (int q = 0; q < NQW; ++q) {
-                    const double ph = (pc + oz)[(t * 16 + 4 * r) * SM_LDA + 64 * q];
+                    double ph = (pc + oz)[(t * 16 + 4 * r) * SM_LDA + 64 * q];
+                    if (q == qm) ph *= cmask;
                     acc[t][q][r] *= ph;
                     r1[q] = fma(ph, cc, r1[q]);
                     r2[q] = fma(ph, db, r2[q]);
@@ -413,7 +433,7 @@ int small_tail_nwg() { return 2 * gpz_cu_count(); }   // persistent workgroups: 
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
     SmallTailArgs a = a0;
     a.ncu = gpz_cu_count();
-    if (a.stagger <= 0) a.stagger = 4;   // (tools/r06_small_stagger.sh: 2 .. 5 within 1 %, none or > 5 slower by 2 %)
+    if (a.stagger <= 0) a.stagger = 1;   // (tools/r06_small_stagger.sh: 1 .. 8 within 2 % since the staging went to LDS-DMA loads; 1 is the fastest by a hair)
     const int nq = ((a.mp >> 4) + 3) / 4;
     const size_t lds = ((size_t)32 * SM_LDA + 32 * SM_LDE + 4 * 32 + 32 + 32 * 4) * sizeof(double);
     dim3 g(nwg), b(256);

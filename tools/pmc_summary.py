@@ -79,7 +79,7 @@ if constants and config:
     block = {"source": dst + " (rocprofv3 PMC passes of the same command, tools/pmc_run.sh; written by tools/pmc_summary.py)",
              "note": "L2 fabric-side bytes per launch (include Infinity-Cache hits): 2 x FETCH_SIZE (gfx950 correction of "
                      "MI355X_MICROARCH.md, HBM section) + WRITE_SIZE; bench arguments: " + what.splitlines()[0]}
-    for name, pre in (("tgemm", ("k_tgemm", "void k_tgemm")), ("syrk", ("void k_syrk<true",)), ("phi", ("void k_phi", "void k_psi32_phi")),
+    for name, pre in (("tgemm", ("k_tgemm", "void k_tgemm", "void k_small_tail")), ("syrk", ("void k_syrk<true",)), ("phi", ("void k_phi", "void k_psi32_phi")),
                       ("moments", ("void k_moments", "void k_psi32_moments"))):
         b, k = fabric(pre)
         if b is not None:
@@ -90,6 +90,9 @@ if constants and config:
             if d.get("SQ_INSTS_MFMA", 0) > 0 and cyc > 0:   # counter-based MFMA utilisation (busy cycles / SIMDs / kernel cycles)
                 block[name + "_mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
                 block[name + "_valu_per_mfma"] = (d.get("SQ_INSTS_VALU", 0) - d["SQ_INSTS_MFMA"]) / d["SQ_INSTS_MFMA"]
+                block[name + "_mfma_instructions"] = d["SQ_INSTS_MFMA"]
+            if cyc > 0 and k in dur_ns and dur_ns[k] > 0:          # the clock the kernel actually ran at (GRBM cycles / kernel-trace duration)
+                block[name + "_kernel_clock_ghz"] = cyc / dur_ns[k]
     allc = {}
     if os.path.exists(constants):
         allc = json.load(open(constants))
