@@ -511,7 +511,9 @@ def main():
             # BASELINE.json's metric names it: "MFMA util on PHI'W PHI".  Flops-based from this run (n m (m+1) algorithmic flops per launch
             # over the kernel's HIP-event time in the timed region); counter-based from the committed rocprofv3 PMC passes of the same
             # command (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles - counters cannot be read inside this process).
-            "roofline_syrk": {"bound": "mfma", "kernel": "k_syrk (PHI' W PHI, n*m*(m+1) flops/launch: the symmetric half)" + (" on fp32-operand MFMAs" if f32_route else ""),
+            "roofline_syrk": {"bound": "mfma", "kernel": ("k_syrk_small (PHI' W PHI, n*m*(m+1) flops/launch: the whole triangle of 16 x 16 blocks in one workgroup; "
+                                                          "the stage time includes the sum of the per-workgroup records)" if "k_syrk_small" in (route or "") else
+                                                          "k_syrk (PHI' W PHI, n*m*(m+1) flops/launch: the symmetric half)") + (" on fp32-operand MFMAs" if f32_route else ""),
                               "achieved": ach_sy, "peak": F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_sy / (F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS), "avg_ms": sy_avg,
                               "mfma_util_counters": (pmc_traffic(args.config) or {}).get("syrk_mfma_util") if world == 1 and not multi and not args.n else None,

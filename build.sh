@@ -11,7 +11,7 @@ EXTRA=""
 if [ "$1" = "--dev" ]; then OBJ=build/dev; LIB=libgpz_hip_dev.so; EXTRA="-DGPZ_DEV_SWITCHES"; fi
 mkdir -p $OUT $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$SRC $EXTRA"
-UNITS="k_phi k_gemm k_small k_chol k_pinv k_rows k_gen k_psi k_psi32 k_psi32m k_pmiss k_pmiss_cov k_pmiss_cov64 k_pmiss_covg k_lbfgs k_wide k_cpsi k_cpsi4 k_cpsi4w k_cpsi4wp k_pmc4 gpz_options gpz_arena gpz_ctx gpz_eval gpz_graph gpz_predict gpz_mgpu"
+UNITS="k_phi k_gemm k_syrk_small k_small k_chol k_pinv k_rows k_gen k_psi k_psi32 k_psi32m k_pmiss k_pmiss_cov k_pmiss_cov64 k_pmiss_covg k_lbfgs k_wide k_cpsi k_cpsi4 k_cpsi4w k_cpsi4wp k_pmc4 gpz_options gpz_arena gpz_ctx gpz_eval gpz_graph gpz_predict gpz_mgpu"
 [ "$1" = "--dev" ] && UNITS="$UNITS k_oz"   # the int8-sliced T-GEMM: a measured route that is not the default
 HDRS="$SRC/gpz_kernels.h $SRC/gpz_dev.h $SRC/gpz_options.h $SRC/gpz_ctx.h $SRC/k_cpsi4_impl.h $SRC/gpz_mgpu_sync.h include/gpz_hip.h"
 pids=()

@@ -136,7 +136,8 @@ struct RowSet {          // a device-resident row selection of the data
     double *Y = nullptr;    // k x n_pad
     double *om = nullptr;   // n_pad, or k x n_pad for an n x k omega (nullptr => ones)
     double *xmu = nullptr;  // de: column means of the rows (missing entries count as 0): centre of k_small_tail's feature expansion
-    double *Xs = nullptr;   // n_pad x (de + 2): rows [1 | x - xmu | 0] (zero rows past n) - what k_small_tail builds its features from
+    double *Xs = nullptr;   // n_pad x xs_ld: rows [1 | x - xmu | 0], or [1 | (x - xmu) mk | mk | 0] with missing values (zero rows past n)
+    int xs_ld = 0;          // (k_small_tail builds its features from these rows)
     long om_ld = 0;         // omega of output o, row i: om[o*om_ld + i]; 0 = one column for every output (GPz.m:48)
     // diagonal kinds only: input-noise variances and the observed-dimension mask (nullptr => absent)
     double *Psic = nullptr, *Psir = nullptr;   // de x n_pad, n_pad x de (0 where the input is missing)
@@ -228,6 +229,7 @@ struct gpz_ctx {
     double *tile_rstats = nullptr;                        // [ntiles][GPZ_NS]: the tiles' row-scalar sums
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
     double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused path
+    bool syrk_small = false;   // mp <= 256, fp64 operands: PHI' W PHI by k_syrk_small (one workgroup holds the whole triangle)
     bool small_tail = false;   // mp <= 256, k = 1, no Psi / missing values / row tiles: T-GEMM + row scalars + moments as ONE kernel (k_small.hip), T never allocated
     int st_nwg = 0, st_nf = 0;
     double *st_slab = nullptr, *st_raw = nullptr;

@@ -83,12 +83,20 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
         if (int e = c->ar.alloc(&rs.xmu, (size_t)de)) return e;
         HIPCHK(hipMemcpy(rs.xmu, mu.data(), (size_t)de * sizeof(double), hipMemcpyHostToDevice));
         if (need_xr && !c->gen && c->k == 1) {   // (the evaluation's training rows; k_small_tail is a single-output route)
-            std::vector<double> xs(np * (size_t)(de + 2), 0.0);
+            const bool masked = c->has_missing || any_missing;       // (setup_data has looked at every row: has_missing is final here)
+            const size_t xl = masked ? 2 * (size_t)de + 2 : (size_t)de + 2;
+            rs.xs_ld = (int)xl;
+            std::vector<double> xs(np * xl, 0.0);
             for (size_t r = 0; r < idx.size(); ++r) {
-                xs[r * (de + 2)] = 1.0;
-                for (int c_ = 0; c_ < d; ++c_) xs[r * (de + 2) + 1 + c_] = h[(size_t)c_ * np + r] - mu[c_];
+                xs[r * xl] = 1.0;
+                for (int c_ = 0; c_ < d; ++c_) {
+                    const double xv = X[(size_t)c_ * n_tot + idx[r]];
+                    const bool obs = xv == xv;
+                    xs[r * xl + 1 + c_] = obs ? xv - mu[c_] : 0.0;
+                    if (masked) xs[r * xl + 1 + de + c_] = obs ? 1.0 : 0.0;
+                }
             }
-            if (int e = c->ar.alloc(&rs.Xs, np * (size_t)(de + 2))) return e;
+            if (int e = c->ar.alloc(&rs.Xs, np * xl)) return e;
             HIPCHK(hipMemcpy(rs.Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
@@ -479,12 +487,12 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     if ((rc = c->ar.alloc(&c->Phi, npt * mp))) return bail(rc);
     // Few basis functions (m + k <= 256 columns, one output, no input noise, nothing missing, rows resident): the product with
     // [inv(SIGMA) | w], the row scalars and the moment sums are ONE kernel that keeps whole rows of T in registers (k_small.hip).
-    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->has_missing && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
-                    small_tail_fits(c->kind, c->de, c->mp) && !c->opt.small_tail_off;
+    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
+                    small_tail_fits(c->kind, c->de, c->mp, c->has_missing) && !c->opt.small_tail_off;
     if (!c->small_tail && (rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);   // (T = PHI [inv(SIGMA) | w] exists in memory only on the other routes)
     if (c->small_tail) {
         c->st_nwg = small_tail_nwg();
-        c->st_nf = small_tail_features(c->kind, c->de);
+        c->st_nf = small_tail_features(c->kind, c->de, c->has_missing);
         if ((rc = c->ar.alloc(&c->st_slab, (size_t)c->st_nwg * m * (c->st_nf + 2)))) return bail(rc);
         if ((rc = c->ar.alloc(&c->st_raw, (size_t)m * (c->st_nf + 2)))) return bail(rc);
     }
@@ -551,6 +559,12 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->rows_per_split_d = rup((int)((np_k + s2 - 1) / s2), 16);
         c->nsplit_d = (int)((np_k + c->rows_per_split_d - 1) / c->rows_per_split_d);
         size_t need = (size_t)(c->nsplit > c->nsplit_d ? c->nsplit : c->nsplit_d) * mp * mp;
+        // few basis functions: the triangle in one workgroup's registers (k_syrk_small.hip); config 5's fp32-operand product stays on k_syrk
+        c->syrk_small = syrk_small_fits(mp) && !c->psi32 && !c->opt.syrk_small_off;
+        if (c->syrk_small) {
+            const size_t ns = syrk_small_slab_count((int)np_k, mp);
+            if (ns > need) need = ns;
+        }
         size_t need_l = (size_t)c->nsplit_l * c->mq * c->mq;
         c->slab_count = need > need_l ? need : need_l;
         if ((rc = c->ar.alloc(&c->slab, c->slab_count))) return bail(rc);
@@ -757,8 +771,9 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
     char rows[96];
     if (c->tile_rows) snprintf(rows, sizeof rows, "; rows: streamed, %d tiles of %d (PHI built twice per evaluation)", c->ntiles, c->tile_rows);
     else rows[0] = 0;
-    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA%s; evaluation graph: %s%s", phi, why,
+    return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA%s%s; evaluation graph: %s%s", phi, why,
                     f32mm ? "fp32-operand (fp64 master sums)" : "fp64",
+                    c->syrk_small ? ", PHI' W PHI with the whole triangle in one workgroup (k_syrk_small)" : "",
                     c->small_tail ? ", T-GEMM + row scalars + moments in one kernel (k_small_tail: T stays in registers)" : "", gs, rows);
 }
 namespace gpzi {

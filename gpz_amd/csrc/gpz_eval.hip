@@ -212,6 +212,12 @@ static int stage_a_tiles(gpz_ctx *c) {
         const int nsp = (rt.rows_pad + c->rows_per_split - 1) / c->rows_per_split;
         const int nsp_d = (rt.rows_pad + c->rows_per_split_d - 1) / c->rows_per_split_d;
         for (int o = 0; o < c->k; ++o) {
+            if (c->syrk_small) {
+                Stage s(c, "syrk");
+                launch_syrk_small(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad + rt.r0, rt.rows_pad, c->mp, c->slab,
+                                  c->comm1 + (size_t)o * c->mp * c->mp, c->mp, t > 0 ? 1 : 0);
+                continue;
+            }
             {
                 Stage s(c, "syrk");
                 launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad + rt.r0, rt.rows_pad, c->mp, nsp, c->rows_per_split,
@@ -249,6 +255,12 @@ int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev) {
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), sums1);
     }
     for (int o = 0; o < c->k && !c->tile_rows; ++o) {
+        if (c->syrk_small) {   // mp <= 256: product and record sum are one stage
+            Stage s(c, "syrk");
+            launch_syrk_small(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->slab,
+                              c->comm1 + (size_t)o * c->mp * c->mp, c->mp, 0);
+            continue;
+        }
         {
             Stage s(c, "syrk");
             launch_syrk(c->st, c->Phi, c->mp, c->wbeta + (size_t)o * c->tr.n_pad, c->tr.n_pad, c->mp, c->nsplit,
@@ -375,7 +387,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             SmallTailArgs a{};
             a.Phi = c->Phi; a.ld = c->mp; a.B = c->Bext; a.ldb = c->mp;
             a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind;
-            a.Xs = c->tr.Xs;
+            a.Xs = c->tr.Xs; a.xs_ld = c->tr.xs_ld; a.missing = c->has_missing ? 1 : 0;
             a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta;
             a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
             a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf; a.stagger = c->opt.small_stagger;
@@ -383,7 +395,7 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             launch_slab_sum(c->st, c->partial, c->st_nwg, GPZ_NS, c->rstats);
             HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
             launch_slab_sum(c->st, c->st_slab, c->st_nwg, m * (c->st_nf + 2), c->st_raw);
-            launch_small_convert(c->st, c->st_raw, c->m, c->de, c->kind, c->st_nf, c->pr.P, c->tr.xmu, c->frec, c->nm);
+            launch_small_convert(c->st, c->st_raw, c->m, c->de, c->kind, c->st_nf, c->pr.P, c->tr.xmu, c->frec, c->nm, c->has_missing ? 1 : 0);
             launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols, 0);
             continue;
         }

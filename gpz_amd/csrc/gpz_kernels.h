@@ -76,6 +76,12 @@ int launch_phi(hipStream_t st, const PhiArgs &a);   // returns 0, or -1 if d is 
 void launch_syrk(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp,
                  int nsplit, int rows_per_split, int nsplit_d, int rows_per_split_d, double *slab, bool tri,
                  bool f32_operands = false);
+// k_syrk_small.hip: the same product for mp <= 256 columns - the whole upper triangle of 16 x 16 blocks in one workgroup's registers,
+// PHI read once; sums its per-workgroup records into S (+ mirror) itself
+bool syrk_small_fits(int mp);
+size_t syrk_small_slab_count(int n_rows, int mp);
+void launch_syrk_small(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp, double *slab, double *S, int lds,
+                       int accumulate);
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds,
                         int accumulate = 0 /* S += instead of S = (row tiles of a streamed evaluation) */);
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
@@ -85,7 +91,9 @@ struct SmallTailArgs {
     const double *Phi; int ld;              // n_pad x ld row-major (columns m .. m+k-1 hold y)
     const double *B; int ldb;               // mp x ldb: [inv(SIGMA) | w]
     int n, n_pad, m, mp, d, kind;           // d = padded dimension of Xr / P
-    const double *Xs;                       // n_pad x (d + 2) rows [1 | x - mu | 0], mu = the column means (centre of the feature expansion)
+    const double *Xs; int xs_ld;            // n_pad x xs_ld rows [1 | x - mu | 0] (xs_ld = d + 2), mu = the column means (centre of the feature
+                                            // expansion); diagonal kinds with missing values: [1 | (x - mu) mk | mk | 0] (xs_ld = 2 d + 2)
+    int missing;                            // 1: the masked features of a diagonal kind with missing values
     const double *y, *omega, *lnbeta, *wbeta;   // n_pad each (omega may be nullptr)
     const double *w, *v;                    // m; without the heteroscedastic term v = w and vscale = 0 (no branch in the kernel)
     double vscale;
@@ -96,12 +104,12 @@ struct SmallTailArgs {
     int stagger;                            // start delay of the second workgroup of a compute unit, in s_sleep(127) units of 8128 cycles (set by the launcher)
     int nf;                                 // features: 1 + 2d (diagonal kinds), 1 + d + d(d+1)/2 (covariance kinds)
 };
-int small_tail_features(int kind, int d);
-bool small_tail_fits(int kind, int d, int mp);   // mp <= 256 columns and <= 32 features
+int small_tail_features(int kind, int d, bool missing);
+bool small_tail_fits(int kind, int d, int mp, bool missing);   // mp <= 256 columns and <= 32 features
 int small_tail_nwg();                            // persistent workgroups: two per compute unit
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a, int nwg);
 void launch_small_convert(hipStream_t st, const double *raw, int m, int d, int kind, int nf, const double *P, const double *xmu,
-                          double *frec, int nm);   // raw sums -> the records of k_moments_fused: [M1 | S | PHI'c, PHI'dbeta] per basis function
+                          double *frec, int nm, int missing);   // raw sums -> the records of k_moments_fused: [M1 | S | PHI'c, PHI'dbeta] per basis function
 int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

@@ -162,8 +162,12 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
     for (int u = 0; u < 4; ++u) {
         const int f = (tid & 7) * 4 + u;
         int ia = 0, ib = 0;
-        if (f >= a.nf) ia = ib = a.d + 1;
-        else if (f >= 1) {
+        if (f >= a.nf) ia = ib = a.xs_ld - 1;                    // (the row's last entry is 0)
+        else if (a.missing) {                                    // row = [1 | x' mk (d) | mk (d) | 0]: features [mk | x' mk | (x' mk)^2]
+            if (f < a.d) ia = 1 + a.d + f;
+            else if (f < 2 * a.d) ia = 1 + f - a.d;
+            else ia = ib = 1 + f - 2 * a.d;
+        } else if (f >= 1) {
             if (f <= a.d) ia = f;
             else if (a.kind == GPZ_KIND_DIAG) ia = ib = f - a.d;
             else {
@@ -175,7 +179,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
         fpa |= (unsigned)ia << (8 * u);
         fpb |= (unsigned)ib << (8 * u);
     }
-    const int xs_ld = a.d + 2;
+    const int xs_ld = a.xs_ld;
     if (tid < 32) { sA[tid * SM_LDA + mp + 2] = 0.0; sA[tid * SM_LDA + mp + 3] = 0.0; }   // rows 2, 3 of the U step's A operand
     int it = 0;
     for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x, ++it) {
@@ -402,11 +406,21 @@ __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
 //   sum dp (x - p)       = R1 - q R0,                        q = p - mu
 //   sum dp (x - p)_a (x - p)_b = R2_ab - q_a R1_b - q_b R1_a + q_a q_b R0
 __global__ void k_small_convert(const double *__restrict__ raw, int m, int d, int kind, int nf, const double *__restrict__ P,
-                                const double *__restrict__ xmu, double *__restrict__ frec, int nm) {
+                                const double *__restrict__ xmu, double *__restrict__ frec, int nm, int missing) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const double *R = raw + (size_t)j * (nf + 2);
     double *o = frec + (size_t)j * (nm + 2);
+    if (missing) {            // per dimension: R0_c = sum dp mk_c, R1_c = sum dp mk_c x'_c, R2_c = sum dp mk_c x'_c^2
+        for (int c = 0; c < d; ++c) {
+            const double q = P[(size_t)j * d + c] - xmu[c], R0c = R[c], R1c = R[d + c], R2c = R[2 * d + c];
+            o[c] = R1c - q * R0c;
+            o[d + c] = fma(q, fma(q, R0c, -2.0 * R1c), R2c);
+        }
+        o[nm] = R[nf];
+        o[nm + 1] = R[nf + 1];
+        return;
+    }
     const double R0 = R[0];
     for (int c = 0; c < d; ++c) o[c] = R[1 + c] - (P[(size_t)j * d + c] - xmu[c]) * R0;
     if (kind == GPZ_KIND_DIAG) {
@@ -426,8 +440,15 @@ __global__ void k_small_convert(const double *__restrict__ raw, int m, int d, in
     o[nm + 1] = R[nf + 1];
 }
 
-int small_tail_features(int kind, int d) { return kind == GPZ_KIND_DIAG ? 1 + 2 * d : 1 + d + d * (d + 1) / 2; }
-bool small_tail_fits(int kind, int d, int mp) { return mp <= 256 && (mp & 15) == 0 && small_tail_features(kind, d) <= 32; }
+// features per basis function: diagonal kinds 1 + 2d ([1 | x' | x'^2], x' = x - mu); with missing values 3d ([mk | x' mk | (x' mk)^2] per
+// dimension, mk = 1 observed / 0 missing: every sum carries the mask of ITS dimension, getPHI.m:64-69, GPz.m:189-194); covariance kinds
+// 1 + d + d(d+1)/2 (missing values there take the per-pattern path)
+int small_tail_features(int kind, int d, bool missing) {
+    return kind == GPZ_KIND_DIAG ? (missing ? 3 * d : 1 + 2 * d) : 1 + d + d * (d + 1) / 2;
+}
+bool small_tail_fits(int kind, int d, int mp, bool missing) {
+    return mp <= 256 && (mp & 15) == 0 && small_tail_features(kind, d, missing) <= 32 && !(missing && kind != GPZ_KIND_DIAG);
+}
 int small_tail_nwg() { return 2 * gpz_cu_count(); }   // persistent workgroups: two per compute unit
 
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
@@ -449,6 +470,6 @@ void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
 #undef SMALL_CASE
 }
 void launch_small_convert(hipStream_t st, const double *raw, int m, int d, int kind, int nf, const double *P, const double *xmu,
-                          double *frec, int nm) {
-    hipLaunchKernelGGL(k_small_convert, dim3((m + 63) / 64), dim3(64), 0, st, raw, m, d, kind, nf, P, xmu, frec, nm);
+                          double *frec, int nm, int missing) {
+    hipLaunchKernelGGL(k_small_convert, dim3((m + 63) / 64), dim3(64), 0, st, raw, m, d, kind, nf, P, xmu, frec, nm, missing);
 }

@@ -1718,10 +1718,57 @@ def test_small_tail_route_against_oracle(method, n, d, m, hetero):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hetero", [False, True])
+@pytest.mark.parametrize("method,n,d,m", [("VD", 3000, 10, 100), ("GD", 1500, 4, 30), ("VL", 2000, 7, 255), ("GL", 997, 1, 9),
+                                          ("VD", 5000, 3, 200)])
+def test_small_tail_route_with_missing_values(method, n, d, m, hetero):
+    """Diagonal kinds with NaN inputs: every moment sum carries the mask of ITS dimension (getPHI.m:64-69, GPz.m:189-194), so the
+    features are [mk_c | x'_c mk_c | (x'_c mk_c)^2] (3 d <= 32).  Against the oracle, with weights, a training mask and validation rows;
+    a row with every dimension missing and a dimension that is never observed in the training rows are in the data."""
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, method, hetero, seed=8800 + n + m, nanfrac=0.25)
+    X[5, :] = np.nan
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    if d >= 3:
+        X[tr, d - 1] = np.nan
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        f2, g2 = ctx.eval(theta)
+        f3, g3 = ctx.eval(theta)
+        stats = dict(ctx.stats)
+        route = ctx.route()
+    finally:
+        ctx.close()
+    assert "k_small_tail" in route, route
+    assert f2 == f and f3 == f and np.array_equal(g, g2) and np.array_equal(g, g3)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= grad_tol(ref.cond), (rel(g, ref.grad), grad_tol(ref.cond))
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
+@pytest.mark.gpu
+def test_small_tail_with_missing_values_agrees_with_the_separate_kernels(tmp_path):
+    """The masked features against k_tgemm + k_row_scalars + k_moments_fused (developer build, GPZ_SMALL_TAIL_OFF) on the same NaN data."""
+    from helpers import eval_with_dev_switches
+    model, theta, X, Y, _, rng = make_problem(4000, 8, 120, 1, "VD", True, seed=4521, nanfrac=0.3)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    assert "k_small_tail" in ctx.route()
+    ctx.close()
+    f, g, info = eval_with_dev_switches(tmp_path, "VD", 120, 8, 1, True, theta, X, Y, None, {"GPZ_SMALL_TAIL_OFF": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-13 * abs(f0) and rel(g, g0) <= 1e-10, (abs(f - f0) / abs(f0), rel(g, g0))
+
+
+@pytest.mark.gpu
 def test_small_tail_is_not_taken_where_it_does_not_apply():
-    """k > 1, input noise, missing values, more than 256 columns, more than 32 features: the separate kernels (and the same oracle parity,
-    covered by the tests above) - the route text must not name k_small_tail."""
-    cases = [dict(k=2), dict(psi=True), dict(nanfrac=0.2), dict(m=256), dict(method="VC", d=7), dict(method="VD", d=16)]
+    """k > 1, input noise, missing values under a covariance kind or with more than 10 dimensions, more than 256 columns, more than 32
+    features: the separate kernels (and the same oracle parity, covered by the tests above) - the route text must not name k_small_tail."""
+    cases = [dict(k=2), dict(psi=True), dict(method="VC", nanfrac=0.2), dict(method="VD", d=11, nanfrac=0.2), dict(m=256),
+             dict(method="VC", d=7), dict(method="VD", d=16)]
     for kw in cases:
         method, d, m, k = kw.get("method", "VD"), kw.get("d", 4), kw.get("m", 40), kw.get("k", 1)
         model, theta, X, Y, Psi, rng = make_problem(600, d, m, k, method, True, seed=11, psi=kw.get("psi", False), nanfrac=kw.get("nanfrac", 0.0))
@@ -1772,6 +1819,85 @@ def test_small_tail_moment_sums_far_from_the_origin():
         b.close()
     assert abs(fs - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(gs, ref.grad) <= max(grad_tol(ref.cond), 1e-7)
     assert abs(fs - f0) <= 1e-9 * abs(f0) and rel(gs, g0) <= 1e-7, (abs(fs - f0) / abs(f0), rel(gs, g0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", list(range(1, 17)))
+def test_syrk_small_every_block_count(nb):
+    """PHI' W PHI for mp = 16 nb <= 256 columns is k_syrk_small (the whole triangle of 16 x 16 blocks in one workgroup: one compiled
+    loop per block count and wave role): every block count, row counts that end inside a chunk of 32 and inside a K step's padding,
+    against the oracle - with weights, a training mask and two outputs where the columns allow (k_small_tail does not apply then, so the
+    separate tail kernels consume the same SIGMA)."""
+    k = 2 if nb >= 2 and nb % 2 == 0 else 1
+    m = 16 * nb - k
+    n = 1500 + 37 * nb + (nb % 3)
+    model, theta, X, Y, _, rng = make_problem(n, 3, m, k, "VD", True, seed=9100 + nb)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        f2, g2 = ctx.eval(theta)
+        route = ctx.route()
+    finally:
+        ctx.close()
+    assert "k_syrk_small" in route, route
+    assert f2 == f and np.array_equal(g, g2)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= grad_tol(ref.cond), (rel(g, ref.grad), grad_tol(ref.cond))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,m,k,n", [("VD", 10, 200, 1, 20000), ("VC", 4, 120, 2, 3000), ("GL", 2, 255, 1, 700), ("VD", 3, 30, 1, 31)])
+def test_syrk_small_agrees_with_the_tiled_kernel(tmp_path, method, d, m, k, n):
+    """The same evaluation with k_syrk's 128 x 128 tiles (developer build, GPZ_SYRK_SMALL_OFF): the two differ in where the row ranges
+    are cut, so they agree to rounding.  n = 31: fewer rows than one chunk."""
+    from helpers import eval_with_dev_switches
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=4600 + m)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    assert "k_syrk_small" in ctx.route()
+    ctx.close()
+    f, g, info = eval_with_dev_switches(tmp_path, method, m, d, k, True, theta, X, Y, None, {"GPZ_SYRK_SMALL_OFF": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-12 * abs(f0) and rel(g, g0) <= 1e-9, (abs(f - f0) / abs(f0), rel(g, g0))
+
+
+@pytest.mark.gpu
+def test_syrk_small_is_not_taken_where_it_does_not_apply():
+    """More than 256 columns and config 5's fp32-operand product keep k_syrk."""
+    model, theta, X, Y, Psi, rng = make_problem(800, 4, 256, 1, "VD", True, seed=12)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    try:
+        ctx.eval(theta)
+        assert "k_syrk_small" not in ctx.route(), ctx.route()
+    finally:
+        ctx.close()
+    model, theta, X, Y, Psi, rng = make_problem(800, 4, 60, 1, "VC", True, seed=13, psi=True)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, dtype="f32")
+    try:
+        ctx.eval(theta)
+        assert "fp32 pair kernels" in ctx.route() and "k_syrk_small" not in ctx.route(), ctx.route()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_small_tail_row_shards_with_missing_values_in_one_shard_only():
+    """Shard 0 holds every NaN (masked features, 3 d sums), shard 1 none (1 + 2 d sums): each converts its own raw sums to the same
+    records before the second all-reduce."""
+    n, d, m = 2400, 5, 50
+    model, theta, X, Y, _, rng = make_problem(n, d, m, 1, "VD", True, seed=98)
+    X[:n // 2][rng.random((n // 2, d)) < 0.3] = np.nan
+    ref = O.GPz(theta, model, X, Y)
+    mg = gpz_amd.GPzMulti(model, X, Y, n_gpus=2, reducer="loopback")
+    try:
+        f, g = mg.eval(theta)
+        assert "k_small_tail" in mg.route(0) and "k_small_tail" in mg.route(1)
+    finally:
+        mg.close()
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g, ref.grad) <= grad_tol(ref.cond)
 
 
 @pytest.mark.gpu

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
-@pytest.mark.parametrize("unit,kernels", [("k_gemm", ("k_tgemm", "k_syrk")), ("k_small", ("k_small_tail",))])
+@pytest.mark.parametrize("unit,kernels", [("k_gemm", ("k_tgemm", "k_syrk")), ("k_small", ("k_small_tail",)),
+                                          ("k_syrk_small", ("k_syrk_small",))])
 def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path, unit, kernels):
     asm = tmp_path / (unit + ".s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),

@@ -38,7 +38,7 @@ try:
         dur_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
 except Exception:
     pass
-keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_", "void k_small_tail"))]
+keys = [k for k in data if k.startswith(("k_tgemm", "void k_tgemm", "void k_syrk<true", "void k_phi", "void k_moments", "void k_row_epilogue", "void k_psi32", "void k_psi_", "void k_small_tail", "void k_syrk_small<"))]
 with open(dst, "w") as out:
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py " + what + "; one counter group per pass; tools/pmc_run.sh)\n"
               "# per-launch averages.  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles;\n"
@@ -79,7 +79,7 @@ if constants and config:
     block = {"source": dst + " (rocprofv3 PMC passes of the same command, tools/pmc_run.sh; written by tools/pmc_summary.py)",
              "note": "L2 fabric-side bytes per launch (include Infinity-Cache hits): 2 x FETCH_SIZE (gfx950 correction of "
                      "MI355X_MICROARCH.md, HBM section) + WRITE_SIZE; bench arguments: " + what.splitlines()[0]}
-    for name, pre in (("tgemm", ("k_tgemm", "void k_tgemm", "void k_small_tail")), ("syrk", ("void k_syrk<true",)), ("phi", ("void k_phi", "void k_psi32_phi")),
+    for name, pre in (("tgemm", ("k_tgemm", "void k_tgemm", "void k_small_tail")), ("syrk", ("void k_syrk<true", "void k_syrk_small<")), ("phi", ("void k_phi", "void k_psi32_phi")),
                       ("moments", ("void k_moments", "void k_psi32_moments"))):
         b, k = fabric(pre)
         if b is not None:

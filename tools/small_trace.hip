@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
     const int mp = (m + 1 + 15) / 16 * 16, n_pad = (n + 1023) / 1024 * 1024, nwg = wpc * gpz_cu_count();
     SmallTailArgs a{};
     double *Phi, *B, *Xr, *xmu, *y, *lnb, *wb, *w, *v, *phiw, *slab, *partial;
-    a.nf = small_tail_features(GPZ_KIND_DIAG, d);
+    a.nf = small_tail_features(GPZ_KIND_DIAG, d, false); a.xs_ld = d + 2; a.missing = 0;
     (void)hipMalloc(&Phi, (size_t)n_pad * mp * 8); (void)hipMalloc(&B, (size_t)mp * mp * 8); (void)hipMalloc(&Xr, (size_t)n_pad * (d + 2) * 8);
     (void)hipMalloc(&xmu, d * 8); (void)hipMalloc(&y, n_pad * 8); (void)hipMalloc(&lnb, n_pad * 8); (void)hipMalloc(&wb, n_pad * 8);
     (void)hipMalloc(&w, m * 8); (void)hipMalloc(&v, m * 8); (void)hipMalloc(&phiw, n_pad * 8);
