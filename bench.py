@@ -489,7 +489,7 @@ def main():
                                   "one process, loopback shards on one device" if multi else "one process, one device"),
                        "rccl": rccl_origin},
             "roofline": {"bound": "mfma", "kernel": ("k_small_tail (T = PHI*[inv(SIGMA)|w] + row scalars + moment sums in one kernel, T in registers; "
-                                                     "2*n*m^2 flops/launch; the stage time includes its 5 small follow-up launches)" if small_tail else
+                                                     "2*n*m^2 flops/launch; the stage time includes k_small_finish, the launch that sums its per-workgroup records)" if small_tail else
                                                      "k_tgemm (T = PHI*[inv(SIGMA)|w], 2*n*m^2 flops/launch)")
                                                     + (" on fp32-operand MFMAs" if f32_route else ""),
                          "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS if f32_route else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

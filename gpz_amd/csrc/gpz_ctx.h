@@ -232,7 +232,7 @@ struct gpz_ctx {
     bool syrk_small = false;   // mp <= 256, fp64 operands: PHI' W PHI by k_syrk_small (one workgroup holds the whole triangle)
     bool small_tail = false;   // mp <= 256, k = 1, no Psi / missing values / row tiles: T-GEMM + row scalars + moments as ONE kernel (k_small.hip), T never allocated
     int st_nwg = 0, st_nf = 0;
-    double *st_slab = nullptr, *st_raw = nullptr;
+    double *st_slab = nullptr;
     bool fused = true;   // dPHI formed on the fly, output by output (no dPHI / dL matrices): k == 1, or k > 1 on the tuned kernels
     double *phipart = nullptr;   // PHI-build column-group partial sums (small row counts)
     int phipart_groups = 0;

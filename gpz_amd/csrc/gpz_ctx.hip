@@ -494,7 +494,6 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
         c->st_nwg = small_tail_nwg();
         c->st_nf = small_tail_features(c->kind, c->de, c->has_missing);
         if ((rc = c->ar.alloc(&c->st_slab, (size_t)c->st_nwg * m * (c->st_nf + 2)))) return bail(rc);
-        if ((rc = c->ar.alloc(&c->st_raw, (size_t)m * (c->st_nf + 2)))) return bail(rc);
     }
     if (c->tile_rows && (rc = c->ar.alloc(&c->tile_rstats, (size_t)c->ntiles * GPZ_NS))) return bail(rc);
     // GC + Psi in fp64, 10 < d <= 32 (evaluation contexts only: prediction and getPHI contexts have no moment stage and no T)

@@ -297,9 +297,12 @@ static void stage_b(gpz_ctx *c, int o) {
     }
     {
         Stage s(c, "lauum");
-        launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
-                    true);
-        launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
+        if (ltl_small_fits(mq) && !c->opt.syrk_small_off) launch_ltl_small(c->st, c->Wm, mq, c->Sinv);
+        else {
+            launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
+                        true);
+            launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
+        }
     }
     {
         Stage s(c, "solve_vectors");
@@ -392,11 +395,8 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
             a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf; a.stagger = c->opt.small_stagger;
             launch_small_tail(c->st, a, c->st_nwg);
-            launch_slab_sum(c->st, c->partial, c->st_nwg, GPZ_NS, c->rstats);
-            HIPCHK(hipMemcpyAsync(scal, c->rstats, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-            launch_slab_sum(c->st, c->st_slab, c->st_nwg, m * (c->st_nf + 2), c->st_raw);
-            launch_small_convert(c->st, c->st_raw, c->m, c->de, c->kind, c->st_nf, c->pr.P, c->tr.xmu, c->frec, c->nm, c->has_missing ? 1 : 0);
-            launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols, 0);
+            launch_small_finish(c->st, c->st_slab, c->partial, c->st_nwg, c->m, c->de, c->kind, c->st_nf, c->has_missing ? 1 : 0, c->pr.P,
+                                c->tr.xmu, c->nm, c->mp, mom, cols, scal);
             continue;
         }
         {

@@ -82,6 +82,8 @@ bool syrk_small_fits(int mp);
 size_t syrk_small_slab_count(int n_rows, int mp);
 void launch_syrk_small(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int mp, double *slab, double *S, int lds,
                        int accumulate);
+bool ltl_small_fits(int mq);                                                  // inv(SIGMA) = inv(L)' inv(L) for mq <= 512 as one launch
+void launch_ltl_small(hipStream_t st, const double *W, int mq, double *S);
 void launch_syrk_reduce(hipStream_t st, const double *slab, int nsplit, int nsplit_d, int mp, double *S, int lds,
                         int accumulate = 0 /* S += instead of S = (row tiles of a streamed evaluation) */);
 int gpz_gemm_wave_cols();   // wave columns per 128-wide tile (slots of nupart per column tile)
@@ -108,8 +110,9 @@ int small_tail_features(int kind, int d, bool missing);
 bool small_tail_fits(int kind, int d, int mp, bool missing);   // mp <= 256 columns and <= 32 features
 int small_tail_nwg();                            // persistent workgroups: two per compute unit
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a, int nwg);
-void launch_small_convert(hipStream_t st, const double *raw, int m, int d, int kind, int nf, const double *P, const double *xmu,
-                          double *frec, int nm, int missing);   // raw sums -> the records of k_moments_fused: [M1 | S | PHI'c, PHI'dbeta] per basis function
+void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
+                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols,
+                         double *scal);   // the workgroups' records -> moments, column sums, scalar sums (one launch)
 int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

@@ -621,9 +621,12 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
         launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet, c->info);
     }
     for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
-    launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
+    if (ltl_small_fits(mq) && !c->opt.syrk_small_off) launch_ltl_small(c->st, c->Wm, mq, c->Sinv);
+    else {
+        launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,
                     true);
-    launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
+        launch_syrk_reduce(c->st, c->slab, c->nsplit_l, c->nsplit_l, mq, c->Sinv, mq);
+    }
     launch_cond_flag(c->st, S, m, alpha0, c->Sinv, mq, m, c->Tmp, c->info);
     int info_h[2] = {0, 0};
     double ld = 0.0;

@@ -22,7 +22,7 @@
 //   * the moment sums are MFMAs again: accumulator register r of a 16 x 16 block IS the A operand (j along M, the four rows
 //     4r .. 4r + 3 along K) of a product with the block's features -ob_i [1 | x - mu | (x - mu)^2 or the packed products
 //     (x - mu)(x - mu)'], staged in LDS as the B operand - 2 feature blocks of 16 cover d <= 15 (diagonal kinds) and d <= 6
-//     (covariance kinds); the sums about the basis centres follow from these raw sums per basis function (k_small_convert; mu = the
+//     (covariance kinds); the sums about the basis centres follow from these raw sums per basis function (k_small_finish; mu = the
 //     column means of the training inputs, so |x - mu| is of the order of the data's spread and the expansion loses
 //     spread^2 / length^2 ulps);
 //   * workgroups are PERSISTENT (two per compute unit) and walk the 32-row blocks, so the moment sums stay in registers for the whole
@@ -402,42 +402,80 @@ __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
     else small_tail_run<NQ - 1, F2>(a, smem, wce);         // (NQ = ceil(nblk / 4): every wave has NQ or NQ - 1)
 }
 
-// raw sums about mu -> the moment records of k_moments_fused: [M1 (d) | S (d, or the packed d(d+1)/2) | PHI'c, PHI'dbeta] per basis function.
-//   sum dp (x - p)       = R1 - q R0,                        q = p - mu
-//   sum dp (x - p)_a (x - p)_b = R2_ab - q_a R1_b - q_b R1_a + q_a q_b R0
-__global__ void k_small_convert(const double *__restrict__ raw, int m, int d, int kind, int nf, const double *__restrict__ P,
-                                const double *__restrict__ xmu, double *__restrict__ frec, int nm, int missing) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const double *R = raw + (size_t)j * (nf + 2);
-    double *o = frec + (size_t)j * (nm + 2);
-    if (missing) {            // per dimension: R0_c = sum dp mk_c, R1_c = sum dp mk_c x'_c, R2_c = sum dp mk_c x'_c^2
-        for (int c = 0; c < d; ++c) {
-            const double q = P[(size_t)j * d + c] - xmu[c], R0c = R[c], R1c = R[d + c], R2c = R[2 * d + c];
-            o[c] = R1c - q * R0c;
-            o[d + c] = fma(q, fma(q, R0c, -2.0 * R1c), R2c);
+// ONE launch behind k_small_tail (it replaced two record sums, a copy, the conversion and the split: five ~5 us launches of an evaluation of
+// 600): block j < m sums the nwg records of basis function j - nf + 2 values, up to 32 record lanes per value (lane q adds records q,
+// q + L, ...: four loads in flight), the lanes combined in a fixed order - converts the raw sums and writes the moments mom[j][nm] and the
+// two column sums cols[.][j]; block m sums the workgroups' scalar partials into scal[0..3] (GPz.m:81-82,236-237).
+__global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict__ slab, const double *__restrict__ partial, int nwg, int m, int d,
+                                                       int kind, int nf, int missing, const double *__restrict__ P,
+                                                       const double *__restrict__ xmu, int nm, int mp, double *__restrict__ mom,
+                                                       double *__restrict__ cols, double *__restrict__ scal) {
+    __shared__ double part[32][36];
+    __shared__ double R[36];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == m) {
+        const int v = tid & 3, sl = tid >> 2;                 // 4 values x 256 record lanes
+        double s = 0.0;
+        for (int r = sl; r < nwg; r += 256) s += partial[(size_t)r * GPZ_NS + v];
+        double *sp = &part[0][0];                             // (1152 doubles: 1024 are used here)
+        sp[sl * 4 + v] = s;
+        __syncthreads();
+        if (tid < 4) {
+            double t = 0.0;
+            for (int q = 0; q < 256; ++q) t += sp[q * 4 + tid];
+            scal[tid] = t;
         }
-        o[nm] = R[nf];
-        o[nm + 1] = R[nf + 1];
         return;
     }
-    const double R0 = R[0];
-    for (int c = 0; c < d; ++c) o[c] = R[1 + c] - (P[(size_t)j * d + c] - xmu[c]) * R0;
-    if (kind == GPZ_KIND_DIAG) {
-        for (int c = 0; c < d; ++c) {
-            const double q = P[(size_t)j * d + c] - xmu[c];
-            o[d + c] = fma(q, fma(q, R0, -2.0 * R[1 + c]), R[1 + d + c]);
+    const int j = blockIdx.x, nv = nf + 2;
+    const int L = 1024 / nv < 32 ? 1024 / nv : 32;
+    const int f = tid % nv, sl = tid / nv;
+    if (sl < L) {
+        const double *p = slab + (size_t)j * nv + f;
+        const size_t stride = (size_t)m * nv;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = sl;
+        for (; r + 3 * L < nwg; r += 4 * L) {
+            s0 += p[(size_t)r * stride];
+            s1 += p[(size_t)(r + L) * stride];
+            s2 += p[(size_t)(r + 2 * L) * stride];
+            s3 += p[(size_t)(r + 3 * L) * stride];
         }
-    } else {
-        int e = 0;
-        for (int aa = 0; aa < d; ++aa)
-            for (int bb = aa; bb < d; ++bb, ++e) {
-                const double qa = P[(size_t)j * d + aa] - xmu[aa], qb = P[(size_t)j * d + bb] - xmu[bb];
-                o[d + e] = R[1 + d + e] - qa * R[1 + bb] - qb * R[1 + aa] + qa * qb * R0;
-            }
+        for (; r < nwg; r += L) s0 += p[(size_t)r * stride];
+        part[sl][f] = (s0 + s1) + (s2 + s3);
     }
-    o[nm] = R[nf];
-    o[nm + 1] = R[nf + 1];
+    __syncthreads();
+    if (tid < nv) {
+        double t = 0.0;
+        for (int q = 0; q < L; ++q) t += part[q][tid];
+        R[tid] = t;
+    }
+    __syncthreads();
+    // raw sums about mu -> the moment records of k_moments_fused: [M1 (d) | S (d, or the packed d(d+1)/2)] and PHI'c, PHI'dbeta:
+    //   sum dp (x - p)             = R1 - q R0,                                   q = p - mu
+    //   sum dp (x - p)_a (x - p)_b = R2_ab - q_a R1_b - q_b R1_a + q_a q_b R0
+    // (with missing values, diagonal kinds: per dimension R0_c = sum dp mk_c, R1_c = sum dp mk_c x'_c, R2_c = sum dp mk_c x'_c^2)
+    const int q = tid;
+    if (q >= nm + 2) return;
+    if (q >= nm) {
+        cols[(size_t)(q - nm) * mp + j] = R[nf + (q - nm)];
+        return;
+    }
+    double val;
+    if (q < d || kind == GPZ_KIND_DIAG) {
+        const int c = q < d ? q : q - d;
+        const double qc = P[(size_t)j * d + c] - xmu[c];
+        const double R0 = missing ? R[c] : R[0], R1 = missing ? R[d + c] : R[1 + c];
+        if (q < d) val = R1 - qc * R0;
+        else val = fma(qc, fma(qc, R0, -2.0 * R1), missing ? R[2 * d + c] : R[1 + d + c]);
+    } else {
+        int e = q - d, aa = 0;
+        while (e >= d - aa) { e -= d - aa; ++aa; }                       // packed pair index -> (aa, bb), aa <= bb
+        const int bb = aa + e;
+        const double qa = P[(size_t)j * d + aa] - xmu[aa], qb = P[(size_t)j * d + bb] - xmu[bb];
+        val = R[1 + q] - qa * R[1 + bb] - qb * R[1 + aa] + qa * qb * R[0];
+    }
+    mom[(size_t)j * nm + q] = val;
 }
 
 // features per basis function: diagonal kinds 1 + 2d ([1 | x' | x'^2], x' = x - mu); with missing values 3d ([mk | x' mk | (x' mk)^2] per
@@ -469,7 +507,8 @@ void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
     else SMALL_CASE(4);
 #undef SMALL_CASE
 }
-void launch_small_convert(hipStream_t st, const double *raw, int m, int d, int kind, int nf, const double *P, const double *xmu,
-                          double *frec, int nm, int missing) {
-    hipLaunchKernelGGL(k_small_convert, dim3((m + 63) / 64), dim3(64), 0, st, raw, m, d, kind, nf, P, xmu, frec, nm, missing);
+void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
+                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols, double *scal) {
+    hipLaunchKernelGGL(k_small_finish, dim3(m + 1), dim3(1024), 0, st, slab, partial, nwg, m, d, kind, nf, missing, P, xmu, nm, mp, mom, cols,
+                       scal);
 }

@@ -8,26 +8,27 @@
 //     (l & 15)] - as A operand (m = l & 15, k = l >> 4) it is column block b of PHI', as B operand (k = l >> 4, n = l & 15) column block
 //     b of PHI.  A wave owns whole block rows of the triangle: row R needs the fragments R .. NB-1 as B and w * f_R as A - one multiply
 //     per owned row and K step (the weight rides on the A operand, as in k_syrk: the products are (w phi_i) phi_j);
-//   * block rows are dealt so that the eight waves carry the same number of products: with NB > 8 the first 16 - NB waves take rows
-//     0 .. 15-NB alone, wave w behind them rows w and its mirror (NB-1 .. ): 2 NB - 15 products each (NB = 13: 13 12 11 11 11 11 11 11;
-//     NB = 16: 17 each).  The roles are compile-time (one instantiation of the loop per wave): every accumulator and fragment a fixed
-//     register, every LDS address a register plus an immediate, no branch around an MFMA;
-//   * rows arrive through LDS-DMA loads (global_load_lds_dwordx4: no registers, no vector ALU) in chunks of 32, double-buffered: the
-//     requests of chunk c + 1 go out right after the barrier that opens chunk c and have its 8 K steps to land - ONE barrier per chunk.
+//   * block rows are dealt to the SIMDs in snake order so that every SIMD issues (nearly) the same number of products per K step; a wave
+//     carries at most two block rows.  The roles are compile-time (one instantiation of the loop per wave): every accumulator and
+//     fragment a fixed register, every LDS address a register plus an immediate, no branch around an MFMA;
+//   * rows (and their weights) arrive through LDS-DMA loads (global_load_lds_dwordx4: no registers, no vector ALU) in chunks of 32, in 2 - 4
+//     buffers: the requests of chunk c + D go out right after the barrier that opens chunk c - ONE barrier per chunk.
 //     LDS row stride = 16 (mod 32) doubles: the 16 lanes of a row cover all 32 banks once, rows k and k + 1 the two halves of the 64;
 //   * every workgroup leaves its triangle as one record [tile][register][lane] (512-byte stores); k_syrk_small_reduce sums the records
 //     in a fixed order and writes S and its mirror (diagonal blocks: the upper half mirrored, so S is exactly symmetric).
 #include "gpz_dev.h"
 #include "gpz_kernels.h"
 
-#define SS_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g), (__attribute__((address_space(3))) void *)(l), 16, 0, 0)
 #define SS_ROWS 32        // rows per chunk (8 K steps)
-
+#define SS_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g), (__attribute__((address_space(3))) void *)(l), 16, 0, 0)
 template <int NB>
 struct SyrkSmallShape {
     static constexpr int LD = 16 * NB + ((NB & 1) ? 0 : 16);     // LDS row stride in doubles: 16 (mod 32)
-    static constexpr int PAIRS = NB > 8 ? NB - 8 : 0;            // waves that carry two block rows
-    static constexpr int SINGLES = 8 - PAIRS;
+    static constexpr int BUF = SS_ROWS * LD + 128;                // doubles per chunk buffer: the rows of PHI, then the 32 weights (+ the unused lanes' copies)
+    // chunk buffers: as many as the 160 KB hold, at most 4 - NB <= 9: 4, NB <= 13: 3, else 2.  A chunk's products are short when NB is
+    // small (NB = 8: 3.5 us): ONE chunk of 36 KB per CU in flight bounds the launch at (256 CUs x 36 KB) / memory latency = 2.4 TB/s
+    static constexpr int NBUF = (160 * 1024 / 8) / BUF >= 4 ? 4 : (160 * 1024 / 8) / BUF;
+    static_assert(NBUF >= 2, "two chunk buffers must fit the LDS");
     static constexpr int tile0(int r) { return r * NB - r * (r - 1) / 2; }   // first tile of block row r (row-major over the upper triangle)
 };
 
@@ -47,12 +48,15 @@ __device__ __forceinline__ void syrk_small_wave(const double *__restrict__ Phi, 
                                                 int ke, double *__restrict__ rec, double *smem) {
     using SH = SyrkSmallShape<NB>;
     constexpr int LD = SH::LD;
-    constexpr int R1 = W < NB ? W : -1;                                                // (NB < 8: waves NB .. 7 only stage rows)
-    constexpr int R2 = (NB > 8 && W >= SH::SINGLES) ? NB - 1 - (W - SH::SINGLES) : -1;
+    // Block rows are dealt to the four SIMDs in snake order (row r of the triangle holds NB - r products): SIMD s carries rows s, 7 - s,
+    // 8 + s and 15 - s as far as they exist - the same number of products on every SIMD at NB = 8 and 16, within one block row's length
+    // of it elsewhere (NB = 13: 24 23 22 22) - split between its two waves s (rows s, 15 - s) and s + 4 (rows 7 - s, 8 + s).
+    constexpr int RA = (W >> 2) ? 7 - (W & 3) : (W & 3), RB = (W >> 2) ? 8 + (W & 3) : 15 - (W & 3);
+    constexpr int R1 = RA < NB ? RA : -1;                                              // (NB < 8: some waves only stage rows)
+    constexpr int R2 = RB < NB ? RB : -1;
     constexpr int N1 = R1 >= 0 ? NB - R1 : 0, N2 = R2 >= 0 ? NB - R2 : 0;
     const int tid = threadIdx.x, lane = tid & 63;
-    double *sP = smem;                        // [2][32][LD]
-    double *sW = smem + 2 * SS_ROWS * LD;     // [2][32]
+    constexpr int NBUF = SH::NBUF, D = NBUF - 1, BUF = SH::BUF;   // D chunks are requested ahead of the one being multiplied
     d4_t acc1[N1 > 0 ? N1 : 1], acc2[N2 > 0 ? N2 : 1];
 #pragma unroll
     for (int b = 0; b < (N1 > 0 ? N1 : 1); ++b) acc1[b] = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -74,10 +78,12 @@ __device__ __forceinline__ void syrk_small_wave(const double *__restrict__ Phi, 
         if (colq[j] >= 16u * NB) colq[j] = 16u * NB - 2u;
         off[j] = rowq[j] * (unsigned)ld + colq[j];
     }
-    auto stage = [&](int ch) {
+    constexpr int CNT = (NQ - W + 7) / 8 + (W == 7 ? 1 : 0);      // requests of this wave per chunk (wave 7 also moves the weights)
+    const long last2 = (long)n_rows - 2;
+    auto stage = [&](int ch, int buf) {
         const long row0 = 4L * (kb + 8 * ch);
         const double *g0 = Phi + (size_t)row0 * ld;
-        double *l0 = sP + (ch & 1) * SS_ROWS * LD;
+        double *l0 = smem + buf * BUF;
         if (row0 + SS_ROWS <= (long)n_rows) {
 #pragma unroll
             for (int j = 0; j < QW; ++j)
@@ -88,34 +94,29 @@ __device__ __forceinline__ void syrk_small_wave(const double *__restrict__ Phi, 
             for (int j = 0; j < QW; ++j)
                 if (W + 8 * j < NQ) SS_GLDS(g0 + ((rowq[j] < lastr ? rowq[j] : lastr) * (unsigned)ld + colq[j]), l0 + 128 * (W + 8 * j));
         }
+        if (W == 7) {   // the chunk's 32 weights: lanes 0 .. 15 two each, the other lanes the same pairs again into the buffer's spare doubles
+            const long r = row0 + 2 * (lane & 15);
+            SS_GLDS(wgt + (r < last2 ? r : last2), l0 + SS_ROWS * LD);
+        }
     };
-    const long last = (long)n_rows - 1;
-    auto wload = [&](int ch) -> double {
-        const long row = 4L * (kb + 8 * ch) + tid;
-        return wgt[row < last ? row : last];
-    };
-    double wreg = 0.0;
-    stage(0);
-    if (W == 0 && tid < SS_ROWS) {
-        sW[tid] = wload(0);
-        if (nch > 1) wreg = wload(1);
-    }
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < nch) stage(c, c);
     const int fo = (lane >> 4) * LD + (lane & 15);       // this lane's place in a K step's four rows
     SS_MARK(0);
+    int bc = 0, bs = D % NBUF;            // buffer of the chunk being multiplied / of the chunk requested next
     for (int ch = 0; ch < nch; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA loads of chunk ch have landed (the compiler does not track them)
-        __syncthreads();                                     // ... everyone's have, and everyone has left chunk ch - 1
-        if (ch + 1 < nch) {
-            stage(ch + 1);
-            if (W == 0 && tid < SS_ROWS) {
-                sW[((ch + 1) & 1) * SS_ROWS + tid] = wreg;
-                if (ch + 2 < nch) wreg = wload(ch + 2);
-            }
-        }
+        // this wave's requests of chunk ch have landed (the compiler does not track LDS-DMA loads; they complete in order): all but the
+        // D - 1 chunks requested after it - fewer are in flight at the end of the range, where the wait is for everything
+        if (ch + D <= nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * CNT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                   // ... everyone's have, and everyone has left chunk ch - 1 (whose buffer the next request takes)
+        if (ch + D < nch) stage(ch + D, bs);
+        bs = bs + 1 == NBUF ? 0 : bs + 1;
         if (N1 > 0) {
             const int nkk = nk - 8 * ch < 8 ? nk - 8 * ch : 8;
-            const double *pf = sP + (ch & 1) * SS_ROWS * LD + fo + 16 * (R1 > 0 ? R1 : 0);
-            const double *pw = sW + (ch & 1) * SS_ROWS + (lane >> 4);
+            const double *pf = smem + bc * BUF + fo + 16 * (R1 > 0 ? R1 : 0);
+            const double *pw = smem + bc * BUF + SS_ROWS * LD + (lane >> 4);
             auto frags = [&](double (&f)[N1 > 0 ? N1 : 1], double &w, int kk) {
                 w = pw[4 * kk];
 #pragma unroll
@@ -130,14 +131,15 @@ __device__ __forceinline__ void syrk_small_wave(const double *__restrict__ Phi, 
                 for (int b = 0; b < N2; ++b) acc2[b] = MFMA_F64(a2, f[R2 - R1 + b], acc2[b]);
             };
             // (measured and dropped, tools/syrk_small_bench.hip at c2's shape: fragments of step kk + 1 requested before the products of
-            // step kk: 97 -> 106 us; the eight steps of a chunk unrolled: 101 us, and NB = 16 spills; s_setprio around the products: 103 us -
-            // the two waves of a SIMD already alternate: one requests and waits while the other's products run)
+            // step kk - no change, 24 more registers; the eight steps of a chunk unrolled: 101 us, and NB = 16 spills; s_setprio around
+            // the products: 103 us.  The loop runs at 0.85 - 0.89 of what its busiest SIMD's MFMA count allows at the clock the kernel gets)
             double f[N1 > 0 ? N1 : 1], w;
             for (int kk = 0; kk < nkk; ++kk) {
                 frags(f, w, kk);
                 burst(f, w);
             }
         }
+        bc = bc + 1 == NBUF ? 0 : bc + 1;
     }
     SS_MARK(1);
     // the record: [tile][register r][lane] - entry (16 bi + (lane >> 4) + 4 r, 16 bj + (lane & 15))
@@ -214,6 +216,45 @@ __global__ __launch_bounds__(1024) void k_syrk_small_reduce(const double *__rest
     if (i != j) S[(size_t)j * lds + i] = accumulate ? S[(size_t)j * lds + i] + tot : tot;
 }
 
+// inv(SIGMA) = W' W for the lower-triangular W = inv(L) (mq x mq, zeros above the diagonal; GPz.m:67 through the Cholesky factor), mq <= 512:
+// one workgroup per 16 x 16 tile of the upper triangle, its four waves take every fourth K step of rows 16 bj .. mq-1 (the rows above hold
+// zeros in column block bj) straight from L2, the four partial tiles are added in a fixed order, the tile and its mirror are written
+// (diagonal tiles: the upper half mirrored).  One launch of ~5 us where k_syrk<tri> + k_syrk_reduce were two of 8 + 7.
+__global__ __launch_bounds__(256) void k_ltl_small(const double *__restrict__ W, int mq, double *__restrict__ S) {
+    __shared__ double red[3][4][64];
+    const int nb = mq >> 4, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int bi = 0, rem = blockIdx.x;
+    while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+    const int bj = bi + rem;
+    const size_t rstep = (size_t)4 * mq;
+    const double *pa = W + (size_t)(16 * bj + (lane >> 4)) * mq + 16 * bi + (lane & 15);
+    const double *pb = W + (size_t)(16 * bj + (lane >> 4)) * mq + 16 * bj + (lane & 15);
+    const int nsteps = (mq - 16 * bj) >> 2;
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int s = wv; s < nsteps; s += 4) acc = MFMA_F64(pa[s * rstep], pb[s * rstep], acc);
+    if (wv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wv) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        const int i = 16 * bi + (lane >> 4) + 4 * r, j = 16 * bj + (lane & 15);
+        if (i <= j) {
+            S[(size_t)i * mq + j] = v;
+            if (i != j) S[(size_t)j * mq + i] = v;
+        }
+    }
+}
+bool ltl_small_fits(int mq) { return mq >= 16 && mq <= 512 && (mq & 15) == 0; }
+void launch_ltl_small(hipStream_t st, const double *W, int mq, double *S) {
+    const int nb = mq >> 4;
+    hipLaunchKernelGGL(k_ltl_small, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, W, mq, S);
+}
+
 bool syrk_small_fits(int mp) { return mp >= 16 && mp <= 256 && (mp & 15) == 0; }
 // Workgroups (= records) of a launch over n_rows rows (a multiple of 4): one per CU, at least one chunk of 32 rows each.
 int syrk_small_plan(int n_rows, int *ksteps_per_wg) {
@@ -233,7 +274,7 @@ size_t syrk_small_slab_count(int n_rows, int mp) {
 template <int NB>
 static void launch_syrk_small_nb(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int nwg, int kpw, double *slab) {
     using SH = SyrkSmallShape<NB>;
-    const size_t lds = (size_t)(2 * SS_ROWS * SH::LD + 2 * SS_ROWS) * sizeof(double);
+    const size_t lds = (size_t)SH::NBUF * SH::BUF * sizeof(double);
     static bool attr = false;                 // (idempotent: a race between contexts sets the same value twice)
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)k_syrk_small<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -53,3 +53,25 @@ def test_no_scratch_traffic_inside_the_mfma_loops(tmp_path, unit, kernels):
             nscratch += 1
     assert seen == set(kernels), seen
     assert not bad, bad
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+@pytest.mark.parametrize("unit", ["k_small", "k_syrk_small"])
+def test_lds_dma_base_is_never_picked_from_a_lane(tmp_path, unit):
+    """global_load_lds takes its LDS base from M0, one value per wave.  A request inside a DIVERGENT branch lets the compiler merge
+    differently-masked requests and choose between their (uniform) bases with a v_readfirstlane of a per-lane select: the first active
+    lane's base is then used for every lane, and rows land on their neighbours (seen in round 6 with a per-row 'lanes below the row's
+    end' staging loop in k_syrk_small - parity broke only for 144 <= mp <= 240 and more than one chunk).  The staging loops keep every
+    request under wave-uniform control flow; this guard fails if a compiler or source change brings the pattern back."""
+    asm = tmp_path / (unit + ".s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "gpz_amd", "csrc"), "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "gpz_amd", "csrc", unit + ".hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
+    lines = [l.strip() for l in asm.read_text().splitlines()]
+    assert any(l.startswith("global_load_lds") for l in lines)
+    bad = []
+    for i, l in enumerate(lines):
+        m = re.match(r"s_mov_b32 m0, (s\d+)", l)
+        if m and any(re.match(r"v_readfirstlane_b32 %s," % m.group(1), p) for p in lines[max(0, i - 8):i]):
+            bad.append((i, lines[max(0, i - 3):i + 2]))
+    assert not bad, bad[:3]

@@ -11,7 +11,7 @@ for spec in "100000 64 VD 1,2,5,10" "100000 200 VD 5,10" "100000 255 VD 10" "100
     python tools/sweep_timing.py $1 $2 $3 $4 2>&1 | grep -v amdgpu.ids >> $O
   done
 done
-python - <<'PY'
+python - > gpurun_out/r06_small_nan_ab_summary.txt <<'PY'
 import re
 rows = {}; cur = None
 for l in open("gpurun_out/r06_small_nan_ab.txt"):
@@ -24,3 +24,4 @@ for k, v in rows.items():
     if "0" in v and "1" in v and k[3] != "psi":
         print("%-18s %-3s %-3s %-6s %12.3f %12.3f %7.2f" % (k[0], k[1], k[2], k[3], v["1"], v["0"], v["0"] / v["1"]))
 PY
+cat gpurun_out/r06_small_nan_ab_summary.txt

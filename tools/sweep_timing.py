@@ -28,7 +28,10 @@ for method in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["VD", "VC"]):
                 ctx = gpz_amd.GPzContext(model, XX, y, **kw)
                 ctx.eval(theta)
                 ctx.enable_timing(True); ctx.eval(theta); ctx.reset_timings()   # the first timed evaluation creates the events
-                t0 = time.perf_counter(); K = 2
+                t0 = time.perf_counter(); f, g = ctx.eval(theta); one = time.perf_counter() - t0
+                K = max(2, min(200, int(0.1 / max(one, 1e-5))))      # ~0.1 s per case: two evaluations of a 0.4 ms shape are timer noise
+                ctx.reset_timings()
+                t0 = time.perf_counter()
                 for _ in range(K): f, g = ctx.eval(theta)
                 dt = (time.perf_counter() - t0) / K
                 tim = ctx.timings()
