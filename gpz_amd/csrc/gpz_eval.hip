@@ -284,14 +284,15 @@ int stage_a(gpz_ctx *c, const double *theta, const double *theta_dev) {
 static void stage_b(gpz_ctx *c, int o) {
     const int mq = c->mq, m = c->m;
     const double *S = c->comm1 + (size_t)o * c->mp * c->mp;
+    // mq <= 256: every step also leaves its block row of inv(L) (k_chol.hip: chol_inverse_block); beyond, the diagonal blocks only and
+    // the recursive levels behind the factorisation
+    const bool rowinv = chol_full_inverse_fits(mq) && !c->opt.chol_rowinv_off;
     {
         Stage s(c, "chol");
         launch_build_sigma(c->st, S, c->mp, c->pr.alpha + (size_t)o * m, m, mq, c->A, mq, c->Wm, c->logdet + o);   // clears Wm, logdet too
-        for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-            launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet + o, c->info);   // + the diagonal blocks of inv(L)
-        }
+        for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet + o, c->info, rowinv);
     }
-    {
+    if (!rowinv) {
         Stage s(c, "trtri");
         for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     }

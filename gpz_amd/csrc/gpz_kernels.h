@@ -137,7 +137,9 @@ void launch_trtri_level(hipStream_t st, const double *L, double *W, double *Tmp,
 void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *alpha, int m, int mq, double *A, int lda, double *Wz = nullptr, double *logdet = nullptr);   // Wz (mq x mq) and *logdet are cleared when given
 // panel + trailing update of one step in a single launch (GPZ_CH_NB == 32)
 // one step: panel + trailing update, the factor into Lm, the diagonal block of inv(L) into W (W cleared beforehand; nullptr: not wanted)
-void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info);
+bool chol_full_inverse_fits(int mq);
+void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info,
+                      bool full_inverse = false);   // full_inverse: + block row k0 / 32 of inv(L) (all steps: no k_trtri_level launches)
 void launch_zero(hipStream_t st, double *p, size_t count);
 // Bext (mp x mp) <- [inv | w column at m | 0]; iS (m x m col-major == row-major, symmetric) copy; w, dwda, diag.
 void launch_post_inverse(hipStream_t st, const double *Sinv, int ldsi, const double *S, int lds, const double *alpha,

@@ -39,6 +39,7 @@ struct gpz_options {
     int syrk_wgs = 0, syrk_s1 = 0, syrk_s2 = 0;   // GPZ_SYRK_WGS / _S1 / _S2   row-split tuning of k_syrk
     int mom_nc = 0;                      // GPZ_MOM_NC                chunk count of the moment kernels
     int small_stagger = 0;               // GPZ_SMALL_STAGGER         k_small_tail: start delay of a compute unit's second workgroup (x 8128 cycles; 0 = default)
+    bool chol_rowinv_off = false;        // GPZ_CHOL_ROWINV_OFF       m + k <= 256: k_trtri_level launches behind the factorisation instead of inv(L) row by row inside it
     bool syrk_small_off = false;         // GPZ_SYRK_SMALL_OFF        m + k <= 256: k_syrk's 128 x 128 tiles instead of k_syrk_small
     bool small_tail_off = false;         // GPZ_SMALL_TAIL_OFF        m + k <= 256: k_tgemm + k_row_scalars + k_moments_fused instead of k_small_tail
     int debug_fail_cut = 0;              // GPZ_DEBUG_FAIL_CUT=k      test hook: the k-th segment cut of a graph recording fails after its hipStreamEndCapture

@@ -41,6 +41,7 @@ gpz_options gpz_options_load() {
     o.debug_fail_cut = (int)env_long("GPZ_DEBUG_FAIL_CUT", 0);
     o.small_tail_off = env_set("GPZ_SMALL_TAIL_OFF");
     o.syrk_small_off = env_set("GPZ_SYRK_SMALL_OFF");
+    o.chol_rowinv_off = env_set("GPZ_CHOL_ROWINV_OFF");
     o.small_stagger = (int)env_long("GPZ_SMALL_STAGGER", 0);
 #endif
     return o;

@@ -618,9 +618,10 @@ extern "C" int gpz_inv_logdet(const double *Ain, int32_t m, int32_t device, doub
     const int mq = c->mq;
     launch_build_sigma(c->st, S, m, alpha0, m, mq, c->A, mq, c->Wm, c->logdet);   // clears Wm too
     for (int k0 = 0; k0 < mq; k0 += GPZ_CH_NB) {
-        launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet, c->info);
+        launch_chol_step(c->st, c->A, c->Lm, c->Wm, mq, mq, k0, c->logdet, c->info, chol_full_inverse_fits(mq) && !c->opt.chol_rowinv_off);
     }
-    for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
+    if (!(chol_full_inverse_fits(mq) && !c->opt.chol_rowinv_off))
+        for (int gs = GPZ_CH_NB; gs < mq; gs *= 2) launch_trtri_level(c->st, c->Lm, c->Wm, c->Tmp, mq, mq, gs);
     if (ltl_small_fits(mq) && !c->opt.syrk_small_off) launch_ltl_small(c->st, c->Wm, mq, c->Sinv);
     else {
         launch_syrk(c->st, c->Wm, mq, nullptr, mq, mq, c->nsplit_l, c->rows_per_split_l, c->nsplit_l, c->rows_per_split_l, c->slab,

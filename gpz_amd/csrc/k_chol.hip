@@ -209,6 +209,73 @@ __device__ __forceinline__ void solve_rows(double (&x)[CH_NB], int lane, const d
     for (int c = H; c < CH_NB; ++c) Xw[lane][c] = x[c];
 }
 
+// Block row k = k0 / 32 of the triangular inverse W = inv(L), 16 columns of block j < k, by a workgroup of its own inside the step's launch (mq <= 256):
+//   W_kj = - W_kk * S_j,   S_j = sum_{i = j .. k-1} L_ki * W_ij        (row by row: L W = I)
+// L_ki are the panel rows earlier steps wrote to Lm, W_ij the block rows earlier steps wrote to Wd; W_kk = inv(L_kk) does not exist
+// before THIS step, so the workgroup repeats what every tile of the step does - wave 0 factors the diagonal block, wave 2 solves the
+// unit rows against the posted columns (the winv path of tile (0, 0)) - while waves 1 and 3 form S_j on the f64 MFMA, one half of the K
+// range each, straight from L2 (32 x K times K x 32, K = 32 (k - j): operands of a few KB, eight K steps of loads in flight).  The
+// product with W_kk is 32 x 32 x 32 from LDS.  With it the k_trtri_level launches behind the factorisation (two per level, 6 at mq =
+// 224, 37 us of c2's 590) are gone; a step's own time does not change (S_j is done before the factor's last column is posted).
+__device__ __forceinline__ void chol_inverse_block(const double *__restrict__ A, const double *__restrict__ Lm, double *__restrict__ Wd, int lda,
+                                                   int k0, int e, double (*D)[CH_NB + 1], double *Dinv, double (*Xs)[64][CH_NB + 1],
+                                                   double (*Ct)[CH_NB / 2 + 1], int *posted, int *badpiv) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int j = e >> 1, ch = e & 1;                                      // block j of the row, columns 16 ch .. 16 ch + 15 of it
+    double x[CH_NB];
+    if (wave == 0) {
+        const double *ar = A + (size_t)(k0 + (lane & (CH_NB - 1))) * lda + k0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) x[c] = ar[c];
+    } else if (wave == 2) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) x[c] = (lane == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();                                                       // posted = 0 is visible
+    if (wave == 0) {
+        chol32_rows(x, lane, D, Dinv, posted, badpiv, Ct);
+    } else if (wave == 2) {
+        solve_rows(x, lane, D, Dinv, posted, Xs[1]);                       // Xs[1][c][r] = W_kk[r][c] (rows c >= 32: zeros)
+    } else {
+        // S_j's 16 columns: wave 1 the first half of the K steps, wave 3 the second; two 16 x 16 tiles (rows 0..15, 16..31) each - the
+        // loop is bound by the wave's own MFMA issue (two products of 64 cycles per K step) and by the latency of its operand loads, which is why a block's two
+        // column halves are two workgroups
+        const int j0 = j * CH_NB, nst = (k0 - j0) >> 2, half = (nst + 1) >> 1;
+        const int s0 = wave == 1 ? 0 : half, s1 = wave == 1 ? half : nst;
+        const double *pa = Lm + (size_t)(k0 + li) * lda + j0 + lk;         // A[m][k] = L[k0 + m][j0 + k]
+        const double *pb = Wd + (size_t)(j0 + lk) * lda + j0 + 16 * ch + li;   // B[k][n] = W[j0 + k][j0 + 16 ch + n]
+        const size_t a16 = (size_t)16 * lda, b4 = (size_t)4 * lda;
+        d4_t acc[2];
+        acc[0] = d4_t{0.0, 0.0, 0.0, 0.0};
+        acc[1] = acc[0];
+#pragma unroll 8
+        for (int s = s0; s < s1; ++s) {
+            const double a0 = pa[4 * s], a1 = pa[a16 + 4 * s];
+            const double b0 = pb[s * b4];
+            acc[0] = MFMA_F64(a0, b0, acc[0]);
+            acc[1] = MFMA_F64(a1, b0, acc[1]);
+        }
+        double (*Sp)[CH_NB + 1] = Xs[0] + (wave == 1 ? 0 : CH_NB);         // this wave's partial S_j: rows 0..31 / 32..63 of Xs[0]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sp[a * 16 + lk + 4 * r][li] = acc[a][r];
+    }
+    __syncthreads();
+    // W_kj = - W_kk S_j: waves 0 and 1 the row tiles
+    if (wave > 1) return;
+    const int ta = wave;
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < CH_NB / 4; ++kk) {
+        const double av = Xs[1][4 * kk + lk][ta * 16 + li];               // A[m][k] = W_kk[16 ta + m][k]
+        const double bv = Xs[0][4 * kk + lk][li] + Xs[0][CH_NB + 4 * kk + lk][li];
+        acc = MFMA_F64(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wd[(size_t)(k0 + ta * 16 + lk + 4 * r) * lda + j * CH_NB + ch * 16 + li] = -acc[r];
+}
+
 // One whole step of the right-looking factorisation in a single launch (CH_NB == 32): every workgroup owns one
 // 64x64 tile (tm >= tn) of the trailing matrix.  Wave 0 factors the diagonal block at k0 in registers (redundantly
 // per workgroup: it must never observe another workgroup's write-back, hence the separate factor buffer Lm) and posts it column
@@ -221,7 +288,7 @@ __device__ __forceinline__ void solve_rows(double (&x)[CH_NB], int lane, const d
 // bound by launch-to-launch latency, not by arithmetic.  Reads of this step touch only columns < k0 + 32 of A,
 // writes only columns >= k0 + 32, so the update is safely in place.
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ Lm, double *__restrict__ Wd, int lda,
-                                                    int mq, int k0, double *__restrict__ logdet, int *__restrict__ info) {
+                                                    int mq, int k0, double *__restrict__ logdet, int *__restrict__ info, int ntiles) {
     __shared__ double D[64][CH_NB + 1];                                    // rows 32..63: lanes without a row (stores without a branch)
     __shared__ double Dinv[CH_NB];
     __shared__ double Xs[2][64][CH_NB + 1];
@@ -230,6 +297,10 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int t0 = k0 + CH_NB;
     if (tid == 0) posted = 0;
+    if ((int)blockIdx.x >= ntiles) {   // workgroups behind the step's tiles: block row k0 / 32 of inv(L) (launch_chol_step: full_inverse)
+        chol_inverse_block(A, Lm, Wd, lda, k0, (int)blockIdx.x - ntiles, D, &Dinv[0], Xs, Ct, &posted, &badpiv);
+        return;
+    }
     // tile index -> (tm, tn), tm >= tn
     int tm = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
     while ((tm + 1) * (tm + 2) / 2 <= (int)blockIdx.x) ++tm;
@@ -429,9 +500,17 @@ void launch_build_sigma(hipStream_t st, const double *S, int lds, const double *
     hipLaunchKernelGGL(k_build_sigma, dim3((mq + 255) / 256, mq), dim3(256), 0, st, S, lds, alpha, m, mq, A, lda, Wz, logdet);
 }
 
-void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info) {
-    const int M = mq - k0 - CH_NB, nt = (M + 63) / 64, tiles = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, st, A, Lm, W, lda, mq, k0, logdet, info);
+// full_inverse: the launch also leaves block row k0 / 32 of W = inv(L) (k0 / 32 more workgroups; every step in order yields all of W and
+// no k_trtri_level launch is needed).  Otherwise only the diagonal block of that row.
+// mq <= 256 (K <= 224).  Measured at mq = 512 (c3): S_j's loads come from other XCDs' writes of the previous launches (~1.5 us per eight
+// K steps in flight), a step went 10.9 -> 15.2 us and the 74 us of k_trtri_level launches were only just paid back (2.196 -> 2.195 ms);
+// at mq = 224 (c2) a step goes 10.8 -> 11.5 us and 37 us of launches disappear (0.593 -> 0.551 ms)
+bool chol_full_inverse_fits(int mq) { return mq <= 256; }
+void launch_chol_step(hipStream_t st, double *A, double *Lm, double *W, int lda, int mq, int k0, double *logdet, int *info,
+                      bool full_inverse) {
+    const int M = mq - k0 - CH_NB, nt = (M + 63) / 64, tiles = nt * (nt + 1) / 2, ntiles = tiles > 0 ? tiles : 1;
+    const int extra = (full_inverse && W) ? 2 * (k0 / CH_NB) : 0;   // two workgroups (column halves) per block of the inverse's row
+    hipLaunchKernelGGL(k_chol_step, dim3(ntiles + extra), dim3(256), 0, st, A, Lm, W, lda, mq, k0, logdet, info, ntiles);
 }
 
 void launch_zero(hipStream_t st, double *p, size_t count) {

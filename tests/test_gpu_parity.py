@@ -1865,6 +1865,26 @@ def test_syrk_small_agrees_with_the_tiled_kernel(tmp_path, method, d, m, k, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,d,m,k", [("VD", 3, 31, 1), ("VD", 4, 40, 1), ("VC", 3, 100, 2), ("VD", 10, 200, 1), ("GL", 2, 255, 1),
+                                          ("VL", 2, 130, 3)])
+def test_inverse_rows_inside_the_factorisation_agree_with_the_recursive_levels(tmp_path, method, d, m, k):
+    """m + k <= 256: every k_chol_step launch also leaves its block row of inv(L) (row by row: L W = I), so no k_trtri_level launch
+    follows.  Against the recursive levels (developer build, GPZ_CHOL_ROWINV_OFF) on the same problem: one step (mq = 32, no row to
+    compute), two, and up to eight; and against the oracle through the parity tests of these shapes above."""
+    from helpers import eval_with_dev_switches
+    model, theta, X, Y, _, rng = make_problem(1500, d, m, k, method, True, seed=4700 + m)
+    ref = O.GPz(theta, model, X, Y)
+    ctx = gpz_amd.GPzContext(model, X, Y)
+    f0, g0 = ctx.eval(theta)
+    w0, iS0, part0 = ctx.solve(theta)
+    ctx.close()
+    assert abs(f0 - ref.nlogML) <= FTOL * abs(ref.nlogML) and rel(g0, ref.grad) <= grad_tol(ref.cond)
+    f, g, info = eval_with_dev_switches(tmp_path, method, m, d, k, True, theta, X, Y, None, {"GPZ_CHOL_ROWINV_OFF": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-12 * abs(f0) and rel(g, g0) <= max(1e-9, 0.01 * grad_tol(ref.cond)), (abs(f - f0) / abs(f0), rel(g, g0))
+
+
+@pytest.mark.gpu
 def test_syrk_small_is_not_taken_where_it_does_not_apply():
     """More than 256 columns and config 5's fp32-operand product keep k_syrk."""
     model, theta, X, Y, Psi, rng = make_problem(800, 4, 256, 1, "VD", True, seed=12)

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
     hipStream_t st; (void)hipStreamCreate(&st);
     auto chain = [&]() {
         launch_build_sigma(st, dS, m, dal, m, mq, A, mq, Wz, logdet);
-        for (int k0 = 0; k0 < mq; k0 += CH_NB) launch_chol_step(st, A, Lm, Wz, mq, mq, k0, logdet, info);
+        for (int k0 = 0; k0 < mq; k0 += CH_NB) launch_chol_step(st, A, Lm, Wz, mq, mq, k0, logdet, info, false);
     };
     double *Tmp; (void)hipMalloc(&Tmp, (size_t)mq * mq * 8);
     auto inverse = [&]() { for (int gs = CH_NB; gs < mq; gs *= 2) launch_trtri_level(st, Lm, Wz, Tmp, mq, mq, gs); };
