@@ -604,6 +604,9 @@ int eval_tail(gpz_ctx *c, bool pinv) {
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->va.om; a.om_ld = c->va.om_ld; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta_v; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw_v;
         a.Psic = c->va.Psic; a.Mc = c->va.Mc; a.ucnt = c->va.ucnt;
+        // few rows: the basis functions are split over workgroups here as in the training build (15 000 validation rows of c2 are 59
+        // workgroups walking 208 columns each: 139 us; split, 30)
+        a.part = a.n_pad <= c->phipart_rows ? c->phipart : nullptr; a.part_groups = c->phipart_groups;
         if (launch_phi(c->st, a)) return gpz_fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw_v, c->va.Y, c->va.om, c->va.om_ld, c->lnbeta_v, c->va.n_pad, c->va.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), vsums);
@@ -688,6 +691,7 @@ extern "C" int gpz_solve(gpz_ctx *c, const double *theta, double *w, double *iSi
         a.v = c->hetero ? c->pr.v : nullptr; a.b = c->pr.b; a.omega = c->tr.om; a.om_ld = c->tr.om_ld; a.Y = nullptr;
         a.Phi = nullptr; a.lnbeta = c->lnbeta; a.wbeta = nullptr; a.w = c->w; a.phiw = c->phiw;
         a.Psic = c->tr.Psic; a.Mc = c->tr.Mc; a.ucnt = c->tr.ucnt;
+        a.part = a.n_pad <= c->phipart_rows ? c->phipart : nullptr; a.part_groups = c->phipart_groups;
         if (launch_phi(c->st, a)) return gpz_fail(GPZ_ERR_UNSUPPORTED, "PHI kernel not instantiated for d=%d", c->de);
         launch_row_stats(c->st, c->phiw, c->tr.Y, c->tr.om, c->tr.om_ld, c->lnbeta, c->tr.n_pad, c->tr.n, c->k, c->partial);
         launch_slab_sum(c->st, c->partial, GPZ_SMALL_NWG, gpz_ns(c->k), c->rstats);
