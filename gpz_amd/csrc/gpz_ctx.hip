@@ -82,7 +82,7 @@ static int upload_rowset(gpz_ctx *c, RowSet &rs, int64_t n_tot, const double *X,
         }
         if (int e = c->ar.alloc(&rs.xmu, (size_t)de)) return e;
         HIPCHK(hipMemcpy(rs.xmu, mu.data(), (size_t)de * sizeof(double), hipMemcpyHostToDevice));
-        if (need_xr && !c->gen && c->k == 1) {   // (the evaluation's training rows; k_small_tail is a single-output route)
+        if (need_xr && !c->gen) {   // (the evaluation's training rows)
             const bool masked = c->has_missing || any_missing;       // (setup_data has looked at every row: has_missing is final here)
             const size_t xl = masked ? 2 * (size_t)de + 2 : (size_t)de + 2;
             rs.xs_ld = (int)xl;
@@ -485,10 +485,10 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     }
     const size_t npt = c->tile_rows ? (size_t)c->tile_rows : np;   // rows PHI / T / the nu partials hold
     if ((rc = c->ar.alloc(&c->Phi, npt * mp))) return bail(rc);
-    // Few basis functions (m + k <= 256 columns, one output, no input noise, nothing missing, rows resident): the product with
+    // Few basis functions (m + k <= 256 columns with y's columns inside one 16-column block, no input noise, rows resident): the product with
     // [inv(SIGMA) | w], the row scalars and the moment sums are ONE kernel that keeps whole rows of T in registers (k_small.hip).
-    c->small_tail = k == 1 && !c->gen && !c->has_psi && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
-                    small_tail_fits(c->kind, c->de, c->mp, c->has_missing) && !c->opt.small_tail_off;
+    c->small_tail = !c->gen && !c->has_psi && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
+                    small_tail_fits(c->kind, c->de, c->m, k, c->mp, c->has_missing) && !c->opt.small_tail_off;
     if (!c->small_tail && (rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);   // (T = PHI [inv(SIGMA) | w] exists in memory only on the other routes)
     if (c->small_tail) {
         c->st_nwg = small_tail_nwg();

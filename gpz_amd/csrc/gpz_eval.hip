@@ -388,16 +388,19 @@ int eval_tail(gpz_ctx *c, bool pinv) {
         if (c->small_tail) {
             // T = PHI [inv(SIGMA) | w], nu, the row scalars, dPHI and the moment sums in one kernel; T stays in registers (k_small.hip)
             Stage s(c, "tail_small");
+            const size_t oo = (size_t)o * c->tr.n_pad;   // this output's columns of the k x n_pad row arrays
             SmallTailArgs a{};
             a.Phi = c->Phi; a.ld = c->mp; a.B = c->Bext; a.ldb = c->mp;
-            a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind;
+            a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind; a.mcol = c->m + o;
             a.Xs = c->tr.Xs; a.xs_ld = c->tr.xs_ld; a.missing = c->has_missing ? 1 : 0;
-            a.y = c->tr.Y; a.omega = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta;
-            a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
-            a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf; a.stagger = c->opt.small_stagger;
+            a.y = c->tr.Y + oo; a.omega = c->tr.om ? c->tr.om + (size_t)o * c->tr.om_ld : nullptr; a.omega1 = c->tr.om;
+            a.lnbeta = c->lnbeta + oo; a.wbeta = c->wbeta + oo;
+            a.w = c->w + (size_t)o * m; a.v = c->hetero ? c->pr.v + (size_t)o * m : a.w; a.vscale = c->hetero ? 1.0 : 0.0;
+            a.phiw = c->phiw + oo; a.slab = c->st_slab; a.partial = c->partial; a.nf = c->st_nf; a.stagger = c->opt.small_stagger;
             launch_small_tail(c->st, a, c->st_nwg);
+            // dPHI is a sum over the outputs (GPz.m:113): the moments accumulate, the column and scalar sums are per output
             launch_small_finish(c->st, c->st_slab, c->partial, c->st_nwg, c->m, c->de, c->kind, c->st_nf, c->has_missing ? 1 : 0, c->pr.P,
-                                c->tr.xmu, c->nm, c->mp, mom, cols, scal);
+                                c->tr.xmu, c->nm, c->mp, mom, cols + (size_t)o * 2 * mp, scal + (size_t)o * 4, o > 0 ? 1 : 0);
             continue;
         }
         {

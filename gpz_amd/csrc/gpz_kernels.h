@@ -93,10 +93,12 @@ struct SmallTailArgs {
     const double *Phi; int ld;              // n_pad x ld row-major (columns m .. m+k-1 hold y)
     const double *B; int ldb;               // mp x ldb: [inv(SIGMA) | w]
     int n, n_pad, m, mp, d, kind;           // d = padded dimension of Xr / P
+    int mcol;                               // column of B that holds w (= column of T that is PHI w): m + the output's index
     const double *Xs; int xs_ld;            // n_pad x xs_ld rows [1 | x - mu | 0] (xs_ld = d + 2), mu = the column means (centre of the feature
                                             // expansion); diagonal kinds with missing values: [1 | (x - mu) mk | mk | 0] (xs_ld = 2 d + 2)
     int missing;                            // 1: the masked features of a diagonal kind with missing values
-    const double *y, *omega, *lnbeta, *wbeta;   // n_pad each (omega may be nullptr)
+    const double *y, *omega, *lnbeta, *wbeta;   // n_pad each, of THIS output (omega may be nullptr)
+    const double *omega1;                   // the first column of an n x k omega (omega(training) of GPz.m:236), = omega otherwise
     const double *w, *v;                    // m; without the heteroscedastic term v = w and vscale = 0 (no branch in the kernel)
     double vscale;
     double *phiw;                           // n_pad: PHI w
@@ -107,12 +109,12 @@ struct SmallTailArgs {
     int nf;                                 // features: 1 + 2d (diagonal kinds), 1 + d + d(d+1)/2 (covariance kinds)
 };
 int small_tail_features(int kind, int d, bool missing);
-bool small_tail_fits(int kind, int d, int mp, bool missing);   // mp <= 256 columns and <= 32 features
+bool small_tail_fits(int kind, int d, int m, int k, int mp, bool missing);   // mp <= 256 columns, <= 32 features, y columns in one block
 int small_tail_nwg();                            // persistent workgroups: two per compute unit
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a, int nwg);
 void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
                          const double *P, const double *xmu, int nm, int mp, double *mom, double *cols,
-                         double *scal);   // the workgroups' records -> moments, column sums, scalar sums (one launch)
+                         double *scal, int accumulate);   // the workgroups' records -> moments, column sums, scalar sums (one launch)
 int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

@@ -148,9 +148,10 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
     const double *pc = sA + (lane >> 4) * SM_LDA + wce * 16 + (lane & 15);
     const double *pe = sE + (lane >> 4) * SM_LDE + (lane & 15);
     const double *prs = sRs + (lane >> 4) * 4;
-    // column m of B is w: T[:, m] = PHI w (GPz.m:77) sits in block (m >> 4) = 4 qm + wce of ONE wave, lanes with (lane & 15) == (m & 15)
+    // column mcol = m + (output) of B is w: T[:, mcol] = PHI w (GPz.m:77) sits in block (m >> 4) = 4 qm + wce of ONE wave (the columns
+    // m .. m+k-1 share a block: small_tail_fits), lanes with (lane & 15) == (mcol & 15)
     const int qm = (((m >> 4) - wce) & 3) == 0 ? ((m >> 4) - wce) >> 2 : -1;
-    const bool pwlane = (lane & 15) == (m & 15);
+    const bool pwlane = (lane & 15) == (a.mcol & 15);
     const double cmask = (lane & 15) < (m & 15) ? 1.0 : 0.0;   // block qm: its columns >= m hold y and padding (PHI_ij = 0 there)
     // staging: wave w takes rows 8 w .. 8 w + 7 of the block, a lane the double2 at columns 2 lane and 128 + 2 lane
     const int c2 = lane * 2;
@@ -254,11 +255,11 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
         }
         SM_MARK(3);
         // the row-scalar inputs of this block's rows (threads 0..31), requested now: they are needed a phase and a barrier later
-        double ry = 0.0, rlb = 0.0, rom = 1.0, rob = 0.0;
+        double ry = 0.0, rlb = 0.0, rom = 1.0, rom1 = 1.0, rob = 0.0;
         if (tid < 32 && i0 + tid < a.n) {
             const int i = i0 + tid;
             ry = a.y[i]; rlb = a.lnbeta[i]; rob = a.wbeta[i];
-            if (a.omega) rom = a.omega[i];
+            if (a.omega) { rom = a.omega[i]; rom1 = a.omega1[i]; }
         }
         // ---- nu partials and PHI w (PHI_ij from the LDS block, accumulator layout: row (lane >> 4) + 4 r, column lane & 15)
         {
@@ -305,7 +306,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 cc = ob * delta;
                 g = ob > 0.0 ? db * gpz_rcp(ob) : 0.0;
                 s0 = fma(cc, delta, s0);
-                s1 = fma(om, delta * delta, s1);
+                s1 = fma(rom1, delta * delta, s1);                       // omega(training): the first column  GPz.m:236
                 s2 += -0.5 * (cc * delta + om * lb);                     // omega (-0.5 beta delta^2 + 0.5 ln beta), ln beta = -lnBeta_i   GPz.m:237
                 s3 += db;
                 a.phiw[i] = pw;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
 __global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict__ slab, const double *__restrict__ partial, int nwg, int m, int d,
                                                        int kind, int nf, int missing, const double *__restrict__ P,
                                                        const double *__restrict__ xmu, int nm, int mp, double *__restrict__ mom,
-                                                       double *__restrict__ cols, double *__restrict__ scal) {
+                                                       double *__restrict__ cols, double *__restrict__ scal, int accumulate) {
     __shared__ double part[32][36];
     __shared__ double R[36];
     const int tid = threadIdx.x;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict_
         const double qa = P[(size_t)j * d + aa] - xmu[aa], qb = P[(size_t)j * d + bb] - xmu[bb];
         val = R[1 + q] - qa * R[1 + bb] - qb * R[1 + aa] + qa * qb * R[0];
     }
-    mom[(size_t)j * nm + q] = val;
+    mom[(size_t)j * nm + q] = accumulate ? mom[(size_t)j * nm + q] + val : val;   // dPHI is a sum over the outputs (GPz.m:113)
 }
 
 // features per basis function: diagonal kinds 1 + 2d ([1 | x' | x'^2], x' = x - mu); with missing values 3d ([mk | x' mk | (x' mk)^2] per
@@ -484,8 +485,10 @@ __global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict_
 int small_tail_features(int kind, int d, bool missing) {
     return kind == GPZ_KIND_DIAG ? (missing ? 3 * d : 1 + 2 * d) : 1 + d + d * (d + 1) / 2;
 }
-bool small_tail_fits(int kind, int d, int mp, bool missing) {
-    return mp <= 256 && (mp & 15) == 0 && small_tail_features(kind, d, missing) <= 32 && !(missing && kind != GPZ_KIND_DIAG);
+// m .. m+k-1 (the columns of PHI that hold y, of B that hold w) in ONE 16-column block: the kernel masks that block's columns >= m
+bool small_tail_fits(int kind, int d, int m, int k, int mp, bool missing) {
+    return mp <= 256 && (mp & 15) == 0 && small_tail_features(kind, d, missing) <= 32 && !(missing && kind != GPZ_KIND_DIAG) &&
+           ((m + k - 1) >> 4) == (m >> 4);
 }
 int small_tail_nwg() { return 2 * gpz_cu_count(); }   // persistent workgroups: two per compute unit
 
@@ -508,7 +511,7 @@ void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
 #undef SMALL_CASE
 }
 void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
-                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols, double *scal) {
+                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols, double *scal, int accumulate) {
     hipLaunchKernelGGL(k_small_finish, dim3(m + 1), dim3(1024), 0, st, slab, partial, nwg, m, d, kind, nf, missing, P, xmu, nm, mp, mom, cols,
-                       scal);
+                       scal, accumulate);
 }

@@ -275,11 +275,9 @@ template <int NB>
 static void launch_syrk_small_nb(hipStream_t st, const double *Phi, int ld, const double *wgt, int n_rows, int nwg, int kpw, double *slab) {
     using SH = SyrkSmallShape<NB>;
     const size_t lds = (size_t)SH::NBUF * SH::BUF * sizeof(double);
-    static bool attr = false;                 // (idempotent: a race between contexts sets the same value twice)
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)k_syrk_small<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    // per launch, not once per process: the attribute belongs to the CURRENT device's copy of the kernel (gpz_mgpu drives several devices
+    // from one process); a host-side call on the recording / eager path only - a replayed graph does not come through here
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_syrk_small<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_syrk_small<NB>, dim3(nwg), dim3(512), lds, st, Phi, ld, wgt, n_rows, kpw, slab);
 }
 

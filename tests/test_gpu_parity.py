@@ -1764,10 +1764,38 @@ def test_small_tail_with_missing_values_agrees_with_the_separate_kernels(tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,n,d,m,k,omk", [("VD", 3000, 6, 100, 2, False), ("VC", 2000, 4, 60, 3, True), ("GL", 1500, 2, 29, 3, False),
+                                                ("VD", 2500, 5, 200, 8, True), ("GD", 1800, 3, 45, 2, True)])
+def test_small_tail_route_with_several_outputs(method, n, d, m, k, omk):
+    """k > 1 on the one-kernel tail: one k_small_tail + k_small_finish per output (w of output o in column m + o of [inv(SIGMA_o) | w_o],
+    the moments summed over the outputs, GPz.m:113), an n x k omega included (the RMSE sum takes its FIRST column, GPz.m:236); the
+    columns m .. m + k - 1 sit in one 16-column block in every case here (m = 29, k = 3: columns 29 .. 31)."""
+    model, theta, X, Y, _, rng = make_problem(n, d, m, k, method, True, seed=9900 + m + k)
+    om = rng.random((n, k if omk else 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, None, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, None, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        f2, g2 = ctx.eval(theta)
+        f3, g3 = ctx.eval(theta)
+        stats = dict(ctx.stats)
+        route = ctx.route()
+    finally:
+        ctx.close()
+    assert "k_small_tail" in route, route
+    assert f2 == f and f3 == f and np.array_equal(g, g2) and np.array_equal(g, g3)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= grad_tol(ref.cond), (rel(g, ref.grad), grad_tol(ref.cond))
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
+@pytest.mark.gpu
 def test_small_tail_is_not_taken_where_it_does_not_apply():
-    """k > 1, input noise, missing values under a covariance kind or with more than 10 dimensions, more than 256 columns, more than 32
-    features: the separate kernels (and the same oracle parity, covered by the tests above) - the route text must not name k_small_tail."""
-    cases = [dict(k=2), dict(psi=True), dict(method="VC", nanfrac=0.2), dict(method="VD", d=11, nanfrac=0.2), dict(m=256),
+    """y's columns m .. m + k - 1 in two 16-column blocks, input noise, missing values under a covariance kind or with more than 10
+    dimensions, more than 256 columns, more than 32 features: the separate kernels (and the same oracle parity, covered by the tests above) - the route text must not name k_small_tail."""
+    cases = [dict(m=31, k=2), dict(psi=True), dict(method="VC", nanfrac=0.2), dict(method="VD", d=11, nanfrac=0.2), dict(m=256),
              dict(method="VC", d=7), dict(method="VD", d=16)]
     for kw in cases:
         method, d, m, k = kw.get("method", "VD"), kw.get("d", 4), kw.get("m", 40), kw.get("k", 1)

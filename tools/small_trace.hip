@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, 0, xmu, (size_t)d, 4u, 0.5);
     for (double *q : {y, lnb, wb}) hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, q, (size_t)n_pad, 5u, 1.0);
     for (double *q : {w, v}) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, 0, q, (size_t)m, 6u, 1.0);
-    a.Phi = Phi; a.ld = mp; a.B = B; a.ldb = mp; a.n = n; a.n_pad = n_pad; a.m = m; a.mp = mp; a.d = d; a.kind = GPZ_KIND_DIAG;
+    a.Phi = Phi; a.ld = mp; a.B = B; a.ldb = mp; a.n = n; a.n_pad = n_pad; a.m = m; a.mp = mp; a.d = d; a.kind = GPZ_KIND_DIAG; a.mcol = m;
     a.Xs = Xr; a.y = y; a.omega = nullptr; a.lnbeta = lnb; a.wbeta = wb; a.w = w; a.v = v; a.vscale = 1.0; a.phiw = phiw;
     a.slab = slab; a.partial = partial; a.stagger = stg;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
