@@ -21,12 +21,17 @@
 #define LB_ROWS 4096          // rows per workgroup of the dot kernel
 #define LB_MAXC 258           // 2 * (corrections + 1)
 
+#define LB_CG 4               // columns of [S | Y] per workgroup of the dot kernel
 // part[chunk][c][q] = sum over the chunk's rows of V_c[r] * x_q[r];  V = [S | Y] (each p x cap, column-major), q < nx <= 3.
+// Grid: (row chunks, groups of LB_CG columns).  (Until round 6 a workgroup walked ALL 2 cap columns of its rows, one after the other with
+// two barriers each: at p = 4 601 - BASELINE config 2 - that was 2 workgroups x 202 columns = 298 us per call, twice per iteration,
+// more than the 0.55 ms evaluation the optimiser drives; now 102 workgroups x 4 columns.  Same sums in the same order.)
 __global__ __launch_bounds__(256) void k_lb_dots(const double *__restrict__ S, const double *__restrict__ Y, long p, int cap,
                                                   const double *__restrict__ x0, const double *__restrict__ x1,
                                                   const double *__restrict__ x2, int nx, double *__restrict__ part) {
-    __shared__ double red[4][3];
+    __shared__ double red[4][LB_CG][3];
     const long r0 = (long)blockIdx.x * LB_ROWS;
+    const int c0 = (int)blockIdx.y * LB_CG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PT = LB_ROWS / 256;
     double xa[PT], xb[PT], xc[PT];
@@ -38,7 +43,9 @@ __global__ __launch_bounds__(256) void k_lb_dots(const double *__restrict__ S, c
         xb[u] = (ok && nx > 1) ? x1[r] : 0.0;
         xc[u] = (ok && nx > 2) ? x2[r] : 0.0;
     }
-    for (int c = 0; c < 2 * cap; ++c) {
+#pragma unroll
+    for (int cc = 0; cc < LB_CG; ++cc) {
+        const int c = c0 + cc < 2 * cap ? c0 + cc : 2 * cap - 1;      // (a group past the last column repeats it: not written)
         const double *v = (c < cap) ? S + (size_t)c * p : Y + (size_t)(c - cap) * p;
         double a = 0.0, b = 0.0, d = 0.0;
 #pragma unroll
@@ -48,10 +55,12 @@ __global__ __launch_bounds__(256) void k_lb_dots(const double *__restrict__ S, c
             a = fma(vv, xa[u], a); b = fma(vv, xb[u], b); d = fma(vv, xc[u], d);
         }
         a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
-        __syncthreads();
-        if (lane == 0) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = d; }
-        __syncthreads();
-        if (tid < 3) part[((size_t)blockIdx.x * 2 * cap + c) * 3 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (lane == 0) { red[wave][cc][0] = a; red[wave][cc][1] = b; red[wave][cc][2] = d; }
+    }
+    __syncthreads();
+    if (tid < 3 * LB_CG) {
+        const int cc = tid / 3, q = tid % 3, c = c0 + cc;
+        if (c < 2 * cap) part[((size_t)blockIdx.x * 2 * cap + c) * 3 + q] = red[0][cc][q] + red[1][cc][q] + red[2][cc][q] + red[3][cc][q];
     }
 }
 // out[e] = sum over chunks (fixed order)
@@ -88,20 +97,29 @@ __global__ void k_lb_store(double *__restrict__ S, double *__restrict__ Y, long 
     Y[(size_t)col * p + r] = g[r] - g_old[r];
 }
 // d = dg*g + sum_c ds[c]*S_c + dy[c]*Y_c     (coefficients in coef[0..2cap] = [ds | dy | dg])
+// A workgroup takes 64 rows; its four waves a quarter of the columns each (every load is issued whatever its coefficient - a zero
+// coefficient multiplies a zero, not the column's value, which may be a rejected pair's - so eight loads per lane are in flight), the
+// four partial sums are added in a fixed order.  (One thread per row walking all 2 cap columns behind a branch each: 41 us at p = 4 601.)
 __global__ __launch_bounds__(256) void k_lb_combine(const double *__restrict__ S, const double *__restrict__ Y, long p, int cap,
                                                      const double *__restrict__ coef, const double *__restrict__ g,
                                                      double *__restrict__ d) {
     __shared__ double cf[2 * LB_MAXC + 1];
+    __shared__ double ps[4][64];
     for (int e = threadIdx.x; e < 2 * cap + 1; e += 256) cf[e] = coef[e];
     __syncthreads();
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= p) return;
-    double acc = cf[2 * cap] * g[r];
-    for (int c = 0; c < cap; ++c) {
-        if (cf[c] != 0.0) acc = fma(cf[c], S[(size_t)c * p + r], acc);
-        if (cf[cap + c] != 0.0) acc = fma(cf[cap + c], Y[(size_t)c * p + r], acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 64 + lane, rr = r < p ? r : p - 1;
+    const int per = (2 * cap + 3) / 4, c0 = wave * per, c1 = min(2 * cap, c0 + per);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+        const double v = (c < cap) ? S[(size_t)c * p + rr] : Y[(size_t)(c - cap) * p + rr];
+        const double k = cf[c];
+        acc = fma(k, k != 0.0 ? v : 0.0, acc);
     }
-    d[r] = acc;
+    ps[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && r < p) d[r] = fma(cf[2 * cap], g[r], ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane]);
 }
 // out4 = [g.d, max|g|, sum|g|, max|d|]  (single workgroup partials -> host reduces nblk records)
 __global__ __launch_bounds__(256) void k_vec_stats(const double *__restrict__ g, const double *__restrict__ d, long p,
@@ -199,7 +217,7 @@ extern "C" int gpz_lbfgs_add(gpz_lbfgs *h, const double *g_dev, const double *g_
     const long p = h->p;
     hipLaunchKernelGGL(k_lb_store, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->st, h->S, h->Y, p, slot, g_dev, g_old_dev, t, d_dev);
     const double *s = h->S + (size_t)slot * p, *y = h->Y + (size_t)slot * p;
-    hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, s, y,
+    hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk, (2 * nc + LB_CG - 1) / LB_CG), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, s, y,
                        (const double *)nullptr, 2, h->part);
     const int cnt = 2 * nc * 3;
     hipLaunchKernelGGL(k_lb_sum, dim3((cnt + 255) / 256), dim3(256), 0, h->st, (const double *)h->part, h->nchunk, cnt, h->red);
@@ -239,7 +257,7 @@ extern "C" int gpz_lbfgs_direction(gpz_lbfgs *h, const double *g_dev, double *d_
     LBCHK(hipSetDevice(h->device));
     const int nc = h->nc, k = (int)h->order.size();
     const long p = h->p;
-    hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, g_dev,
+    hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk, (2 * nc + LB_CG - 1) / LB_CG), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, g_dev,
                        (const double *)nullptr, (const double *)nullptr, 1, h->part);
     const int cnt = 2 * nc * 3;
     hipLaunchKernelGGL(k_lb_sum, dim3((cnt + 255) / 256), dim3(256), 0, h->st, (const double *)h->part, h->nchunk, cnt, h->red);
@@ -275,7 +293,7 @@ extern "C" int gpz_lbfgs_direction(gpz_lbfgs *h, const double *g_dev, double *d_
     for (int c : h->order) { coef[c] = ds[c]; coef[nc + c] = dy[c]; }
     coef[2 * nc] = dg;
     LBCHK(hipMemcpyAsync(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, h->st));
-    hipLaunchKernelGGL(k_lb_combine, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p,
+    hipLaunchKernelGGL(k_lb_combine, dim3((unsigned)((p + 63) / 64)), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p,
                        nc, (const double *)h->coef, g_dev, d_dev);
     LBCHK(hipStreamSynchronize(h->st));   // coef is a stack vector
     return GPZ_OK;

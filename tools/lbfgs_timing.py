@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gpz_amd import host
-p, corr = 113001, 100
+p, corr = (int(sys.argv[1]) if len(sys.argv) > 1 else 113001), 100
 rng = np.random.default_rng(0)
 hm, dm = host._LBFGS(p, corr), host._LBFGSDevice(p, corr)
 g_old = rng.standard_normal(p)
