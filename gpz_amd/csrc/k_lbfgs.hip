@@ -170,6 +170,8 @@ struct gpz_lbfgs {
     double hdiag = 1.0;
     std::vector<double> SS, SY, YY;     // Gram blocks over physical columns: SS[a*nc+b] = s_a.s_b, SY[a*nc+b] = s_a.y_b, YY likewise
     std::vector<double> hbuf;
+    std::vector<double> gdots;          // [S Y]' g of the g gpz_lbfgs_add was called with (the direction call that follows it takes them)
+    const double *g_of_gdots = nullptr;
 };
 #define LBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(lb_err, sizeof lb_err, "%s: %s", #x, hipGetErrorString(e_)); return GPZ_ERR_HIP; } } while (0)
 
@@ -217,13 +219,18 @@ extern "C" int gpz_lbfgs_add(gpz_lbfgs *h, const double *g_dev, const double *g_
     const long p = h->p;
     hipLaunchKernelGGL(k_lb_store, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->st, h->S, h->Y, p, slot, g_dev, g_old_dev, t, d_dev);
     const double *s = h->S + (size_t)slot * p, *y = h->Y + (size_t)slot * p;
+    // the third vector is g itself: minFunc asks for the direction at this g next (gpz_lbfgs_direction), and [S Y]' g costs nothing
+    // beside [S Y]' [s y] - one pass over the memory, one read-back and one synchronisation less per iteration
     hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk, (2 * nc + LB_CG - 1) / LB_CG), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, s, y,
-                       (const double *)nullptr, 2, h->part);
+                       g_dev, 3, h->part);
     const int cnt = 2 * nc * 3;
     hipLaunchKernelGGL(k_lb_sum, dim3((cnt + 255) / 256), dim3(256), 0, h->st, (const double *)h->part, h->nchunk, cnt, h->red);
     LBCHK(hipMemcpyAsync(h->hbuf.data(), h->red, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->st));
     LBCHK(hipStreamSynchronize(h->st));
-    // hbuf[c*3 + q]: column c of [S|Y] dotted with s (q = 0) / y (q = 1)
+    // hbuf[c*3 + q]: column c of [S|Y] dotted with s (q = 0) / y (q = 1) / g (q = 2)
+    h->gdots.resize((size_t)2 * nc);
+    for (int c = 0; c < 2 * nc; ++c) h->gdots[c] = h->hbuf[(size_t)c * 3 + 2];
+    h->g_of_gdots = g_dev;
     const double ys = h->hbuf[(size_t)(nc + slot) * 3 + 0];        // y_slot . s
     const double yy = h->hbuf[(size_t)(nc + slot) * 3 + 1];        // y_slot . y
     if (!(ys > 1e-10)) {                                           // lbfgsAdd.m:3
@@ -257,12 +264,17 @@ extern "C" int gpz_lbfgs_direction(gpz_lbfgs *h, const double *g_dev, double *d_
     LBCHK(hipSetDevice(h->device));
     const int nc = h->nc, k = (int)h->order.size();
     const long p = h->p;
-    hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk, (2 * nc + LB_CG - 1) / LB_CG), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, g_dev,
-                       (const double *)nullptr, (const double *)nullptr, 1, h->part);
-    const int cnt = 2 * nc * 3;
-    hipLaunchKernelGGL(k_lb_sum, dim3((cnt + 255) / 256), dim3(256), 0, h->st, (const double *)h->part, h->nchunk, cnt, h->red);
-    LBCHK(hipMemcpyAsync(h->hbuf.data(), h->red, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->st));
-    LBCHK(hipStreamSynchronize(h->st));
+    if (h->g_of_gdots == g_dev && (int)h->gdots.size() == 2 * nc) {   // the g of the gpz_lbfgs_add just before: its dots are here already
+        for (int c = 0; c < 2 * nc; ++c) h->hbuf[(size_t)c * 3] = h->gdots[c];
+    } else {
+        hipLaunchKernelGGL(k_lb_dots, dim3(h->nchunk, (2 * nc + LB_CG - 1) / LB_CG), dim3(256), 0, h->st, (const double *)h->S, (const double *)h->Y, p, nc, g_dev,
+                           (const double *)nullptr, (const double *)nullptr, 1, h->part);
+        const int cnt = 2 * nc * 3;
+        hipLaunchKernelGGL(k_lb_sum, dim3((cnt + 255) / 256), dim3(256), 0, h->st, (const double *)h->part, h->nchunk, cnt, h->red);
+        LBCHK(hipMemcpyAsync(h->hbuf.data(), h->red, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->st));
+        LBCHK(hipStreamSynchronize(h->st));
+    }
+    h->g_of_gdots = nullptr;   // (one use: the same address may hold another vector at the next call)
     std::vector<double> ds(nc, 0.0), dy(nc, 0.0), al(nc, 0.0);
     double dg = -1.0;                                                          // q = -g
     auto sg = [&](int c) { return h->hbuf[(size_t)c * 3]; };                   // s_c . g

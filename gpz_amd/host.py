@@ -73,6 +73,7 @@ class DevVec:
     def __init__(self, t):
         self.t = t
         self._own = None        # [., max|v|, sum|v|, .] of this vector, computed once (vectors are never modified in place)
+        self._max = None        # max|v| alone, when a product g'v of another vector brought it along (gpz_vec_stats out[3])
 
     @staticmethod
     def from_host(a, device=0):
@@ -98,6 +99,8 @@ class DevVec:
         st = self._stats(other)                 # one kernel gives g'd and the maxima of both vectors
         if self._own is None:
             self._own = tuple(st)
+        if other._max is None:
+            other._max = float(st[3])
         return float(st[0])
 
     def _self_stats(self):
@@ -106,13 +109,15 @@ class DevVec:
         return self._own
 
     def amax(self):
+        if self._own is None and self._max is not None:
+            return self._max
         return float(self._self_stats()[1])
 
     def asum(self):
         return float(self._self_stats()[2])
 
     def legal(self):
-        return bool(np.isfinite(self._self_stats()[1]))
+        return bool(np.isfinite(self.amax()))
 
     def __rmul__(self, a):
         return _Scaled(float(a), self)          # t*d is only ever added to x or measured: no kernel, no temporary
@@ -384,10 +389,10 @@ def minfunc_lbfgs(fun, x0, max_iter=200, output_fcn=None, corrections=100, opt_t
             mem.add_step(g, g_old, t, d)
             d = mem.direction(g)
         g_old = g.copy()
+        gtd = _vdot(g, d)                      # (first: on device vectors the same kernel brings max|d| for the legality test)
         if not _legal(d):
             exitflag, msg = -3, "Step direction is illegal"
             break
-        gtd = _vdot(g, d)
         if gtd > -prog_tol:
             exitflag, msg = 2, "Directional Derivative below progTol"
             break

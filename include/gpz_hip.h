@@ -204,6 +204,7 @@ int gpz_predict_missing(const gpz_desc *desc, const double *theta, const double 
  * S and Y (p x corrections) live on the device; all vector arguments are device pointers.
  * gpz_lbfgs_add:        y = g - g_old, s = t*d; skipped (added = 0) when y's <= 1e-10        (lbfgsAdd.m:2-4)
  * gpz_lbfgs_direction:  d = -H*g with Hdiag = y's/y'y of the newest pair                      (lbfgsProd.m, minFunc.m:553-578)
+ *                       (called with the g of the gpz_lbfgs_add just before - minFunc's order - it reuses the products [S Y]'g of that pass)
  * gpz_vec_stats:        out = [g.d, max|g|, sum|g|, max|d|] (NaN-propagating), the scalars of minFunc's tests
  * gpz_vec_axpy:         out = x + t*d */
 typedef struct gpz_lbfgs gpz_lbfgs;
