@@ -634,10 +634,47 @@ __global__ __launch_bounds__(256) void k_prior_iter(const double *__restrict__ N
     }
 }
 
+// The same iteration for m <= 256 with a WAVE per row (lane l holds columns l, l + 64, l + 128, l + 192): the row sum is a wave
+// reduction - no LDS, no barrier in the row loop (the workgroup-per-row form above pays two barriers per row: 88 us a pass at
+// n = 1e5, m = 200, where the 160 MB of N are 40 us of HBM time; getPrior runs up to 100 passes, twice per train()).
+__global__ __launch_bounds__(256) void k_prior_iter_wave(const double *__restrict__ N, int ld, int n, int m,
+                                                          const double *__restrict__ prior, double *__restrict__ colslab) {
+    __shared__ double sacc[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double pq[4], acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        pq[q] = (j < m) ? prior[j] : 0.0;
+        acc[q] = 0.0;
+    }
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        double wv[4], part = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            wv[q] = (j < m) ? N[(size_t)i * ld + j] * pq[q] : 0.0;
+            part += wv[q];
+        }
+        const double tot = wave_sum(part);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += wv[q] / tot;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sacc[wave][lane + 64 * q] = acc[q];
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < m) colslab[(size_t)blockIdx.x * m + j] = ((sacc[0][j] + sacc[1][j]) + sacc[2][j]) + sacc[3][j];
+}
+
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
                        int nwg) {
     const int nj = (m + 255) / 256;
     dim3 g(nwg), b(256);
+    if (m <= 256) {
+        hipLaunchKernelGGL(k_prior_iter_wave, g, b, 0, st, N, ld, n, m, prior, colslab);
+        return;
+    }
     if (nj <= 1) hipLaunchKernelGGL(k_prior_iter<1>, g, b, 0, st, N, ld, n, m, prior, colslab);
     else if (nj <= 2) hipLaunchKernelGGL(k_prior_iter<2>, g, b, 0, st, N, ld, n, m, prior, colslab);
     else if (nj <= 4) hipLaunchKernelGGL(k_prior_iter<4>, g, b, 0, st, N, ld, n, m, prior, colslab);
