@@ -393,6 +393,7 @@ void launch_predict_noisy(hipStream_t st, int kind, int n, long ldx, int m, int 
                           double *ws = nullptr, int flags = 0);
 void launch_predict_noisy_final(hipStream_t st, const double *sums, long ldx, int n, int k, const double *mu,
                                 const double *lnbeta, const double *b, double *gamma, double *nu, double *beta_i);
+void launch_prior_update(hipStream_t st, const double *colsum, double ns, int m, double *prior, double *keep);
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
                        int nwg);
 

@@ -556,13 +556,14 @@ extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double
     gpz_opts_scope opts_scope(&c->opt);
     const int m = c->m;
     int rc = run_phi_only(c, theta);
-    double *nd = nullptr, *pd = nullptr, *slab = nullptr, *colsum = nullptr;
+    double *nd = nullptr, *pd = nullptr, *slab = nullptr, *colsum = nullptr, *hist = nullptr;
     const int nwg = ns < 1024 ? (int)ns : 1024;
     if (!rc) rc = c->ar.alloc(&nd, (size_t)c->tr.n_pad * c->mp);
     if (!rc) rc = c->ar.alloc(&pd, (size_t)m);
     if (!rc) rc = c->ar.alloc(&slab, (size_t)nwg * m);
     if (!rc) rc = c->ar.alloc(&colsum, (size_t)m);
-    std::vector<double> pr(m, 1.0 / m), old(m), cs(m);                     // getPrior.m:5
+    if (!rc) rc = c->ar.alloc(&hist, (size_t)10 * m);
+    std::vector<double> pr(m, 1.0 / m), old(m);                     // getPrior.m:5
     int it = 0;
     if (!rc) {
         NormArgs a{};
@@ -570,21 +571,35 @@ extern "C" int gpz_prior(const gpz_desc *desc, const double *theta, const double
         a.gen = c->gen ? 1 : 0; a.G = c->pr.G; a.Rc = c->pr.Rc; a.Mr = c->tr.Mr; a.ucnt = c->tr.ucnt;
         a.gid = c->tr.gid; a.pat = c->pat_d; a.lnS = c->lnS; a.N = nd;
         launch_phi_norm(c->st, a);
-        for (it = 1; it <= 100 && !rc; ++it) {                             // getPrior.m:7
-            old = pr;
-            hipError_t e = hipMemcpyAsync(pd, pr.data(), m * sizeof(double), hipMemcpyHostToDevice, c->st);
-            launch_prior_iter(c->st, nd, c->mp, (int)ns, m, pd, slab, nwg);
-            launch_slab_sum(c->st, slab, nwg, (size_t)m, colsum);
-            if (e == hipSuccess) e = hipMemcpyAsync(cs.data(), colsum, m * sizeof(double), hipMemcpyDeviceToHost, c->st);
+        // getPrior.m:7-20.  The iterations run on the device in batches of PRIOR_BATCH - prior <- colsum / n by a kernel, every new
+        // prior kept - and the host applies the convergence test of getPrior.m:17-19 to the batch's priors IN ORDER, so the answer
+        // and the iteration count are those of testing after every pass (a read-back and a synchronisation per pass were 77 of
+        // the 122 us a pass cost at n = 1e5, m = 200); the passes of a batch behind the converged one are wasted.
+        constexpr int PRIOR_BATCH = 10;
+        hipError_t e = hipMemcpyAsync(pd, pr.data(), m * sizeof(double), hipMemcpyHostToDevice, c->st);
+        std::vector<double> hh((size_t)PRIOR_BATCH * m);
+        bool done = false;
+        it = 1;
+        while (it <= 100 && !rc && !done) {
+            const int nb = 100 - it + 1 < PRIOR_BATCH ? 100 - it + 1 : PRIOR_BATCH;
+            for (int b = 0; b < nb; ++b) {
+                launch_prior_iter(c->st, nd, c->mp, (int)ns, m, pd, slab, nwg);
+                launch_slab_sum(c->st, slab, nwg, (size_t)m, colsum);
+                launch_prior_update(c->st, colsum, (double)ns, m, pd, hist + (size_t)b * m);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), hist, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, c->st);
             if (e == hipSuccess) e = hipStreamSynchronize(c->st);
             if (e != hipSuccess) { rc = gpz_fail(GPZ_ERR_HIP, "gpz_prior: %s", hipGetErrorString(e)); break; }
-            double num = 0.0, den = 0.0;
-            for (int j = 0; j < m; ++j) {
-                pr[j] = cs[j] / (double)ns;                                // mean(w)   getPrior.m:15
-                num += (old[j] - pr[j]) * (old[j] - pr[j]);
-                den += (old[j] + pr[j]) * (old[j] + pr[j]);
+            for (int b = 0; b < nb; ++b, ++it) {
+                old = pr;
+                double num = 0.0, den = 0.0;
+                for (int j = 0; j < m; ++j) {
+                    pr[j] = hh[(size_t)b * m + j];                         // mean(w)   getPrior.m:15
+                    num += (old[j] - pr[j]) * (old[j] - pr[j]);
+                    den += (old[j] + pr[j]) * (old[j] + pr[j]);
+                }
+                if (sqrt(num) / sqrt(den) < 1e-10) { done = true; break; } // getPrior.m:17-19
             }
-            if (sqrt(num) / sqrt(den) < 1e-10) break;                      // getPrior.m:17-19
         }
     }
     if (!rc) {

@@ -667,6 +667,18 @@ __global__ __launch_bounds__(256) void k_prior_iter_wave(const double *__restric
     if (j < m) colslab[(size_t)blockIdx.x * m + j] = ((sacc[0][j] + sacc[1][j]) + sacc[2][j]) + sacc[3][j];
 }
 
+// prior <- colsum / n (getPrior.m:15: mean(w)), a copy kept in `keep` for the host's convergence test
+__global__ void k_prior_update(const double *__restrict__ colsum, double ns, int m, double *__restrict__ prior, double *__restrict__ keep) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double v = colsum[j] / ns;
+    prior[j] = v;
+    keep[j] = v;
+}
+void launch_prior_update(hipStream_t st, const double *colsum, double ns, int m, double *prior, double *keep) {
+    hipLaunchKernelGGL(k_prior_update, dim3((m + 255) / 256), dim3(256), 0, st, colsum, ns, m, prior, keep);
+}
+
 void launch_prior_iter(hipStream_t st, const double *N, int ld, int n, int m, const double *prior, double *colslab,
                        int nwg) {
     const int nj = (m + 255) / 256;
@@ -756,7 +768,29 @@ __global__ void k_phi_norm(NormArgs a) {
     }
 }
 
+// The same without missing values on the tuned routes: cn depends on the basis function alone, so a thread keeps ONE column and walks
+// rows - d logarithms and an exponential once per thread instead of once per element (0.73 ms -> the time of the copy at n = 1e5, m = 200).
+__global__ __launch_bounds__(256) void k_phi_norm_cols(NormArgs a) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= a.m) return;
+    double s = 0.0;
+    if (a.kind == GPZ_KIND_DIAG) {
+        for (int c = 0; c < a.d; ++c) s += log(fabs(a.G[(size_t)j * a.de + c]));
+    } else {
+        const int nt = a.de * (a.de + 1) / 2;
+        const double *rj = a.Rc + (size_t)j * (nt + a.de);
+        for (int q = 0; q < a.d; ++q) s += log(fabs(rj[q * a.de - q * (q - 1) / 2]));
+    }
+    const double ecn = exp(s - 0.5 * (double)a.d * GPZ_LOG2PI);
+    for (size_t i = blockIdx.x; i < (size_t)a.n; i += gridDim.x) a.N[i * a.ld + j] = a.Phi[i * a.ld + j] * ecn;
+}
+
 void launch_phi_norm(hipStream_t st, const NormArgs &a) {
+    if (!a.gen && !a.Mr && !a.ucnt) {
+        const int nb = a.n < 2048 ? (a.n > 0 ? a.n : 1) : 2048;
+        hipLaunchKernelGGL(k_phi_norm_cols, dim3(nb, (a.m + 255) / 256), dim3(256), 0, st, a);
+        return;
+    }
     hipLaunchKernelGGL(k_phi_norm, dim3(1024), dim3(256), 0, st, a);
 }
 

@@ -30,7 +30,8 @@ for method in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["VD", "VC"]):
                 ctx.enable_timing(True); ctx.eval(theta); ctx.reset_timings()   # the first timed evaluation creates the events
                 t0 = time.perf_counter(); f, g = ctx.eval(theta); one = time.perf_counter() - t0
                 K = max(2, min(200, int(0.1 / max(one, 1e-5))))      # ~0.1 s per case: two evaluations of a 0.4 ms shape are timer noise
-                ctx.reset_timings()
+                for _ in range(K): ctx.eval(theta)                    # warm-up of the same length: the first case after the host-side data
+                ctx.reset_timings()                                   # generation otherwise runs at the clock of an idle device
                 t0 = time.perf_counter()
                 for _ in range(K): f, g = ctx.eval(theta)
                 dt = (time.perf_counter() - t0) / K
