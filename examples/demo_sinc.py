@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--method", default="VL")              # demo_sinc.m:9
     ap.add_argument("--maxIter", type=int, default=500)
     ap.add_argument("--maxAttempts", type=int, default=50)
-    ap.add_argument("--device-resident", action="store_true", help="keep theta, g and the L-BFGS memory on the GPU")
+    ap.add_argument("--device-resident", action="store_true", help="keep theta, g and the L-BFGS memory on the GPU (also the default where device vectors are available)")
+    ap.add_argument("--host-vectors", action="store_true", help="optimiser vectors on the host: minFunc's own arithmetic order")
     args = ap.parse_args()
 
     rng = np.random.default_rng(1)                         # demo_sinc.m:1  rng(1)
@@ -39,7 +40,7 @@ def main():
     tr, va, te = gpz_amd.sample(n, 0.70, 0.15, 0.15, rng)  # demo_sinc.m:30-32
     model = gpz_amd.init(Xn, Y, args.method, args.m, heteroscedastic=True, training=tr, Psi=Psi, rng=rng)
     model = gpz_amd.train(model, Xn, Y, maxIter=args.maxIter, maxAttempts=args.maxAttempts, training=tr, validation=va,
-                          Psi=Psi, device_resident=args.device_resident)
+                          Psi=Psi, device_resident=True if args.device_resident else (False if args.host_vectors else None))
 
     def report(name, mu, sigma):
         err = mu[:, 0] - Y[te, 0]

@@ -590,12 +590,25 @@ def init(X, Y, method, m, heteroscedastic=True, normalize=True, omega=None, trai
     return model
 
 
+def _device_vectors_available():
+    """DevVec needs torch (as plain device memory) and a visible GPU."""
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
 def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=None, validation=None, Psi=None,
-          verbose=True, device=0, device_resident=False, dtype="f64", n_gpus=None, reducer="rccl"):
+          verbose=True, device=0, device_resident=None, dtype="f64", n_gpus=None, reducer="rccl"):
     """model = train(model,X,Y,...)   (train.m + callBack.m): L-BFGS on the negative log marginal likelihood with
     per-iteration statistics, best-on-validation tracking and early stopping after maxAttempts non-improving
     iterations.  device_resident=True keeps theta, the gradient, the search direction and the L-BFGS memory on the GPU
-    (gpz_eval_dev + gpz_lbfgs_*): per evaluation only f and the statistics cross PCIe.
+    (gpz_eval_dev + gpz_lbfgs_*): per evaluation only f and the statistics cross PCIe.  The default (None) takes that route
+    on one GPU whenever device vectors are available (torch with a visible GPU) - at 100 corrections the NumPy two-loop
+    of the host route costs more than a small problem's evaluation (profiles/r06_train_timing.txt: 2.5 x the bare evaluation
+    per evaluation at BASELINE config 2 against 1.4 x) - and the host route otherwise; False forces the host route
+    (minFunc's own arithmetic order, what the CPU tests run).
     n_gpus (0 = every GPU of the node): the closure is evaluated on several GPUs behind one synchronous call (GPzMulti /
     gpz_mgpu_*: rows sharded, RCCL inside the library) - what the MEX gateway does for a MATLAB train.m; reducer
     "loopback" puts the shards on one GPU (single-GPU machines)."""
@@ -609,6 +622,8 @@ def train(model, X, Y, maxIter=200, maxAttempts=np.inf, omega=None, training=Non
     training_only = validation is None or not np.asarray(validation).any()
     state = {"best_theta": model.sets["best"]["theta"].copy(), "best_valid": model.sets["best"].get("LL", -np.inf),
              "attempts": 0, "tic": time.time(), "log": []}
+    if device_resident is None:
+        device_resident = n_gpus is None and _device_vectors_available()
     if n_gpus is not None:
         if device_resident:
             raise ValueError("device_resident optimiser vectors live on one GPU: use it without n_gpus")

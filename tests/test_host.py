@@ -229,13 +229,15 @@ def test_device_resident_training_matches_host_training():
     import copy
     # the two memories sum in different orders (two-loop vs Gram-matrix form), so the iterates drift apart at the
     # rounding level and the drift grows with the iteration count: compare a short run tightly, a long one by outcome
-    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=12, maxAttempts=50, training=tr, validation=va, verbose=False)
+    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=12, maxAttempts=50, training=tr, validation=va, verbose=False,
+                       device_resident=False)
     mb = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=12, maxAttempts=50, training=tr, validation=va, verbose=False,
                        device_resident=True)
     assert ma.train_info["funEvals"] == mb.train_info["funEvals"]
     assert abs(ma.train_info["f"] - mb.train_info["f"]) <= 1e-7 * abs(ma.train_info["f"])
     assert rel(mb.sets["last"]["theta"], ma.sets["last"]["theta"]) < 1e-5
-    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False)
+    ma = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False,
+                       device_resident=False)
     mb = gpz_amd.train(copy.deepcopy(m0), X, Y, maxIter=150, maxAttempts=50, training=tr, validation=va, verbose=False,
                        device_resident=True)
     assert abs(ma.train_info["f"] - mb.train_info["f"]) <= 2e-2 * abs(ma.train_info["f"])
@@ -272,7 +274,7 @@ def test_train_over_three_loopback_shards_reproduces_the_single_context_run():
     tr, va, te = gpz_amd.sample(X.shape[0], 0.7, 0.15, 0.15, rng)
     base = gpz_amd.init(X, Y, "VL", 12, training=tr, rng=np.random.default_rng(4))
     import copy
-    m1 = gpz_amd.train(copy.deepcopy(base), X, Y, maxIter=25, training=tr, validation=va, verbose=False)
+    m1 = gpz_amd.train(copy.deepcopy(base), X, Y, maxIter=25, training=tr, validation=va, verbose=False, device_resident=False)
     m3 = gpz_amd.train(copy.deepcopy(base), X, Y, maxIter=25, training=tr, validation=va, verbose=False, n_gpus=3,
                        reducer="loopback")
     assert m1.train_info["funEvals"] == m3.train_info["funEvals"]
