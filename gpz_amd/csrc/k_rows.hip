@@ -476,10 +476,11 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                 if (PSI) {
                     const double psi = Psir[(size_t)i * D + c];
                     const double iu = gpz_rcp(fma(psi, g2[c], 1.0));
-                    const double dr = dl * iu;
-                    M1[c] = fma(dp * dl, g2[c] * iu, M1[c]);
-                    S[c] = fma(dp * dr, dr, S[c]);
-                    S3[c] = fma(dp, -psi * iu, S3[c]);
+                    const double q = dp * iu;                       // dPHI / u: three multiplies and three multiply-adds per (i, j, c)
+                    const double t = dl * q;                        // (five and three with dPHI Delta, gamma^2 / u and psi / u formed apart)
+                    M1[c] = fma(g2[c], t, M1[c]);                   // sum dPHI Delta gamma^2 / u
+                    S[c] = fma(t, dl * iu, S[c]);                   // sum dPHI (Delta / u)^2
+                    S3[c] = fma(-psi, q, S3[c]);                    // sum dPHI (-psi / u)
                 } else {
                     const double t = dp * dl;
                     M1[c] += t;
