@@ -230,6 +230,7 @@ struct gpz_ctx {
     double *partial = nullptr, *rstats = nullptr, *dGfull = nullptr, *spart = nullptr;
     double *nupart = nullptr, *rowscal = nullptr, *frec = nullptr;   // fused path
     bool syrk_small = false;   // mp <= 256, fp64 operands: PHI' W PHI by k_syrk_small (one workgroup holds the whole triangle)
+    bool small_tail_dp = false;   // diagonal kinds + input noise, mp <= 256, k = 1: k_small_tail writes dPHI (into T's buffer), k_moments_diag sums it
     bool small_tail = false;   // mp <= 256, k = 1, no Psi / missing values / row tiles: T-GEMM + row scalars + moments as ONE kernel (k_small.hip), T never allocated
     int st_nwg = 0, st_nf = 0;
     double *st_slab = nullptr;

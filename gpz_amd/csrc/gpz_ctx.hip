@@ -490,6 +490,15 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
     c->small_tail = !c->gen && !c->has_psi && !c->tile_rows &&   // (dtype f32 changes nothing here: no input noise)
                     small_tail_fits(c->kind, c->de, c->m, k, c->mp, c->has_missing) && !c->opt.small_tail_off;
     if (!c->small_tail && (rc = c->ar.alloc(&c->T, npt * mp))) return bail(rc);   // (T = PHI [inv(SIGMA) | w] exists in memory only on the other routes)
+    // ... and with input noise under a diagonal kind (moment sums that are not linear in row features: 1 / (1 + psi_ic gamma_jc^2)): the same
+    // kernel without features, dPHI written where T would have been, the sums by k_moments_diag from that ONE matrix
+    c->small_tail_dp = k == 1 && !c->gen && c->has_psi && c->kind == GPZ_KIND_DIAG && !c->tile_rows && !c->small_tail && c->de <= 100 &&   // (row entries are indexed by a byte)
+                       small_tail_fits(c->kind, 0, c->m, k, c->mp, false) && !c->opt.small_tail_off;
+    if (c->small_tail_dp) {
+        c->st_nwg = small_tail_nwg();
+        c->st_nf = 0;
+        if ((rc = c->ar.alloc(&c->st_slab, (size_t)c->st_nwg * m * 2))) return bail(rc);
+    }
     if (c->small_tail) {
         c->st_nwg = small_tail_nwg();
         c->st_nf = small_tail_features(c->kind, c->de, c->has_missing);
@@ -773,7 +782,8 @@ extern "C" int gpz_ctx_route(const gpz_ctx *c, char *buf, int cap) {
     return snprintf(buf, (size_t)cap, "pair/PHI kernels: %s%s; contractions: %s MFMA%s%s; evaluation graph: %s%s", phi, why,
                     f32mm ? "fp32-operand (fp64 master sums)" : "fp64",
                     c->syrk_small ? ", PHI' W PHI with the whole triangle in one workgroup (k_syrk_small)" : "",
-                    c->small_tail ? ", T-GEMM + row scalars + moments in one kernel (k_small_tail: T stays in registers)" : "", gs, rows);
+                    c->small_tail ? ", T-GEMM + row scalars + moments in one kernel (k_small_tail: T stays in registers)" :
+                    c->small_tail_dp ? ", T-GEMM + row scalars + dPHI in one kernel (k_small_tail; moment sums with input noise by k_moments_diag)" : "", gs, rows);
 }
 namespace gpzi {
 

@@ -385,6 +385,32 @@ int eval_tail(gpz_ctx *c, bool pinv) {
             launch_split_fused(c->st, c->frec, c->m, c->nm, c->mp, mom, cols + (size_t)o * 2 * mp, o > 0 ? 1 : 0);
             continue;
         }
+        if (c->small_tail_dp) {
+            // diagonal kinds with input noise, few basis functions: T-GEMM, nu, row scalars and dPHI = -omega beta PHI o U in k_small_tail (no
+            // features: the sums carry 1 / (1 + psi_ic gamma_jc^2)), dPHI in T's buffer, the moment sums from that one matrix
+            {
+                Stage s(c, "tail_small");
+                SmallTailArgs a{};
+                a.Phi = c->Phi; a.ld = c->mp; a.B = c->Bext; a.ldb = c->mp;
+                a.n = c->tr.n; a.n_pad = c->tr.n_pad; a.m = c->m; a.mp = c->mp; a.d = c->de; a.kind = c->kind; a.mcol = c->m;
+                a.Xs = c->tr.Xs; a.xs_ld = c->tr.xs_ld; a.missing = 0;
+                a.y = c->tr.Y; a.omega = c->tr.om; a.omega1 = c->tr.om; a.lnbeta = c->lnbeta; a.wbeta = c->wbeta;
+                a.w = c->w; a.v = c->hetero ? c->pr.v : c->w; a.vscale = c->hetero ? 1.0 : 0.0;
+                a.phiw = c->phiw; a.slab = c->st_slab; a.partial = c->partial; a.nf = 0; a.stagger = c->opt.small_stagger;
+                a.dphi = c->T; a.ldd = c->mp;
+                launch_small_tail(c->st, a, c->st_nwg);
+                launch_small_finish(c->st, c->st_slab, c->partial, c->st_nwg, c->m, c->de, c->kind, 0, 0, c->pr.P, c->tr.xmu, c->nm, c->mp, mom,
+                                    cols, scal, 0, 1);
+            }
+            Stage s(c, "moments");
+            MomentArgs ma{};
+            ma.dPhi = c->T; ma.ld = c->mp; ma.Xr = c->tr.Xr; ma.n = c->tr.n; ma.n_pad = c->tr.n_pad; ma.m = c->m; ma.d = c->de;
+            ma.kind = c->kind; ma.P = c->pr.P; ma.nchunk = c->nchunk; ma.rows_per_chunk = c->rows_per_chunk; ma.slab = c->mom_slab;
+            ma.nm = c->nm; ma.Psir = c->tr.Psir; ma.Mr = c->tr.Mr; ma.G2 = c->pr.G2;
+            if (launch_moments(c->st, ma)) return gpz_fail(GPZ_ERR_UNSUPPORTED, "moment kernel not instantiated for d=%d", c->de);
+            launch_slab_sum(c->st, c->mom_slab, c->nchunk, m * c->nm, mom);
+            continue;
+        }
         if (c->small_tail) {
             // T = PHI [inv(SIGMA) | w], nu, the row scalars, dPHI and the moment sums in one kernel; T stays in registers (k_small.hip)
             Stage s(c, "tail_small");

@@ -102,6 +102,8 @@ struct SmallTailArgs {
     const double *w, *v;                    // m; without the heteroscedastic term v = w and vscale = 0 (no branch in the kernel)
     double vscale;
     double *phiw;                           // n_pad: PHI w
+    double *dphi; int ldd;                  // when non-null: dPHI (n_pad x ldd, GPz.m:113) is written as well - the input-noise route of the diagonal
+                                            // kinds takes its moment sums from it (k_moments_diag), with nf = 0 features here
     double *slab;                           // [nwg][m][nf + 2]: raw sums about xmu, PHI'c, PHI'dbeta
     double *partial;                        // [nwg][GPZ_NS]: sum c delta, sum omega delta^2, sum LL, sum dbeta
     int ncu;                                // compute units (set by the launcher)
@@ -114,7 +116,7 @@ int small_tail_nwg();                            // persistent workgroups: two p
 void launch_small_tail(hipStream_t st, const SmallTailArgs &a, int nwg);
 void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
                          const double *P, const double *xmu, int nm, int mp, double *mom, double *cols,
-                         double *scal, int accumulate);   // the workgroups' records -> moments, column sums, scalar sums (one launch)
+                         double *scal, int accumulate, int cols_only = 0);   // cols_only: records without raw sums (nf = 0)   // the workgroups' records -> moments, column sums, scalar sums (one launch)
 int gpz_cu_count();         // compute units of the current device (k_gemm.hip)
 // nupart (optional): [gpz_gemm_wave_cols()*ceil(mp/128)][n_pad] per-wave-column partial sums of PHI.*T over columns < m; phiw: column mcol of T
 void launch_tgemm(hipStream_t st, const double *Phi, int ld, const double *B, int ldb, double *T, int n_pad, int mp,

@@ -111,7 +111,8 @@ __device__ __forceinline__ double row_sum16x8(const double (&v)[8], int lane) {
 //     and the row factor -ob_i goes into the FEATURES (32 x 32 values per block instead of 32 x mp elements): one multiply per element;
 //   * operands arrive through buffer loads (resource in SGPRs, loop-invariant VGPR offset, scalar row / K offset): no address arithmetic;
 //   * the feature table of a thread (which two entries of the centred row [1 | x - mu] it multiplies) is fixed before the block loop.
-template <int NQW, bool F2>
+// DP: the variant that writes dPHI and takes no features (no feature staging, no moment accumulators, no moment products).
+template <int NQW, bool F2, bool DP>
 __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *smem, int wce) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, mp = a.mp, ld = a.ld;
@@ -206,14 +207,16 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 for (int r = 0; r < 8; ++r) SM_GLDS(g0 + (size_t)r * ld + 128, l0 + r * SM_LDA + 128);
             }
             // features (times -omega beta of the row: the row factor of dPHI lives here, see above)
-            const int r = tid >> 3, i = i0 + r;
-            const double *xs = a.Xs + (size_t)i * xs_ld;
-            double xa[4], xb[4];
+            if constexpr (!DP) {
+                const int r = tid >> 3, i = i0 + r;
+                const double *xs = a.Xs + (size_t)i * xs_ld;
+                double xa[4], xb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { xa[u] = xs[(fpa >> (8 * u)) & 255]; xb[u] = xs[(fpb >> (8 * u)) & 255]; }
-            const double nob = -a.wbeta[i];                    // (rows >= n: omega beta = 0)
+                for (int u = 0; u < 4; ++u) { xa[u] = xs[(fpa >> (8 * u)) & 255]; xb[u] = xs[(fpb >> (8 * u)) & 255]; }
+                const double nob = -a.wbeta[i];                    // (rows >= n: omega beta = 0)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sE[r * SM_LDE + (tid & 7) * 4 + u] = nob * (xa[u] * xb[u]);
+                for (int u = 0; u < 4; ++u) sE[r * SM_LDE + (tid & 7) * 4 + u] = nob * (xa[u] * xb[u]);
+            }
         }
         // ---- T block = PHI(i0 .. i0+31, :) * B: no barrier inside, every wave runs its own columns
         d4_t acc[2][NQW > 0 ? NQW : 1];
@@ -311,7 +314,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 s3 += db;
                 a.phiw[i] = pw;
             }
-            sRs[tid * 4 + 0] = cc; sRs[tid * 4 + 1] = db;
+            sRs[tid * 4 + 0] = cc; sRs[tid * 4 + 1] = db; sRs[tid * 4 + 2] = -rob;   // (-omega beta: the row factor of dPHI where it is written out)
             sA[tid * SM_LDA + mp] = delta; sA[tid * SM_LDA + mp + 1] = -g;   // A operand of the U step
         }
         __syncthreads();
@@ -340,6 +343,18 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                     r2[q] = fma(ph, db, r2[q]);
                 }
             }
+        if constexpr (DP) {   // dPHI_ij = -omega beta_i PHI_ij U_ij for the moment kernels that cannot take features
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double nob = (prs + oz)[(t * 16 + 4 * r) * 4 + 2];
+                    double *dr = a.dphi + (size_t)(i0 + t * 16 + (lane >> 4) + 4 * r) * a.ldd + wce * 16 + (lane & 15);
+#pragma unroll
+                    for (int q = 0; q < NQW; ++q) dr[64 * q] = nob * acc[t][q][r];
+                }
+        }
+        if constexpr (!DP) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -351,6 +366,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                     if (F2) Mq[q][1] = MFMA_F64(acc[t][q][r], e1, Mq[q][1]);
                 }
             }
+        }
         SM_MARK(6);
         __syncthreads();   // sA, sE, sNu, sRs are rewritten by the next block
         SM_MARK(7);
@@ -361,6 +377,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
 #pragma unroll
     for (int q = 0; q < NQW; ++q) {
         // Mq[q][fb][r]: row (lane >> 4) + 4 r of the block = basis j, column lane & 15 of the feature block
+        if constexpr (!DP) {
 #pragma unroll
         for (int fb2 = 0; fb2 < (F2 ? 2 : 1); ++fb2)
 #pragma unroll
@@ -368,6 +385,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
                 const int j = (4 * q + wce) * 16 + (lane >> 4) + 4 * r, f = fb2 * 16 + (lane & 15);
                 if (j < m && f < a.nf) rec[(size_t)j * nrec + f] = Mq[q][fb2][r];
             }
+        }
         double t1 = r1[q], t2 = r2[q];                    // this lane's rows -> all rows of the wave: lanes l, l + 16, l + 32, l + 48
         t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
         t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
@@ -385,7 +403,7 @@ __device__ __forceinline__ void small_tail_run(const SmallTailArgs &a, double *s
     }
 }
 
-template <int NQ, bool F2>
+template <int NQ, bool F2, bool DP>
 __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
     extern __shared__ double smem[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -399,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
     // workgroup of the chip stages its 53 KB at the same moment - 27 MB in one burst, 13 000 cycles - and both K loops share the SIMDs)
     if ((blockIdx.x / a.ncu) & 1)
         for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(127);
-    if (nqw == NQ) small_tail_run<NQ, F2>(a, smem, wce);
-    else small_tail_run<NQ - 1, F2>(a, smem, wce);         // (NQ = ceil(nblk / 4): every wave has NQ or NQ - 1)
+    if (nqw == NQ) small_tail_run<NQ, F2, DP>(a, smem, wce);
+    else small_tail_run<NQ - 1, F2, DP>(a, smem, wce);         // (NQ = ceil(nblk / 4): every wave has NQ or NQ - 1)
 }
 
 // ONE launch behind k_small_tail (it replaced two record sums, a copy, the conversion and the split: five ~5 us launches of an evaluation of
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_small_tail(SmallTailArgs a) {
 __global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict__ slab, const double *__restrict__ partial, int nwg, int m, int d,
                                                        int kind, int nf, int missing, const double *__restrict__ P,
                                                        const double *__restrict__ xmu, int nm, int mp, double *__restrict__ mom,
-                                                       double *__restrict__ cols, double *__restrict__ scal, int accumulate) {
+                                                       double *__restrict__ cols, double *__restrict__ scal, int accumulate, int cols_only) {
     __shared__ double part[32][36];
     __shared__ double R[36];
     const int tid = threadIdx.x;
@@ -462,6 +480,7 @@ __global__ __launch_bounds__(1024) void k_small_finish(const double *__restrict_
         cols[(size_t)(q - nm) * mp + j] = R[nf + (q - nm)];
         return;
     }
+    if (cols_only) return;
     double val;
     if (q < d || kind == GPZ_KIND_DIAG) {
         const int c = q < d ? q : q - d;
@@ -501,8 +520,9 @@ void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
     dim3 g(nwg), b(256);
 #define SMALL_CASE(NQ_)                                                                                   \
     do {                                                                                                  \
-        if (a.nf > 16) hipLaunchKernelGGL((k_small_tail<NQ_, true>), g, b, lds, st, a);                   \
-        else hipLaunchKernelGGL((k_small_tail<NQ_, false>), g, b, lds, st, a);                            \
+        if (a.dphi) hipLaunchKernelGGL((k_small_tail<NQ_, false, true>), g, b, lds, st, a);               \
+        else if (a.nf > 16) hipLaunchKernelGGL((k_small_tail<NQ_, true, false>), g, b, lds, st, a);       \
+        else hipLaunchKernelGGL((k_small_tail<NQ_, false, false>), g, b, lds, st, a);                     \
     } while (0)
     if (nq <= 1) SMALL_CASE(1);
     else if (nq == 2) SMALL_CASE(2);
@@ -511,7 +531,8 @@ void launch_small_tail(hipStream_t st, const SmallTailArgs &a0, int nwg) {
 #undef SMALL_CASE
 }
 void launch_small_finish(hipStream_t st, const double *slab, const double *partial, int nwg, int m, int d, int kind, int nf, int missing,
-                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols, double *scal, int accumulate) {
+                         const double *P, const double *xmu, int nm, int mp, double *mom, double *cols, double *scal, int accumulate,
+                         int cols_only) {
     hipLaunchKernelGGL(k_small_finish, dim3(m + 1), dim3(1024), 0, st, slab, partial, nwg, m, d, kind, nf, missing, P, xmu, nm, mp, mom, cols,
-                       scal, accumulate);
+                       scal, accumulate, cols_only);
 }

@@ -1792,10 +1792,53 @@ def test_small_tail_route_with_several_outputs(method, n, d, m, k, omk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hetero", [False, True])
+@pytest.mark.parametrize("method,n,d,m,nanfrac", [("VD", 3000, 10, 200, 0.0), ("GD", 1500, 4, 30, 0.0), ("VL", 2000, 1, 100, 0.0),
+                                                  ("GL", 997, 3, 9, 0.0), ("VD", 2500, 6, 120, 0.25), ("VD", 1200, 24, 40, 0.0)])
+def test_small_tail_route_with_input_noise(method, n, d, m, nanfrac, hetero):
+    """Diagonal kinds with input noise, m + 1 <= 256 columns: the moment sums carry 1 / (1 + psi_ic gamma_jc^2) and are not linear in row
+    features, so k_small_tail runs without features and writes dPHI = -omega beta PHI o U where T would have been; k_moments_diag sums
+    that one matrix (GPz.m:198-206).  Against the oracle with weights, a training mask and validation rows; missing values beside the
+    noise; d = 24 (the runtime-d moment kernel); and against the separate kernels (developer build, GPZ_SMALL_TAIL_OFF)."""
+    model, theta, X, Y, Psi, rng = make_problem(n, d, m, 1, method, hetero, seed=9300 + n + m, psi=True, nanfrac=nanfrac)
+    om = rng.random((n, 1)) + 0.5
+    tr = rng.random(n) < 0.8
+    ref = O.GPz(theta, model, X, Y, Psi, om, tr, ~tr)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi, om, tr, ~tr)
+    try:
+        f, g = ctx.eval(theta)
+        f2, g2 = ctx.eval(theta)
+        f3, g3 = ctx.eval(theta)
+        stats = dict(ctx.stats)
+        route = ctx.route()
+    finally:
+        ctx.close()
+    assert "k_small_tail" in route and "k_moments_diag" in route, route
+    assert f2 == f and f3 == f and np.array_equal(g, g2) and np.array_equal(g, g3)
+    assert abs(f - ref.nlogML) <= FTOL * abs(ref.nlogML)
+    assert rel(g, ref.grad) <= grad_tol(ref.cond), (rel(g, ref.grad), grad_tol(ref.cond))
+    for key, val in ref.stats.items():
+        assert abs(stats[key] - val) <= 1e-10 * max(1.0, abs(val)), key
+
+
+@pytest.mark.gpu
+def test_small_tail_with_input_noise_agrees_with_the_separate_kernels(tmp_path):
+    from helpers import eval_with_dev_switches
+    model, theta, X, Y, Psi, rng = make_problem(4000, 8, 150, 1, "VD", True, seed=4533, psi=True)
+    ctx = gpz_amd.GPzContext(model, X, Y, Psi)
+    f0, g0 = ctx.eval(theta)
+    assert "k_moments_diag" in ctx.route()
+    ctx.close()
+    f, g, info = eval_with_dev_switches(tmp_path, "VD", 150, 8, 1, True, theta, X, Y, Psi, {"GPZ_SMALL_TAIL_OFF": 1})
+    assert info == 0
+    assert abs(f - f0) <= 1e-13 * abs(f0) and rel(g, g0) <= 1e-10, (abs(f - f0) / abs(f0), rel(g, g0))
+
+
+@pytest.mark.gpu
 def test_small_tail_is_not_taken_where_it_does_not_apply():
-    """y's columns m .. m + k - 1 in two 16-column blocks, input noise, missing values under a covariance kind or with more than 10
+    """y's columns m .. m + k - 1 in two 16-column blocks, input noise under a covariance kind or with two outputs, missing values under a covariance kind or with more than 10
     dimensions, more than 256 columns, more than 32 features: the separate kernels (and the same oracle parity, covered by the tests above) - the route text must not name k_small_tail."""
-    cases = [dict(m=31, k=2), dict(psi=True), dict(method="VC", nanfrac=0.2), dict(method="VD", d=11, nanfrac=0.2), dict(m=256),
+    cases = [dict(m=31, k=2), dict(method="VC", d=3, psi=True), dict(k=2, psi=True), dict(method="VC", nanfrac=0.2), dict(method="VD", d=11, nanfrac=0.2), dict(m=256),
              dict(method="VC", d=7), dict(method="VD", d=16)]
     for kw in cases:
         method, d, m, k = kw.get("method", "VD"), kw.get("d", 4), kw.get("m", 40), kw.get("k", 1)
