@@ -618,6 +618,9 @@ extern "C" int gpz_ctx_create_sharded(const gpz_desc *desc, int64_t n_tot, const
             nc = (int)(512 * rounds / ncg);
             if (nc < 1) nc = 1;
         }
+        // diagonal kinds, fewer than 256 basis functions: the moment kernels' workgroups are m lanes wide (64 .. 192 threads), so as many
+        // more of them fill the chip
+        if (nc_env <= 0 && c->kind == GPZ_KIND_DIAG && c->m < 256) nc = nc * 256 / ((c->m + 63) / 64 * 64);
         const int max_nc = c->tr.n / 32 > 0 ? c->tr.n / 32 : 1;
         if (nc > max_nc) nc = max_nc;
         if (nc < 1) nc = 1;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
                                                        double *__restrict__ slab, int nm,
                                                        const double *__restrict__ Psir, const double *__restrict__ Mr,
                                                        const double *__restrict__ G2) {
-    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;   // (blockDim.x = 64 .. 256: few basis functions do not leave lanes idle)
     const int chunk = blockIdx.x;
     const bool act = j < m;
     const int jc = act ? j : 0;
@@ -309,14 +309,17 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
     hipLaunchKernelGGL((k_moments_cov<D, A0, A1>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, a.rows_per_chunk, a.slab, a.nm, a.chunktab)
 #define MOM_DIAG(D) \
     do { \
-        if (a.Psir) hipLaunchKernelGGL((k_moments_diag<D, true>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
+        if (a.Psir) hipLaunchKernelGGL((k_moments_diag<D, true>), gd, bd, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
                                        a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2); \
-        else hipLaunchKernelGGL((k_moments_diag<D, false>), g, b, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
+        else hipLaunchKernelGGL((k_moments_diag<D, false>), gd, bd, 0, st, a.dPhi, a.ld, a.Xr, a.n, a.m, a.P, \
                                 a.rows_per_chunk, a.slab, a.nm, a.Psir, a.Mr, a.G2); \
     } while (0)
 
 int launch_moments(hipStream_t st, const MomentArgs &a) {
     dim3 g(a.nchunk, (a.m + 255) / 256), b(256);
+    // diagonal kinds: lanes run along basis functions - with m = 64 or 128 a 256-thread workgroup left 75 / 50 % of them idle
+    const int bs = a.m >= 256 ? 256 : (a.m + 63) / 64 * 64;
+    dim3 gd(a.nchunk, (a.m + bs - 1) / bs), bd(bs);
     if (a.kind == GPZ_KIND_COV) {
         switch (a.d) {
             case 1: MOM_COV(1, 0, 1); break;
