@@ -37,7 +37,7 @@ for method in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["VD", "VC"]):
                 for _ in range(K): ctx.eval(theta)
                 tim = ctx.timings()
                 print("%s d=%-2d %-5s %8.2f ms  " % (method, d, name, dt * 1e3) +
-                      " ".join("%s=%.2f" % (k, v[0] / K) for k, v in sorted(tim.items(), key=lambda x: -x[1][0])[:4]), flush=True)
+                      " ".join("%s=%.2f" % (k, v[0] / K) for k, v in sorted(tim.items(), key=lambda x: -x[1][0])[:int(os.environ.get("GPZ_SWEEP_TOP", "4"))]), flush=True)
                 ctx.close()
             except Exception as e:
                 print(method, d, name, "ERR", str(e)[:100], flush=True)
