@@ -33,6 +33,15 @@ __device__ __forceinline__ double gpz_rcp(double u) {
     return y;
 }
 
+// The same with ONE Newton step: the v_rcp_f64 seed is good to ~2^-27, one step squares that - a few ulps, not correctly rounded.  For the
+// per-(row, basis function, dimension) factors 1 / (1 + psi gamma^2) of the input-noise kernels, whose results are summed over d dimensions
+// and n rows and gated at 1e-8: two multiply-adds less of the ~14 a triple costs.
+__device__ __forceinline__ double gpz_rcp1(double u) {
+    double y = __builtin_amdgcn_rcp(u);
+    const double e = fma(-u, y, 1.0);
+    return fma(y, e, y);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

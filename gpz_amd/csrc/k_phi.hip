@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_phi_diag(const double *__restrict__ Xc,
                             if (decltype(masked)::value) dl *= mk[r][c];
                             if (PSI) {
                                 const double u = fma(ps[r][c], gc, 1.0);   // 1 + psi/sigma  (psi = 0 where missing)
-                                q[r] = fma(dl * dl, gc * gpz_rcp(u), q[r]);   // Delta^2/(psi+sigma)
+                                q[r] = fma(dl * dl, gc * gpz_rcp1(u), q[r]);   // Delta^2/(psi+sigma)
                                 pr[r] *= u;
                             } else {
                                 q[r] = fma(dl * dl, gc, q[r]);             // getPHI.m:97  Delta.^2 ./ Sigma

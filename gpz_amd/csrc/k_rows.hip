@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_moments_diag(const double *__restrict__
             const double dl = (xi[c] - p[c]) * mk;
             if (PSI) {
                 const double psi = Psir[(size_t)i * D + c];
-                const double iu = gpz_rcp(fma(psi, g2[c], 1.0));
+                const double iu = gpz_rcp1(fma(psi, g2[c], 1.0));
                 const double dr = dl * iu;
                 A1v[c] = fma(dp * dl, g2[c] * iu, A1v[c]);
                 A2v[c] = fma(dp * dr, dr, A2v[c]);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_moments_fused(const double *__restrict_
                 const double dl = (sc[3 + c] - p[c]) * mk;
                 if (PSI) {
                     const double psi = Psir[(size_t)i * D + c];
-                    const double iu = gpz_rcp(fma(psi, g2[c], 1.0));
+                    const double iu = gpz_rcp1(fma(psi, g2[c], 1.0));
                     const double q = dp * iu;                       // dPHI / u: three multiplies and three multiply-adds per (i, j, c)
                     const double t = dl * q;                        // (five and three with dPHI Delta, gamma^2 / u and psi / u formed apart)
                     M1[c] = fma(g2[c], t, M1[c]);                   // sum dPHI Delta gamma^2 / u
